@@ -1,0 +1,228 @@
+/*
+ * loam_livox_hip.h -- C ABI of libloamlivox_hip.so: MI355X (gfx950) scan-to-map registration core for
+ * Loam-Livox.  This is the drop-in boundary for the hot path of hku-mars/loam_livox; every entry point
+ * cites the reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every host buffer, the library owns all device memory;
+ *   - pose[7] = {qx,qy,qz,qw,tx,ty,tz}: the storage order of m_para_buffer_RT / m_para_buffer_incremental
+ *     (source/point_cloud_registration.hpp:51-56, source/laser_mapping.hpp:206-213);
+ *   - clouds are AoS float xyzi (4 floats per point) like pcl::PointXYZI payloads; feature clouds carry the
+ *     per-point time stamp in the intensity slot (source/livox_feature_extractor.hpp:246,255);
+ *   - return value: >= 0 success (meaning per function), < 0 library error (text via ll_last_error()).
+ *     No exceptions, no abort.  There is NO CPU fallback: without a HIP device every *_create fails.
+ *   - handles are not thread-safe individually (the reference serialises the extractor with a mutex,
+ *     laser_feature_extractor.hpp:244); different handles may be used from different threads, and one
+ *     ll_map may be shared read-only by several ll_reg (laser_mapping.hpp:1737-1742 runs several
+ *     process_new_scan concurrently against one map snapshot).
+ */
+#ifndef LOAM_LIVOX_HIP_H
+#define LOAM_LIVOX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ll_fe ll_fe;   /* replaces class Livox_laser                (livox_feature_extractor.hpp:77)  */
+typedef struct ll_map ll_map; /* replaces the map clouds + KdTreeFLANN pair (point_cloud_registration.hpp:72-73,
+                                 laser_mapping.hpp:539-546)                                               */
+typedef struct ll_reg ll_reg; /* replaces class Point_cloud_registration    (point_cloud_registration.hpp:38) */
+
+/* Point-type bit masks (livox_feature_extractor.hpp:82-92) and feature labels (:94-103). */
+enum { LL_PT_NORMAL = 0, LL_PT_000 = 1, LL_PT_TOO_NEAR = 2, LL_PT_REFL_LOW = 4, LL_PT_REFL_HIGH = 8,
+       LL_PT_CIRCLE_EDGE = 16, LL_PT_NAN = 32, LL_PT_SMALL_VIEW_ANGLE = 64 };
+enum { LL_LABEL_INVALID = -1, LL_LABEL_UNLABELED = 0, LL_LABEL_CORNER = 1, LL_LABEL_SURFACE = 2,
+       LL_LABEL_NEAR_NAN = 4, LL_LABEL_NEAR_ZERO = 8, LL_LABEL_HIGH_INTENSITY = 16 };
+
+/* ------------------------------------------------------------------------------------------------ extractor */
+
+/* Public tunables of Livox_laser (livox_feature_extractor.hpp:143-167) as the node sets them
+ * (laser_feature_extractor.hpp:146-154,854,859), plus capacities. */
+typedef struct {
+    float thr_corner_curvature;  /* :153, ROS feature_extraction/corner_curvature   */
+    float thr_surface_curvature; /* :154, ROS feature_extraction/surface_curvature  */
+    float minimum_view_angle;    /* :155, ROS feature_extraction/minimum_view_angle */
+    float livox_min_allow_dis;   /* :166, ROS feature_extraction/livox_min_dis      */
+    float livox_min_sigma;       /* :167, ROS feature_extraction/livox_min_sigma    */
+    float max_fov;               /* :143 (17 deg) */
+    float time_internal_pts;     /* :145 (1e-5 s) */
+    int32_t device;              /* HIP device ordinal */
+    int32_t max_points;          /* capacity: points per scan */
+    int32_t max_scans;           /* capacity: scans resident at once (1 for the per-message node path) */
+    int32_t piecewise_number;    /* ROS common/piecewise_number (laser_feature_extractor.hpp:142); 1 when deblur */
+} ll_fe_params;
+
+void ll_fe_default_params(ll_fe_params *p); /* node defaults, max_points 24000, max_scans 1 */
+int ll_fe_create(const ll_fe_params *p, ll_fe **out);
+void ll_fe_destroy(ll_fe *h);
+
+/* Livox_laser::extract_laser_features(cloud, time_stamp) (livox_feature_extractor.hpp:722-766) for ONE scan
+ * given on the host: projection_scan_3d_2d (:458), eval_point (:343), add_mask_of_point (:322),
+ * compute_features (:361), petal split + split_laser_scan (:657).  Keeps the sequential time base of the
+ * class (:150-152,724-736).  Synchronous.  *n_petal_clouds = laserCloudScans.size() of the reference
+ * (the caller drops the scan when it is <= 5, laser_feature_extractor.hpp:287).  Returns 0. */
+int ll_fe_extract(ll_fe *h, const float *xyzi, int32_t n, double time_stamp, int32_t *n_petal_clouds);
+
+/* m_pts_info_vec fields of scan slot `scan` (livox_feature_extractor.hpp:118-133). Any pointer may be NULL. */
+int ll_fe_labels(ll_fe *h, int32_t scan, int32_t *pt_type, int32_t *pt_label, float *depth_sq2,
+                 float *polar_dis_sq2, float *curvature, float *view_angle, float *time_stamp, float *polar_angle);
+
+/* split bookkeeping of scan slot `scan`: split_idx (livox_feature_extractor.hpp:465-565; capacity
+ * max_points/50+8), the return value of projection_scan_3d_2d (:606), and for every surviving petal cloud the
+ * index of its first/last point (what laser_feature_extractor.hpp:321-322 reads through find_pt_info),
+ * plus the piece-wise windows of laser_feature_extractor.hpp:305-323 (piecewise_number entries). */
+int ll_fe_splits(ll_fe *h, int32_t scan, int32_t *split_idx, int32_t *n_split, int32_t *clutter_size,
+                 int32_t *n_petal_clouds, int32_t *first_idx, int32_t *last_idx, float *piece_start, float *piece_end);
+
+/* Livox_laser::get_features(corners, surface, full, minimum_blur, maximum_blur)
+ * (livox_feature_extractor.hpp:219-272) on scan slot 0: ascending index lists (the integer parity artefact)
+ * and, optionally, the packed clouds (xyz + time stamp).  Output buffers sized max_points; NULL to skip. */
+int ll_fe_select(ll_fe *h, float minimum_blur, float maximum_blur, int32_t *corner_idx, int32_t *n_corner,
+                 int32_t *surf_idx, int32_t *n_surf, int32_t *full_idx, int32_t *n_full, float *corner_xyzi,
+                 float *surf_xyzi);
+
+/* Batched, device-resident form (offline map building / throughput): scans are independent, so the time base
+ * is given explicitly per scan (current_time = m_current_time of livox_feature_extractor.hpp:727-731). */
+int ll_fe_upload(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points,
+                 const double *current_time);
+int ll_fe_extract_batch(ll_fe *h, int32_t n_scans); /* asynchronous on the handle's stream */
+/* piece >= 0: use the device-computed piece-wise window `piece`; piece < 0: explicit [minimum,maximum]_blur */
+int ll_fe_select_batch(ll_fe *h, int32_t n_scans, int32_t piece, float minimum_blur, float maximum_blur);
+int ll_fe_counts(ll_fe *h, int32_t n_scans, int32_t *n_corner, int32_t *n_surf, int32_t *n_full,
+                 int32_t *n_ambiguous); /* synchronises */
+int ll_fe_sync(ll_fe *h);
+/* Labels depend on `view_angle > minimum_view_angle` where view_angle comes from the C library's acosf
+ * (tools_eigen_math.hpp:38).  Device and host acosf can differ in the last ulp, so the kernels flag the (very
+ * rare) points whose angle falls inside a few-ulp band around the threshold; this call re-derives those labels
+ * with the host libm (what the reference executable itself would have computed on this machine) and patches
+ * them on the device.  Synchronises; returns the number of flagged points.  ll_fe_extract calls it itself;
+ * batch users call it between ll_fe_extract_batch and ll_fe_select_batch. */
+int ll_fe_resolve(ll_fe *h);
+
+/* ------------------------------------------------------------------------------------------------ map */
+
+enum { LL_MAP_CORNER = 0, LL_MAP_SURF = 1 };
+
+int ll_map_create(int32_t device, ll_map **out);
+void ll_map_destroy(ll_map *m);
+/* Replaces pcl::KdTreeFLANN::setInputCloud for the match buffers (laser_mapping.hpp:544-545,
+ * point_cloud_registration.hpp:596-597): uploads the cloud and builds the device search grid.
+ * xyz: m points, stride_floats apart (3 = xyz, 4 = xyzi).  cell_size <= 0 selects the default
+ * (0.5 m corner / 1.0 m surface).  Point indices reported by the library refer to this input order. */
+int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size);
+int64_t ll_map_size(const ll_map *m, int32_t kind);
+
+/* pcl::KdTreeFLANN::nearestKSearch(pt, 5, idx, sq_dis) (point_cloud_registration.hpp:249,351) for a batch of
+ * host query points: exact 5-NN among map points with squared distance < max_sq_dis, ascending (d2, idx);
+ * missing entries are idx -1 / d2 +inf.  Returns 0. */
+int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, int32_t n_queries, float max_sq_dis,
+                int32_t *idx5, float *sq_dis5);
+
+/* ------------------------------------------------------------------------------------------------ registrar */
+
+/* Public configuration fields of Point_cloud_registration set by Laser_mapping::init_pointcloud_registration
+ * (laser_mapping.hpp:1266-1297) and class defaults (point_cloud_registration.hpp:45-103). */
+typedef struct {
+    int32_t if_motion_deblur;               /* :60  */
+    int32_t icp_max_iterations;             /* :89  m_para_icp_max_iterations   */
+    int32_t ceres_max_iterations;           /* :90  m_para_cere_max_iterations  */
+    int32_t ceres_prerun_times;             /* :91  (2) */
+    int32_t icp_line;                       /* :50  ICP_LINE  */
+    int32_t icp_plane;                      /* :49  ICP_PLANE */
+    int32_t current_frame_index;            /* :83  */
+    int32_t mapping_init_accumulate_frames; /* :84  */
+    int32_t maximum_allow_residual_block;   /* :103; random sub-sampling (:232-238,339-345,438-458) is only
+                                               engaged when feature counts exceed it; must be >= feature count
+                                               for deterministic parity runs */
+    int32_t force_all_iterations;           /* harness switch: ignore the :521-526 convergence break */
+    double maximum_dis_line_for_match;      /* :65 (2.0)  squared distance */
+    double maximum_dis_plane_for_match;     /* :64 (50.0) squared distance */
+    double huber_a;                         /* :220 ceres::HuberLoss(0.1) */
+    double inliner_dis;                     /* :97  */
+    double inlier_ratio;                    /* :98  */
+    double minimum_icp_R_diff;              /* :94  */
+    double minimum_icp_T_diff;              /* :95  */
+    float para_max_angular_rate;            /* :86  (ROS optimization/max_allow_incre_R) */
+    float para_max_speed;                   /* :87  (ROS optimization/max_allow_incre_T): box bound on t_incre */
+    float max_final_cost;                   /* :88  (ROS optimization/max_allow_final_cost) */
+    float minimum_pt_time_stamp;            /* :92  */
+    float maximum_pt_time_stamp;            /* :93  */
+} ll_reg_params;
+
+void ll_reg_default_params(ll_reg_params *p);
+
+/* What callers read back from the object after the call (point_cloud_registration.hpp:62-63,100-102,555-559). */
+typedef struct {
+    double final_cost, initial_cost;  /* summary of the last ceres::Solve */
+    double inlier_threshold;          /* m_inlier_threshold (:100,:559) */
+    double angular_diff_deg, t_diff;  /* m_angular_diff, m_t_diff (:517-518) */
+    int32_t icp_iterations;
+    int32_t n_blocks_last;            /* summary.num_residual_blocks */
+    int32_t corner_avail, surf_avail; /* :325,:425 */
+    int32_t lm_iterations_total;
+    int32_t accepted;                 /* return value of find_out_incremental_transfrom */
+    int32_t gated;                    /* :199 gate skipped the optimisation */
+} ll_reg_report;
+
+int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_features_per_scan, ll_reg **out);
+void ll_reg_destroy(ll_reg *r);
+
+/* int Point_cloud_registration::find_out_incremental_transfrom(map_corner, map_surf, kd_corner, kd_surf,
+ * scan_corner, scan_surf) (point_cloud_registration.hpp:163-583; the 4-argument overload :585-605 is the same
+ * call after ll_map_upload).  pose_last = m_q_w_last/m_t_w_last, pose_curr in = initial guess
+ * (m_q_w_curr/m_t_w_curr) / out = result, pose_incre in/out = m_para_buffer_incremental (identity for a fresh
+ * object, laser_mapping.hpp:1348).  Returns 1 (accepted, or skipped by the :199 gate), 0 (rejected: pose_curr
+ * restored to pose_last, :561-573), < 0 library error. */
+int ll_reg_solve(ll_reg *r, const ll_map *map, const float *scan_corner_xyzi, int32_t n_corner,
+                 const float *scan_surf_xyzi, int32_t n_surf, const ll_reg_params *prm, const double pose_last[7],
+                 double pose_curr[7], double pose_incre[7], ll_reg_report *rep);
+
+/* Batched form: n_scans independent registrations against the same map snapshot (the reference's
+ * maximum_parallel_thread model, laser_mapping.hpp:1737-1742).  Features are taken from the extractor's
+ * device-resident selection (ll_fe_select_batch) without a host round trip.  poses_* are [n_scans][7],
+ * reports [n_scans], results[n_scans] = per-scan return value.  Returns 0. */
+int ll_reg_solve_batch_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
+                          const double *poses_last, double *poses_curr, double *poses_incre, ll_reg_report *reports,
+                          int32_t *results);
+/* Same with host feature clouds: corner_xyzi [n_scans][stride_c][4] with counts n_corner[n_scans], etc. */
+int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans, const float *corner_xyzi,
+                       const int32_t *n_corner, int32_t stride_corner, const float *surf_xyzi, const int32_t *n_surf,
+                       int32_t stride_surf, const ll_reg_params *prm, const double *poses_last, double *poses_curr,
+                       double *poses_incre, ll_reg_report *reports, int32_t *results);
+
+/* Asynchronous halves of ll_reg_solve_batch_fe for benchmarking with inputs resident in HBM:
+ * _enqueue uploads only the poses (n_scans*7 doubles) and launches; _collect synchronises and downloads. */
+int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
+                      const double *poses_last, const double *poses_curr, const double *poses_incre);
+int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, double *poses_incre, ll_reg_report *reports,
+                   int32_t *results);
+
+/* Debug/parity taps of the first ICP iteration of scan slot `scan` after a solve: 5-NN indices/sq-distances
+ * per corner / surface query (row = query, -1/inf when not found within the match radius). NULL to skip. */
+int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corner_d25, int32_t *surf_idx5,
+                     float *surf_d25);
+int ll_reg_set_debug(ll_reg *r, int32_t enable);
+
+/* unsigned int Point_cloud_registration::pointcloudAssociateToMap(pc_in, pc_out, if_undistore = 0)
+ * (point_cloud_registration.hpp:673-685, no-deblur branch :629): p_w = q*p + t in double, stored float. */
+int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t n, const double pose[7]);
+
+/* HIP-event timing of the kernels launched by the last enqueue/solve on this handle (milliseconds, summed
+ * over launches) and launch counts: [0] knn+block-build, [1] solver, [2] finalize. Enabled by
+ * ll_reg_set_profiling(r, 1). */
+int ll_reg_set_profiling(ll_reg *r, int32_t enable);
+int ll_reg_kernel_times(ll_reg *r, float ms[3], int32_t launches[3]);
+
+/* The HIP stream the handle launches on (hipStream_t), for callers that want their own events on it. */
+void *ll_reg_stream(ll_reg *r);
+void *ll_fe_stream(ll_fe *h);
+
+const char *ll_last_error(void);
+const char *ll_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's call surface for the hot path, on top of the C ABI.
+
+Class and method names follow hku-mars/loam_livox so that parity tests read like calls into the reference:
+
+  Livox_laser               source/livox_feature_extractor.hpp:77     (extract_laser_features :722, get_features :219)
+  Point_cloud_registration  source/point_cloud_registration.hpp:38    (find_out_incremental_transfrom :163/:585,
+                                                                       pointcloudAssociateToMap :673)
+  Map_buffer                the (cloud, KdTreeFLANN) pairs of source/laser_mapping.hpp:539-546
+
+Poses are numpy float64[7] = (qx,qy,qz,qw,tx,ty,tz).  PyTorch is not needed here: device memory and streams are
+owned by the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import FeParams, RegParams, RegReport, check, ptr
+
+
+class Livox_laser:
+    """Device-backed Livox_laser.  Tunables are the public fields of the reference class
+    (livox_feature_extractor.hpp:143-167); they are fixed at construction."""
+
+    def __init__(self, max_points: int = 24000, max_scans: int = 1, device: int = 0, piecewise_number: int = 3, **tunables):
+        self.L = capi.load()
+        p = capi.fe_default_params()
+        p.max_points, p.max_scans, p.device, p.piecewise_number = max_points, max_scans, device, piecewise_number
+        for k, v in tunables.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self.params = p
+        self.h = C.c_void_p()
+        check(self.L.ll_fe_create(C.byref(p), C.byref(self.h)), "ll_fe_create")
+        self.m_input_points_size = 0
+        self._n = [0] * max_scans
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ll_fe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- per-message path (laser_feature_extractor.hpp:285) ---------------------------------------------------
+    def extract_laser_features(self, xyzi: np.ndarray, time_stamp: float) -> int:
+        """Returns laserCloudScans.size() (number of surviving petal clouds)."""
+        xyzi = capi.as_f32(xyzi, 4)
+        n = xyzi.shape[0]
+        npc = C.c_int32(0)
+        check(self.L.ll_fe_extract(self.h, ptr(xyzi), n, float(time_stamp), C.byref(npc)), "ll_fe_extract")
+        self.m_input_points_size = n
+        self._n[0] = n
+        return npc.value
+
+    def get_features(self, minimum_blur: float = 0.0, maximum_blur: float = 0.3):
+        """Returns dict(corner_idx, surf_idx, full_idx, pc_corners, pc_surface) for scan slot 0."""
+        n = self.params.max_points
+        ci, si, fi = (np.zeros(n, np.int32) for _ in range(3))
+        cc, sc = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+        nc, ns, nf = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self.L.ll_fe_select(self.h, minimum_blur, maximum_blur, ptr(ci), C.byref(nc), ptr(si), C.byref(ns), ptr(fi),
+                                  C.byref(nf), ptr(cc), ptr(sc)), "ll_fe_select")
+        return dict(corner_idx=ci[:nc.value].copy(), surf_idx=si[:ns.value].copy(), full_idx=fi[:nf.value].copy(),
+                    pc_corners=cc[:nc.value].copy(), pc_surface=sc[:ns.value].copy())
+
+    def pts_info(self, scan: int = 0):
+        """m_pts_info_vec as a dict of arrays."""
+        n = self._n[scan]
+        out = dict(pt_type=np.zeros(n, np.int32), pt_label=np.zeros(n, np.int32), depth_sq2=np.zeros(n, np.float32),
+                   polar_dis_sq2=np.zeros(n, np.float32), curvature=np.zeros(n, np.float32),
+                   view_angle=np.zeros(n, np.float32), time_stamp=np.zeros(n, np.float32),
+                   polar_angle=np.zeros(n, np.float32))
+        check(self.L.ll_fe_labels(self.h, scan, ptr(out["pt_type"]), ptr(out["pt_label"]), ptr(out["depth_sq2"]),
+                                  ptr(out["polar_dis_sq2"]), ptr(out["curvature"]), ptr(out["view_angle"]),
+                                  ptr(out["time_stamp"]), ptr(out["polar_angle"])), "ll_fe_labels")
+        return out
+
+    def splits(self, scan: int = 0):
+        cap = self.params.max_points // 50 + 8
+        split = np.zeros(cap, np.int32)
+        first, last = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        ps, pe = np.zeros(8, np.float32), np.zeros(8, np.float32)
+        ns, cl, npc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self.L.ll_fe_splits(self.h, scan, ptr(split), C.byref(ns), C.byref(cl), C.byref(npc), ptr(first), ptr(last),
+                                  ptr(ps), ptr(pe)), "ll_fe_splits")
+        P = self.params.piecewise_number
+        return dict(split_idx=split[:ns.value].copy(), clutter_size=cl.value, n_petal_clouds=npc.value,
+                    first_idx=first[:npc.value].copy(), last_idx=last[:npc.value].copy(), piece_start=ps[:P].copy(),
+                    piece_end=pe[:P].copy())
+
+    # -- batched, device-resident path ------------------------------------------------------------------------
+    def upload(self, scans: np.ndarray, current_time: np.ndarray, first_scan: int = 0):
+        scans = np.ascontiguousarray(scans, np.float32)
+        assert scans.ndim == 3 and scans.shape[2] == 4
+        ct = np.ascontiguousarray(current_time, np.float64)
+        check(self.L.ll_fe_upload(self.h, first_scan, scans.shape[0], ptr(scans), scans.shape[1], ptr(ct)), "ll_fe_upload")
+        for i in range(scans.shape[0]):
+            self._n[first_scan + i] = scans.shape[1]
+
+    def extract_batch(self, n_scans: int):
+        check(self.L.ll_fe_extract_batch(self.h, n_scans), "ll_fe_extract_batch")
+
+    def resolve(self) -> int:
+        return check(self.L.ll_fe_resolve(self.h), "ll_fe_resolve")
+
+    def select_batch(self, n_scans: int, piece: int = -1, minimum_blur: float = 0.0, maximum_blur: float = 1.0):
+        check(self.L.ll_fe_select_batch(self.h, n_scans, piece, minimum_blur, maximum_blur), "ll_fe_select_batch")
+
+    def counts(self, n_scans: int):
+        nc, ns, nf = (np.zeros(n_scans, np.int32) for _ in range(3))
+        na = np.zeros(1, np.int32)
+        check(self.L.ll_fe_counts(self.h, n_scans, ptr(nc), ptr(ns), ptr(nf), ptr(na)), "ll_fe_counts")
+        return nc, ns, nf, int(na[0])
+
+    def sync(self):
+        check(self.L.ll_fe_sync(self.h), "ll_fe_sync")
+
+
+class Map_buffer:
+    """m_laser_cloud_{corner,surf}_from_map + their kd-trees (laser_mapping.hpp:539-546) as device grids."""
+
+    CORNER, SURF = 0, 1
+
+    def __init__(self, device: int = 0):
+        self.L = capi.load()
+        self.h = C.c_void_p()
+        check(self.L.ll_map_create(device, C.byref(self.h)), "ll_map_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ll_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setInputCloud(self, kind: int, cloud: np.ndarray, cell_size: float = 0.0):
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        assert cloud.ndim == 2 and cloud.shape[1] >= 3
+        check(self.L.ll_map_upload(self.h, kind, ptr(cloud), cloud.shape[1], cloud.shape[0], cell_size), "ll_map_upload")
+
+    def size(self, kind: int) -> int:
+        return int(self.L.ll_map_size(self.h, kind))
+
+    def nearestKSearch(self, kind: int, queries: np.ndarray, max_sq_dis: float):
+        q = capi.as_f32(queries, 3)
+        idx = np.zeros((q.shape[0], 5), np.int32)
+        d2 = np.zeros((q.shape[0], 5), np.float32)
+        check(self.L.ll_map_knn5(self.h, kind, ptr(q), q.shape[0], max_sq_dis, ptr(idx), ptr(d2)), "ll_map_knn5")
+        return idx, d2
+
+
+class Point_cloud_registration:
+    """Device-backed Point_cloud_registration.  Configuration fields keep the reference names
+    (point_cloud_registration.hpp:45-103); poses are the m_q_w_*/m_t_w_* pairs packed as float64[7]."""
+
+    def __init__(self, max_scans: int = 1, max_features: int = 24000, device: int = 0):
+        self.L = capi.load()
+        self.h = C.c_void_p()
+        check(self.L.ll_reg_create(device, max_scans, max_features, C.byref(self.h)), "ll_reg_create")
+        self.params = capi.reg_default_params()
+        self.max_scans = max_scans
+        ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+        self.m_pose_w_last = ident.copy()   # m_q_w_last, m_t_w_last
+        self.m_pose_w_curr = ident.copy()   # m_q_w_curr, m_t_w_curr
+        self.m_para_buffer_incremental = ident.copy()
+        self.report = RegReport()
+        self.m_inlier_threshold = 0.0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ll_reg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def find_out_incremental_transfrom(self, map_buffer: Map_buffer, laserCloudCornerStack: np.ndarray,
+                                       laserCloudSurfStack: np.ndarray) -> int:
+        c = capi.as_f32(laserCloudCornerStack, 4)
+        s = capi.as_f32(laserCloudSurfStack, 4)
+        pl = np.ascontiguousarray(self.m_pose_w_last, np.float64)
+        pc = np.ascontiguousarray(self.m_pose_w_curr, np.float64).copy()
+        pi = np.ascontiguousarray(self.m_para_buffer_incremental, np.float64).copy()
+        rep = RegReport()
+        ret = check(self.L.ll_reg_solve(self.h, map_buffer.h, ptr(c), c.shape[0], ptr(s), s.shape[0], C.byref(self.params),
+                                        ptr(pl), ptr(pc), ptr(pi), C.byref(rep)), "ll_reg_solve")
+        self.m_pose_w_curr, self.m_para_buffer_incremental, self.report = pc, pi, rep
+        self.m_inlier_threshold = rep.inlier_threshold
+        return ret
+
+    def solve_batch(self, map_buffer: Map_buffer, corners: list, surfs: list, poses_last: np.ndarray, poses_curr: np.ndarray):
+        n = len(corners)
+        nc = np.array([len(c) for c in corners], np.int32)
+        ns = np.array([len(s) for s in surfs], np.int32)
+        sc, ss = max(1, int(nc.max())), max(1, int(ns.max()))
+        cbuf = np.zeros((n, sc, 4), np.float32)
+        sbuf = np.zeros((n, ss, 4), np.float32)
+        for i in range(n):
+            cbuf[i, :nc[i]] = corners[i]
+            sbuf[i, :ns[i]] = surfs[i]
+        pl = np.ascontiguousarray(poses_last, np.float64).reshape(n, 7)
+        pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n, 7).copy()
+        pi = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], np.float64), (n, 1))
+        reps = (RegReport * n)()
+        res = np.zeros(n, np.int32)
+        check(self.L.ll_reg_solve_batch(self.h, map_buffer.h, n, ptr(cbuf), ptr(nc), sc, ptr(sbuf), ptr(ns), ss,
+                                        C.byref(self.params), ptr(pl), ptr(pc), ptr(pi), reps, ptr(res)), "ll_reg_solve_batch")
+        return res, pc, pi, list(reps)
+
+    def enqueue_fe(self, map_buffer: Map_buffer, fe: Livox_laser, n_scans: int, poses_last, poses_curr):
+        pl = np.ascontiguousarray(poses_last, np.float64).reshape(n_scans, 7)
+        pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n_scans, 7)
+        check(self.L.ll_reg_enqueue_fe(self.h, map_buffer.h, fe.h, n_scans, C.byref(self.params), ptr(pl), ptr(pc), None),
+              "ll_reg_enqueue_fe")
+
+    def collect(self, n_scans: int):
+        pc = np.zeros((n_scans, 7), np.float64)
+        pi = np.zeros((n_scans, 7), np.float64)
+        reps = (RegReport * n_scans)()
+        res = np.zeros(n_scans, np.int32)
+        check(self.L.ll_reg_collect(self.h, n_scans, ptr(pc), ptr(pi), reps, ptr(res)), "ll_reg_collect")
+        return res, pc, pi, list(reps)
+
+    def solve_batch_fe(self, map_buffer: Map_buffer, fe: Livox_laser, n_scans: int, poses_last, poses_curr):
+        self.enqueue_fe(map_buffer, fe, n_scans, poses_last, poses_curr)
+        return self.collect(n_scans)
+
+    def set_debug(self, enable: bool = True):
+        check(self.L.ll_reg_set_debug(self.h, int(enable)), "ll_reg_set_debug")
+
+    def debug_knn(self, scan: int, n_corner: int, n_surf: int):
+        ci, cd = np.zeros((n_corner, 5), np.int32), np.zeros((n_corner, 5), np.float32)
+        si, sd = np.zeros((n_surf, 5), np.int32), np.zeros((n_surf, 5), np.float32)
+        check(self.L.ll_reg_debug_knn(self.h, scan, ptr(ci), ptr(cd), ptr(si), ptr(sd)), "ll_reg_debug_knn")
+        return ci, cd, si, sd
+
+    def set_profiling(self, enable: bool = True):
+        check(self.L.ll_reg_set_profiling(self.h, int(enable)), "ll_reg_set_profiling")
+
+    def kernel_times(self):
+        ms = np.zeros(3, np.float32)
+        n = np.zeros(3, np.int32)
+        check(self.L.ll_reg_kernel_times(self.h, ptr(ms), ptr(n)), "ll_reg_kernel_times")
+        return ms, n
+
+    def pointcloudAssociateToMap(self, pc_in: np.ndarray, pose: np.ndarray | None = None) -> np.ndarray:
+        pc_in = capi.as_f32(pc_in, 4)
+        out = np.empty_like(pc_in)
+        p = np.ascontiguousarray(self.m_pose_w_curr if pose is None else pose, np.float64)
+        check(self.L.ll_cloud_transform(self.h, ptr(pc_in), ptr(out), pc_in.shape[0], ptr(p)), "ll_cloud_transform")
+        return out

@@ -1,0 +1,850 @@
+// ll_api.hip -- host side of the C ABI declared in include/loam_livox_hip.h.
+// Owns device memory, HIP streams and launch order; all arithmetic of the hot path runs in the kernels of
+// ll_fe_kernels.hip / ll_map_kernels.hip / ll_reg_kernels.hip.  There is no CPU fallback: every entry point
+// fails with an error string when HIP reports no usable device.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/loam_livox_hip.h"
+#include "ll_device.h"
+#include "ll_reg_core.h"
+
+using namespace ll;
+
+static thread_local std::string g_err;
+static int set_err(const char *where, const char *what)
+{
+    g_err = std::string(where) + ": " + what;
+    return -1;
+}
+#define HC(call)                                                        \
+    do {                                                                \
+        hipError_t e_ = (call);                                         \
+        if (e_ != hipSuccess) return set_err(#call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *ll_last_error(void) { return g_err.c_str(); }
+extern "C" const char *ll_version(void) { return "loam_livox_hip 0.1 (gfx950)"; }
+
+template <typename T>
+static int dmalloc(T **p, size_t count)
+{
+    HC(hipMalloc((void **)p, (count > 0 ? count : 1) * sizeof(T)));
+    return 0;
+}
+#define DM(p, count)                        \
+    do {                                    \
+        if (dmalloc(&(p), (count)) != 0) return -1; \
+    } while (0)
+
+static int check_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return set_err("hipGetDeviceCount", "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= count) return set_err("device", "ordinal out of range");
+    HC(hipSetDevice(device));
+    return 0;
+}
+
+// ============================================================================================== extractor
+
+struct ll_fe {
+    ll_fe_params prm;
+    FeConst fc;
+    FeDev dev;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_done = nullptr;
+    int max_n_uploaded = 0;
+    // sequential time base of Livox_laser (LFE:150-152)
+    double first_receive_time = -1.0, last_maximum_time_stamp = 0.0;
+    // mutable device arrays (non-const views of dev.*)
+    float4 *d_xyzi = nullptr;
+    int *d_npts = nullptr;
+    double *d_time0 = nullptr;
+    std::vector<int> h_npts;
+};
+
+extern "C" void ll_fe_default_params(ll_fe_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->thr_corner_curvature = 0.05f;   // LFX:152 default
+    p->thr_surface_curvature = 0.01f;  // LFX:153
+    p->minimum_view_angle = 10.0f;     // LFX:154
+    p->livox_min_allow_dis = 0.1f;     // LFX:854
+    p->livox_min_sigma = 7e-4f;        // LFX:859
+    p->max_fov = 17.0f;                // LFE:143
+    p->time_internal_pts = 1.0e-5f;    // LFE:145
+    p->device = 0;
+    p->max_points = 24000;
+    p->max_scans = 1;
+    p->piecewise_number = 3;           // LFX:142
+}
+
+static FeConst make_fe_const(const ll_fe_params &p)
+{
+    FeConst c;
+    c.thr_corner_curvature = p.thr_corner_curvature;
+    c.thr_surface_curvature = p.thr_surface_curvature;
+    c.minimum_view_angle = p.minimum_view_angle;
+    c.min_dis_sq = p.livox_min_allow_dis * p.livox_min_allow_dis;
+    c.min_sigma = p.livox_min_sigma;
+    c.max_edge_polar_pos = (float)pow(tan((double)p.max_fov / 57.3) * 1, 2);  // LFE:185
+    c.time_internal_pts = p.time_internal_pts;
+    // acosf implementations differ by <= 1 ulp; *57.3 and the float store add < 1 ulp more: 8 ulp of the
+    // threshold is a generous band
+    c.view_angle_band = 8.0f * (nextafterf(fabsf(p.minimum_view_angle) + 1.0f, INFINITY) - (fabsf(p.minimum_view_angle) + 1.0f));
+    return c;
+}
+
+extern "C" int ll_fe_create(const ll_fe_params *p, ll_fe **out)
+{
+    if (!p || !out) return set_err("ll_fe_create", "null argument");
+    if (p->max_points < 1 || p->max_scans < 1) return set_err("ll_fe_create", "bad capacity");
+    if (p->piecewise_number < 1 || p->piecewise_number > LL_MAX_PIECES) return set_err("ll_fe_create", "piecewise_number out of range");
+    if (check_device(p->device)) return -1;
+    ll_fe *h = new ll_fe();
+    h->prm = *p;
+    h->fc = make_fe_const(*p);
+    const size_t B = p->max_scans, N = p->max_points, BN = B * N;
+    FeDev &d = h->dev;
+    memset(&d, 0, sizeof(d));
+    d.stride = (int)N;
+    d.split_cap = (int)(N / 50 + 8);
+    d.ambig_cap = 4096;
+    HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HC(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    DM(h->d_xyzi, BN);
+    DM(h->d_npts, B);
+    DM(h->d_time0, B);
+    d.xyzi = h->d_xyzi;
+    d.npts = h->d_npts;
+    d.time0 = h->d_time0;
+    DM(d.type, BN);
+    DM(d.label, BN);
+    DM(d.depth2, BN);
+    DM(d.polar2, BN);
+    DM(d.curv, BN);
+    DM(d.view, BN);
+    DM(d.tstamp, BN);
+    DM(d.polar_angle, BN);
+    DM(d.img, BN);
+    DM(d.flags, BN);
+    DM(d.cand, BN);
+    DM(d.split_idx, B * d.split_cap);
+    DM(d.petal_first, B * d.split_cap);
+    DM(d.petal_last, B * d.split_cap);
+    DM(d.run_angle, B * d.split_cap);
+    DM(d.info, B);
+    DM(d.corner_idx, BN);
+    DM(d.surf_idx, BN);
+    DM(d.full_idx, BN);
+    DM(d.corner_feat, BN);
+    DM(d.surf_feat, BN);
+    DM(d.n_corner, B);
+    DM(d.n_surf, B);
+    DM(d.n_full, B);
+    DM(d.n_ambig, 1);
+    DM(d.ambig_list, d.ambig_cap);
+    HC(hipMemset(d.n_ambig, 0, sizeof(int)));
+    HC(hipMemset(h->d_npts, 0, B * sizeof(int)));
+    HC(hipMemset(d.n_corner, 0, B * sizeof(int)));
+    HC(hipMemset(d.n_surf, 0, B * sizeof(int)));
+    HC(hipMemset(d.n_full, 0, B * sizeof(int)));
+    HC(hipMemset(d.info, 0, B * sizeof(FeScanInfo)));
+    h->h_npts.assign(B, 0);
+    *out = h;
+    return 0;
+}
+
+extern "C" void ll_fe_destroy(ll_fe *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->prm.device);
+    FeDev &d = h->dev;
+    void *ptrs[] = {h->d_xyzi, h->d_npts, h->d_time0, d.type, d.label, d.depth2, d.polar2, d.curv, d.view, d.tstamp,
+                    d.polar_angle, d.img, d.flags, d.cand, d.split_idx, d.petal_first, d.petal_last, d.run_angle, d.info,
+                    d.corner_idx, d.surf_idx, d.full_idx, d.corner_feat, d.surf_feat, d.n_corner, d.n_surf, d.n_full,
+                    d.n_ambig, d.ambig_list};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" void *ll_fe_stream(ll_fe *h) { return h ? (void *)h->stream : nullptr; }
+extern "C" int ll_fe_sync(ll_fe *h)
+{
+    if (!h) return set_err("ll_fe_sync", "null handle");
+    HC(hipSetDevice(h->prm.device));
+    HC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int ll_fe_upload(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points,
+                            const double *current_time)
+{
+    if (!h || !xyzi || !current_time) return set_err("ll_fe_upload", "null argument");
+    if (first_scan < 0 || n_scans < 0 || first_scan + n_scans > h->prm.max_scans) return set_err("ll_fe_upload", "scan range exceeds max_scans");
+    if (n_points < 0 || n_points > h->prm.max_points) return set_err("ll_fe_upload", "n_points exceeds max_points");
+    HC(hipSetDevice(h->prm.device));
+    const size_t N = h->prm.max_points;
+    if (n_points > 0)
+        HC(hipMemcpy2DAsync(h->d_xyzi + (size_t)first_scan * N, N * sizeof(float4), xyzi, (size_t)n_points * sizeof(float4),
+                            (size_t)n_points * sizeof(float4), n_scans, hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < n_scans; i++) h->h_npts[first_scan + i] = n_points;
+    HC(hipMemcpyAsync(h->d_npts + first_scan, h->h_npts.data() + first_scan, n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HC(hipMemcpyAsync(h->d_time0 + first_scan, current_time, n_scans * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HC(hipStreamSynchronize(h->stream));  // the caller's buffers may be reused right away
+    return 0;
+}
+
+extern "C" int ll_fe_extract_batch(ll_fe *h, int32_t n_scans)
+{
+    if (!h) return set_err("ll_fe_extract_batch", "null handle");
+    if (n_scans < 1 || n_scans > h->prm.max_scans) return set_err("ll_fe_extract_batch", "n_scans out of range");
+    HC(hipSetDevice(h->prm.device));
+    int max_n = 0;
+    for (int i = 0; i < n_scans; i++) max_n = h->h_npts[i] > max_n ? h->h_npts[i] : max_n;
+    HC(hipMemsetAsync(h->dev.n_ambig, 0, sizeof(int), h->stream));
+    if (max_n > 0) launch_fe_point(h->dev, h->fc, n_scans, max_n, h->stream);
+    launch_fe_split(h->dev, h->prm.piecewise_number, n_scans, h->stream);
+    HC(hipGetLastError());
+    return 0;
+}
+
+// Re-derive, with the host libm acosf the reference uses, the labels of the (very rare) points whose view angle
+// fell inside the acosf ambiguity band.  Synchronises.  Returns the number of such points.
+static int fe_resolve_ambiguous(ll_fe *h)
+{
+    int n_amb = 0;
+    HC(hipMemcpyAsync(&n_amb, h->dev.n_ambig, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HC(hipStreamSynchronize(h->stream));
+    if (n_amb <= 0) return 0;
+    const int n_list = n_amb < h->dev.ambig_cap ? n_amb : h->dev.ambig_cap;
+    std::vector<int2> list(n_list);
+    HC(hipMemcpy(list.data(), h->dev.ambig_list, n_list * sizeof(int2), hipMemcpyDeviceToHost));
+    const size_t N = h->prm.max_points;
+    for (const int2 &e : list) {
+        const int b = e.x, i = e.y, n = h->h_npts[b];
+        if (i < 2 || i >= n - 2) continue;
+        float4 raw[5];
+        HC(hipMemcpy(raw, h->d_xyzi + (size_t)b * N + i - 2, sizeof(raw), hipMemcpyDeviceToHost));
+        float p[5][3], d[5];
+        int t[5];
+        for (int k = 0; k < 5; k++) {
+            const PointOwn o = point_own(raw[k].x, raw[k].y, raw[k].z, raw[k].w, i - 2 + k, h->fc);
+            p[k][0] = raw[k].x;
+            p[k][1] = raw[k].y;
+            p[k][2] = raw[k].z;
+            t[k] = o.type_self;
+            d[k] = o.depth_sq2;
+        }
+        const LabelOut lo = point_label(p, t, d, h->fc);  // host build: glibc acosf
+        HC(hipMemcpy(h->dev.label + (size_t)b * N + i, &lo.label, sizeof(int), hipMemcpyHostToDevice));
+        HC(hipMemcpy(h->dev.view + (size_t)b * N + i, &lo.view_angle, sizeof(float), hipMemcpyHostToDevice));
+    }
+    return n_amb;
+}
+
+extern "C" int ll_fe_counts(ll_fe *h, int32_t n_scans, int32_t *n_corner, int32_t *n_surf, int32_t *n_full, int32_t *n_ambiguous)
+{
+    if (!h) return set_err("ll_fe_counts", "null handle");
+    if (n_scans < 1 || n_scans > h->prm.max_scans) return set_err("ll_fe_counts", "n_scans out of range");
+    HC(hipSetDevice(h->prm.device));
+    HC(hipStreamSynchronize(h->stream));
+    if (n_corner) HC(hipMemcpy(n_corner, h->dev.n_corner, n_scans * sizeof(int), hipMemcpyDeviceToHost));
+    if (n_surf) HC(hipMemcpy(n_surf, h->dev.n_surf, n_scans * sizeof(int), hipMemcpyDeviceToHost));
+    if (n_full) HC(hipMemcpy(n_full, h->dev.n_full, n_scans * sizeof(int), hipMemcpyDeviceToHost));
+    if (n_ambiguous) HC(hipMemcpy(n_ambiguous, h->dev.n_ambig, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ll_fe_resolve(ll_fe *h)
+{
+    if (!h) return set_err("ll_fe_resolve", "null handle");
+    HC(hipSetDevice(h->prm.device));
+    return fe_resolve_ambiguous(h);
+}
+
+extern "C" int ll_fe_extract(ll_fe *h, const float *xyzi, int32_t n, double time_stamp, int32_t *n_petal_clouds)
+{
+    if (!h || (!xyzi && n > 0)) return set_err("ll_fe_extract", "null argument");
+    if (time_stamp < 0.0) return set_err("ll_fe_extract", "time_stamp must be >= 0 (assert at livox_feature_extractor.hpp:724)");
+    if (n < 0 || n > h->prm.max_points) return set_err("ll_fe_extract", "n exceeds max_points");
+    // LFE:724-736
+    double current_time;
+    if (time_stamp <= 0.0000001 || (time_stamp < h->last_maximum_time_stamp))
+        current_time = h->last_maximum_time_stamp;
+    else
+        current_time = time_stamp - h->first_receive_time;
+    if (h->first_receive_time <= 0) h->first_receive_time = time_stamp;
+    static const float dummy[4] = {0, 0, 0, 0};
+    if (ll_fe_upload(h, 0, 1, n > 0 ? xyzi : dummy, n, &current_time)) return -1;
+    if (ll_fe_extract_batch(h, 1)) return -1;
+    if (fe_resolve_ambiguous(h) < 0) return -1;
+    if (n > 0) h->last_maximum_time_stamp = (double)point_time_stamp(current_time, n - 1, h->prm.time_internal_pts);  // LFE:482
+    FeScanInfo info;
+    HC(hipMemcpy(&info, h->dev.info, sizeof(info), hipMemcpyDeviceToHost));
+    if (n_petal_clouds) *n_petal_clouds = info.n_petal_clouds;
+    return 0;
+}
+
+#define D2H_OPT(dst, src, count, type)                                                              \
+    do {                                                                                            \
+        if (dst) HC(hipMemcpy(dst, src, (size_t)(count) * sizeof(type), hipMemcpyDeviceToHost));    \
+    } while (0)
+
+extern "C" int ll_fe_labels(ll_fe *h, int32_t scan, int32_t *pt_type, int32_t *pt_label, float *depth_sq2, float *polar_dis_sq2,
+                            float *curvature, float *view_angle, float *time_stamp, float *polar_angle)
+{
+    if (!h) return set_err("ll_fe_labels", "null handle");
+    if (scan < 0 || scan >= h->prm.max_scans) return set_err("ll_fe_labels", "scan out of range");
+    HC(hipSetDevice(h->prm.device));
+    HC(hipStreamSynchronize(h->stream));
+    const size_t off = (size_t)scan * h->prm.max_points;
+    const int n = h->h_npts[scan];
+    D2H_OPT(pt_type, h->dev.type + off, n, int);
+    D2H_OPT(pt_label, h->dev.label + off, n, int);
+    D2H_OPT(depth_sq2, h->dev.depth2 + off, n, float);
+    D2H_OPT(polar_dis_sq2, h->dev.polar2 + off, n, float);
+    D2H_OPT(curvature, h->dev.curv + off, n, float);
+    D2H_OPT(view_angle, h->dev.view + off, n, float);
+    D2H_OPT(time_stamp, h->dev.tstamp + off, n, float);
+    D2H_OPT(polar_angle, h->dev.polar_angle + off, n, float);
+    return 0;
+}
+
+extern "C" int ll_fe_splits(ll_fe *h, int32_t scan, int32_t *split_idx, int32_t *n_split, int32_t *clutter_size,
+                            int32_t *n_petal_clouds, int32_t *first_idx, int32_t *last_idx, float *piece_start, float *piece_end)
+{
+    if (!h) return set_err("ll_fe_splits", "null handle");
+    if (scan < 0 || scan >= h->prm.max_scans) return set_err("ll_fe_splits", "scan out of range");
+    HC(hipSetDevice(h->prm.device));
+    HC(hipStreamSynchronize(h->stream));
+    FeScanInfo info;
+    HC(hipMemcpy(&info, h->dev.info + scan, sizeof(info), hipMemcpyDeviceToHost));
+    if (n_split) *n_split = info.n_split;
+    if (clutter_size) *clutter_size = info.clutter_size;
+    if (n_petal_clouds) *n_petal_clouds = info.n_petal_clouds;
+    const size_t off = (size_t)scan * h->dev.split_cap;
+    D2H_OPT(split_idx, h->dev.split_idx + off, info.n_split, int);
+    D2H_OPT(first_idx, h->dev.petal_first + off, info.n_petal_clouds, int);
+    D2H_OPT(last_idx, h->dev.petal_last + off, info.n_petal_clouds, int);
+    for (int i = 0; i < h->prm.piecewise_number; i++) {
+        if (piece_start) piece_start[i] = info.piece_start[i];
+        if (piece_end) piece_end[i] = info.piece_end[i];
+    }
+    return 0;
+}
+
+extern "C" int ll_fe_select_batch(ll_fe *h, int32_t n_scans, int32_t piece, float minimum_blur, float maximum_blur)
+{
+    if (!h) return set_err("ll_fe_select_batch", "null handle");
+    if (n_scans < 1 || n_scans > h->prm.max_scans) return set_err("ll_fe_select_batch", "n_scans out of range");
+    if (piece >= h->prm.piecewise_number) return set_err("ll_fe_select_batch", "piece out of range");
+    HC(hipSetDevice(h->prm.device));
+    launch_fe_select(h->dev, n_scans, piece, minimum_blur, maximum_blur, h->stream);
+    HC(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ll_fe_select(ll_fe *h, float minimum_blur, float maximum_blur, int32_t *corner_idx, int32_t *n_corner,
+                            int32_t *surf_idx, int32_t *n_surf, int32_t *full_idx, int32_t *n_full, float *corner_xyzi,
+                            float *surf_xyzi)
+{
+    if (ll_fe_select_batch(h, 1, -1, minimum_blur, maximum_blur)) return -1;
+    HC(hipStreamSynchronize(h->stream));
+    int nc = 0, ns = 0, nf = 0;
+    HC(hipMemcpy(&nc, h->dev.n_corner, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&ns, h->dev.n_surf, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&nf, h->dev.n_full, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_corner) *n_corner = nc;
+    if (n_surf) *n_surf = ns;
+    if (n_full) *n_full = nf;
+    D2H_OPT(corner_idx, h->dev.corner_idx, nc, int);
+    D2H_OPT(surf_idx, h->dev.surf_idx, ns, int);
+    D2H_OPT(full_idx, h->dev.full_idx, nf, int);
+    D2H_OPT(corner_xyzi, h->dev.corner_feat, nc, float4);
+    D2H_OPT(surf_xyzi, h->dev.surf_feat, ns, float4);
+    return 0;
+}
+
+// ============================================================================================== map
+
+struct ll_map {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    MapKind kind[2];
+};
+
+extern "C" int ll_map_create(int32_t device, ll_map **out)
+{
+    if (!out) return set_err("ll_map_create", "null argument");
+    if (check_device(device)) return -1;
+    ll_map *m = new ll_map();
+    m->device = device;
+    HC(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    *out = m;
+    return 0;
+}
+
+extern "C" void ll_map_destroy(ll_map *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    map_free(m->kind[0]);
+    map_free(m->kind[1]);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size)
+{
+    if (!m || (!xyz && n > 0)) return set_err("ll_map_upload", "null argument");
+    if (kind != LL_MAP_CORNER && kind != LL_MAP_SURF) return set_err("ll_map_upload", "bad kind");
+    if (stride_floats < 3) return set_err("ll_map_upload", "stride_floats must be >= 3");
+    if (n < 0 || n > 0x7fffffffLL) return set_err("ll_map_upload", "point count out of range");
+    HC(hipSetDevice(m->device));
+    if (!(cell_size > 0.f)) cell_size = (kind == LL_MAP_CORNER) ? 0.5f : 1.0f;
+    float *d_raw = nullptr;
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * stride_floats * sizeof(float);
+    HC(hipMalloc(&d_raw, bytes));
+    if (n > 0) HC(hipMemcpyAsync(d_raw, xyz, (size_t)n * stride_floats * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const char *err = nullptr;
+    const int rc = map_build(m->kind[kind], d_raw, stride_floats, n, cell_size, m->stream, &err);
+    (void)hipFree(d_raw);
+    if (rc != 0) return set_err("map_build", err ? err : "failed");
+    return 0;
+}
+
+extern "C" int64_t ll_map_size(const ll_map *m, int32_t kind)
+{
+    if (!m || kind < 0 || kind > 1) return -1;
+    return m->kind[kind].n;
+}
+
+extern "C" int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, int32_t n_queries, float max_sq_dis, int32_t *idx5,
+                           float *sq_dis5)
+{
+    if (!m || !queries_xyz || !idx5 || !sq_dis5) return set_err("ll_map_knn5", "null argument");
+    if (kind < 0 || kind > 1 || !m->kind[kind].pts) return set_err("ll_map_knn5", "map kind not uploaded");
+    if (n_queries <= 0) return 0;
+    HC(hipSetDevice(m->device));
+    float *d_q = nullptr, *d_d2 = nullptr;
+    int *d_idx = nullptr;
+    DM(d_q, (size_t)n_queries * 3);
+    DM(d_d2, (size_t)n_queries * 5);
+    DM(d_idx, (size_t)n_queries * 5);
+    HC(hipMemcpyAsync(d_q, queries_xyz, (size_t)n_queries * 3 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    launch_knn5(m->kind[kind].grid, d_q, n_queries, max_sq_dis, d_idx, d_d2, m->stream);
+    HC(hipGetLastError());
+    HC(hipMemcpyAsync(idx5, d_idx, (size_t)n_queries * 5 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HC(hipMemcpyAsync(sq_dis5, d_d2, (size_t)n_queries * 5 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HC(hipStreamSynchronize(m->stream));
+    (void)hipFree(d_q);
+    (void)hipFree(d_d2);
+    (void)hipFree(d_idx);
+    return 0;
+}
+
+// ============================================================================================== registrar
+
+struct ll_reg {
+    int device = 0;
+    int max_scans = 0, max_feat = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_wait = nullptr;
+    RegDev dev;
+    RegConst rc;
+    // own feature storage (host-provided features)
+    float4 *d_corner = nullptr, *d_surf = nullptr;
+    int *d_nc = nullptr, *d_ns = nullptr;
+    std::vector<RegState> h_state;
+    int debug = 0, profiling = 0;
+    int last_n_scans = 0, last_gated = 0;
+    // profiling
+    std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> ev_class;
+    float prof_ms[3] = {0, 0, 0};
+    int prof_launches[3] = {0, 0, 0};
+    double *d_pose_tmp = nullptr;
+};
+
+extern "C" void ll_reg_default_params(ll_reg_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->if_motion_deblur = 0;              // PCR:60
+    p->icp_max_iterations = 20;           // PCR:89
+    p->ceres_max_iterations = 100;        // PCR:90
+    p->ceres_prerun_times = 2;            // PCR:91
+    p->icp_line = 1;                      // PCR:50
+    p->icp_plane = 1;                     // PCR:49
+    p->current_frame_index = 101;
+    p->mapping_init_accumulate_frames = 100;  // PCR:84
+    p->maximum_allow_residual_block = 100000; // PCR:103
+    p->force_all_iterations = 0;
+    p->maximum_dis_line_for_match = 2.0;  // PCR:65
+    p->maximum_dis_plane_for_match = 50.0; // PCR:64
+    p->huber_a = 0.1;                     // PCR:220
+    p->inliner_dis = 0.02;                // PCR:97
+    p->inlier_ratio = 0.80;               // PCR:98
+    p->minimum_icp_R_diff = 0.01;         // PCR:94
+    p->minimum_icp_T_diff = 0.01;         // PCR:95
+    p->para_max_angular_rate = 200.0f / 50.0f; // PCR:86
+    p->para_max_speed = 100.0f / 50.0f;   // PCR:87
+    p->max_final_cost = 100.0f;           // PCR:88
+    p->minimum_pt_time_stamp = 0.f;       // PCR:92
+    p->maximum_pt_time_stamp = 1.0f;      // PCR:93
+}
+
+extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_features_per_scan, ll_reg **out)
+{
+    if (!out) return set_err("ll_reg_create", "null argument");
+    if (max_scans < 1 || max_features_per_scan < 1) return set_err("ll_reg_create", "bad capacity");
+    if (check_device(device)) return -1;
+    ll_reg *r = new ll_reg();
+    r->device = device;
+    r->max_scans = max_scans;
+    r->max_feat = max_features_per_scan;
+    HC(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    HC(hipEventCreateWithFlags(&r->ev_wait, hipEventDisableTiming));
+    RegDev &d = r->dev;
+    memset(&d, 0, sizeof(d));
+    const size_t B = max_scans, F = max_features_per_scan;
+    d.cap_c = (int)F;
+    d.cap_s = (int)F;
+    d.cap = d.cap_c + d.cap_s;
+    int hc = 1;
+    while (hc < 2 * d.cap) hc <<= 1;
+    d.hash_cap = hc;
+    DM(d.state, B);
+    DM(d.blk_f, B * d.cap);
+    DM(d.blk_av, B * 6 * d.cap);
+    DM(d.blk_flag, B * d.cap);
+    DM(d.blk_l1, B * d.cap);
+    DM(d.hash, B * (size_t)d.hash_cap);
+    DM(r->d_corner, B * F);
+    DM(r->d_surf, B * F);
+    DM(r->d_nc, B);
+    DM(r->d_ns, B);
+    DM(r->d_pose_tmp, 8);
+    HC(hipMemset(d.blk_flag, 0, B * d.cap));
+    r->h_state.resize(B);
+    *out = r;
+    return 0;
+}
+
+extern "C" void ll_reg_destroy(ll_reg *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    RegDev &d = r->dev;
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+                    r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : r->ev) (void)hipEventDestroy(e);
+    if (r->ev_wait) (void)hipEventDestroy(r->ev_wait);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" void *ll_reg_stream(ll_reg *r) { return r ? (void *)r->stream : nullptr; }
+
+extern "C" int ll_reg_set_debug(ll_reg *r, int32_t enable)
+{
+    if (!r) return set_err("ll_reg_set_debug", "null handle");
+    HC(hipSetDevice(r->device));
+    r->debug = enable ? 1 : 0;
+    if (enable && !r->dev.dbg_idx) {
+        DM(r->dev.dbg_idx, (size_t)r->max_scans * r->dev.cap * 5);
+        DM(r->dev.dbg_d2, (size_t)r->max_scans * r->dev.cap * 5);
+    }
+    return 0;
+}
+
+extern "C" int ll_reg_set_profiling(ll_reg *r, int32_t enable)
+{
+    if (!r) return set_err("ll_reg_set_profiling", "null handle");
+    r->profiling = enable ? 1 : 0;
+    return 0;
+}
+
+static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->if_motion_deblur = p->if_motion_deblur;
+    c->icp_max_iterations = p->icp_max_iterations;
+    c->ceres_max_iterations = p->ceres_max_iterations;
+    c->ceres_prerun_times = p->ceres_prerun_times;
+    c->icp_line = p->icp_line;
+    c->icp_plane = p->icp_plane;
+    c->force_all_iterations = p->force_all_iterations;
+    c->debug_knn = debug;
+    c->max_d2_line_d = p->maximum_dis_line_for_match;
+    c->max_d2_plane_d = p->maximum_dis_plane_for_match;
+    // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)
+    float fl = (float)p->maximum_dis_line_for_match, fp = (float)p->maximum_dis_plane_for_match;
+    if ((double)fl < p->maximum_dis_line_for_match) fl = nextafterf(fl, INFINITY);
+    if ((double)fp < p->maximum_dis_plane_for_match) fp = nextafterf(fp, INFINITY);
+    c->max_d2_line = fl;
+    c->max_d2_plane = fp;
+    c->huber_a = p->huber_a;
+    c->inliner_dis = p->inliner_dis;
+    c->inlier_ratio = p->inlier_ratio;
+    c->minimum_icp_R_diff = p->minimum_icp_R_diff;
+    c->minimum_icp_T_diff = p->minimum_icp_T_diff;
+    c->bound = (double)p->para_max_speed;
+    c->para_max_angular_rate = p->para_max_angular_rate;
+    c->max_final_cost = p->max_final_cost;
+    c->min_ts = p->minimum_pt_time_stamp;
+    c->max_ts = p->maximum_pt_time_stamp;
+    return 0;
+}
+
+static void prof_begin(ll_reg *r, int cls)
+{
+    if (!r->profiling) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, r->stream);
+    r->ev.push_back(a);
+    r->ev.push_back(b);
+    r->ev_class.push_back(cls);
+}
+static void prof_end(ll_reg *r)
+{
+    if (!r->profiling) return;
+    (void)hipEventRecord(r->ev.back(), r->stream);
+}
+
+// common launch sequence; the feature pointers in r->dev must be set
+static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_params *prm, const double *poses_last,
+                       const double *poses_curr, const double *poses_incre)
+{
+    if (!map || !prm || !poses_last || !poses_curr) return set_err("ll_reg", "null argument");
+    if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg", "n_scans out of range");
+    if (prm->if_motion_deblur) return set_err("ll_reg", "if_motion_deblur=1 is not implemented in this build");
+    if (prm->icp_max_iterations < 0 || prm->ceres_max_iterations < 0 || prm->ceres_prerun_times < 0)
+        return set_err("ll_reg", "negative iteration count");
+    if (map->device != r->device) return set_err("ll_reg", "map lives on another device");
+    make_reg_const(prm, r->debug, &r->rc);
+    // PCR:199 gate
+    const bool run = map->kind[0].n > 0 && map->kind[1].n > 50 && prm->current_frame_index > prm->mapping_init_accumulate_frames;
+    r->last_gated = run ? 0 : 1;
+    r->last_n_scans = n_scans;
+    for (int b = 0; b < n_scans; b++) {
+        RegState &s = r->h_state[b];
+        memset(&s, 0, sizeof(s));
+        for (int i = 0; i < 7; i++) {
+            s.pose_last[i] = poses_last[7 * b + i];
+            s.pose_curr[i] = poses_curr[7 * b + i];
+            s.inc[i] = poses_incre ? poses_incre[7 * b + i] : (i == 3 ? 1.0 : 0.0);
+        }
+        s.prev_q[3] = 1.0;  // q_last_optimize(1,0,0,0), PCR:204
+        s.gated = run ? 0 : 1;
+        s.done = run ? 0 : 1;
+        s.result = 1;
+        s.accepted = 1;
+    }
+    for (hipEvent_t e : r->ev) (void)hipEventDestroy(e);
+    r->ev.clear();
+    r->ev_class.clear();
+    HC(hipMemcpyAsync(r->dev.state, r->h_state.data(), (size_t)n_scans * sizeof(RegState), hipMemcpyHostToDevice, r->stream));
+    if (run) {
+        if (!map->kind[0].pts || !map->kind[1].pts) return set_err("ll_reg", "map not uploaded");
+        for (int it = 0; it < prm->icp_max_iterations; it++) {
+            prof_begin(r, 0);
+            launch_reg_knn_build(r->dev, r->rc, map->kind[0].grid, map->kind[1].grid, n_scans, it, r->stream);
+            prof_end(r);
+            prof_begin(r, 1);
+            launch_reg_solve(r->dev, r->rc, n_scans, r->stream);
+            prof_end(r);
+        }
+    }
+    prof_begin(r, 2);
+    launch_reg_finalize(r->dev, r->rc, n_scans, r->stream);
+    prof_end(r);
+    HC(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, double *poses_incre, ll_reg_report *reports,
+                              int32_t *results)
+{
+    if (!r) return set_err("ll_reg_collect", "null handle");
+    if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_collect", "n_scans out of range");
+    HC(hipSetDevice(r->device));
+    HC(hipMemcpyAsync(r->h_state.data(), r->dev.state, (size_t)n_scans * sizeof(RegState), hipMemcpyDeviceToHost, r->stream));
+    HC(hipStreamSynchronize(r->stream));
+    for (int b = 0; b < n_scans; b++) {
+        const RegState &s = r->h_state[b];
+        for (int i = 0; i < 7; i++) {
+            if (poses_curr) poses_curr[7 * b + i] = s.pose_curr[i];
+            if (poses_incre) poses_incre[7 * b + i] = s.inc[i];
+        }
+        if (results) results[b] = s.result;
+        if (reports) {
+            ll_reg_report &rp = reports[b];
+            rp.final_cost = s.final_cost;
+            rp.initial_cost = s.initial_cost;
+            rp.inlier_threshold = s.inlier_thr;
+            rp.angular_diff_deg = s.angular_diff;
+            rp.t_diff = s.t_diff;
+            rp.icp_iterations = s.icp_iters;
+            rp.n_blocks_last = s.n_blocks_last;
+            rp.corner_avail = s.corner_avail;
+            rp.surf_avail = s.surf_avail;
+            rp.lm_iterations_total = s.lm_total;
+            rp.accepted = s.accepted;
+            rp.gated = s.gated;
+        }
+    }
+    if (r->profiling) {
+        for (int k = 0; k < 3; k++) {
+            r->prof_ms[k] = 0.f;
+            r->prof_launches[k] = 0;
+        }
+        for (size_t i = 0; i < r->ev_class.size(); i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r->ev[2 * i], r->ev[2 * i + 1]) == hipSuccess) {
+                r->prof_ms[r->ev_class[i]] += ms;
+                r->prof_launches[r->ev_class[i]]++;
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int ll_reg_kernel_times(ll_reg *r, float ms[3], int32_t launches[3])
+{
+    if (!r) return set_err("ll_reg_kernel_times", "null handle");
+    for (int k = 0; k < 3; k++) {
+        if (ms) ms[k] = r->prof_ms[k];
+        if (launches) launches[k] = r->prof_launches[k];
+    }
+    return 0;
+}
+
+extern "C" int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
+                                 const double *poses_last, const double *poses_curr, const double *poses_incre)
+{
+    if (!r || !fe) return set_err("ll_reg_enqueue_fe", "null handle");
+    if (fe->prm.device != r->device) return set_err("ll_reg_enqueue_fe", "extractor lives on another device");
+    if (n_scans > fe->prm.max_scans) return set_err("ll_reg_enqueue_fe", "n_scans exceeds the extractor capacity");
+    if (fe->prm.max_points > r->max_feat) return set_err("ll_reg_enqueue_fe", "registrar feature capacity < extractor max_points");
+    HC(hipSetDevice(r->device));
+    // order after the extractor's stream
+    HC(hipEventRecord(r->ev_wait, fe->stream));
+    HC(hipStreamWaitEvent(r->stream, r->ev_wait, 0));
+    r->dev.corner_feat = fe->dev.corner_feat;
+    r->dev.surf_feat = fe->dev.surf_feat;
+    r->dev.n_corner = fe->dev.n_corner;
+    r->dev.n_surf = fe->dev.n_surf;
+    r->dev.feat_stride_c = fe->dev.stride;
+    r->dev.feat_stride_s = fe->dev.stride;
+    return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
+}
+
+extern "C" int ll_reg_solve_batch_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
+                                     const double *poses_last, double *poses_curr, double *poses_incre, ll_reg_report *reports,
+                                     int32_t *results)
+{
+    if (ll_reg_enqueue_fe(r, map, fe, n_scans, prm, poses_last, poses_curr, poses_incre)) return -1;
+    return ll_reg_collect(r, n_scans, poses_curr, poses_incre, reports, results);
+}
+
+extern "C" int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans, const float *corner_xyzi, const int32_t *n_corner,
+                                  int32_t stride_corner, const float *surf_xyzi, const int32_t *n_surf, int32_t stride_surf,
+                                  const ll_reg_params *prm, const double *poses_last, double *poses_curr, double *poses_incre,
+                                  ll_reg_report *reports, int32_t *results)
+{
+    if (!r || !n_corner || !n_surf) return set_err("ll_reg_solve_batch", "null argument");
+    if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_solve_batch", "n_scans out of range");
+    HC(hipSetDevice(r->device));
+    const size_t F = r->max_feat;
+    for (int b = 0; b < n_scans; b++) {
+        if (n_corner[b] < 0 || n_corner[b] > r->max_feat || n_surf[b] < 0 || n_surf[b] > r->max_feat)
+            return set_err("ll_reg_solve_batch", "feature count exceeds capacity");
+        if (prm && (n_corner[b] > prm->maximum_allow_residual_block || n_surf[b] > prm->maximum_allow_residual_block))
+            return set_err("ll_reg_solve_batch",
+                           "feature count exceeds maximum_allow_residual_block: the reference's random sub-sampling "
+                           "(point_cloud_registration.hpp:232-238,339-345,438-458) is not reproduced; raise the limit");
+        if (n_corner[b] > 0)
+            HC(hipMemcpyAsync(r->d_corner + b * F, corner_xyzi + (size_t)b * stride_corner * 4, (size_t)n_corner[b] * sizeof(float4),
+                              hipMemcpyHostToDevice, r->stream));
+        if (n_surf[b] > 0)
+            HC(hipMemcpyAsync(r->d_surf + b * F, surf_xyzi + (size_t)b * stride_surf * 4, (size_t)n_surf[b] * sizeof(float4),
+                              hipMemcpyHostToDevice, r->stream));
+    }
+    HC(hipMemcpyAsync(r->d_nc, n_corner, n_scans * sizeof(int), hipMemcpyHostToDevice, r->stream));
+    HC(hipMemcpyAsync(r->d_ns, n_surf, n_scans * sizeof(int), hipMemcpyHostToDevice, r->stream));
+    HC(hipStreamSynchronize(r->stream));
+    r->dev.corner_feat = r->d_corner;
+    r->dev.surf_feat = r->d_surf;
+    r->dev.n_corner = r->d_nc;
+    r->dev.n_surf = r->d_ns;
+    r->dev.feat_stride_c = (int)F;
+    r->dev.feat_stride_s = (int)F;
+    if (reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre)) return -1;
+    return ll_reg_collect(r, n_scans, poses_curr, poses_incre, reports, results);
+}
+
+extern "C" int ll_reg_solve(ll_reg *r, const ll_map *map, const float *scan_corner_xyzi, int32_t n_corner,
+                            const float *scan_surf_xyzi, int32_t n_surf, const ll_reg_params *prm, const double pose_last[7],
+                            double pose_curr[7], double pose_incre[7], ll_reg_report *rep)
+{
+    int32_t res = 1;
+    double inc_local[7] = {0, 0, 0, 1, 0, 0, 0};
+    double *inc = pose_incre ? pose_incre : inc_local;
+    const int rc = ll_reg_solve_batch(r, map, 1, scan_corner_xyzi, &n_corner, n_corner, scan_surf_xyzi, &n_surf, n_surf, prm,
+                                      pose_last, pose_curr, inc, rep, &res);
+    if (rc < 0) return rc;
+    return res;
+}
+
+extern "C" int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corner_d25, int32_t *surf_idx5, float *surf_d25)
+{
+    if (!r) return set_err("ll_reg_debug_knn", "null handle");
+    if (!r->dev.dbg_idx) return set_err("ll_reg_debug_knn", "debug taps not enabled (ll_reg_set_debug)");
+    if (scan < 0 || scan >= r->max_scans) return set_err("ll_reg_debug_knn", "scan out of range");
+    HC(hipSetDevice(r->device));
+    HC(hipStreamSynchronize(r->stream));
+    int nc = 0, ns = 0;
+    HC(hipMemcpy(&nc, r->dev.n_corner + scan, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&ns, r->dev.n_surf + scan, sizeof(int), hipMemcpyDeviceToHost));
+    const size_t base = (size_t)scan * r->dev.cap * 5;
+    D2H_OPT(corner_idx5, r->dev.dbg_idx + base, (size_t)nc * 5, int);
+    D2H_OPT(corner_d25, r->dev.dbg_d2 + base, (size_t)nc * 5, float);
+    D2H_OPT(surf_idx5, r->dev.dbg_idx + base + (size_t)r->dev.cap_c * 5, (size_t)ns * 5, int);
+    D2H_OPT(surf_d25, r->dev.dbg_d2 + base + (size_t)r->dev.cap_c * 5, (size_t)ns * 5, float);
+    return 0;
+}
+
+extern "C" int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t n, const double pose[7])
+{
+    if (!r || !pose || (n > 0 && (!in_xyzi || !out_xyzi))) return set_err("ll_cloud_transform", "null argument");
+    if (n <= 0) return 0;
+    HC(hipSetDevice(r->device));
+    float4 *d_in = nullptr, *d_out = nullptr;
+    DM(d_in, (size_t)n);
+    DM(d_out, (size_t)n);
+    HC(hipMemcpyAsync(d_in, in_xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, r->stream));
+    HC(hipMemcpyAsync(r->d_pose_tmp, pose, 7 * sizeof(double), hipMemcpyHostToDevice, r->stream));
+    launch_cloud_transform(d_in, d_out, n, r->d_pose_tmp, r->stream);
+    HC(hipGetLastError());
+    HC(hipMemcpyAsync(out_xyzi, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
+    HC(hipStreamSynchronize(r->stream));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return 0;
+}

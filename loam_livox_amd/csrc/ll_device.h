@@ -1,0 +1,118 @@
+// ll_device.h -- device-side data layout shared by the kernel files and the C-ABI host code (ll_api.hip).
+// All buffers are HBM-resident SoA planes; [scan][point] with a fixed per-scan stride so one launch covers a
+// whole batch of scans.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ll_fe_core.h"
+#include "ll_knn_core.h"
+
+namespace ll {
+
+#define LL_MAX_PIECES 8
+
+struct FeScanInfo {
+    int n_split;         // entries in split_idx (incl. the closing n-1)
+    int clutter_size;    // return value of projection_scan_3d_2d (LFE:606; 0 when fewer than 6 entries)
+    int n_petal_clouds;  // laserCloudScans.size() after split_laser_scan (LFE:718)
+    int pad;
+    float piece_start[LL_MAX_PIECES], piece_end[LL_MAX_PIECES];  // LFX:321-322
+};
+
+struct FeDev {
+    // inputs
+    const float4 *xyzi;   // [B][stride] raw points (x,y,z,intensity)
+    const int *npts;      // [B]
+    const double *time0;  // [B] m_current_time of each scan
+    int stride;           // points per scan slot
+    // per-point planes [B][stride]
+    int *type, *label;
+    float *depth2, *polar2, *curv, *view, *tstamp, *polar_angle;
+    float2 *img;
+    signed char *flags;   // bit0: defines own polar/img values, bit1: reached the split logic
+    int *cand;            // split candidates scratch
+    // per-scan split bookkeeping [B][split_cap]
+    int split_cap;
+    int *split_idx, *petal_first, *petal_last;
+    float *run_angle;
+    FeScanInfo *info;     // [B]
+    // selection [B][stride]
+    int *corner_idx, *surf_idx, *full_idx;
+    float4 *corner_feat, *surf_feat;
+    int *n_corner, *n_surf, *n_full;  // [B]
+    // view-angle ambiguity list
+    int *n_ambig;
+    int2 *ambig_list;
+    int ambig_cap;
+};
+
+void launch_fe_point(const FeDev &fb, const FeConst &fc, int n_scans, int max_n, hipStream_t s);
+void launch_fe_split(const FeDev &fb, int pieces, int n_scans, hipStream_t s);
+void launch_fe_select(const FeDev &fb, int n_scans, int piece, float min_blur, float max_blur, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ map grid
+
+struct MapKind {
+    f4 *pts = nullptr;          // sorted by cell, w = original index bits
+    int *cell_start = nullptr;  // [ncell + 1]
+    int64_t n = 0;              // points given
+    int64_t n_valid = 0;        // finite points stored in the grid
+    Grid grid{};                // device pointers + geometry
+    size_t ncell = 0;
+};
+
+// builds the grid for `n` device-resident raw points (stride floats apart); fills mk. Returns 0 or a HIP error.
+int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err);
+void map_free(MapKind &mk);
+void launch_knn5(const Grid &g, const float *d_q, int nq, float max_d2, int *d_idx, float *d_d2, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ registrar
+
+// Per-scan solver state, resident in HBM between the kernels of one registration.
+struct RegState {
+    double pose_last[7], pose_curr[7], inc[7];
+    double prev_q[4], prev_t[3];          // q_last_optimize / t_last_optimize (PCR:204-205,529-530)
+    double interp_theta, hat[9], hat_sq[9];  // m_interpolatation_* (PCR:58,66-68)
+    double inlier_thr, final_cost, initial_cost, angular_diff, t_diff;
+    int icp_iters, n_blocks_last, corner_avail, surf_avail, lm_total;
+    int done, accepted, gated, result;
+    int pad;
+};
+
+struct RegConst {
+    int if_motion_deblur, icp_max_iterations, ceres_max_iterations, ceres_prerun_times;
+    int icp_line, icp_plane, force_all_iterations, debug_knn;
+    float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
+    double max_d2_line_d, max_d2_plane_d;
+    double huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff;
+    double bound;                          // m_para_max_speed (PCR:143-151)
+    float para_max_angular_rate, max_final_cost, min_ts, max_ts;
+};
+
+struct RegDev {
+    RegState *state;              // [B]
+    const float4 *corner_feat;    // [B][feat_stride_c]
+    const float4 *surf_feat;      // [B][feat_stride_s]
+    const int *n_corner, *n_surf; // [B]
+    int feat_stride_c, feat_stride_s;
+    // residual blocks, slot layout per scan: [0, cap_c) corner queries, [cap_c, cap_c + cap_s) surface queries
+    int cap_c, cap_s, cap;        // cap = cap_c + cap_s
+    float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
+    double *blk_av;               // [B][6][cap] a'(3) then v'(3) in the frame of pose_last
+    unsigned char *blk_flag;      // [B][cap]  BLK_* bits
+    double *blk_l1;               // [B][cap]  scratch for the inlier threshold
+    unsigned long long *hash;     // [B][hash_cap] dedup table for the std::set semantics of PCR:155-160
+    int hash_cap;
+    // debug taps (first ICP iteration)
+    int *dbg_idx;                 // [B][cap][5]
+    float *dbg_d2;                // [B][cap][5]
+};
+
+void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
+                          hipStream_t s);
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
+void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
+void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);
+
+}  // namespace ll

@@ -1,0 +1,185 @@
+// ll_knn_core.h -- exact 5-nearest-neighbour search on a uniform cell grid; the per-query routine shared by
+// the HIP kernels and tests/hostcheck.  Stands in for pcl::KdTreeFLANN::nearestKSearch at
+// hku-mars/loam_livox source/point_cloud_registration.hpp:249,351: exact k-NN, squared L2 accumulated in
+// fp32 in x,y,z order (FLANN L2_Simple<float>), ascending; ties ordered by ascending original index.
+//
+// Grid layout (built by ll_map_kernels.hip):
+//   pts[j]        float4 {x, y, z, bit-cast original index}, sorted by cell key (x fastest, then y, then z)
+//   cell_start[c] index in pts of the first point of cell c, c in [0, ncell]; cell_start[ncell] = #points
+// Because x is the fastest-varying key digit, the cells (cx-k..cx+k, cy, cz) of one row are one contiguous
+// run of pts: a query walks (2k+1)^2 runs per ring instead of (2k+1)^3 cells.
+#pragma once
+#include "ll_fe_core.h"  // LL_HD
+
+namespace ll {
+
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
+struct Grid {
+    const f4 *pts;
+    const int *cell_start;
+    float ox, oy, oz;  // origin (min corner)
+    float inv_h, h;
+    float slack;  // conservative allowance for fp32 rounding of cell assignment (metres)
+    int nx, ny, nz;
+};
+
+struct Knn5 {
+    float d2[5];
+    int idx[5];  // original (upload-order) index: the tie-break key and what callers see
+    int pos[5];  // position in the cell-sorted array (to fetch the coordinates again)
+    int count;
+};
+
+#define LL_KNN_EMPTY 0x7fffffff
+
+LL_HD void knn5_init(Knn5 &r)
+{
+    for (int i = 0; i < 5; i++) {
+        r.d2[i] = INFINITY;
+        r.idx[i] = LL_KNN_EMPTY;
+        r.pos[i] = -1;
+    }
+    r.count = 0;
+}
+
+LL_HD int as_int(float f)
+{
+    union {
+        float f;
+        int i;
+    } u;
+    u.f = f;
+    return u.i;
+}
+
+LL_HD bool lex_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+
+// Ordered insertion by (d2, idx): carry the displaced element down a fully unrolled compare-swap chain
+// (static indices only, so the five slots stay in registers on the GPU).
+LL_HD void knn5_push(Knn5 &r, float d2, int idx, int pos)
+{
+    if (!lex_less(d2, idx, r.d2[4], r.idx[4])) return;
+    if (r.count < 5) r.count++;
+    float cd = d2;
+    int ci = idx, cp = pos;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (lex_less(cd, ci, r.d2[i], r.idx[i])) {
+            const float td = r.d2[i];
+            const int ti = r.idx[i], tp = r.pos[i];
+            r.d2[i] = cd;
+            r.idx[i] = ci;
+            r.pos[i] = cp;
+            cd = td;
+            ci = ti;
+            cp = tp;
+        }
+    }
+}
+
+// FLANN L2_Simple<float>: result = 0; result += diff*diff for x, y, z.  No FMA contraction.
+LL_HD float dist2_xyz(float qx, float qy, float qz, float px, float py, float pz)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    float dx = qx - px, dy = qy - py, dz = qz - pz;
+    float r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    return r;
+}
+
+LL_HD int cell_coord(float v, float o, float inv_h)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return (int)floorf((v - o) * inv_h);
+}
+
+LL_HD void scan_run(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of one x-run*/, float qx, float qy,
+                    float qz, float max_d2, Knn5 &r)
+{
+    const int b = g.cell_start[c_lo], e = g.cell_start[c_hi + 1];
+    for (int j = b; j < e; j++) {
+        const f4 p = g.pts[j];
+        const float d2 = dist2_xyz(qx, qy, qz, p.x, p.y, p.z);
+        if (d2 < max_d2) knn5_push(r, d2, as_int(p.w), j);
+    }
+}
+
+// Exact 5-NN of (qx,qy,qz) among points with squared distance < max_d2.
+// Ring k visits the shell of cells at Chebyshev distance k from the query's cell.  After ring k every unvisited
+// point is farther than  bound_k = k*h + m  (m = distance from the query to the nearest wall of its own cell),
+// so the search stops once the 5th best is inside that bound, or the bound passes the match radius.
+LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2, Knn5 &r)
+{
+    knn5_init(r);
+    if (!ll_isfinite(qx) || !ll_isfinite(qy) || !ll_isfinite(qz)) return;
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    // far outside the grid: nothing can be within the match radius (also keeps the int conversion defined)
+    const float rmax_cells = sqrtf(max_d2) * g.inv_h + 2.0f;
+    if (fx < -rmax_cells || fy < -rmax_cells || fz < -rmax_cells || fx > (float)g.nx + rmax_cells ||
+        fy > (float)g.ny + rmax_cells || fz > (float)g.nz + rmax_cells)
+        return;
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    // distance (in metres) from the query to the nearest wall of its own cell, slightly under-estimated
+    float mx = fminf(fx - (float)cx, (float)(cx + 1) - fx);
+    float my = fminf(fy - (float)cy, (float)(cy + 1) - fy);
+    float mz = fminf(fz - (float)cz, (float)(cz + 1) - fz);
+    float m = fmaxf(fminf(mx, fminf(my, mz)), 0.0f) * g.h;
+    const float slack = g.slack;
+    const int kmax = (int)ceilf(sqrtf(max_d2) * g.inv_h) + 1;
+
+    for (int k = 0; k <= kmax; k++) {
+        if (k == 0) {
+            // ring 0 and ring 1 together: the 3x3 block of x-runs around the query cell
+            for (int dz = -1; dz <= 1; dz++) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    int x0 = cx - 1, x1 = cx + 1;
+                    if (x0 < 0) x0 = 0;
+                    if (x1 >= g.nx) x1 = g.nx - 1;
+                    if (x0 > x1) continue;
+                    const int base = (z * g.ny + y) * g.nx;
+                    scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
+                }
+            }
+            k = 1;
+        } else {
+            for (int dz = -k; dz <= k; dz++) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+                for (int dy = -k; dy <= k; dy++) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    const int base = (z * g.ny + y) * g.nx;
+                    const bool full_row = (dz == -k || dz == k || dy == -k || dy == k);
+                    if (full_row) {
+                        int x0 = cx - k, x1 = cx + k;
+                        if (x0 < 0) x0 = 0;
+                        if (x1 >= g.nx) x1 = g.nx - 1;
+                        if (x0 <= x1) scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
+                    } else {
+                        const int xa = cx - k, xb = cx + k;
+                        if (xa >= 0 && xa < g.nx) scan_run(g, base + xa, base + xa, qx, qy, qz, max_d2, r);
+                        if (xb >= 0 && xb < g.nx) scan_run(g, base + xb, base + xb, qx, qy, qz, max_d2, r);
+                    }
+                }
+            }
+        }
+        const float bound = (float)k * g.h + m - slack;
+        const float b2 = bound * bound;
+        if (b2 >= max_d2) break;                     // every point within the match radius has been seen
+        if (r.count == 5 && r.d2[4] < b2) break;     // the 5 best cannot be displaced by an unvisited point
+    }
+}
+
+}  // namespace ll

@@ -1,0 +1,215 @@
+// ll_map_kernels.hip -- K5: device search-grid build for the match-buffer clouds, and the stand-alone 5-NN
+// query kernel.  Replaces pcl::KdTreeFLANN::setInputCloud (hku-mars/loam_livox source/laser_mapping.hpp:544-545,
+// source/point_cloud_registration.hpp:596-597): instead of a pointer-chasing k-d tree the map is counting-sorted
+// into a uniform cell grid (x fastest), stored as float4 {x,y,z,original index} so that a query streams
+// contiguous 16-byte records.  Build traffic ~ 2*(16+8) B/point, once per map refresh.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "ll_device.h"
+
+namespace ll {
+
+#define HIPCHK(x)                                  \
+    do {                                           \
+        hipError_t e_ = (x);                       \
+        if (e_ != hipSuccess) {                    \
+            *err = hipGetErrorString(e_);          \
+            return -1;                             \
+        }                                          \
+    } while (0)
+
+__global__ void aabb_kernel(const float *raw, int stride, int64_t n, float *mn, float *mx)
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = raw[i * stride], y = raw[i * stride + 1], z = raw[i * stride + 2];
+        if (ll_isfinite(x) && ll_isfinite(y) && ll_isfinite(z)) {
+            lo[0] = fminf(lo[0], x);
+            lo[1] = fminf(lo[1], y);
+            lo[2] = fminf(lo[2], z);
+            hi[0] = fmaxf(hi[0], x);
+            hi[1] = fmaxf(hi[1], y);
+            hi[2] = fmaxf(hi[2], z);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_down(lo[d], off));
+            hi[d] = fmaxf(hi[d], __shfl_down(hi[d], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // float atomics on min/max via int ordering tricks are avoided: one atomic per wave on a tiny array,
+        // implemented with CAS loops
+        for (int d = 0; d < 3; d++) {
+            float old = mn[d];
+            while (lo[d] < old) {
+                const float prev = __int_as_float(atomicCAS((int *)&mn[d], __float_as_int(old), __float_as_int(lo[d])));
+                if (prev == old) break;
+                old = prev;
+            }
+            old = mx[d];
+            while (hi[d] > old) {
+                const float prev = __int_as_float(atomicCAS((int *)&mx[d], __float_as_int(old), __float_as_int(hi[d])));
+                if (prev == old) break;
+                old = prev;
+            }
+        }
+    }
+}
+
+__global__ void cellkey_kernel(const float *raw, int stride, int64_t n, Grid g, unsigned int ncell, unsigned int *keys,
+                               int *vals, int *counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = raw[i * stride], y = raw[i * stride + 1], z = raw[i * stride + 2];
+    unsigned int key = ncell;  // non-finite points sort to the end and are dropped
+    if (ll_isfinite(x) && ll_isfinite(y) && ll_isfinite(z)) {
+        int cx = cell_coord(x, g.ox, g.inv_h), cy = cell_coord(y, g.oy, g.inv_h), cz = cell_coord(z, g.oz, g.inv_h);
+        cx = min(max(cx, 0), g.nx - 1);
+        cy = min(max(cy, 0), g.ny - 1);
+        cz = min(max(cz, 0), g.nz - 1);
+        key = (unsigned int)((cz * g.ny + cy) * g.nx + cx);
+        atomicAdd(&counts[key], 1);
+    }
+    keys[i] = key;
+    vals[i] = (int)i;
+}
+
+__global__ void gather_kernel(const float *raw, int stride, int64_t n_valid, const int *vals_sorted, f4 *pts)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_valid) return;
+    const int i = vals_sorted[j];
+    f4 p;
+    p.x = raw[(int64_t)i * stride];
+    p.y = raw[(int64_t)i * stride + 1];
+    p.z = raw[(int64_t)i * stride + 2];
+    p.w = __int_as_float(i);
+    pts[j] = p;
+}
+
+int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err)
+{
+    map_free(mk);
+    mk.n = n;
+    float *d_mm = nullptr;
+    HIPCHK(hipMalloc(&d_mm, 6 * sizeof(float)));
+    const float init[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, s));
+    if (n > 0) hipLaunchKernelGGL(aabb_kernel, dim3(1024), dim3(256), 0, s, d_raw, stride, n, d_mm, d_mm + 3);
+    float mm[6];
+    HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d_mm));
+    Grid g{};
+    if (!(mm[0] <= mm[3])) {  // no finite point
+        mm[0] = mm[1] = mm[2] = 0.f;
+        mm[3] = mm[4] = mm[5] = 0.f;
+    }
+    // grow the cell until the dense table fits (<= 2^27 cells)
+    float h = cell;
+    for (;;) {
+        const double nx = floor((double)(mm[3] - mm[0]) / h) + 1, ny = floor((double)(mm[4] - mm[1]) / h) + 1,
+                     nz = floor((double)(mm[5] - mm[2]) / h) + 1;
+        if (nx * ny * nz <= (double)(1u << 27)) {
+            g.nx = (int)nx;
+            g.ny = (int)ny;
+            g.nz = (int)nz;
+            break;
+        }
+        h *= 1.5f;
+    }
+    g.h = h;
+    g.inv_h = 1.0f / h;
+    g.ox = mm[0];
+    g.oy = mm[1];
+    g.oz = mm[2];
+    const float ext = fmaxf(fmaxf(fabsf(mm[0]), fabsf(mm[3])), fmaxf(fmaxf(fabsf(mm[1]), fabsf(mm[4])), fmaxf(fabsf(mm[2]), fabsf(mm[5])))) +
+                      fmaxf(mm[3] - mm[0], fmaxf(mm[4] - mm[1], mm[5] - mm[2]));
+    g.slack = 1e-3f * h + 2e-6f * ext;
+    const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+    mk.ncell = ncell;
+
+    unsigned int *d_keys = nullptr, *d_keys2 = nullptr;
+    int *d_vals = nullptr, *d_vals2 = nullptr, *d_counts = nullptr;
+    void *d_tmp = nullptr;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    HIPCHK(hipMalloc(&d_keys, nn * sizeof(unsigned int)));
+    HIPCHK(hipMalloc(&d_keys2, nn * sizeof(unsigned int)));
+    HIPCHK(hipMalloc(&d_vals, nn * sizeof(int)));
+    HIPCHK(hipMalloc(&d_vals2, nn * sizeof(int)));
+    HIPCHK(hipMalloc(&d_counts, (ncell + 1) * sizeof(int)));
+    HIPCHK(hipMalloc(&mk.cell_start, (ncell + 1) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(d_counts, 0, (ncell + 1) * sizeof(int), s));
+    if (n > 0)
+        hipLaunchKernelGGL(cellkey_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_raw, stride, n, g,
+                           (unsigned int)ncell, d_keys, d_vals, d_counts);
+    // exclusive scan of counts -> cell_start[0..ncell]
+    size_t tmp_bytes = 0, tmp2 = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_counts, mk.cell_start, (int)(ncell + 1), s));
+    int end_bit = 1;
+    while (((size_t)1 << end_bit) <= ncell && end_bit < 32) end_bit++;
+    if (n > 0)
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, d_keys, d_keys2, d_vals, d_vals2, (int)n, 0, end_bit, s));
+    if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+    HIPCHK(hipMalloc(&d_tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    size_t tb = tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_counts, mk.cell_start, (int)(ncell + 1), s));
+    tb = tmp_bytes;
+    // stable LSD radix sort: points of one cell stay in ascending original-index order
+    if (n > 0) HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)n, 0, end_bit, s));
+    int n_valid = 0;
+    HIPCHK(hipMemcpyAsync(&n_valid, mk.cell_start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    mk.n_valid = n_valid;
+    HIPCHK(hipMalloc(&mk.pts, (size_t)(n_valid > 0 ? n_valid : 1) * sizeof(f4)));
+    if (n_valid > 0)
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, s, d_raw, stride,
+                           (int64_t)n_valid, d_vals2, mk.pts);
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_keys);
+    (void)hipFree(d_keys2);
+    (void)hipFree(d_vals);
+    (void)hipFree(d_vals2);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_tmp);
+    g.pts = mk.pts;
+    g.cell_start = mk.cell_start;
+    mk.grid = g;
+    return 0;
+}
+
+void map_free(MapKind &mk)
+{
+    if (mk.pts) (void)hipFree(mk.pts);
+    if (mk.cell_start) (void)hipFree(mk.cell_start);
+    mk.pts = nullptr;
+    mk.cell_start = nullptr;
+    mk.n = mk.n_valid = 0;
+    mk.ncell = 0;
+}
+
+__global__ void knn5_kernel(Grid g, const float *q, int nq, float max_d2, int *idx, float *d2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    Knn5 r;
+    knn5_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+        d2[5 * i + k] = r.d2[k];
+    }
+}
+
+void launch_knn5(const Grid &g, const float *d_q, int nq, float max_d2, int *d_idx, float *d_d2, hipStream_t s)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(knn5_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, g, d_q, nq, max_d2, d_idx, d_d2);
+}
+
+}  // namespace ll

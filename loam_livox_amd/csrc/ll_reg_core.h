@@ -1,0 +1,604 @@
+// ll_reg_core.h -- per-thread arithmetic of the scan-to-map registrar shared by the HIP kernels
+// (ll_reg_kernels.hip) and tests/hostcheck: pose algebra, residual-block construction, per-block
+// cost / gradient / Gauss-Newton accumulation, and the Levenberg-Marquardt step controller that replaces the
+// ceres::Solve calls of hku-mars/loam_livox source/point_cloud_registration.hpp:474,508.
+//
+// Formulation (SURVEY App. C.2 "replacement contract").  With x = (q_inc, t_inc) the increment optimised by
+// the reference and T_last the pose before the scan, the reference residuals (source/ceres_icp.hpp:262-288,
+// 338-366) are  r = A (R_last (R_inc f + t_inc) + t_last - a),  A = I - u u^T (line) or n n^T (plane, n not
+// normalised).  We pre-rotate the block constants into the frame of T_last:  a' = R_last^T (a - t_last),
+// u' = R_last^T u, so  r' = R_last^T r = A' (R_inc f + t_inc - a').  |r'| = |r|, and J'^T J' = J^T J.
+// The tangent space is Ceres' EigenQuaternionParameterization: q+ = [sin|d| d/|d|, cos|d|] (x) q, i.e.
+// R_inc+ = Exp(2 d) R_inc, hence  d(R_inc f)/dd = -2 [R_inc f]x.
+#pragma once
+#include <float.h>
+
+#include "ll_fe_core.h"
+
+namespace ll {
+
+// ---------------------------------------------------------------------------------------------- pose algebra
+
+LL_HD void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+LL_HD double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// Eigen QuaternionBase::_transformVector: v + w*uv + qv x uv, uv = 2 (qv x v). q = (x,y,z,w).
+LL_HD void quat_rot(const double q[4], const double v[3], double o[3])
+{
+    double uv[3], t[3];
+    cross3(q, v, uv);
+    uv[0] += uv[0];
+    uv[1] += uv[1];
+    uv[2] += uv[2];
+    cross3(q, uv, t);
+    o[0] = v[0] + q[3] * uv[0] + t[0];
+    o[1] = v[1] + q[3] * uv[1] + t[1];
+    o[2] = v[2] + q[3] * uv[2] + t[2];
+}
+// rotate by the conjugate (R^T v)
+LL_HD void quat_rot_inv(const double q[4], const double v[3], double o[3])
+{
+    const double qc[4] = {-q[0], -q[1], -q[2], q[3]};
+    quat_rot(qc, v, o);
+}
+// Eigen quaternion product a*b, (x,y,z,w) storage
+LL_HD void quat_mul(const double a[4], const double b[4], double r[4])
+{
+    const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    r[0] = x;
+    r[1] = y;
+    r[2] = z;
+    r[3] = w;
+}
+// Eigen angularDistance: 2 atan2(|vec(a b*)|, |w(a b*)|)
+LL_HD double quat_angular_distance(const double a[4], const double b[4])
+{
+    const double bc[4] = {-b[0], -b[1], -b[2], b[3]};
+    double d[4];
+    quat_mul(a, bc, d);
+    return 2.0 * atan2(sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), fabs(d[3]));
+}
+// rotation matrix (row-major) that applies the same map as quat_rot for a unit quaternion
+LL_HD void quat_to_mat(const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z);
+    R[1] = 2 * (x * y - z * w);
+    R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);
+    R[4] = 1 - 2 * (x * x + z * z);
+    R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);
+    R[7] = 2 * (y * z + x * w);
+    R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// pointAssociateToMap, no-deblur branch (point_cloud_registration.hpp:629,656-658): double math, float store
+LL_HD void point_to_map(const double pose[7], float px, float py, float pz, float out[3])
+{
+    const double v[3] = {(double)px, (double)py, (double)pz};
+    double o[3];
+    quat_rot(pose, v, o);
+    out[0] = (float)(o[0] + pose[4]);
+    out[1] = (float)(o[1] + pose[5]);
+    out[2] = (float)(o[2] + pose[6]);
+}
+
+// refine_blur (point_cloud_registration.hpp:128-141), float arithmetic
+LL_HD float refine_blur(int deblur, float in_blur, float min_blur, float max_blur)
+{
+    if (!deblur) return 1.0f;
+    const float res = (in_blur - min_blur) / (max_blur - min_blur);
+    if (!ll_isfinite(res) || res > 1.0f) return 1.0f;
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------- residual blocks
+
+enum : int { BLK_NONE = 0, BLK_LINE = 1, BLK_PLANE = 2, BLK_ACTIVE = 4 };
+
+// line block from the two nearest map points (point_cloud_registration.hpp:300-303, ceres_icp.hpp:255-256).
+// a_out / v_out are expressed in the frame of pose_last.  Returns false when |a-b| < 1e-4 (:302).
+LL_HD bool block_line(const double pose_last[7], const double pa[3], const double pb[3], double a_out[3], double v_out[3])
+{
+    double d[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    if (sqrt(dot3(d, d)) < 0.0001) return false;
+    double u[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double n = sqrt(dot3(u, u));
+    u[0] = u[0] / n;
+    u[1] = u[1] / n;
+    u[2] = u[2] / n;
+    const double rel[3] = {pa[0] - pose_last[4], pa[1] - pose_last[5], pa[2] - pose_last[6]};
+    quat_rot_inv(pose_last, rel, a_out);
+    quat_rot_inv(pose_last, u, v_out);
+    return true;
+}
+
+// plane block from neighbours 0, k/2, k-1 (point_cloud_registration.hpp:416-418, ceres_icp.hpp:328-334);
+// n = (ab/|ab|) x (ac/|ac|) is NOT re-normalised.  Degenerate triples (a==b or a==c) are skipped (the
+// reference would produce NaN residuals).
+LL_HD bool block_plane(const double pose_last[7], const double pa[3], const double pb[3], const double pc[3],
+                       double a_out[3], double v_out[3])
+{
+    double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    double ac[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+    const double nab = sqrt(dot3(ab, ab)), nac = sqrt(dot3(ac, ac));
+    if (nab == 0.0 || nac == 0.0) return false;
+    for (int i = 0; i < 3; i++) {
+        ab[i] = ab[i] / nab;
+        ac[i] = ac[i] / nac;
+    }
+    double n[3];
+    cross3(ab, ac, n);
+    const double rel[3] = {pa[0] - pose_last[4], pa[1] - pose_last[5], pa[2] - pose_last[6]};
+    quat_rot_inv(pose_last, rel, a_out);
+    quat_rot_inv(pose_last, n, v_out);
+    return true;
+}
+
+// ceres::HuberLoss(a): rho(s), rho'(s)
+LL_HD void huber(double a, double s, double *rho0, double *rho1)
+{
+    const double b = a * a;
+    if (s > b) {
+        const double r = sqrt(s);
+        *rho0 = 2.0 * a * r - b;
+        *rho1 = fmax(DBL_MIN, a / r);
+    } else {
+        *rho0 = s;
+        *rho1 = 1.0;
+    }
+}
+
+// Accumulator layout: acc[0..20] = upper triangle of H = sum rho' J^T J (row-major, a <= b),
+// acc[21..26] = g = sum rho' J^T r, acc[27] = cost = 1/2 sum rho(|r|^2).
+#define LL_NACC 28
+LL_HD int hidx(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }  // a <= b
+
+// residual (frame of pose_last) of one block at increment (R = R_inc row-major, t = t_inc):
+// returns s = |r|^2; fills y = R f, r.
+LL_HD double block_residual(int kind, const double R[9], const double t[3], const double f[3], const double a[3],
+                            const double v[3], double y[3], double r[3], double *dd_out)
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    y[0] = R[0] * f[0] + R[1] * f[1] + R[2] * f[2];
+    y[1] = R[3] * f[0] + R[4] * f[1] + R[5] * f[2];
+    y[2] = R[6] * f[0] + R[7] * f[1] + R[8] * f[2];
+    const double d[3] = {y[0] + t[0] - a[0], y[1] + t[1] - a[1], y[2] + t[2] - a[2]};
+    const double dd = dot3(d, v);
+    *dd_out = dd;
+    if (kind == BLK_LINE) {
+        r[0] = d[0] - dd * v[0];
+        r[1] = d[1] - dd * v[1];
+        r[2] = d[2] - dd * v[2];
+    } else {
+        r[0] = dd * v[0];
+        r[1] = dd * v[1];
+        r[2] = dd * v[2];
+    }
+    return dot3(r, r);
+}
+
+// cost only
+LL_HD double block_cost(int kind, const double R[9], const double t[3], const double f[3], const double a[3],
+                        const double v[3], double huber_a)
+{
+    double y[3], r[3], dd, rho0, rho1;
+    const double s = block_residual(kind, R, t, f, a, v, y, r, &dd);
+    huber(huber_a, s, &rho0, &rho1);
+    return 0.5 * rho0;
+}
+
+// cost + gradient + Gauss-Newton matrix of one block, accumulated into acc[28]
+LL_HD void block_accumulate(int kind, const double R[9], const double t[3], const double f[3], const double a[3],
+                            const double v[3], double huber_a, double acc[LL_NACC])
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    double y[3], r[3], dd, rho0, w;
+    const double s = block_residual(kind, R, t, f, a, v, y, r, &dd);
+    huber(huber_a, s, &rho0, &w);
+    acc[27] += 0.5 * rho0;
+    // c(z) = B^T z = [2 y x z ; z]  with B = [-2[y]x | I]
+    double cv[6];
+    {
+        double yxv[3];
+        cross3(y, v, yxv);
+        cv[0] = 2.0 * yxv[0];
+        cv[1] = 2.0 * yxv[1];
+        cv[2] = 2.0 * yxv[2];
+        cv[3] = v[0];
+        cv[4] = v[1];
+        cv[5] = v[2];
+    }
+    if (kind == BLK_PLANE) {
+        // J = n (B^T n)^T : J^T J = (n.n) cn cn^T, J^T r = dd (n.n) cn
+        const double nn2 = dot3(v, v);
+        const double wn = w * nn2;
+        const double gs = wn * dd;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc[21 + i] += gs * cv[i];
+            const double wi = wn * cv[i];
+#pragma unroll
+            for (int j = i; j < 6; j++) acc[hidx(i, j)] += wi * cv[j];
+        }
+    } else {
+        // J = A B, A = I - u u^T.  J^T r = B^T (A r);  J^T J = B^T A^T A B = B^T B - kappa cu cu^T, kappa = 2 - u.u
+        const double ur = dot3(v, r);
+        const double ar[3] = {r[0] - ur * v[0], r[1] - ur * v[1], r[2] - ur * v[2]};
+        double yxr[3];
+        cross3(y, ar, yxr);
+        acc[21] += w * 2.0 * yxr[0];
+        acc[22] += w * 2.0 * yxr[1];
+        acc[23] += w * 2.0 * yxr[2];
+        acc[24] += w * ar[0];
+        acc[25] += w * ar[1];
+        acc[26] += w * ar[2];
+        const double kappa = 2.0 - dot3(v, v);
+        const double yy = dot3(y, y);
+        // B^T B: [4(|y|^2 I - y y^T), 2[y]x ; . , I]
+        double BtB[21];
+        BtB[hidx(0, 0)] = 4.0 * (yy - y[0] * y[0]);
+        BtB[hidx(0, 1)] = -4.0 * y[0] * y[1];
+        BtB[hidx(0, 2)] = -4.0 * y[0] * y[2];
+        BtB[hidx(1, 1)] = 4.0 * (yy - y[1] * y[1]);
+        BtB[hidx(1, 2)] = -4.0 * y[1] * y[2];
+        BtB[hidx(2, 2)] = 4.0 * (yy - y[2] * y[2]);
+        BtB[hidx(0, 3)] = 0.0;
+        BtB[hidx(0, 4)] = -2.0 * y[2];
+        BtB[hidx(0, 5)] = 2.0 * y[1];
+        BtB[hidx(1, 3)] = 2.0 * y[2];
+        BtB[hidx(1, 4)] = 0.0;
+        BtB[hidx(1, 5)] = -2.0 * y[0];
+        BtB[hidx(2, 3)] = -2.0 * y[1];
+        BtB[hidx(2, 4)] = 2.0 * y[0];
+        BtB[hidx(2, 5)] = 0.0;
+        BtB[hidx(3, 3)] = 1.0;
+        BtB[hidx(3, 4)] = 0.0;
+        BtB[hidx(3, 5)] = 0.0;
+        BtB[hidx(4, 4)] = 1.0;
+        BtB[hidx(4, 5)] = 0.0;
+        BtB[hidx(5, 5)] = 1.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double ki = kappa * cv[i];
+#pragma unroll
+            for (int j = i; j < 6; j++) acc[hidx(i, j)] += w * (BtB[hidx(i, j)] - ki * cv[j]);
+        }
+    }
+}
+
+// loss-corrected L1 norm of the world-frame residual (problem.Evaluate + point_cloud_registration.hpp:158,489)
+LL_HD double block_l1(int kind, const double R[9], const double t[3], const double f[3], const double a[3],
+                      const double v[3], double huber_a, const double q_last[4])
+{
+    double y[3], r[3], dd, rho0, w, rw[3];
+    const double s = block_residual(kind, R, t, f, a, v, y, r, &dd);
+    huber(huber_a, s, &rho0, &w);
+    quat_rot(q_last, r, rw);
+    const double sq = sqrt(w);
+    return fabs(sq * rw[0]) + fabs(sq * rw[1]) + fabs(sq * rw[2]);
+}
+
+// ---------------------------------------------------------------------------------------------- LM controller
+
+// ProgramEvaluator::Plus: EigenQuaternionParameterization::Plus on q, t += d then clamp to +-bound
+LL_HD void state_plus(const double x[7], const double d[6], double bound, double out[7])
+{
+    const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (nd == 0.0) {
+        out[0] = x[0];
+        out[1] = x[1];
+        out[2] = x[2];
+        out[3] = x[3];
+    } else {
+        const double sn = sin(nd) / nd;
+        const double dq[4] = {sn * d[0], sn * d[1], sn * d[2], cos(nd)};
+        quat_mul(dq, x, out);
+    }
+    for (int i = 0; i < 3; i++) {
+        double v = x[4 + i] + d[3 + i];
+        if (bound >= 0) {
+            v = fmax(v, -bound);
+            v = fmin(v, bound);
+        }
+        out[4 + i] = v;
+    }
+}
+
+LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
+{
+    double L[36];
+    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    for (int i = 0; i < 6; i++) {
+        for (int j = 0; j <= i; j++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) {
+                if (!(s > 0.0)) return 0;
+                L[i * 6 + i] = sqrt(s);
+            } else {
+                L[i * 6 + j] = s / L[j * 6 + j];
+            }
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    for (int i = 0; i < 6; i++)
+        if (!((x[i] - x[i]) == 0.0)) return 0;
+    return 1;
+}
+
+// Trust-region Levenberg-Marquardt step controller with Ceres' default options (see oracle/ll_oracle_reg.c
+// header for the list).  The caller evaluates (cost, g, H) at the points the controller asks for.
+struct LmCtl {
+    // configuration
+    int max_iter;
+    double bound;
+    // current iterate
+    double x[7], x_norm, cost, g[6], H[21], gmax;
+    double scale[6], diag[6];
+    double radius, decrease_factor;
+    int reuse_diagonal, invalid_steps, iteration;
+    // summary
+    double initial_cost, final_cost;
+    // pending step
+    double delta[6], model_cost_change, gd, dmax;
+    double cand[7];
+    double first_eval[LL_NACC];  // evaluation at the full step (kept for a failed line search)
+    double first_cand[7];
+    double ls_step;
+    int ls_iter, ls_active;
+    int done;
+};
+
+LL_HD double lm_gradient_max_norm(const double x[7], const double g[6], double bound)
+{
+    double ng[6], xp[7], m = 0.0;
+    for (int i = 0; i < 6; i++) ng[i] = -g[i];
+    state_plus(x, ng, bound, xp);
+    for (int i = 0; i < 7; i++) m = fmax(m, fabs(x[i] - xp[i]));
+    return m;
+}
+
+LL_HD double lm_cubic_min_step(double f0, double g0, double x1, double f1, double g1, double lo, double hi)
+{
+    const double x12 = x1 * x1, x13 = x12 * x1;
+    const double r0 = f1 - f0 - g0 * x1, r1 = g1 - g0;
+    const double det = x13 * 2.0 * x1 - x12 * 3.0 * x12;
+    const double a = (r0 * 2.0 * x1 - x12 * r1) / det;
+    const double b = (x13 * r1 - 3.0 * x12 * r0) / det;
+    double best_x = lo;
+    double best_v = ((a * lo + b) * lo + g0) * lo + f0;
+    const double vh = ((a * hi + b) * hi + g0) * hi + f0;
+    if (vh < best_v) {
+        best_v = vh;
+        best_x = hi;
+    }
+    const double A = 3.0 * a, B = 2.0 * b, C = g0;
+    double roots[2];
+    int nr = 0;
+    if (fabs(A) < 1e-300) {
+        if (fabs(B) > 1e-300) roots[nr++] = -C / B;
+    } else {
+        const double disc = B * B - 4.0 * A * C;
+        if (disc >= 0) {
+            const double sq = sqrt(disc);
+            roots[nr++] = (-B + sq) / (2.0 * A);
+            roots[nr++] = (-B - sq) / (2.0 * A);
+        }
+    }
+    for (int i = 0; i < nr; i++) {
+        if (roots[i] > lo && roots[i] < hi) {
+            const double v = ((a * roots[i] + b) * roots[i] + g0) * roots[i] + f0;
+            if (v < best_v) {
+                best_v = v;
+                best_x = roots[i];
+            }
+        }
+    }
+    return best_x;
+}
+
+// Start a solve at x0: projects onto the bounds; the caller must evaluate at c.x and call lm_init.
+LL_HD_NOINLINE void lm_begin(LmCtl &c, const double x0[7], int max_iter, double bound)
+{
+    const double zero6[6] = {0, 0, 0, 0, 0, 0};
+    c.max_iter = max_iter;
+    c.bound = bound;
+    state_plus(x0, zero6, bound, c.x);
+    double n = 0;
+    for (int i = 0; i < 7; i++) n += c.x[i] * c.x[i];
+    c.x_norm = sqrt(n);
+    c.done = 0;
+}
+
+// Decide the next trial step from the current iterate.  Returns 1 if c.cand must be evaluated, 0 if finished.
+LL_HD_NOINLINE int lm_propose(LmCtl &c)
+{
+    for (;;) {
+        if (c.iteration >= c.max_iter || c.gmax <= 1e-10 || c.radius < 1e-32) {
+            c.done = 1;
+            return 0;
+        }
+        c.iteration++;
+        double Hs[36], gs[6], A[36], y[6], step[6];
+        for (int a = 0; a < 6; a++) {
+            gs[a] = c.g[a] * c.scale[a];
+            for (int b = 0; b < 6; b++) {
+                const double h = (a <= b) ? c.H[hidx(a, b)] : c.H[hidx(b, a)];
+                Hs[a * 6 + b] = h * c.scale[a] * c.scale[b];
+            }
+        }
+        if (!c.reuse_diagonal)
+            for (int j = 0; j < 6; j++) c.diag[j] = fmin(fmax(Hs[j * 6 + j], 1e-6), 1e32);
+        for (int i = 0; i < 36; i++) A[i] = Hs[i];
+        for (int j = 0; j < 6; j++) A[j * 6 + j] += c.diag[j] / c.radius;
+        const int ok = chol_solve6(A, gs, y);
+        c.reuse_diagonal = 1;
+        double mcc = 0.0;
+        if (ok) {
+            double sg = 0.0, sHs = 0.0;
+            for (int a = 0; a < 6; a++) step[a] = -y[a];
+            for (int a = 0; a < 6; a++) {
+                sg += step[a] * gs[a];
+                double t = 0.0;
+                for (int b = 0; b < 6; b++) t += Hs[a * 6 + b] * step[b];
+                sHs += step[a] * t;
+            }
+            mcc = -sg - 0.5 * sHs;
+        }
+        if (!ok || !(mcc > 0.0)) {
+            if (++c.invalid_steps >= 5) {
+                c.done = 1;
+                return 0;
+            }
+            c.radius *= 0.5;
+            c.reuse_diagonal = 1;
+            continue;
+        }
+        c.invalid_steps = 0;
+        c.model_cost_change = mcc;
+        c.gd = 0.0;
+        c.dmax = 0.0;
+        for (int j = 0; j < 6; j++) {
+            c.delta[j] = step[j] * c.scale[j];
+            c.gd += c.g[j] * c.delta[j];
+            c.dmax = fmax(c.dmax, fabs(c.delta[j]));
+        }
+        state_plus(c.x, c.delta, c.bound, c.cand);
+        c.ls_step = 1.0;
+        c.ls_iter = 0;
+        c.ls_active = 0;
+        return 1;
+    }
+}
+
+// First evaluation (at c.x after lm_begin).  e = acc[28].  Returns like lm_propose.
+LL_HD_NOINLINE int lm_init(LmCtl &c, const double e[LL_NACC], int n_active)
+{
+    c.cost = e[27];
+    for (int i = 0; i < 6; i++) c.g[i] = e[21 + i];
+    for (int i = 0; i < 21; i++) c.H[i] = e[i];
+    for (int j = 0; j < 6; j++) c.scale[j] = 1.0 / (1.0 + sqrt(c.H[hidx(j, j)]));
+    c.gmax = lm_gradient_max_norm(c.x, c.g, c.bound);
+    c.initial_cost = c.cost;
+    c.final_cost = c.cost;
+    c.iteration = 0;
+    c.radius = 1e4;
+    c.decrease_factor = 2.0;
+    c.reuse_diagonal = 0;
+    c.invalid_steps = 0;
+    if (n_active == 0) {
+        c.done = 1;
+        return 0;
+    }
+    return lm_propose(c);
+}
+
+// Evaluation e at c.cand is available.  Returns 1 if another evaluation (at the new c.cand) is needed.
+LL_HD_NOINLINE int lm_update(LmCtl &c, const double e_in[LL_NACC])
+{
+    double e[LL_NACC];
+    for (int i = 0; i < LL_NACC; i++) e[i] = e_in[i];
+    if (c.bound >= 0) {
+        // projected ARMIJO line search (TrustRegionMinimizer::DoLineSearch)
+        if (!c.ls_active) {
+            for (int i = 0; i < LL_NACC; i++) c.first_eval[i] = e[i];
+            for (int i = 0; i < 7; i++) c.first_cand[i] = c.cand[i];
+            c.ls_active = 1;
+        }
+        const double cur_cost = e[27];
+        const bool finite_cost = (cur_cost - cur_cost) == 0.0;
+        if (!finite_cost || cur_cost > c.cost + 1e-4 * c.gd * c.ls_step) {
+            int failed = 0;
+            double new_step = 0.0;
+            if (++c.ls_iter >= 20) {
+                failed = 1;
+            } else {
+                if (!finite_cost) {
+                    new_step = fmin(fmax(c.ls_step * 0.5, 1e-3 * c.ls_step), 0.6 * c.ls_step);
+                } else {
+                    double cg = 0.0;
+                    for (int j = 0; j < 6; j++) cg += e[21 + j] * c.delta[j];
+                    new_step = lm_cubic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, 1e-3 * c.ls_step, 0.6 * c.ls_step);
+                }
+                if (new_step * c.dmax < 1e-9) failed = 1;
+            }
+            if (!failed) {
+                c.ls_step = new_step;
+                double sd[6];
+                for (int j = 0; j < 6; j++) sd[j] = c.delta[j] * c.ls_step;
+                state_plus(c.x, sd, c.bound, c.cand);
+                return 1;
+            }
+            // failed search: Ceres keeps the full step
+            for (int i = 0; i < LL_NACC; i++) e[i] = c.first_eval[i];
+            for (int i = 0; i < 7; i++) c.cand[i] = c.first_cand[i];
+        } else if (c.ls_step != 1.0) {
+            for (int j = 0; j < 6; j++) c.delta[j] *= c.ls_step;
+        }
+    }
+    double cand_cost = e[27];
+    if (!((cand_cost - cand_cost) == 0.0)) cand_cost = DBL_MAX;
+
+    double step_norm = 0.0;
+    for (int i = 0; i < 7; i++) step_norm += (c.x[i] - c.cand[i]) * (c.x[i] - c.cand[i]);
+    step_norm = sqrt(step_norm);
+    if (step_norm <= 1e-8 * (c.x_norm + 1e-8)) {  // ParameterToleranceReached
+        c.done = 1;
+        return 0;
+    }
+    const double cost_change = c.cost - cand_cost;
+    if (fabs(cost_change) <= 1e-6 * c.cost) {  // FunctionToleranceReached
+        c.done = 1;
+        return 0;
+    }
+    const double relative_decrease = cost_change / c.model_cost_change;
+    if (relative_decrease > 1e-3) {
+        double n = 0;
+        for (int i = 0; i < 7; i++) {
+            c.x[i] = c.cand[i];
+            n += c.x[i] * c.x[i];
+        }
+        c.x_norm = sqrt(n);
+        c.cost = cand_cost;
+        for (int i = 0; i < 6; i++) c.g[i] = e[21 + i];
+        for (int i = 0; i < 21; i++) c.H[i] = e[i];
+        c.gmax = lm_gradient_max_norm(c.x, c.g, c.bound);
+        if (c.cost < c.final_cost) c.final_cost = c.cost;
+        const double t = 2.0 * relative_decrease - 1.0;
+        c.radius = c.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        c.radius = fmin(1e16, c.radius);
+        c.decrease_factor = 2.0;
+        c.reuse_diagonal = 0;
+    } else {
+        c.radius = c.radius / c.decrease_factor;
+        c.decrease_factor *= 2.0;
+        c.reuse_diagonal = 1;
+    }
+    return lm_propose(c);
+}
+
+}  // namespace ll

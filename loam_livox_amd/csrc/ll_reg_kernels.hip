@@ -1,0 +1,506 @@
+// ll_reg_kernels.hip -- HIP kernels (gfx950, wave64) of the scan-to-map registrar.
+//
+//   K6  reg_knn_build_kernel : per query: transform with the current pose (pointAssociateToMap,
+//                              point_cloud_registration.hpp:622-661), exact 5-NN on the cell grid
+//                              (:249,351), match-radius tests (:254,353), line / plane block constants
+//                              (:300-323, :416-423; ceres_icp.hpp:255-256, 328-334)
+//   K8/K9 reg_solve_kernel   : ONE workgroup per scan runs what the reference does between :460 and :531:
+//                              the 2-iteration prerun solve, the loss-corrected L1 evaluation, the
+//                              std::set-deduplicated 80-th percentile inlier threshold (:153-161), the prune,
+//                              the final solve and the pose composition -- replacing ceres::Solve /
+//                              Problem::Evaluate by a 28-value (21 H + 6 g + 1 cost) workgroup reduction and a
+//                              Levenberg-Marquardt controller on lane 0.  No host round trip per iteration.
+//        reg_finalize_kernel : accept / reject (:559-573)
+//
+// No MFMA: 6x6 systems are reduced, not multiplied.  Blocks live in HBM as SoA planes (64 B + 1 flag per
+// block), read coalesced once per cost evaluation.
+#include <hip/hip_runtime.h>
+
+#include "ll_device.h"
+#include "ll_reg_core.h"
+
+namespace ll {
+
+#define KB_THREADS 128
+#define RS_THREADS 1024
+#define RS_WAVES (RS_THREADS / 64)
+#define HASH_EMPTY 0xffffffffffffffffull
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KB_THREADS) void reg_knn_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+{
+    const int b = blockIdx.y;
+    const int kind = blockIdx.z;  // 0 corner / line, 1 surface / plane
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
+    if (q >= n) return;
+    const int slot = (kind ? rd.cap_c : 0) + q;
+    const size_t sb = (size_t)b * rd.cap;
+    const float4 f = kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
+
+    unsigned char flag = BLK_NONE;
+    Knn5 r;
+    knn5_init(r);
+    float sblur = 1.0f;
+    if (ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z)) {  // PCR:242-245 (surface: defined deviation)
+        sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
+        float pw[3];
+        if (rc.if_motion_deblur == 0 || (double)sblur == 1.0) {
+            point_to_map(st->pose_curr, f.x, f.y, f.z, pw);  // PCR:629
+        } else {
+            // Rodrigues interpolation, PCR:641-646
+            const double s = (double)sblur;
+            const double T[3] = {st->inc[4] * (s * 1.0), st->inc[5] * (s * 1.0), st->inc[6] * (s * 1.0)};
+            const double th = st->interp_theta * s;
+            const double sn = sin(th), cs1 = 1.0 - cos(th);
+            const double pc[3] = {(double)f.x, (double)f.y, (double)f.z};
+            double inner[3], o[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const double rij = ((i == j) ? 1.0 : 0.0) + sn * st->hat[i * 3 + j] + cs1 * st->hat_sq[i * 3 + j];
+                    acc += rij * pc[j];
+                }
+                inner[i] = acc + T[i];
+            }
+            quat_rot(st->pose_last, inner, o);
+            pw[0] = (float)(o[0] + st->pose_last[4]);
+            pw[1] = (float)(o[1] + st->pose_last[5]);
+            pw[2] = (float)(o[2] + st->pose_last[6]);
+        }
+        const Grid &g = kind ? gs : gc;
+        knn5_search(g, pw[0], pw[1], pw[2], kind ? rc.max_d2_plane : rc.max_d2_line, r);
+        // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
+        if (r.count == 5) {
+            double a_out[3], v_out[3];
+            if (kind == 0) {
+                if (rc.icp_line) {
+                    const f4 p0 = g.pts[r.pos[0]], p1 = g.pts[r.pos[1]];  // PCR:300-301
+                    const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
+                    const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
+                    if (block_line(st->pose_last, pa, pb, a_out, v_out)) flag = BLK_LINE | BLK_ACTIVE | 8;
+                }
+            } else {
+                flag = 8;  // surf_avail counts even when ICP_PLANE == 0 (PCR:425)
+                if (rc.icp_plane) {
+                    const f4 p0 = g.pts[r.pos[0]], p1 = g.pts[r.pos[2]], p2 = g.pts[r.pos[4]];  // PCR:416-418 (0, k/2, k-1)
+                    const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
+                    const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
+                    const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
+                    if (block_plane(st->pose_last, pa, pb, pc, a_out, v_out))
+                        flag = BLK_PLANE | BLK_ACTIVE | 8;
+                    else
+                        flag = BLK_NONE;
+                }
+            }
+            if (flag & BLK_ACTIVE) {
+                rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, rc.if_motion_deblur ? sblur : 1.0f);
+                double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    av[(size_t)c * rd.cap + slot] = a_out[c];
+                    av[(size_t)(3 + c) * rd.cap + slot] = v_out[c];
+                }
+            }
+        }
+    }
+    rd.blk_flag[sb + slot] = flag;
+    if (rc.debug_knn && iter == 0 && rd.dbg_idx) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            rd.dbg_idx[(sb + slot) * 5 + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+            rd.dbg_d2[(sb + slot) * 5 + k] = r.d2[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct SolveShared {
+    LmCtl ctl;
+    double red[RS_WAVES][LL_NACC];
+    double sum[LL_NACC];
+    int need;
+    int hist[256];
+    int isum[RS_WAVES];
+    unsigned long long sel_prefix;
+    int sel_rank;
+    int n_active, n_corner_avail, n_surf_avail, n_unique;
+    double thr;
+};
+
+__device__ __forceinline__ int slot_of(int j, int nC, int cap_c) { return j < nC ? j : cap_c + (j - nC); }
+
+// workgroup evaluation of cost / g / H at x (LDS) over the active blocks -> sh.sum
+__device__ void solver_eval(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a, SolveShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t sb = (size_t)b * rd.cap;
+    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+    double R[9], t[3];
+    {
+        const double q[4] = {x[0], x[1], x[2], x[3]};
+        quat_to_mat(q, R);
+        t[0] = x[4];
+        t[1] = x[5];
+        t[2] = x[6];
+    }
+    double acc[LL_NACC];
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
+    const int total = nC + nS;
+    for (int j = tid; j < total; j += RS_THREADS) {
+        const int slot = slot_of(j, nC, rd.cap_c);
+        const unsigned char fl = rd.blk_flag[sb + slot];
+        if (!(fl & BLK_ACTIVE)) continue;
+        const float4 ff = rd.blk_f[sb + slot];
+        const double f[3] = {(double)ff.x, (double)ff.y, (double)ff.z};
+        const double a[3] = {av[slot], av[(size_t)rd.cap + slot], av[(size_t)2 * rd.cap + slot]};
+        const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
+        block_accumulate(fl & 3, R, t, f, a, v, huber_a, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) sh.red[wave][i] = s;
+    }
+    __syncthreads();
+    if (tid < LL_NACC) {
+        double s = 0.0;
+        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
+        sh.sum[tid] = s;
+    }
+    __syncthreads();
+}
+
+__device__ int block_sum_int(int v, SolveShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) sh.isum[wave] = v;
+    __syncthreads();
+    int s = 0;
+    for (int w = 0; w < RS_WAVES; w++) s += sh.isum[w];
+    __syncthreads();
+    return s;
+}
+
+// one ceres::Solve: starts at x0 (global/LDS), leaves the result in sh.ctl
+__device__ void solver_lm(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
+                          int n_active, SolveShared &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
+    __syncthreads();
+    solver_eval(rd, b, nC, nS, sh.ctl.x, rc.huber_a, sh);
+    if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
+    __syncthreads();
+    while (sh.need) {
+        solver_eval(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, sh);
+        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ unsigned long long hash64(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// compute_interpolatation_rodrigue, PCR:607-620 (Eigen AngleAxis from quaternion)
+__device__ void compute_interp(const double q[4], RegState *st)
+{
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    double axis[3];
+    if (q[3] < 0) n = -n;
+    if (n != 0.0) {
+        st->interp_theta = 2.0 * atan2(n, fabs(q[3]));
+        axis[0] = q[0] / n;
+        axis[1] = q[1] / n;
+        axis[2] = q[2] / n;
+    } else {
+        st->interp_theta = 0.0;
+        axis[0] = 1.0;
+        axis[1] = 0.0;
+        axis[2] = 0.0;
+    }
+    const double an = sqrt(dot3(axis, axis));
+    axis[0] /= an;
+    axis[1] /= an;
+    axis[2] /= an;
+    for (int i = 0; i < 9; i++) st->hat[i] = 0.0;
+    st->hat[1] = -axis[2];
+    st->hat[3] = axis[2];
+    st->hat[2] = axis[1];
+    st->hat[6] = -axis[1];
+    st->hat[5] = -axis[0];
+    st->hat[7] = axis[0];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += st->hat[i * 3 + k] * st->hat[k * 3 + j];
+            st->hat_sq[i * 3 + j] = s;
+        }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc)
+{
+    const int b = blockIdx.x;
+    RegState *st = rd.state + b;
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
+    const int total = nC + nS;
+    const size_t sb = (size_t)b * rd.cap;
+    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+    __shared__ SolveShared sh;
+
+    // ---- census: active blocks, corner_avail / surf_avail (PCR:325,425) -----------------------------------
+    {
+        int na = 0, nca = 0, nsa = 0;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const unsigned char fl = rd.blk_flag[sb + slot_of(j, nC, rd.cap_c)];
+            na += (fl & BLK_ACTIVE) ? 1 : 0;
+            if (fl & 8) {
+                if (j < nC) nca++; else nsa++;
+            }
+        }
+        na = block_sum_int(na, sh);
+        nca = block_sum_int(nca, sh);
+        nsa = block_sum_int(nsa, sh);
+        if (tid == 0) {
+            sh.n_active = na;
+            sh.n_corner_avail = nca;
+            sh.n_surf_avail = nsa;
+        }
+        __syncthreads();
+    }
+
+    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
+    solver_lm(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, sh);
+    int lm_iters = sh.ctl.iteration;
+
+    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483) -----------------------------------
+    unsigned long long *table = rd.hash + (size_t)b * rd.hash_cap;
+    for (int k = tid; k < rd.hash_cap; k += RS_THREADS) table[k] = HASH_EMPTY;
+    {
+        double R[9], t[3];
+        const double q[4] = {sh.ctl.x[0], sh.ctl.x[1], sh.ctl.x[2], sh.ctl.x[3]};
+        quat_to_mat(q, R);
+        t[0] = sh.ctl.x[4];
+        t[1] = sh.ctl.x[5];
+        t[2] = sh.ctl.x[6];
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const int slot = slot_of(j, nC, rd.cap_c);
+            const unsigned char fl = rd.blk_flag[sb + slot];
+            if (!(fl & BLK_ACTIVE)) continue;
+            const float4 ff = rd.blk_f[sb + slot];
+            const double f[3] = {(double)ff.x, (double)ff.y, (double)ff.z};
+            const double a[3] = {av[slot], av[(size_t)rd.cap + slot], av[(size_t)2 * rd.cap + slot]};
+            const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
+            rd.blk_l1[sb + slot] = block_l1(fl & 3, R, t, f, a, v, rc.huber_a, st->pose_last);
+        }
+    }
+    __syncthreads();
+
+    // ---- std::set semantics: count distinct L1 values, select the one of rank (int)(ratio * n_distinct) ----
+    // (first occurrences are tagged with flag bit 16)
+    {
+        int my = 0;
+        const unsigned long long mask = (unsigned long long)rd.hash_cap - 1ull;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const int slot = slot_of(j, nC, rd.cap_c);
+            const unsigned char fl0 = rd.blk_flag[sb + slot];
+            if (!(fl0 & BLK_ACTIVE)) continue;
+            const double l1 = rd.blk_l1[sb + slot];
+            if (!(l1 == l1)) continue;  // NaN never enters the set
+            const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
+            unsigned long long h = hash64(key) & mask;
+            for (;;) {
+                const unsigned long long old = atomicCAS(&table[h], HASH_EMPTY, key);
+                if (old == HASH_EMPTY) {
+                    rd.blk_flag[sb + slot] = fl0 | 16;
+                    my++;
+                    break;
+                }
+                if (old == key) break;
+                h = (h + 1ull) & mask;
+            }
+        }
+        const int nu = block_sum_int(my, sh);
+        if (tid == 0) {
+            sh.n_unique = nu;
+            sh.sel_prefix = 0ull;
+            int target = (int)(rc.inlier_ratio * (double)nu);  // PCR:160
+            if (target > nu - 1) target = nu - 1;
+            sh.sel_rank = target;
+        }
+        __syncthreads();
+    }
+    if (sh.n_unique > 0) {
+        // MSB-first radix select (8 bits per pass) over the distinct keys; non-negative doubles order like uint64
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            for (int k = tid; k < 256; k += RS_THREADS) sh.hist[k] = 0;
+            __syncthreads();
+            const unsigned long long prefix = sh.sel_prefix;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot = slot_of(j, nC, rd.cap_c);
+                if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(rd.blk_l1[sb + slot]);
+                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rank = sh.sel_rank, d = 0, cum = 0;
+                for (d = 0; d < 256; d++) {
+                    if (cum + sh.hist[d] > rank) break;
+                    cum += sh.hist[d];
+                }
+                if (d > 255) d = 255;
+                sh.sel_rank = rank - cum;
+                sh.sel_prefix = (prefix << 8) | (unsigned long long)d;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sh.sel_prefix));  // PCR:485
+    } else {
+        if (tid == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
+    }
+    __syncthreads();
+    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
+    {
+        const double thr = sh.thr;
+        int na = 0;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const int slot = slot_of(j, nC, rd.cap_c);
+            unsigned char fl = rd.blk_flag[sb + slot];
+            if (!(fl & BLK_ACTIVE)) continue;
+            fl &= ~16;
+            if (rd.blk_l1[sb + slot] > thr)
+                fl &= ~BLK_ACTIVE;
+            else
+                na++;
+            rd.blk_flag[sb + slot] = fl;
+        }
+        na = block_sum_int(na, sh);
+        if (tid == 0) sh.n_active = na;
+        __syncthreads();
+    }
+
+    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
+    {
+        // the prerun result is the start; copy it out of ctl before lm_begin overwrites ctl.x
+        __shared__ double x_start[7];
+        if (tid < 7) x_start[tid] = sh.ctl.x[tid];
+        __syncthreads();
+        solver_lm(rd, rc, b, nC, nS, x_start, rc.ceres_max_iterations, sh.n_active, sh);
+    }
+    lm_iters += sh.ctl.iteration;
+
+    // ---- pose composition, convergence (PCR:509-531) ---------------------------------------------------------
+    if (tid == 0) {
+        for (int i = 0; i < 7; i++) st->inc[i] = sh.ctl.x[i];
+        if (rc.if_motion_deblur) compute_interp(st->inc, st);
+        double tw[3];
+        quat_rot(st->pose_last, &st->inc[4], tw);  // PCR:514
+        st->pose_curr[4] = tw[0] + st->pose_last[4];
+        st->pose_curr[5] = tw[1] + st->pose_last[5];
+        st->pose_curr[6] = tw[2] + st->pose_last[6];
+        double qc[4];
+        quat_mul(st->pose_last, st->inc, qc);  // PCR:515
+        for (int i = 0; i < 4; i++) st->pose_curr[i] = qc[i];
+        st->angular_diff = (double)((float)quat_angular_distance(qc, st->pose_last)) * 57.3;  // PCR:517
+        const double dt[3] = {st->pose_curr[4] - st->pose_last[4], st->pose_curr[5] - st->pose_last[5],
+                              st->pose_curr[6] - st->pose_last[6]};
+        st->t_diff = sqrt(dot3(dt, dt));
+        st->final_cost = sh.ctl.final_cost;
+        st->initial_cost = sh.ctl.initial_cost;
+        st->inlier_thr = sh.thr;
+        st->n_blocks_last = sh.n_active;
+        st->corner_avail = sh.n_corner_avail;
+        st->surf_avail = sh.n_surf_avail;
+        st->lm_total += lm_iters;
+        st->icp_iters += 1;
+        const double dto[3] = {st->prev_t[0] - st->inc[4], st->prev_t[1] - st->inc[5], st->prev_t[2] - st->inc[6]};
+        const bool conv = quat_angular_distance(st->prev_q, st->inc) < 57.3 * rc.minimum_icp_R_diff &&
+                          sqrt(dot3(dto, dto)) < rc.minimum_icp_T_diff;  // PCR:521-522
+        if (conv && !rc.force_all_iterations) {
+            st->done = 1;
+        } else {
+            for (int i = 0; i < 4; i++) st->prev_q[i] = st->inc[i];
+            for (int i = 0; i < 3; i++) st->prev_t[i] = st->inc[4 + i];
+        }
+        if (st->icp_iters >= rc.icp_max_iterations) st->done = 1;
+    }
+}
+
+__global__ void reg_finalize_kernel(RegDev rd, RegConst rc, int n_scans)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_scans) return;
+    RegState *st = rd.state + b;
+    st->result = 1;
+    st->accepted = 1;
+    if (st->gated || st->icp_iters == 0) return;
+    st->inlier_thr = st->inlier_thr * st->final_cost / st->initial_cost;  // PCR:559
+    const float minimize_cost = (float)st->final_cost;                    // PCR:192,519
+    if (st->angular_diff > (double)rc.para_max_angular_rate || minimize_cost > rc.max_final_cost) {  // PCR:561
+        for (int i = 0; i < 7; i++) st->pose_curr[i] = st->pose_last[i];
+        st->result = 0;
+        st->accepted = 0;
+    }
+}
+
+__global__ void cloud_transform_kernel(const float4 *in, float4 *out, int n, const double *pose)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = pose[k];
+    const float4 v = in[i];
+    float o[3];
+    point_to_map(p, v.x, v.y, v.z, o);
+    out[i] = make_float4(o[0], o[1], o[2], v.w);  // intensity copied, PCR:659
+}
+
+// ---- launch wrappers -------------------------------------------------------------------------------------------
+void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
+                          hipStream_t s)
+{
+    const int capq = rd.cap_c > rd.cap_s ? rd.cap_c : rd.cap_s;
+    dim3 grid((capq + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
+    hipLaunchKernelGGL(reg_knn_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+}
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
+{
+    hipLaunchKernelGGL(reg_solve_kernel, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
+}
+void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
+{
+    hipLaunchKernelGGL(reg_finalize_kernel, dim3((n_scans + 63) / 64), dim3(64), 0, s, rd, rc, n_scans);
+}
+void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cloud_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, d_pose);
+}
+
+}  // namespace ll

@@ -1,0 +1,134 @@
+"""ctypes binding of tests/hostcheck/libhostcheck.so (TEST-ONLY host build of the device math headers)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libhostcheck.so")
+_SRC = os.path.join(_HERE, "hostcheck.cpp")
+_CSRC = os.path.join(_HERE, "..", "..", "loam_livox_amd", "csrc")
+
+
+def build():
+    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("ll_fe_core.h", "ll_knn_core.h", "ll_reg_core.h")]
+    if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-o", _LIB, _SRC])
+    return _LIB
+
+
+class FeParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("thr_corner_curvature", "thr_surface_curvature", "minimum_view_angle",
+                                         "livox_min_allow_dis", "livox_min_sigma", "max_fov", "time_internal_pts")]
+
+
+class RegParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("if_motion_deblur", "icp_max_iterations", "ceres_max_iterations",
+                                       "ceres_prerun_times", "icp_line", "icp_plane", "force_all_iterations")] + \
+               [(n, C.c_double) for n in ("max_d2_line", "max_d2_plane", "huber_a", "inliner_dis", "inlier_ratio",
+                                          "minimum_icp_R_diff", "minimum_icp_T_diff", "bound")] + \
+               [(n, C.c_float) for n in ("para_max_angular_rate", "max_final_cost", "min_ts", "max_ts")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.hc_grid_build.restype = C.c_void_p
+        L.hc_grid_build.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_float]
+        L.hc_grid_free.argtypes = [C.c_void_p]
+        L.hc_knn5.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.hc_fe_points.argtypes = [C.POINTER(FeParams), C.c_void_p, C.c_int, C.c_double] + [C.c_void_p] * 8
+        L.hc_select.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 6
+        L.hc_eval_blocks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.hc_make_block.argtypes = [C.c_int] + [C.c_void_p] * 6
+        L.hc_reg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(RegParams),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fe_points(xyzi, t0, prm: FeParams):
+    xyzi = np.ascontiguousarray(xyzi, np.float32)
+    n = xyzi.shape[0]
+    out = dict(type=np.zeros(n, np.int32), label=np.zeros(n, np.int32), depth2=np.zeros(n, np.float32),
+               curv=np.zeros(n, np.float32), view=np.zeros(n, np.float32), tstamp=np.zeros(n, np.float32),
+               polar2_own=np.zeros(n, np.float32), flags=np.zeros(n, np.int32))
+    lib().hc_fe_points(C.byref(prm), _p(xyzi), n, t0, _p(out["type"]), _p(out["label"]), _p(out["depth2"]), _p(out["curv"]),
+                       _p(out["view"]), _p(out["tstamp"]), _p(out["polar2_own"]), _p(out["flags"]))
+    return out
+
+
+def select(type_, label, depth2, min_blur, max_blur):
+    n = len(type_)
+    ci, si, fi = (np.zeros(n, np.int32) for _ in range(3))
+    nc, ns, nf = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    lib().hc_select(n, _p(type_), _p(label), _p(depth2), min_blur, max_blur, _p(ci), C.byref(nc), _p(si), C.byref(ns),
+                    _p(fi), C.byref(nf))
+    return ci[:nc.value].copy(), si[:ns.value].copy(), fi[:nf.value].copy()
+
+
+class Grid:
+    def __init__(self, xyz, cell):
+        self.xyz = np.ascontiguousarray(xyz, np.float32)
+        self.h = lib().hc_grid_build(_p(self.xyz), self.xyz.shape[1], self.xyz.shape[0], cell)
+
+    def __del__(self):
+        try:
+            lib().hc_grid_free(self.h)
+        except Exception:
+            pass
+
+    def knn5(self, q, max_d2):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        idx = np.zeros((q.shape[0], 5), np.int32)
+        d2 = np.zeros((q.shape[0], 5), np.float32)
+        lib().hc_knn5(self.h, _p(q), q.shape[0], max_d2, _p(idx), _p(d2))
+        return idx, d2
+
+
+def eval_blocks(kind, f, a, v, x, huber_a=0.1):
+    kind = np.ascontiguousarray(kind, np.int32)
+    f, a, v = (np.ascontiguousarray(t, np.float64) for t in (f, a, v))
+    x = np.ascontiguousarray(x, np.float64)
+    acc = np.zeros(28)
+    lib().hc_eval_blocks(len(kind), _p(kind), _p(f), _p(a), _p(v), _p(x), huber_a, _p(acc))
+    H = np.zeros((6, 6))
+    k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            H[i, j] = H[j, i] = acc[k]
+            k += 1
+    return acc[27], acc[21:27].copy(), H
+
+
+def make_block(kind, pose_last, pa, pb, pc=None):
+    a, v = np.zeros(3), np.zeros(3)
+    pc = np.zeros(3) if pc is None else np.asarray(pc, np.float64)
+    ok = lib().hc_make_block(kind, _p(np.asarray(pose_last, np.float64)), _p(np.asarray(pa, np.float64)),
+                             _p(np.asarray(pb, np.float64)), _p(pc), _p(a), _p(v))
+    return ok, a, v
+
+
+def reg_solve(gc: Grid, gs: Grid, corner, surf, prm: RegParams, pose_last, pose_curr, inc=None):
+    corner = np.ascontiguousarray(corner, np.float32).reshape(-1, 4)
+    surf = np.ascontiguousarray(surf, np.float32).reshape(-1, 4)
+    pl = np.ascontiguousarray(pose_last, np.float64).copy()
+    pc = np.ascontiguousarray(pose_curr, np.float64).copy()
+    pi = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if inc is None else np.ascontiguousarray(inc, np.float64).copy()
+    rep = np.zeros(8)
+    ret = lib().hc_reg_solve(gc.h, gs.h, _p(corner), corner.shape[0], _p(surf), surf.shape[0], C.byref(prm), _p(pl), _p(pc),
+                             _p(pi), _p(rep))
+    return ret, pc, pi, rep

@@ -1,0 +1,360 @@
+// tests/hostcheck/hostcheck.cpp -- TEST-ONLY host build of the device math headers.
+//
+// The per-thread arithmetic of the HIP kernels lives in loam_livox_amd/csrc/ll_*_core.h as
+// __host__ __device__ inline functions.  This file compiles those headers with g++ and drives them with plain
+// serial loops that stand in for the kernels' thread indexing, so that the no-GPU test tier can check the
+// arithmetic (labels, 5-NN ring search, block construction, analytic Jacobians, LM controller) against the
+// oracle.  It is NOT part of the product: libloamlivox_hip.so never links it and has no CPU path.  The
+// GPU-only plumbing (LDS staging, wave reductions, hash de-duplication, radix select, stream compaction) is
+// covered by the `-m gpu` tests.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../loam_livox_amd/csrc/ll_fe_core.h"
+#include "../../loam_livox_amd/csrc/ll_knn_core.h"
+#include "../../loam_livox_amd/csrc/ll_reg_core.h"
+
+using namespace ll;
+
+extern "C" {
+
+struct hc_fe_params {
+    float thr_corner_curvature, thr_surface_curvature, minimum_view_angle, livox_min_allow_dis, livox_min_sigma, max_fov,
+        time_internal_pts;
+};
+
+static FeConst make_const(const hc_fe_params *p)
+{
+    FeConst c;
+    c.thr_corner_curvature = p->thr_corner_curvature;
+    c.thr_surface_curvature = p->thr_surface_curvature;
+    c.minimum_view_angle = p->minimum_view_angle;
+    c.min_dis_sq = p->livox_min_allow_dis * p->livox_min_allow_dis;
+    c.min_sigma = p->livox_min_sigma;
+    c.max_edge_polar_pos = (float)pow(tan((double)p->max_fov / 57.3) * 1, 2);
+    c.time_internal_pts = p->time_internal_pts;
+    c.view_angle_band = 0.0f;
+    return c;
+}
+
+// stands in for fe_point_kernel
+int hc_fe_points(const hc_fe_params *p, const float *xyzi, int n, double t0, int32_t *type, int32_t *label, float *depth2,
+                 float *curv, float *view, float *tstamp, float *polar2_own, int32_t *flags)
+{
+    const FeConst c = make_const(p);
+    std::vector<PointOwn> own(n);
+    for (int i = 0; i < n; i++) {
+        own[i] = point_own(xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2], xyzi[4 * i + 3], i, c);
+        depth2[i] = own[i].depth_sq2;
+        polar2_own[i] = own[i].polar_sq2;
+        flags[i] = own[i].defines | (own[i].reached << 1);
+        tstamp[i] = point_time_stamp(t0, i, c.time_internal_pts);
+    }
+    auto edge = [&](int k) { return (k >= 0 && k < n) ? own[k].edge : 0; };
+    for (int i = 0; i < n; i++) {
+        type[i] = own[i].type_self | ((edge(i - 1) | edge(i + 1) | edge(i + 2)) ? PT_CIRCLE_EDGE : 0);
+        LabelOut lo;
+        lo.label = 0;
+        lo.curvature = 0.f;
+        lo.view_angle = 0.f;
+        if (n >= 5 && i >= 2 && i < n - 2) {
+            float pp[5][3], d[5];
+            int t[5];
+            for (int k = 0; k < 5; k++) {
+                pp[k][0] = xyzi[4 * (i - 2 + k)];
+                pp[k][1] = xyzi[4 * (i - 2 + k) + 1];
+                pp[k][2] = xyzi[4 * (i - 2 + k) + 2];
+                t[k] = own[i - 2 + k].type_self;
+                d[k] = own[i - 2 + k].depth_sq2;
+            }
+            lo = point_label(pp, t, d, c);
+        }
+        label[i] = lo.label;
+        curv[i] = lo.curvature;
+        view[i] = lo.view_angle;
+    }
+    return 0;
+}
+
+int hc_select(int n, const int32_t *type, const int32_t *label, const float *depth2, float min_blur, float max_blur,
+              int32_t *ci, int32_t *nc, int32_t *si, int32_t *ns, int32_t *fi, int32_t *nf)
+{
+    const float maximum_idx = max_blur * n, minimum_idx = min_blur * n;
+    int c = 0, s = 0, f = 0;
+    for (int i = 0; i < n; i++) {
+        const int sel = select_point(i, type[i], label[i], depth2[i], minimum_idx, maximum_idx);
+        if (sel & 1) ci[c++] = i;
+        if (sel & 2) si[s++] = i;
+        if (sel & 4) fi[f++] = i;
+    }
+    *nc = c;
+    *ns = s;
+    *nf = f;
+    return 0;
+}
+
+// ---- grid (host stand-in for map_build) -----------------------------------------------------------------------
+struct hc_grid {
+    std::vector<f4> pts;
+    std::vector<int> cell_start;
+    Grid g;
+};
+
+hc_grid *hc_grid_build(const float *xyz, int stride, int64_t n, float cell)
+{
+    hc_grid *G = new hc_grid();
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; i++) {
+        const float *p = xyz + i * stride;
+        if (ll_isfinite(p[0]) && ll_isfinite(p[1]) && ll_isfinite(p[2]))
+            for (int d = 0; d < 3; d++) {
+                mn[d] = fminf(mn[d], p[d]);
+                mx[d] = fmaxf(mx[d], p[d]);
+            }
+    }
+    if (!(mn[0] <= mx[0])) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0.f;
+    Grid &g = G->g;
+    g.h = cell;
+    g.inv_h = 1.0f / cell;
+    g.ox = mn[0];
+    g.oy = mn[1];
+    g.oz = mn[2];
+    g.nx = (int)floor((double)(mx[0] - mn[0]) / cell) + 1;
+    g.ny = (int)floor((double)(mx[1] - mn[1]) / cell) + 1;
+    g.nz = (int)floor((double)(mx[2] - mn[2]) / cell) + 1;
+    const float ext = fmaxf(fmaxf(fabsf(mn[0]), fabsf(mx[0])), fmaxf(fmaxf(fabsf(mn[1]), fabsf(mx[1])), fmaxf(fabsf(mn[2]), fabsf(mx[2])))) +
+                      fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+    g.slack = 1e-3f * cell + 2e-6f * ext;
+    const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+    std::vector<std::pair<unsigned, int>> kv;
+    kv.reserve(n);
+    for (int64_t i = 0; i < n; i++) {
+        const float *p = xyz + i * stride;
+        if (!(ll_isfinite(p[0]) && ll_isfinite(p[1]) && ll_isfinite(p[2]))) continue;
+        int cx = std::min(std::max(cell_coord(p[0], g.ox, g.inv_h), 0), g.nx - 1);
+        int cy = std::min(std::max(cell_coord(p[1], g.oy, g.inv_h), 0), g.ny - 1);
+        int cz = std::min(std::max(cell_coord(p[2], g.oz, g.inv_h), 0), g.nz - 1);
+        kv.emplace_back((unsigned)((cz * g.ny + cy) * g.nx + cx), (int)i);
+    }
+    std::stable_sort(kv.begin(), kv.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    G->pts.resize(kv.size());
+    G->cell_start.assign(ncell + 1, 0);
+    for (size_t j = 0; j < kv.size(); j++) {
+        const float *p = xyz + (int64_t)kv[j].second * stride;
+        f4 q;
+        q.x = p[0];
+        q.y = p[1];
+        q.z = p[2];
+        union {
+            int i;
+            float f;
+        } u;
+        u.i = kv[j].second;
+        q.w = u.f;
+        G->pts[j] = q;
+        G->cell_start[kv[j].first + 1]++;
+    }
+    for (size_t c = 0; c < ncell; c++) G->cell_start[c + 1] += G->cell_start[c];
+    g.pts = G->pts.data();
+    g.cell_start = G->cell_start.data();
+    return G;
+}
+void hc_grid_free(hc_grid *G) { delete G; }
+
+int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx, float *d2)
+{
+    for (int i = 0; i < nq; i++) {
+        Knn5 r;
+        knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
+        for (int k = 0; k < 5; k++) {
+            idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+            d2[5 * i + k] = r.d2[k];
+        }
+    }
+    return 0;
+}
+
+// ---- registration (host stand-in for reg_knn_build_kernel + reg_solve_kernel + reg_finalize_kernel) ----------
+struct hc_reg_params {
+    int if_motion_deblur, icp_max_iterations, ceres_max_iterations, ceres_prerun_times, icp_line, icp_plane,
+        force_all_iterations;
+    double max_d2_line, max_d2_plane, huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff, bound;
+    float para_max_angular_rate, max_final_cost, min_ts, max_ts;
+};
+
+struct hc_blk {
+    int kind;
+    int active;
+    double f[3], a[3], v[3];
+};
+
+static void eval_all(const std::vector<hc_blk> &blk, const double x[7], double huber_a, double acc[LL_NACC])
+{
+    double R[9], t[3] = {x[4], x[5], x[6]};
+    quat_to_mat(x, R);
+    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
+    for (const hc_blk &b : blk)
+        if (b.active) block_accumulate(b.kind, R, t, b.f, b.a, b.v, huber_a, acc);
+}
+
+static void lm_run(const std::vector<hc_blk> &blk, const double x0[7], int max_iter, double bound, double huber_a, LmCtl &c)
+{
+    int n_active = 0;
+    for (const hc_blk &b : blk) n_active += b.active;
+    double acc[LL_NACC];
+    lm_begin(c, x0, max_iter, bound);
+    eval_all(blk, c.x, huber_a, acc);
+    int need = lm_init(c, acc, n_active);
+    while (need) {
+        eval_all(blk, c.cand, huber_a, acc);
+        need = lm_update(c, acc);
+    }
+}
+
+// blocks evaluation only (for Jacobian checks): kind[], f[3n], a[3n], v[3n] in the pose_last frame
+int hc_eval_blocks(int n, const int32_t *kind, const double *f, const double *a, const double *v, const double *x, double huber_a,
+                   double *acc28)
+{
+    std::vector<hc_blk> blk(n);
+    for (int i = 0; i < n; i++) {
+        blk[i].kind = kind[i];
+        blk[i].active = 1;
+        for (int k = 0; k < 3; k++) {
+            blk[i].f[k] = f[3 * i + k];
+            blk[i].a[k] = a[3 * i + k];
+            blk[i].v[k] = v[3 * i + k];
+        }
+    }
+    eval_all(blk, x, huber_a, acc28);
+    return 0;
+}
+
+// world-frame neighbours -> block constants in the pose_last frame
+int hc_make_block(int kind, const double *pose_last, const double *pa, const double *pb, const double *pc, double *a_out, double *v_out)
+{
+    if (kind == BLK_LINE) return block_line(pose_last, pa, pb, a_out, v_out) ? 1 : 0;
+    return block_plane(pose_last, pa, pb, pc, a_out, v_out) ? 1 : 0;
+}
+
+int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int nC, const float *surf, int nS,
+                 const hc_reg_params *p, const double *pose_last, double *pose_curr, double *inc, double *report /*[8]*/)
+{
+    double prev_q[4] = {0, 0, 0, 1}, prev_t[3] = {0, 0, 0};
+    double final_cost = 0, initial_cost = 0, inlier_thr = 0, angular_diff = 0, t_diff = 0;
+    int icp_iters = 0, n_blocks_last = 0, corner_avail = 0, surf_avail = 0, lm_total = 0;
+    float fl = (float)p->max_d2_line, fp = (float)p->max_d2_plane;
+    if ((double)fl < p->max_d2_line) fl = nextafterf(fl, INFINITY);
+    if ((double)fp < p->max_d2_plane) fp = nextafterf(fp, INFINITY);
+    for (int it = 0; it < p->icp_max_iterations; it++) {
+        std::vector<hc_blk> blk;
+        corner_avail = surf_avail = 0;
+        for (int kind = 0; kind < 2; kind++) {
+            const int n = kind ? nS : nC;
+            const float *feat = kind ? surf : corner;
+            const hc_grid *G = kind ? gs : gc;
+            for (int q = 0; q < n; q++) {
+                const float *f = feat + 4 * q;
+                if (!(ll_isfinite(f[0]) && ll_isfinite(f[1]) && ll_isfinite(f[2]))) continue;
+                float pw[3];
+                point_to_map(pose_curr, f[0], f[1], f[2], pw);
+                Knn5 r;
+                knn5_search(G->g, pw[0], pw[1], pw[2], kind ? fp : fl, r);
+                if (r.count != 5) continue;
+                hc_blk b;
+                b.active = 1;
+                b.f[0] = f[0];
+                b.f[1] = f[1];
+                b.f[2] = f[2];
+                if (kind == 0) {
+                    if (!p->icp_line) continue;
+                    const f4 p0 = G->g.pts[r.pos[0]], p1 = G->g.pts[r.pos[1]];
+                    const double pa[3] = {p0.x, p0.y, p0.z}, pb[3] = {p1.x, p1.y, p1.z};
+                    if (!block_line(pose_last, pa, pb, b.a, b.v)) continue;
+                    b.kind = BLK_LINE;
+                    blk.push_back(b);
+                    corner_avail++;
+                } else {
+                    if (p->icp_plane) {
+                        const f4 p0 = G->g.pts[r.pos[0]], p1 = G->g.pts[r.pos[2]], p2 = G->g.pts[r.pos[4]];
+                        const double pa[3] = {p0.x, p0.y, p0.z}, pb[3] = {p1.x, p1.y, p1.z}, pc[3] = {p2.x, p2.y, p2.z};
+                        if (!block_plane(pose_last, pa, pb, pc, b.a, b.v)) continue;
+                        b.kind = BLK_PLANE;
+                        blk.push_back(b);
+                    }
+                    surf_avail++;
+                }
+            }
+        }
+        LmCtl c;
+        lm_run(blk, inc, p->ceres_prerun_times, p->bound, p->huber_a, c);
+        int lm_iters = c.iteration;
+        // L1 + std::set threshold
+        {
+            double R[9], t[3] = {c.x[4], c.x[5], c.x[6]};
+            quat_to_mat(c.x, R);
+            std::vector<double> l1(blk.size());
+            for (size_t i = 0; i < blk.size(); i++) l1[i] = block_l1(blk[i].kind, R, t, blk[i].f, blk[i].a, blk[i].v, p->huber_a, pose_last);
+            std::vector<double> u;
+            for (double v : l1)
+                if (v == v) u.push_back(v);
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            double thr = p->inliner_dis;
+            if (!u.empty()) {
+                int target = (int)(p->inlier_ratio * (double)u.size());
+                if (target > (int)u.size() - 1) target = (int)u.size() - 1;
+                thr = fmax(p->inliner_dis, u[target]);
+            }
+            inlier_thr = thr;
+            for (size_t i = 0; i < blk.size(); i++)
+                if (l1[i] > thr) blk[i].active = 0;
+        }
+        double xs[7];
+        for (int i = 0; i < 7; i++) xs[i] = c.x[i];
+        lm_run(blk, xs, p->ceres_max_iterations, p->bound, p->huber_a, c);
+        lm_iters += c.iteration;
+        n_blocks_last = 0;
+        for (const hc_blk &b : blk) n_blocks_last += b.active;
+        for (int i = 0; i < 7; i++) inc[i] = c.x[i];
+        double tw[3], qc[4];
+        quat_rot(pose_last, &inc[4], tw);
+        pose_curr[4] = tw[0] + pose_last[4];
+        pose_curr[5] = tw[1] + pose_last[5];
+        pose_curr[6] = tw[2] + pose_last[6];
+        quat_mul(pose_last, inc, qc);
+        for (int i = 0; i < 4; i++) pose_curr[i] = qc[i];
+        angular_diff = (double)((float)quat_angular_distance(qc, pose_last)) * 57.3;
+        const double dt[3] = {pose_curr[4] - pose_last[4], pose_curr[5] - pose_last[5], pose_curr[6] - pose_last[6]};
+        t_diff = sqrt(dot3(dt, dt));
+        final_cost = c.final_cost;
+        initial_cost = c.initial_cost;
+        lm_total += lm_iters;
+        icp_iters++;
+        const double dto[3] = {prev_t[0] - inc[4], prev_t[1] - inc[5], prev_t[2] - inc[6]};
+        const bool conv = quat_angular_distance(prev_q, inc) < 57.3 * p->minimum_icp_R_diff && sqrt(dot3(dto, dto)) < p->minimum_icp_T_diff;
+        if (conv && !p->force_all_iterations) break;
+        for (int i = 0; i < 4; i++) prev_q[i] = inc[i];
+        for (int i = 0; i < 3; i++) prev_t[i] = inc[4 + i];
+    }
+    int result = 1;
+    if (icp_iters > 0) {
+        inlier_thr = inlier_thr * final_cost / initial_cost;
+        if (angular_diff > (double)p->para_max_angular_rate || (float)final_cost > p->max_final_cost) {
+            for (int i = 0; i < 7; i++) pose_curr[i] = pose_last[i];
+            result = 0;
+        }
+    }
+    report[0] = final_cost;
+    report[1] = initial_cost;
+    report[2] = inlier_thr;
+    report[3] = icp_iters;
+    report[4] = n_blocks_last;
+    report[5] = corner_avail;
+    report[6] = surf_avail;
+    report[7] = lm_total;
+    return result;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+"""-m gpu: the HIP feature extractor (through the C ABI) against the CPU oracle.
+Integer artefacts (pt_type, pt_label, split indices, petal bookkeeping, corner/surface/full index sets) must be
+bit-exact; fp32 planes that do not pass through acosf/atan2f must be bit-exact too."""
+import numpy as np
+import pytest
+
+from loam_livox_amd import synth
+from loam_livox_amd.api import Livox_laser
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def compare_scan(dev: Livox_laser, xyzi, stamp_current_time, scan_slot=0, o=None):
+    o = o or orc.fe_extract(xyzi, stamp_current_time)
+    info = dev.pts_info(scan_slot)
+    assert np.array_equal(info["pt_type"], o.pt_type)
+    assert np.array_equal(info["pt_label"], o.pt_label)
+    assert np.array_equal(info["depth_sq2"], o.depth_sq2)
+    assert np.array_equal(info["polar_dis_sq2"], o.polar_dis_sq2, equal_nan=True)
+    assert np.array_equal(info["curvature"], o.curvature, equal_nan=True)
+    assert np.array_equal(info["time_stamp"], o.time_stamp)
+    # view angle goes through acosf: device = correctly rounded, host libm may differ by an ulp or two
+    assert np.allclose(info["view_angle"], o.view_angle, rtol=3e-6, atol=1e-5, equal_nan=True)
+    assert np.allclose(info["polar_angle"], o.polar_angle, rtol=1e-5, atol=1e-3)
+    sp = dev.splits(scan_slot)
+    assert np.array_equal(sp["split_idx"], o.split_idx)
+    assert sp["clutter_size"] == o.n_petals
+    S, first, last = orc.fe_split_scan(o)
+    assert sp["n_petal_clouds"] == S
+    assert np.array_equal(sp["first_idx"], first) and np.array_equal(sp["last_idx"], last)
+    return o, sp, (S, first, last)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_extract_and_select_match_oracle(gpu_lib, scans, k):
+    sc = scans[k]
+    dev = Livox_laser(max_points=24000, piecewise_number=3)
+    npc = dev.extract_laser_features(sc.xyzi, 100.0)  # first call: current_time = stamp + 1 (LFE:731 quirk)
+    o, sp, (S, first, last) = compare_scan(dev, sc.xyzi, 101.0)
+    assert npc == S
+    ps, pe = orc.fe_piecewise(o.n, first, last, 3)
+    assert np.array_equal(sp["piece_start"], ps) and np.array_equal(sp["piece_end"], pe)
+    for (lo, hi) in [(0.0, 0.3), (0.0, 1.0)] + list(zip(ps.tolist(), pe.tolist())):
+        ci, si, fi = orc.fe_get_features(o, lo, hi)
+        g = dev.get_features(lo, hi)
+        assert np.array_equal(g["corner_idx"], ci) and np.array_equal(g["surf_idx"], si) and np.array_equal(g["full_idx"], fi)
+        assert np.array_equal(g["pc_corners"], orc.feature_cloud(o, ci), equal_nan=True)
+        assert np.array_equal(g["pc_surface"], orc.feature_cloud(o, si), equal_nan=True)
+    dev.close()
+
+
+def test_sequential_time_base(gpu_lib, scans):
+    """the per-handle time base of Livox_laser (LFE:150-152,724-736)"""
+    dev = Livox_laser(max_points=24000)
+    tb = orc.Timebase()
+    L = orc.lib()
+    L.orc_fe_timebase_init(tb)
+    for stamp, sc in zip((50.0, 50.1, 50.05, 50.4), scans):
+        ct = L.orc_fe_timebase_next(tb, stamp)
+        o = orc.fe_extract(sc.xyzi, ct)
+        tb.last_maximum_time_stamp = o.last_time_stamp
+        dev.extract_laser_features(sc.xyzi, stamp)
+        assert np.array_equal(dev.pts_info()["time_stamp"], o.time_stamp)
+    dev.close()
+
+
+def test_edge_case_scans(gpu_lib):
+    rng = np.random.default_rng(11)
+    dev = Livox_laser(max_points=5000)
+    cases = []
+    n = 3000
+    p = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    p[:, 0] = rng.uniform(0.0, 6.0, n)
+    p[:, 3] = rng.uniform(0, 100, n)
+    p[rng.uniform(size=n) < 0.05, :3] = 0.0
+    p[rng.uniform(size=n) < 0.03, 0] = 0.0
+    p[rng.uniform(size=n) < 0.03, 1] = np.nan
+    p[rng.uniform(size=n) < 0.01, 2] = np.inf
+    p[0, :3] = 0.0
+    cases.append(p)
+    cases.append(np.zeros((700, 4), np.float32))                        # all (0,0,0)
+    cases.append(np.full((300, 4), np.nan, np.float32))                 # all NaN
+    for m in (1, 2, 4, 5, 6, 255, 256, 257, 1023, 1024, 1025):          # tile / chunk boundaries, tiny scans
+        cases.append(p[:m].copy())
+    for q in cases:
+        dev2 = Livox_laser(max_points=5000)
+        dev2.extract_laser_features(q, 7.0)
+        o = orc.fe_extract(q, 8.0)
+        compare_scan(dev2, q, 8.0, o=o)
+        ci, si, fi = orc.fe_get_features(o, 0.0, 1.0)
+        g = dev2.get_features(0.0, 1.0)
+        assert np.array_equal(g["corner_idx"], ci) and np.array_equal(g["surf_idx"], si) and np.array_equal(g["full_idx"], fi)
+        dev2.close()
+    dev.close()
+
+
+def test_empty_scan(gpu_lib):
+    dev = Livox_laser(max_points=100)
+    assert dev.extract_laser_features(np.zeros((0, 4), np.float32), 1.0) == 0
+    g = dev.get_features(0.0, 1.0)
+    assert len(g["corner_idx"]) == len(g["surf_idx"]) == len(g["full_idx"]) == 0
+    dev.close()
+
+
+def test_duplicate_points_use_first_occurrence(gpu_lib, scans):
+    """find_pt_info returns the first inserted point with equal xyz (LFE:478, LFX:321-322)"""
+    x = scans[0].xyzi.copy()
+    o0 = orc.fe_extract(x, 1.0)
+    S, first, last = orc.fe_split_scan(o0)
+    x[int(first[S // 3])] = x[5]  # the first point of a piece boundary petal duplicates an early point
+    x[int(last[S // 3 - 1])] = x[9]
+    dev = Livox_laser(max_points=24000, piecewise_number=3)
+    dev.extract_laser_features(x, 0.5)
+    o, sp, (S, first, last) = compare_scan(dev, x, 1.5)
+    ps, pe = orc.fe_piecewise(o.n, first, last, 3)
+    assert np.array_equal(sp["piece_start"], ps) and np.array_equal(sp["piece_end"], pe)
+    dev.close()
+
+
+def test_batch_equals_single_and_ragged_params(gpu_lib, scans):
+    B = 4
+    dev = Livox_laser(max_points=24000, max_scans=B, piecewise_number=1)
+    batch = np.stack([s.xyzi for s in scans])
+    ct = np.array([1.0, 2.5, 0.0, 7.25])
+    dev.upload(batch, ct)
+    dev.extract_batch(B)
+    dev.resolve()
+    dev.select_batch(B, piece=-1, minimum_blur=0.0, maximum_blur=1.0)
+    nc, ns, nf, _ = dev.counts(B)
+    for b in range(B):
+        o = orc.fe_extract(batch[b], ct[b])
+        compare_scan(dev, batch[b], ct[b], scan_slot=b, o=o)
+        ci, si, fi = orc.fe_get_features(o, 0.0, 1.0)
+        assert (nc[b], ns[b], nf[b]) == (len(ci), len(si), len(fi))
+    # piece window computed on the device (deblur-style single piece, LFX:305-323)
+    dev.select_batch(B, piece=0)
+    nc2, ns2, nf2, _ = dev.counts(B)
+    for b in range(B):
+        o = orc.fe_extract(batch[b], ct[b])
+        S, first, last = orc.fe_split_scan(o)
+        ps, pe = orc.fe_piecewise(o.n, first, last, 1)
+        ci, si, fi = orc.fe_get_features(o, float(ps[0]), float(pe[0]))
+        assert (nc2[b], ns2[b], nf2[b]) == (len(ci), len(si), len(fi))
+    dev.close()
+
+
+def test_alternative_thresholds(gpu_lib, scans):
+    """config/performance_precision.yaml thresholds (corner 0.1, surface 0.005, view angle 5)"""
+    prm = orc.FeParams(0.1, 0.005, 5.0, 0.1, 7e-4, 17.0, 1e-5)
+    dev = Livox_laser(max_points=24000, thr_corner_curvature=0.1, thr_surface_curvature=0.005, minimum_view_angle=5.0)
+    dev.extract_laser_features(scans[2].xyzi, 3.0)
+    o = orc.fe_extract(scans[2].xyzi, 4.0, prm)
+    assert np.array_equal(dev.pts_info()["pt_label"], o.pt_label)
+    dev.close()

@@ -1,0 +1,204 @@
+"""-m gpu: grid 5-NN and the registrar (through the C ABI) against the CPU oracle.
+Neighbour index lists must be identical; the final SE(3) pose must agree within 1e-4 m / 1e-4 rad
+(BASELINE.json north_star) -- in practice the agreement is ~1e-9."""
+import numpy as np
+import pytest
+
+from loam_livox_amd import capi, synth
+from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration
+from oracle import orc
+from tests.conftest import oracle_features
+
+pytestmark = pytest.mark.gpu
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev_map(gpu_lib, small_world):
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, small_world["corner"])
+    m.setInputCloud(Map_buffer.SURF, small_world["surf"])
+    yield m
+    m.close()
+
+
+def set_params(reg, icp=10, ceres=20, force=1):
+    p = reg.params
+    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = icp, ceres, force
+    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 100.0
+    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+    return p
+
+
+def test_knn5_identical_to_oracle(dev_map, small_world, scans):
+    for sc in scans[:2]:
+        _, _, _, _, fc, fs = oracle_features(sc)
+        qs = synth.transform_points(sc.pose_init, fs[:, :3])
+        oi, od = small_world["tree_s"].knn(qs, 5)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.SURF, qs, 50.0)
+        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
+        qc = synth.transform_points(sc.pose_init, fc[:, :3])
+        oi, od = small_world["tree_c"].knn(qc, 5)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.CORNER, qc, 2.0)
+        inside = od < 2.0
+        assert np.array_equal(np.where(inside, oi, -1), gi)
+        assert np.array_equal(np.where(inside, od, np.inf), gd)
+
+
+def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(0, 30, (4000, 3)).astype(np.float32)
+    pts[100:104] = pts[100]
+    pts[7, 0] = np.nan
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.SURF, pts, 0.7)
+    tree = orc.KdTree(np.where(np.isfinite(pts), pts, 1e9).astype(np.float32))
+    q = np.concatenate([rng.uniform(-8, 38, (500, 3)), pts[100:101], [[1e6, 0, 0]], [[np.nan, 0, 0]]]).astype(np.float32)
+    gi, gd = m.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    oi, od = tree.knn(np.nan_to_num(q, nan=1e9), 5)
+    inside = od < 50.0
+    assert np.array_equal(np.where(inside, oi, -1)[:-2], gi[:-2])
+    assert np.all(gi[-2:] == -1)
+    assert gi[500].tolist()[:4] == [100, 101, 102, 103]
+    # xyzi stride-4 input gives the same answer
+    m2 = Map_buffer()
+    m2.setInputCloud(Map_buffer.SURF, np.c_[pts, np.ones(len(pts), np.float32)], 0.7)
+    gi2, _ = m2.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    assert np.array_equal(gi, gi2)
+    m.close(); m2.close()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("force", [0, 1])
+def test_registration_matches_oracle(dev_map, small_world, scans, k, force):
+    sc = scans[k]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(True)
+    set_params(reg, 10, 20, force)
+    reg.m_pose_w_last = sc.pose_init.copy()
+    reg.m_pose_w_curr = sc.pose_init.copy()
+    gret = reg.find_out_incremental_transfrom(dev_map, fc, fs)
+    dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+    assert gret == ret
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    assert dt < 1e-7 and dr < 1e-7  # what we actually expect from identical algorithms in fp64
+    g = reg.report
+    assert g.icp_iterations == rep.icp_iterations and g.n_blocks_last == rep.n_blocks_last
+    assert g.corner_avail == rep.corner_avail and g.surf_avail == rep.surf_avail
+    assert g.lm_iterations_total == rep.lm_iterations_total
+    assert np.isclose(g.final_cost, rep.final_cost, rtol=1e-8) and np.isclose(g.initial_cost, rep.initial_cost, rtol=1e-8)
+    assert np.isclose(g.inlier_threshold, rep.inlier_threshold, rtol=1e-8)
+    assert np.isclose(g.angular_diff_deg, rep.angular_diff_deg, atol=1e-6) and np.isclose(g.t_diff, rep.t_diff, atol=1e-8)
+    # neighbour lists of the first ICP iteration are identical (inside the match radius)
+    ci, cd, si, sd = reg.debug_knn(0, len(fc), len(fs))
+    qs = synth.transform_points(sc.pose_init, fs[:, :3])
+    oi, od = small_world["tree_s"].knn(qs, 5)
+    assert np.array_equal(oi, si) and np.array_equal(od, sd)
+    qc = synth.transform_points(sc.pose_init, fc[:, :3])
+    oi, od = small_world["tree_c"].knn(qc, 5)
+    inside = od < 2.0
+    assert np.array_equal(np.where(inside, oi, -1), ci)
+    reg.close()
+
+
+def test_reject_gate_and_bounds(dev_map, small_world, scans):
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    reg = Point_cloud_registration()
+    p = set_params(reg, 3, 20, 0)
+    p.max_final_cost = 1e-6
+    reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+    assert reg.find_out_incremental_transfrom(dev_map, fc, fs) == 0          # PCR:561-573
+    assert np.array_equal(reg.m_pose_w_curr, sc.pose_init) and reg.report.accepted == 0
+    p = set_params(reg, 3, 20, 0)
+    p.current_frame_index = 10                                                # PCR:199 gate
+    reg.m_pose_w_curr = sc.pose_init.copy(); reg.m_para_buffer_incremental = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    assert reg.find_out_incremental_transfrom(dev_map, fc, fs) == 1 and reg.report.gated == 1
+    assert np.array_equal(reg.m_pose_w_curr, sc.pose_init)
+    p = set_params(reg, 2, 20, 0)
+    p.para_max_speed = 0.01                                                   # PCR:143-151
+    prm = orc.RegParams.defaults(icp_iters=2); prm.para_max_speed = 0.01
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    reg.m_pose_w_curr = sc.pose_init.copy(); reg.m_para_buffer_incremental = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    reg.find_out_incremental_transfrom(dev_map, fc, fs)
+    assert np.all(np.abs(reg.m_para_buffer_incremental[4:]) <= 0.01 + 1e-15)
+    dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+    assert dt < 1e-7 and dr < 1e-7
+    reg.close()
+
+
+def test_empty_and_nonfinite_features(dev_map, scans):
+    sc = scans[0]
+    reg = Point_cloud_registration(max_features=1000)
+    set_params(reg, 2, 5, 0)
+    reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+    empty = np.zeros((0, 4), np.float32)
+    assert reg.find_out_incremental_transfrom(dev_map, empty, empty) == 1
+    assert np.allclose(reg.m_pose_w_curr, sc.pose_init, atol=1e-15) and reg.report.n_blocks_last == 0
+    bad = np.full((10, 4), np.nan, np.float32)
+    assert reg.find_out_incremental_transfrom(dev_map, bad, bad) == 1 and reg.report.surf_avail == 0
+    reg.close()
+
+
+def test_batch_pipeline_equals_single_calls(dev_map, small_world, scans):
+    """extractor -> device-resident selection -> batched registration == oracle per scan"""
+    B = 4
+    fe = Livox_laser(max_points=24000, max_scans=B, piecewise_number=1)
+    batch = np.stack([s.xyzi for s in scans])
+    ct = np.full(B, 1.0)
+    fe.upload(batch, ct)
+    fe.extract_batch(B); fe.resolve(); fe.select_batch(B, -1, 0.0, 1.0)
+    reg = Point_cloud_registration(max_scans=B, max_features=24000)
+    set_params(reg, 10, 20, 1)
+    init = np.stack([s.pose_init for s in scans])
+    res, pc, pi, reps = reg.solve_batch_fe(dev_map, fe, B, init, init)
+    for b, sc in enumerate(scans):
+        _, _, _, _, fc, fs = oracle_features(sc)
+        prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=1)
+        ret, opc, opi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+        dt, dr = synth.pose_error(pc[b], opc)
+        assert res[b] == ret and dt < 1e-7 and dr < 1e-7
+        assert reps[b].n_blocks_last == rep.n_blocks_last and reps[b].lm_iterations_total == rep.lm_iterations_total
+    # host-feature batch entry point gives the same poses
+    feats = [oracle_features(sc)[4:] for sc in scans]
+    res2, pc2, _, _ = reg.solve_batch(dev_map, [f[0] for f in feats], [f[1] for f in feats], init, init)
+    assert np.array_equal(res, res2) and np.allclose(pc, pc2, atol=1e-12)
+    fe.close(); reg.close()
+
+
+def test_run_to_run_determinism(dev_map, scans):
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    outs = []
+    for _ in range(3):
+        reg = Point_cloud_registration()
+        set_params(reg, 5, 20, 1)
+        reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+        reg.find_out_incremental_transfrom(dev_map, fc, fs)
+        outs.append(reg.m_pose_w_curr.copy())
+        reg.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_cloud_transform_bit_exact(gpu_lib):
+    rng = np.random.default_rng(4)
+    pose = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), 1.1), 100.0, -50.0, 2.0]
+    pts = rng.uniform(-40, 40, (5000, 4)).astype(np.float32)
+    reg = Point_cloud_registration(max_features=16)
+    out = reg.pointcloudAssociateToMap(pts, pose)
+    assert np.array_equal(out, orc.cloud_transform(pose, pts))  # PCR:629,656-659
+    reg.close()
+
+
+def test_errors_are_reported_not_fatal(gpu_lib, dev_map):
+    reg = Point_cloud_registration(max_features=10)
+    reg.params.if_motion_deblur = 1
+    with pytest.raises(capi.LoamLivoxError):
+        reg.find_out_incremental_transfrom(dev_map, np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32))
+    reg.params.if_motion_deblur = 0
+    with pytest.raises(capi.LoamLivoxError):
+        reg.find_out_incremental_transfrom(dev_map, np.zeros((11, 4), np.float32), np.zeros((1, 4), np.float32))
+    reg.close()

@@ -1,0 +1,145 @@
+"""No-GPU tier: the device math headers (loam_livox_amd/csrc/ll_*_core.h), compiled for the host by
+tests/hostcheck, against the oracle.  This checks the arithmetic the kernels execute per thread; the kernels
+themselves (launch geometry, LDS, reductions, compaction) are checked by the -m gpu tests."""
+import numpy as np
+import pytest
+
+from loam_livox_amd import synth
+from oracle import orc
+from tests.conftest import oracle_features
+from tests.hostcheck import hc
+
+
+def hc_fe_params():
+    p = orc.FeParams.node_defaults()
+    return hc.FeParams(*[getattr(p, f[0]) for f in p._fields_])
+
+
+def hc_reg_params(icp=10, ceres=20, force=1, bound=0.3, max_cost=100.0):
+    return hc.RegParams(0, icp, ceres, 2, 1, 1, force, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, bound, 20.0, max_cost, 0.0, 1.0)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_point_math_bit_exact(scans, k):
+    sc = scans[k]
+    fe = orc.fe_extract(sc.xyzi, 1.0)
+    h = hc.fe_points(sc.xyzi, 1.0, hc_fe_params())
+    assert np.array_equal(h["type"], fe.pt_type)
+    assert np.array_equal(h["label"], fe.pt_label)
+    assert np.array_equal(h["depth2"], fe.depth_sq2)
+    assert np.array_equal(h["curv"], fe.curvature)
+    assert np.array_equal(h["view"], fe.view_angle)
+    assert np.array_equal(h["tstamp"], fe.time_stamp)
+    for (lo, hi) in ((0.0, 1.0), (0.0, 0.3), (0.31, 0.67)):
+        o = orc.fe_get_features(fe, lo, hi)
+        d = hc.select(h["type"], h["label"], h["depth2"], lo, hi)
+        assert all(np.array_equal(a, b) for a, b in zip(o, d))
+
+
+def test_point_math_edge_cases():
+    rng = np.random.default_rng(11)
+    n = 3000
+    p = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    p[:, 0] = rng.uniform(0.0, 6.0, n)
+    p[:, 3] = rng.uniform(0, 100, n)
+    p[rng.uniform(size=n) < 0.05, :3] = 0.0
+    p[rng.uniform(size=n) < 0.03, 0] = 0.0          # x == 0 but y,z != 0
+    p[rng.uniform(size=n) < 0.03, 1] = np.nan
+    p[rng.uniform(size=n) < 0.01, 2] = np.inf
+    p[0, :3] = 0.0                                    # first point zero: division by zero path (LFE:495-504)
+    fe = orc.fe_extract(p, 3.0)
+    h = hc.fe_points(p, 3.0, hc_fe_params())
+    assert np.array_equal(h["type"], fe.pt_type) and np.array_equal(h["label"], fe.pt_label)
+    assert np.array_equal(h["curv"], fe.curvature, equal_nan=True)
+
+
+def test_grid_knn_identical_to_kdtree(small_world, scans):
+    gs, gc = hc.Grid(small_world["surf"], 1.0), hc.Grid(small_world["corner"], 0.5)
+    for sc in scans[:2]:
+        _, _, _, _, fc, fs = oracle_features(sc)
+        qs = synth.transform_points(sc.pose_init, fs[::7, :3])
+        oi, od = small_world["tree_s"].knn(qs, 5)
+        hi, hd = gs.knn5(qs, 50.0)
+        assert np.array_equal(oi, hi) and np.array_equal(od, hd)
+        qc = synth.transform_points(sc.pose_init, fc[:, :3])
+        oi, od = small_world["tree_c"].knn(qc, 5)
+        hi, hd = gc.knn5(qc, 2.0)
+        # within the match radius the lists are identical; beyond it entries are -1/inf (never used: PCR:254)
+        inside = od < 2.0
+        assert np.array_equal(np.where(inside, oi, -1), hi)
+        assert np.array_equal(np.where(inside, od, np.inf), hd)
+
+
+def test_grid_knn_sparse_outside_and_ties():
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(0, 30, (4000, 3)).astype(np.float32)
+    pts[100:104] = pts[100]                      # exact duplicates -> ties by index
+    pts[7, 0] = np.nan                           # non-finite map point is ignored
+    tree = orc.KdTree(np.where(np.isfinite(pts), pts, 1e9).astype(np.float32))
+    g = hc.Grid(pts, 0.7)
+    q = np.concatenate([rng.uniform(-8, 38, (500, 3)), pts[100:101], [[1e6, 0, 0]], [[np.nan, 0, 0]]]).astype(np.float32)
+    hi, hd = g.knn5(q, 50.0)
+    oi, od = tree.knn(np.nan_to_num(q, nan=1e9), 5)
+    inside = od < 50.0
+    assert np.array_equal(np.where(inside, oi, -1)[:-2], hi[:-2])
+    assert np.all(hi[-2:] == -1)
+    assert hi[500].tolist()[:4] == [100, 101, 102, 103]
+
+
+def test_analytic_gauss_newton_matches_jets():
+    rng = np.random.default_rng(9)
+    pose_last = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), 0.8), rng.uniform(-50, 50, 3)]
+    x = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), 0.03), rng.uniform(-0.1, 0.1, 3)]
+    oblocks, kind, F, A, V = [], [], [], [], []
+    for i in range(200):
+        f = rng.uniform(-8, 8, 3)
+        pw = synth.quat_to_mat(pose_last[:4]) @ f + pose_last[4:]
+        a = pw + rng.normal(0, 0.04 if i % 4 else 0.4, 3)
+        b, c = a + rng.normal(size=3), a + rng.normal(size=3)
+        if i % 2:
+            oblocks.append(orc.make_block_line(f, a, b))
+            ok, aa, vv = hc.make_block(1, pose_last, a, b)
+        else:
+            oblocks.append(orc.make_block_plane(f, a, b, c))
+            ok, aa, vv = hc.make_block(2, pose_last, a, b, c)
+        assert ok
+        kind.append(1 if i % 2 else 2)
+        F.append(f); A.append(aa); V.append(vv)
+    oc, og, oH = orc.blocks_eval(oblocks, pose_last, x)
+    hc_c, hg, hH = hc.eval_blocks(kind, np.array(F), np.array(A), np.array(V), x)
+    assert np.isclose(oc, hc_c, rtol=1e-12)
+    assert np.allclose(og, hg, rtol=1e-9, atol=1e-12)
+    assert np.allclose(oH, hH, rtol=1e-9, atol=1e-10)
+
+
+def test_degenerate_blocks_are_skipped():
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], float)
+    assert hc.make_block(1, ident, [1, 1, 1], [1, 1, 1 + 5e-5])[0] == 0      # |a-b| < 1e-4 (PCR:302)
+    assert hc.make_block(2, ident, [1, 1, 1], [1, 1, 1], [2, 2, 2])[0] == 0  # a == b: NaN normal in the reference
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_full_registration_matches_oracle(small_world, scans, k):
+    sc = scans[k]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 1.0)
+    for force in (0, 1):
+        prm = orc.RegParams.defaults(icp_iters=6, ceres_iters=20, force_all=force)
+        ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+        hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hc_reg_params(6, 20, force), sc.pose_init, sc.pose_init)
+        dt, dr = synth.pose_error(pc, hpc)
+        assert ret == hret and dt < 1e-9 and dr < 1e-9
+        assert rep.icp_iterations == hrep[3] and rep.n_blocks_last == hrep[4]
+        assert rep.corner_avail == hrep[5] and rep.surf_avail == hrep[6] and rep.lm_iterations_total == hrep[7]
+        assert np.isclose(rep.final_cost, hrep[0], rtol=1e-9) and np.isclose(rep.inlier_threshold, hrep[2], rtol=1e-9)
+
+
+def test_rejection_matches_oracle(small_world, scans):
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 1.0)
+    prm = orc.RegParams.defaults(icp_iters=2)
+    prm.max_final_cost = 1e-6
+    ret, pc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    hret, hpc, _, _ = hc.reg_solve(gc, gs, fc, fs, hc_reg_params(2, 20, 0, 0.3, 1e-6), sc.pose_init, sc.pose_init)
+    assert ret == hret == 0 and np.array_equal(pc, hpc)
