@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on one node: scans/s of the scan-to-map hot path.
+
+Workload (BASELINE config C2): 24 000-point synthetic Livox Mid-40 scans against a fixed 5 M-point
+corner+surface map, 10 ICP iterations (convergence break disabled), k = 5, fp32 points; every extracted
+feature is a query ("Q-full": maximum_residual_blocks >= feature count, no random sub-sampling).
+
+One "step" = one pass of the hot path over one batch of B independent scans that are already resident in HBM:
+feature extraction (K1-K4) -> selection (K3) -> per ICP iteration {transform + 5-NN + block build (K6),
+prerun solve + inlier prune + final solve (K8/K9)} -> accept/reject.  Scans are independent units (the
+reference's maximum_parallel_thread model, laser_mapping.hpp:1737-1742), so N GPUs run N independent shards
+with no data-path collective ("weak" scaling); value = scans processed by all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="independent scans per step and per GPU")
+    ap.add_argument("--map-points", type=int, default=5_000_000)
+    ap.add_argument("--scan-points", type=int, default=24000)
+    ap.add_argument("--icp-iters", type=int, default=10)
+    ap.add_argument("--distinct-scans", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scans", type=int, default=3)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist = dist_mod
+    dev = local_rank if torch.cuda.is_available() else 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
+    torch.cuda.set_device(dev)
+
+    from loam_livox_amd import synth
+    from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration
+
+    B, N = args.batch, args.scan_points
+    t0 = time.time()
+    world_model, corner, surf = synth.make_maps(args.map_points)
+    n_distinct = min(args.distinct_scans, B)
+    base = [synth.make_scan(world_model, 100 * rank + k, n=N) for k in range(n_distinct)]
+    rng = np.random.default_rng(4242 + rank)
+    scans = np.stack([base[b % n_distinct].xyzi for b in range(B)])
+    poses_true = np.stack([base[b % n_distinct].pose_true for b in range(B)])
+    # every slot gets its own initial-guess perturbation: distinct work per slot
+    init = np.stack([
+        synth.pose_compose(poses_true[b], np.r_[synth.quat_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0, 1.0))),
+                                                 rng.uniform(-0.1, 0.1, 3)]) for b in range(B)])
+    t_data = time.time() - t0
+
+    mp = Map_buffer(device=dev)
+    t0 = time.time()
+    mp.setInputCloud(Map_buffer.CORNER, corner)
+    mp.setInputCloud(Map_buffer.SURF, surf)
+    t_map = time.time() - t0
+    fe = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
+    fe.upload(scans, np.full(B, 1.0))
+    reg = Point_cloud_registration(max_scans=B, max_features=N, device=dev)
+    p = reg.params
+    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = args.icp_iters, 20, 1
+    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
+    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+    p.maximum_allow_residual_block = N
+    reg.set_profiling(True)
+
+    def step():
+        fe.extract_batch(B)
+        fe.resolve()
+        fe.select_batch(B, -1, 0.0, 1.0)
+        reg.enqueue_fe(mp, fe, B, init, init)
+        return reg.collect(B)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    k_ms = np.zeros(3)
+    k_n = np.zeros(3)
+    out = None
+    for _ in range(args.steps):
+        out = step()
+        ms, n = reg.kernel_times()
+        k_ms += ms
+        k_n += n
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res, pc, pi, reps = out
+    nc, ns, nf, n_amb = fe.counts(B)
+    total_scans = B * args.steps * world
+    value = total_scans / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # single-scan latency (batch of 1 through the same code path)
+    lat = []
+    fe1 = Livox_laser(max_points=N, max_scans=1, device=dev, piecewise_number=1)
+    fe1.upload(scans[:1], np.full(1, 1.0))
+    reg1 = Point_cloud_registration(max_scans=1, max_features=N, device=dev)
+    for f_ in ("icp_max_iterations", "ceres_max_iterations", "force_all_iterations", "para_max_angular_rate", "para_max_speed",
+               "max_final_cost", "current_frame_index", "mapping_init_accumulate_frames", "maximum_allow_residual_block"):
+        setattr(reg1.params, f_, getattr(p, f_))
+    for i in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fe1.extract_batch(1); fe1.resolve(); fe1.select_batch(1, -1, 0.0, 1.0)
+        reg1.enqueue_fe(mp, fe1, 1, init[:1], init[:1]); reg1.collect(1)
+        lat.append(time.perf_counter() - t1)
+    latency_ms = 1e3 * float(np.median(lat[1:]))
+
+    # roofline of the dominant kernel (HIP events on the registrar's stream, see ll_reg_set_profiling)
+    names = ["reg_knn_build_kernel", "reg_solve_kernel", "reg_finalize_kernel"]
+    dom = int(np.argmax(k_ms))
+    avg_ms = float(k_ms[dom] / max(1.0, k_n[dom]))
+    blocks = float(sum(r.corner_avail + r.surf_avail for r in reps))
+    queries = float(nc.sum() + ns.sum())
+    if dom == 1:
+        # algorithmic bytes of one solver launch: every residual block's constants read once (16 B point + 48 B
+        # a',v' + 1 B flag) + the 28 reduced doubles per scan (DESIGN.md "roofline")
+        alg_bytes = blocks * 65.0 + B * 224.0
+    else:
+        # k-NN + block build launch: 16 B/query in, 65 B/block out (candidate gather is cache-resident)
+        alg_bytes = queries * 16.0 + blocks * 65.0
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes)}
+
+    result = {
+        "metric": "scans_per_s", "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 points / f64 solve", "data": "synthetic",
+        "config": {"workload": "C2: 24k-pt Mid-40 scan vs 5M-pt corner+surface map, 10 ICP iters (fixed), k=5, Q-full",
+                   "scan_points": N, "map_points": int(len(corner) + len(surf)), "map_corner": int(len(corner)),
+                   "map_surf": int(len(surf)), "icp_iters": args.icp_iters, "batch_scans_per_step_per_gpu": B,
+                   "parallelism": f"replicas x{world} (independent scans, no data-path collective)"},
+        "roofline": roofline,
+        "kernel_ms_per_step": {names[i]: round(float(k_ms[i] / args.steps), 3) for i in range(3)},
+        "per_iter_knn_jtj_ms_per_batch": round(float((k_ms[0] + k_ms[1]) / args.steps / max(1, args.icp_iters)), 4),
+        "single_scan_latency_ms": round(latency_ms, 3),
+        "features_per_scan": {"corner": float(nc.mean()), "surface": float(ns.mean())},
+        "accepted_frac": float(np.mean(res)), "lm_iters_per_scan": float(np.mean([r.lm_iterations_total for r in reps])),
+        "ambiguous_labels": int(n_amb), "setup_s": {"synthetic_data": round(t_data, 1), "map_upload_grid_build": round(t_map, 2)},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (C restatement of the reference algorithm; the reference binary cannot be built
+        # here) on one host core, bounded sample of the same workload.  It is the checker, never the product.
+        from oracle import orc
+        tb = time.perf_counter()
+        tc, ts = orc.KdTree(corner), orc.KdTree(surf)
+        t_tree = time.perf_counter() - tb
+        prm = orc.RegParams.defaults(icp_iters=args.icp_iters, ceres_iters=20, force_all=1)
+        prm.max_final_cost = 1000.0
+        t_cpu, errs, same_sets = 0.0, [], True
+        n_cpu = min(args.cpu_scans, B)
+        for b in range(n_cpu):
+            tb = time.perf_counter()
+            o = orc.fe_extract(scans[b], 1.0)
+            ci, si, fi = orc.fe_get_features(o, 0.0, 1.0)
+            ret, opc, _, orep = orc.reg_solve(tc, ts, orc.feature_cloud(o, ci), orc.feature_cloud(o, si), prm, init[b], init[b])
+            t_cpu += time.perf_counter() - tb
+            errs.append(synth.pose_error(pc[b], opc))
+            same_sets &= (len(ci) == nc[b] and len(si) == ns[b])
+        result["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 4), "unit": "scans/s", "cores": 1, "kind": "port",
+                                  "sample": f"{n_cpu} of the {B} scans of one step (extract + {args.icp_iters} ICP iters each) "
+                                            f"vs the same {len(corner) + len(surf)}-pt map; k-d tree build {t_tree:.1f}s excluded",
+                                  "host_cores_available": os.cpu_count()}
+        result["parity_vs_cpu"] = {"max_pose_err_m": float(max(e[0] for e in errs)), "max_pose_err_rad": float(max(e[1] for e in errs)),
+                                   "feature_counts_identical": bool(same_sets)}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

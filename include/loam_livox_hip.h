@@ -71,8 +71,8 @@ int ll_fe_labels(ll_fe *h, int32_t scan, int32_t *pt_type, int32_t *pt_label, fl
 
 /* split bookkeeping of scan slot `scan`: split_idx (livox_feature_extractor.hpp:465-565; capacity
  * max_points/50+8), the return value of projection_scan_3d_2d (:606), and for every surviving petal cloud the
- * index of its first/last point (what laser_feature_extractor.hpp:321-322 reads through find_pt_info),
- * plus the piece-wise windows of laser_feature_extractor.hpp:305-323 (piecewise_number entries). */
+ * index of its first/last point, plus the piece-wise windows of laser_feature_extractor.hpp:305-323
+ * (piecewise_number entries; boundary points go through find_pt_info's first-occurrence lookup, :321-322). */
 int ll_fe_splits(ll_fe *h, int32_t scan, int32_t *split_idx, int32_t *n_split, int32_t *clutter_size,
                  int32_t *n_petal_clouds, int32_t *first_idx, int32_t *last_idx, float *piece_start, float *piece_end);
 

@@ -107,13 +107,14 @@ void orc_fe_get_features(int n, const int32_t *pt_type, const int32_t *pt_label,
                          int32_t *full_idx, int32_t *n_full);
 
 /* split_laser_scan (LFE:657-719): returns the number of surviving petal clouds S; for each, the index of its
- * first and last surviving point (what LFX:317-322 looks up through find_pt_info).
+ * first and last surviving point (the points LFX:317-322 then looks up through find_pt_info).
  * clutter_size is the value returned by orc_fe_extract. first_idx/last_idx have capacity clutter_size. */
 int orc_fe_split_scan(int n, int clutter_size, const float *xyzi, const int32_t *pt_type,
                       const float *polar_angle, int32_t *first_idx, int32_t *last_idx);
 
-/* piece-wise windows (LFX:305-323): start/end blur for each of `pieces` windows. */
-void orc_fe_piecewise(int n, int n_petal_clouds, const int32_t *first_idx, const int32_t *last_idx,
+/* piece-wise windows (LFX:305-323): start/end blur for each of `pieces` windows (boundary points resolved
+ * through the first-occurrence semantics of find_pt_info). */
+void orc_fe_piecewise(int n, const float *xyzi, int n_petal_clouds, const int32_t *first_idx, const int32_t *last_idx,
                       int pieces, float *piece_start, float *piece_end);
 
 /* ---------------- k-NN (PCL KdTreeFLANN restatement) ---------------- */

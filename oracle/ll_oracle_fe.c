@@ -335,8 +335,8 @@ int orc_fe_split_scan(int n, int clutter_size, const float *xyzi, const int32_t 
             }
         }
         if (first >= 0) { /* empty petals are dropped, LFE:713-716 */
-            first_idx[out] = first_occurrence(xyzi, first);
-            last_idx[out] = first_occurrence(xyzi, last);
+            first_idx[out] = first;
+            last_idx[out] = last;
             out++;
         }
     }
@@ -344,15 +344,16 @@ int orc_fe_split_scan(int n, int clutter_size, const float *xyzi, const int32_t 
     return out;
 }
 
-/* LFX:305-323 */
-void orc_fe_piecewise(int n, int n_petal_clouds, const int32_t *first_idx, const int32_t *last_idx,
+/* LFX:305-323.  find_pt_info (LFE:206-217) looks the boundary points up by xyz: a point that duplicates an
+ * earlier one resolves to the EARLIER index (the unordered_map keeps the first insertion, LFE:478). */
+void orc_fe_piecewise(int n, const float *xyzi, int n_petal_clouds, const int32_t *first_idx, const int32_t *last_idx,
                       int pieces, float *piece_start, float *piece_end)
 {
     int m_laser_scan_number = n_petal_clouds; /* LFX:90,292: int member */
     for (int i = 0; i < pieces; i++) {
         int start_scans = (m_laser_scan_number * (i)) / pieces; /* integer division, LFX:317-318 */
         int end_scans = (m_laser_scan_number * (i + 1)) / pieces - 1;
-        piece_start[i] = ((float)first_idx[start_scans]) / n; /* float / size_t -> float */
-        piece_end[i] = ((float)last_idx[end_scans]) / n;
+        piece_start[i] = ((float)first_occurrence(xyzi, first_idx[start_scans])) / n; /* float / size_t -> float */
+        piece_end[i] = ((float)first_occurrence(xyzi, last_idx[end_scans])) / n;
     }
 }

@@ -90,7 +90,7 @@ def lib():
         L.orc_fe_get_features.argtypes = [C.c_int, ip, ip, fp, C.c_float, C.c_float, ip, ip, ip, ip, ip, ip]
         L.orc_fe_split_scan.argtypes = [C.c_int, C.c_int, fp, ip, fp, ip, ip]
         L.orc_fe_split_scan.restype = C.c_int
-        L.orc_fe_piecewise.argtypes = [C.c_int, C.c_int, ip, ip, C.c_int, fp, fp]
+        L.orc_fe_piecewise.argtypes = [C.c_int, fp, C.c_int, ip, ip, C.c_int, fp, fp]
         L.orc_kdtree_build.argtypes = [fp, C.c_int, C.c_int64]
         L.orc_kdtree_build.restype = C.c_void_p
         L.orc_kdtree_free.argtypes = [C.c_void_p]
@@ -176,12 +176,14 @@ def fe_split_scan(r: FeResult):
     return s, first[:s].copy(), last[:s].copy()
 
 
-def fe_piecewise(n, first, last, pieces):
+def fe_piecewise(r, first, last, pieces):
+    # r: FeResult (its xyzi feeds the find_pt_info first-occurrence lookup)
     L = lib()
+    n = r.n
     ps, pe = np.zeros(pieces, np.float32), np.zeros(pieces, np.float32)
     first = np.ascontiguousarray(first, np.int32)
     last = np.ascontiguousarray(last, np.int32)
-    L.orc_fe_piecewise(n, len(first), _ip(first), _ip(last), pieces, _fp(ps), _fp(pe))
+    L.orc_fe_piecewise(n, _fp(r.xyzi), len(first), _ip(first), _ip(last), pieces, _fp(ps), _fp(pe))
     return ps, pe
 
 

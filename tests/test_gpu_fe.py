@@ -39,7 +39,7 @@ def test_extract_and_select_match_oracle(gpu_lib, scans, k):
     npc = dev.extract_laser_features(sc.xyzi, 100.0)  # first call: current_time = stamp + 1 (LFE:731 quirk)
     o, sp, (S, first, last) = compare_scan(dev, sc.xyzi, 101.0)
     assert npc == S
-    ps, pe = orc.fe_piecewise(o.n, first, last, 3)
+    ps, pe = orc.fe_piecewise(o, first, last, 3)
     assert np.array_equal(sp["piece_start"], ps) and np.array_equal(sp["piece_end"], pe)
     for (lo, hi) in [(0.0, 0.3), (0.0, 1.0)] + list(zip(ps.tolist(), pe.tolist())):
         ci, si, fi = orc.fe_get_features(o, lo, hi)
@@ -113,7 +113,7 @@ def test_duplicate_points_use_first_occurrence(gpu_lib, scans):
     dev = Livox_laser(max_points=24000, piecewise_number=3)
     dev.extract_laser_features(x, 0.5)
     o, sp, (S, first, last) = compare_scan(dev, x, 1.5)
-    ps, pe = orc.fe_piecewise(o.n, first, last, 3)
+    ps, pe = orc.fe_piecewise(o, first, last, 3)
     assert np.array_equal(sp["piece_start"], ps) and np.array_equal(sp["piece_end"], pe)
     dev.close()
 
@@ -139,7 +139,7 @@ def test_batch_equals_single_and_ragged_params(gpu_lib, scans):
     for b in range(B):
         o = orc.fe_extract(batch[b], ct[b])
         S, first, last = orc.fe_split_scan(o)
-        ps, pe = orc.fe_piecewise(o.n, first, last, 1)
+        ps, pe = orc.fe_piecewise(o, first, last, 1)
         ci, si, fi = orc.fe_get_features(o, float(ps[0]), float(pe[0]))
         assert (nc2[b], ns2[b], nf2[b]) == (len(ci), len(si), len(fi))
     dev.close()

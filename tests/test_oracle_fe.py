@@ -170,7 +170,7 @@ def test_petal_split_and_windows(scans):
     S, first, last = orc.fe_split_scan(r)
     assert 0 < S <= r.n_petals - 1      # last petal dropped (LFE:681), empty ones removed
     assert np.all(first <= last) and np.all(np.diff(first) > 0)
-    ps, pe = orc.fe_piecewise(r.n, first, last, 3)
+    ps, pe = orc.fe_piecewise(r, first, last, 3)
     assert ps[0] == np.float32(first[0]) / r.n and pe[2] == np.float32(last[-1]) / r.n
     assert np.all(ps <= pe) and np.all(ps[1:] > pe[:-1])
 
