@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--scan-points", type=int, default=24000)
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--distinct-scans", type=int, default=16)
+    ap.add_argument("--cell-corner", type=float, default=0.0, help="grid cell size override (0 = library default)")
+    ap.add_argument("--cell-surf", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
     return ap.parse_args()
@@ -81,8 +83,8 @@ def main():
 
     mp = Map_buffer(device=dev)
     t0 = time.time()
-    mp.setInputCloud(Map_buffer.CORNER, corner)
-    mp.setInputCloud(Map_buffer.SURF, surf)
+    mp.setInputCloud(Map_buffer.CORNER, corner, args.cell_corner)
+    mp.setInputCloud(Map_buffer.SURF, surf, args.cell_surf)
     t_map = time.time() - t0
     fe = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
     fe.upload(scans, np.full(B, 1.0))

@@ -529,6 +529,7 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(d.blk_f, B * d.cap);
     DM(d.blk_av, B * 6 * d.cap);
     DM(d.blk_flag, B * d.cap);
+    DM(d.nn, B * d.cap);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -547,7 +548,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -113,9 +113,14 @@ LL_HD void scan_run(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of o
 }
 
 // Exact 5-NN of (qx,qy,qz) among points with squared distance < max_d2.
-// Ring k visits the shell of cells at Chebyshev distance k from the query's cell.  After ring k every unvisited
-// point is farther than  bound_k = k*h + m  (m = distance from the query to the nearest wall of its own cell),
-// so the search stops once the 5th best is inside that bound, or the bound passes the match radius.
+//
+// Phase 1 visits the 3x3x3 block of cells around the query as nine x-runs, nearest run first, and prunes with the
+// running 5th-best distance: a run (or its outer cells) whose box is farther than the current 5th best cannot
+// contribute.  Box distances are shrunk by `slack` so that fp32 rounding of the cell assignment can never
+// prune a real candidate; the comparison is strict, so exact-distance ties (ordered by index) are still seen.
+// After phase 1 every unvisited point is farther than  bound_1 = h + m  (m = distance from the query to the
+// nearest wall of its own cell); if the 5th best is not inside that bound, phase 2 grows Chebyshev rings
+// k = 2, 3, ... until it is, or until the bound passes the match radius.
 LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2, Knn5 &r)
 {
     knn5_init(r);
@@ -127,33 +132,50 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
         fy > (float)g.ny + rmax_cells || fz > (float)g.nz + rmax_cells)
         return;
     const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-    // distance (in metres) from the query to the nearest wall of its own cell, slightly under-estimated
-    float mx = fminf(fx - (float)cx, (float)(cx + 1) - fx);
-    float my = fminf(fy - (float)cy, (float)(cy + 1) - fy);
-    float mz = fminf(fz - (float)cz, (float)(cz + 1) - fz);
-    float m = fmaxf(fminf(mx, fminf(my, mz)), 0.0f) * g.h;
     const float slack = g.slack;
-    const int kmax = (int)ceilf(sqrtf(max_d2) * g.inv_h) + 1;
+    // distances (metres, under-estimated by `slack`) from the query to the walls of its own cell
+    const float xm = fmaxf((fx - (float)cx) * g.h - slack, 0.0f), xp = fmaxf(((float)(cx + 1) - fx) * g.h - slack, 0.0f);
+    const float ym = fmaxf((fy - (float)cy) * g.h - slack, 0.0f), yp = fmaxf(((float)(cy + 1) - fy) * g.h - slack, 0.0f);
+    const float zm = fmaxf((fz - (float)cz) * g.h - slack, 0.0f), zp = fmaxf(((float)(cz + 1) - fz) * g.h - slack, 0.0f);
+    const float xm2 = xm * xm, xp2 = xp * xp;
 
-    for (int k = 0; k <= kmax; k++) {
-        if (k == 0) {
-            // ring 0 and ring 1 together: the 3x3 block of x-runs around the query cell
-            for (int dz = -1; dz <= 1; dz++) {
-                const int z = cz + dz;
-                if (z < 0 || z >= g.nz) continue;
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int y = cy + dy;
-                    if (y < 0 || y >= g.ny) continue;
-                    int x0 = cx - 1, x1 = cx + 1;
-                    if (x0 < 0) x0 = 0;
-                    if (x1 >= g.nx) x1 = g.nx - 1;
-                    if (x0 > x1) continue;
-                    const int base = (z * g.ny + y) * g.nx;
-                    scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
-                }
-            }
-            k = 1;
-        } else {
+    // ---- phase 1: 3x3 runs, own run first, then the 4 face neighbours, then the 4 diagonal ones -----------
+#define LL_KNN_ROW(DY, DZ)                                                                            \
+    {                                                                                                 \
+        const int y = cy + (DY), z = cz + (DZ);                                                       \
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {                                               \
+            const float dy = (DY) < 0 ? ym : ((DY) > 0 ? yp : 0.0f);                                  \
+            const float dz = (DZ) < 0 ? zm : ((DZ) > 0 ? zp : 0.0f);                                  \
+            const float row2 = dy * dy + dz * dz;                                                     \
+            const float lim = (r.count == 5) ? r.d2[4] : max_d2;                                      \
+            if (!(row2 > lim)) {                                                                      \
+                int x0 = (xm2 + row2 > lim) ? cx : cx - 1;                                            \
+                int x1 = (xp2 + row2 > lim) ? cx : cx + 1;                                            \
+                if (x0 < 0) x0 = 0;                                                                   \
+                if (x1 >= g.nx) x1 = g.nx - 1;                                                        \
+                if (x0 <= x1) {                                                                       \
+                    const int base = (z * g.ny + y) * g.nx;                                           \
+                    scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);                         \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+    }
+    LL_KNN_ROW(0, 0)
+    LL_KNN_ROW(-1, 0)
+    LL_KNN_ROW(1, 0)
+    LL_KNN_ROW(0, -1)
+    LL_KNN_ROW(0, 1)
+    LL_KNN_ROW(-1, -1)
+    LL_KNN_ROW(1, -1)
+    LL_KNN_ROW(-1, 1)
+    LL_KNN_ROW(1, 1)
+#undef LL_KNN_ROW
+
+    const float m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));  // already shrunk by slack
+    const int kmax = (int)ceilf(sqrtf(max_d2) * g.inv_h) + 1;
+    for (int k = 1; k <= kmax; k++) {
+        if (k >= 2) {
+            // ---- phase 2 (rare): the full shell at Chebyshev distance k ------------------------------------
             for (int dz = -k; dz <= k; dz++) {
                 const int z = cz + dz;
                 if (z < 0 || z >= g.nz) continue;
@@ -175,10 +197,10 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
                 }
             }
         }
-        const float bound = (float)k * g.h + m - slack;
+        const float bound = (float)k * g.h + m - ((k >= 2) ? slack : 0.0f);
         const float b2 = bound * bound;
-        if (b2 >= max_d2) break;                     // every point within the match radius has been seen
-        if (r.count == 5 && r.d2[4] < b2) break;     // the 5 best cannot be displaced by an unvisited point
+        if (b2 >= max_d2) break;                  // every point within the match radius has been seen
+        if (r.count == 5 && r.d2[4] < b2) break;  // the 5 best cannot be displaced by an unvisited point
     }
 }
 

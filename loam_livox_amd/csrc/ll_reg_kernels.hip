@@ -1,6 +1,6 @@
 // ll_reg_kernels.hip -- HIP kernels (gfx950, wave64) of the scan-to-map registrar.
 //
-//   K6  reg_knn_build_kernel : per query: transform with the current pose (pointAssociateToMap,
+//   K6  reg_knn_kernel + reg_build_kernel : per query: transform with the current pose (pointAssociateToMap,
 //                              point_cloud_registration.hpp:622-661), exact 5-NN on the cell grid
 //                              (:249,351), match-radius tests (:254,353), line / plane block constants
 //                              (:300-323, :416-423; ceres_icp.hpp:255-256, 328-334)
@@ -34,7 +34,10 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KB_THREADS) void reg_knn_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+// K6a: one lane per query: pose transform (fp64 -> fp32 like the reference) + exact 5-NN.  Kept free of the
+// fp64 block algebra so that the register footprint stays small (occupancy hides the gather latency).
+// Output per query: positions (cell-sorted order) of the neighbours the block needs + "5 found" flag.
+__global__ __launch_bounds__(KB_THREADS) void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 {
     const int b = blockIdx.y;
     const int kind = blockIdx.z;  // 0 corner / line, 1 surface / plane
@@ -47,12 +50,10 @@ __global__ __launch_bounds__(KB_THREADS) void reg_knn_build_kernel(RegDev rd, Re
     const size_t sb = (size_t)b * rd.cap;
     const float4 f = kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
 
-    unsigned char flag = BLK_NONE;
     Knn5 r;
     knn5_init(r);
-    float sblur = 1.0f;
     if (ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z)) {  // PCR:242-245 (surface: defined deviation)
-        sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
+        const float sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
         float pw[3];
         if (rc.if_motion_deblur == 0 || (double)sblur == 1.0) {
             point_to_map(st->pose_curr, f.x, f.y, f.z, pw);  // PCR:629
@@ -79,43 +80,15 @@ __global__ __launch_bounds__(KB_THREADS) void reg_knn_build_kernel(RegDev rd, Re
             pw[1] = (float)(o[1] + st->pose_last[5]);
             pw[2] = (float)(o[2] + st->pose_last[6]);
         }
-        const Grid &g = kind ? gs : gc;
-        knn5_search(g, pw[0], pw[1], pw[2], kind ? rc.max_d2_plane : rc.max_d2_line, r);
-        // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
-        if (r.count == 5) {
-            double a_out[3], v_out[3];
-            if (kind == 0) {
-                if (rc.icp_line) {
-                    const f4 p0 = g.pts[r.pos[0]], p1 = g.pts[r.pos[1]];  // PCR:300-301
-                    const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
-                    const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
-                    if (block_line(st->pose_last, pa, pb, a_out, v_out)) flag = BLK_LINE | BLK_ACTIVE | 8;
-                }
-            } else {
-                flag = 8;  // surf_avail counts even when ICP_PLANE == 0 (PCR:425)
-                if (rc.icp_plane) {
-                    const f4 p0 = g.pts[r.pos[0]], p1 = g.pts[r.pos[2]], p2 = g.pts[r.pos[4]];  // PCR:416-418 (0, k/2, k-1)
-                    const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
-                    const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
-                    const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
-                    if (block_plane(st->pose_last, pa, pb, pc, a_out, v_out))
-                        flag = BLK_PLANE | BLK_ACTIVE | 8;
-                    else
-                        flag = BLK_NONE;
-                }
-            }
-            if (flag & BLK_ACTIVE) {
-                rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, rc.if_motion_deblur ? sblur : 1.0f);
-                double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    av[(size_t)c * rd.cap + slot] = a_out[c];
-                    av[(size_t)(3 + c) * rd.cap + slot] = v_out[c];
-                }
-            }
-        }
+        knn5_search(kind ? gs : gc, pw[0], pw[1], pw[2], kind ? rc.max_d2_plane : rc.max_d2_line, r);
     }
-    rd.blk_flag[sb + slot] = flag;
+    // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
+    int4 nn;
+    nn.w = (r.count == 5) ? 1 : 0;
+    nn.x = r.pos[0];
+    nn.y = kind ? r.pos[2] : r.pos[1];  // plane: 0, k/2, k-1 (PCR:416-418); line: 0, 1 (PCR:300-301)
+    nn.z = r.pos[4];
+    rd.nn[sb + slot] = nn;
     if (rc.debug_knn && iter == 0 && rd.dbg_idx) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -123,6 +96,51 @@ __global__ __launch_bounds__(KB_THREADS) void reg_knn_build_kernel(RegDev rd, Re
             rd.dbg_d2[(sb + slot) * 5 + k] = r.d2[k];
         }
     }
+}
+
+// K6b: residual-block constants (fp64) from the neighbours found by K6a.
+__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs)
+{
+    const int b = blockIdx.y;
+    const int kind = blockIdx.z;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
+    if (q >= n) return;
+    const int slot = (kind ? rd.cap_c : 0) + q;
+    const size_t sb = (size_t)b * rd.cap;
+    const int4 nn = rd.nn[sb + slot];
+    unsigned char flag = BLK_NONE;
+    if (nn.w) {
+        const Grid &g = kind ? gs : gc;
+        double a_out[3], v_out[3];
+        const f4 p0 = g.pts[nn.x], p1 = g.pts[nn.y];
+        const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
+        const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
+        if (kind == 0) {
+            if (rc.icp_line && block_line(st->pose_last, pa, pb, a_out, v_out)) flag = BLK_LINE | BLK_ACTIVE | 8;
+        } else {
+            flag = 8;  // surf_avail counts even when ICP_PLANE == 0 (PCR:425)
+            if (rc.icp_plane) {
+                const f4 p2 = g.pts[nn.z];
+                const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
+                flag = block_plane(st->pose_last, pa, pb, pc, a_out, v_out) ? (BLK_PLANE | BLK_ACTIVE | 8) : BLK_NONE;
+            }
+        }
+        if (flag & BLK_ACTIVE) {
+            const float4 f = kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
+            const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
+            rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
+            double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                av[(size_t)c * rd.cap + slot] = a_out[c];
+                av[(size_t)(3 + c) * rd.cap + slot] = v_out[c];
+            }
+        }
+    }
+    rd.blk_flag[sb + slot] = flag;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -487,7 +505,8 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
 {
     const int capq = rd.cap_c > rd.cap_s ? rd.cap_c : rd.cap_s;
     dim3 grid((capq + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
-    hipLaunchKernelGGL(reg_knn_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+    hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+    hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {
