@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libloamlivox_hip.so")
+LIB_PATH = os.environ.get("LOAM_LIVOX_LIB", os.path.join(_HERE, "libloamlivox_hip.so"))  # override: experiments only
 
 
 class LoamLivoxError(RuntimeError):

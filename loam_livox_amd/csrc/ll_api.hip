@@ -564,8 +564,8 @@ extern "C" int ll_reg_set_debug(ll_reg *r, int32_t enable)
 {
     if (!r) return set_err("ll_reg_set_debug", "null handle");
     HC(hipSetDevice(r->device));
-    r->debug = enable ? 1 : 0;
-    if (enable && !r->dev.dbg_idx) {
+    r->debug = enable;
+    if ((enable & 1) && !r->dev.dbg_idx) {
         DM(r->dev.dbg_idx, (size_t)r->max_scans * r->dev.cap * 5);
         DM(r->dev.dbg_d2, (size_t)r->max_scans * r->dev.cap * 5);
     }
@@ -589,7 +589,8 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->icp_line = p->icp_line;
     c->icp_plane = p->icp_plane;
     c->force_all_iterations = p->force_all_iterations;
-    c->debug_knn = debug;
+    c->debug_knn = debug & 1;
+    c->force_general = (debug & 2) ? 1 : 0;
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)

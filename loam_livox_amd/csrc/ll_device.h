@@ -83,6 +83,7 @@ struct RegState {
 struct RegConst {
     int if_motion_deblur, icp_max_iterations, ceres_max_iterations, ceres_prerun_times;
     int icp_line, icp_plane, force_all_iterations, debug_knn;
+    int force_general, pad0;              // test switch: run the HBM-resident solver path even for small scans
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
     double max_d2_line_d, max_d2_plane_d;
     double huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff;

@@ -22,7 +22,12 @@
 namespace ll {
 
 #define KB_THREADS 128
-#define RS_THREADS 1024
+#ifndef RS_THREADS
+#define RS_THREADS 512
+#endif
+#ifndef RS_PREFETCH
+#define RS_PREFETCH 1
+#endif
 #define RS_WAVES (RS_THREADS / 64)
 #define HASH_EMPTY 0xffffffffffffffffull
 
@@ -277,17 +282,55 @@ __device__ void compute_interp(const double q[4], RegState *st)
         }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc)
+// pose composition, convergence test and per-iteration report (PCR:509-531); lane 0 only
+__device__ void solve_epilogue(const RegConst &rc, RegState *st, SolveShared &sh, int lm_iters)
 {
-    const int b = blockIdx.x;
-    RegState *st = rd.state + b;
-    if (st->done) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        for (int i = 0; i < 7; i++) st->inc[i] = sh.ctl.x[i];
+        if (rc.if_motion_deblur) compute_interp(st->inc, st);
+        double tw[3];
+        quat_rot(st->pose_last, &st->inc[4], tw);  // PCR:514
+        st->pose_curr[4] = tw[0] + st->pose_last[4];
+        st->pose_curr[5] = tw[1] + st->pose_last[5];
+        st->pose_curr[6] = tw[2] + st->pose_last[6];
+        double qc[4];
+        quat_mul(st->pose_last, st->inc, qc);  // PCR:515
+        for (int i = 0; i < 4; i++) st->pose_curr[i] = qc[i];
+        st->angular_diff = (double)((float)quat_angular_distance(qc, st->pose_last)) * 57.3;  // PCR:517
+        const double dt[3] = {st->pose_curr[4] - st->pose_last[4], st->pose_curr[5] - st->pose_last[5],
+                              st->pose_curr[6] - st->pose_last[6]};
+        st->t_diff = sqrt(dot3(dt, dt));
+        st->final_cost = sh.ctl.final_cost;
+        st->initial_cost = sh.ctl.initial_cost;
+        st->inlier_thr = sh.thr;
+        st->n_blocks_last = sh.n_active;
+        st->corner_avail = sh.n_corner_avail;
+        st->surf_avail = sh.n_surf_avail;
+        st->lm_total += lm_iters;
+        st->icp_iters += 1;
+        const double dto[3] = {st->prev_t[0] - st->inc[4], st->prev_t[1] - st->inc[5], st->prev_t[2] - st->inc[6]};
+        const bool conv = quat_angular_distance(st->prev_q, st->inc) < 57.3 * rc.minimum_icp_R_diff &&
+                          sqrt(dot3(dto, dto)) < rc.minimum_icp_T_diff;  // PCR:521-522
+        if (conv && !rc.force_all_iterations) {
+            st->done = 1;
+        } else {
+            for (int i = 0; i < 4; i++) st->prev_q[i] = st->inc[i];
+            for (int i = 0; i < 3; i++) st->prev_t[i] = st->inc[4 + i];
+        }
+        if (st->icp_iters >= rc.icp_max_iterations) st->done = 1;
+    }
+}
+
+
+// General path: any number of blocks per scan; flags, L1 values and the de-duplication table live in HBM.
+__device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh)
+{
     const int tid = threadIdx.x;
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
     const int total = nC + nS;
     const size_t sb = (size_t)b * rd.cap;
     const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    __shared__ SolveShared sh;
 
     // ---- census: active blocks, corner_avail / surf_avail (PCR:325,425) -----------------------------------
     {
@@ -432,41 +475,290 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     }
     lm_iters += sh.ctl.iteration;
 
-    // ---- pose composition, convergence (PCR:509-531) ---------------------------------------------------------
-    if (tid == 0) {
-        for (int i = 0; i < 7; i++) st->inc[i] = sh.ctl.x[i];
-        if (rc.if_motion_deblur) compute_interp(st->inc, st);
-        double tw[3];
-        quat_rot(st->pose_last, &st->inc[4], tw);  // PCR:514
-        st->pose_curr[4] = tw[0] + st->pose_last[4];
-        st->pose_curr[5] = tw[1] + st->pose_last[5];
-        st->pose_curr[6] = tw[2] + st->pose_last[6];
-        double qc[4];
-        quat_mul(st->pose_last, st->inc, qc);  // PCR:515
-        for (int i = 0; i < 4; i++) st->pose_curr[i] = qc[i];
-        st->angular_diff = (double)((float)quat_angular_distance(qc, st->pose_last)) * 57.3;  // PCR:517
-        const double dt[3] = {st->pose_curr[4] - st->pose_last[4], st->pose_curr[5] - st->pose_last[5],
-                              st->pose_curr[6] - st->pose_last[6]};
-        st->t_diff = sqrt(dot3(dt, dt));
-        st->final_cost = sh.ctl.final_cost;
-        st->initial_cost = sh.ctl.initial_cost;
-        st->inlier_thr = sh.thr;
-        st->n_blocks_last = sh.n_active;
-        st->corner_avail = sh.n_corner_avail;
-        st->surf_avail = sh.n_surf_avail;
-        st->lm_total += lm_iters;
-        st->icp_iters += 1;
-        const double dto[3] = {st->prev_t[0] - st->inc[4], st->prev_t[1] - st->inc[5], st->prev_t[2] - st->inc[6]};
-        const bool conv = quat_angular_distance(st->prev_q, st->inc) < 57.3 * rc.minimum_icp_R_diff &&
-                          sqrt(dot3(dto, dto)) < rc.minimum_icp_T_diff;  // PCR:521-522
-        if (conv && !rc.force_all_iterations) {
-            st->done = 1;
-        } else {
-            for (int i = 0; i < 4; i++) st->prev_q[i] = st->inc[i];
-            for (int i = 0; i < 3; i++) st->prev_t[i] = st->inc[4 + i];
-        }
-        if (st->icp_iters >= rc.icp_max_iterations) st->done = 1;
+    solve_epilogue(rc, st, sh, lm_iters);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path (<= FAST_MAX_BLOCKS residual blocks per scan, i.e. every BASELINE Mid-40 configuration): block
+// flags live in LDS, the per-block L1 values of the inlier test live in registers, the std::set
+// de-duplication runs in an LDS hash table and the rank select reads registers -- the only HBM traffic left is
+// one coalesced sweep over the block constants per cost evaluation, software-pipelined one block ahead.
+#define FAST_MAX_BLOCKS 24576
+#define FAST_MAXK (FAST_MAX_BLOCKS / RS_THREADS)
+#define HT_SIZE 16384
+#define HT_PART 6144  // keys per de-duplication round (load factor <= 0.375)
+
+struct BlkRegs {
+    float4 f;
+    double a0, a1, a2, v0, v1, v2;
+};
+
+__device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const double *av, int slot, BlkRegs &r)
+{
+    r.f = rd.blk_f[sb + slot];
+    r.a0 = av[slot];
+    r.a1 = av[(size_t)rd.cap + slot];
+    r.a2 = av[(size_t)2 * rd.cap + slot];
+    r.v0 = av[(size_t)3 * rd.cap + slot];
+    r.v1 = av[(size_t)4 * rd.cap + slot];
+    r.v2 = av[(size_t)5 * rd.cap + slot];
+}
+
+__device__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a,
+                                 const unsigned char *s_flag, SolveShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t sb = (size_t)b * rd.cap;
+    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+    double R[9], t[3];
+    {
+        const double q[4] = {x[0], x[1], x[2], x[3]};
+        quat_to_mat(q, R);
+        t[0] = x[4];
+        t[1] = x[5];
+        t[2] = x[6];
     }
+    double acc[LL_NACC];
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
+#if RS_PREFETCH
+    int j = tid;
+    BlkRegs cur, nxt;
+    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
+    while (j < total) {
+        const int jn = j + RS_THREADS;
+        if (jn < total) load_blk(rd, sb, av, slot_of(jn, nC, rd.cap_c), nxt);  // in flight while we compute
+        const unsigned char fl = s_flag[j];
+        if (fl & BLK_ACTIVE) {
+            const double f[3] = {(double)cur.f.x, (double)cur.f.y, (double)cur.f.z};
+            const double a[3] = {cur.a0, cur.a1, cur.a2};
+            const double v[3] = {cur.v0, cur.v1, cur.v2};
+            block_accumulate(fl & 3, R, t, f, a, v, huber_a, acc);
+        }
+        cur = nxt;
+        j = jn;
+    }
+#else
+    for (int j = tid; j < total; j += RS_THREADS) {
+        BlkRegs cur;
+        load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);  // unconditional: no dependence on the flag
+        const unsigned char fl = s_flag[j];
+        if (fl & BLK_ACTIVE) {
+            const double f[3] = {(double)cur.f.x, (double)cur.f.y, (double)cur.f.z};
+            const double a[3] = {cur.a0, cur.a1, cur.a2};
+            const double v[3] = {cur.v0, cur.v1, cur.v2};
+            block_accumulate(fl & 3, R, t, f, a, v, huber_a, acc);
+        }
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) sh.red[wave][i] = s;
+    }
+    __syncthreads();
+    if (tid < LL_NACC) {
+        double s = 0.0;
+        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
+        sh.sum[tid] = s;
+    }
+    __syncthreads();
+}
+
+__device__ void solver_lm_fast(const RegDev &rd, const RegConst &rc, int b, int nC, int total, const double *x0, int max_iter,
+                               int n_active, const unsigned char *s_flag, SolveShared &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
+    __syncthreads();
+    solver_eval_fast(rd, b, nC, total, sh.ctl.x, rc.huber_a, s_flag, sh);
+    if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
+    __syncthreads();
+    while (sh.need) {
+        solver_eval_fast(rd, b, nC, total, sh.ctl.cand, rc.huber_a, s_flag, sh);
+        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
+        __syncthreads();
+    }
+}
+
+__device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
+                           unsigned long long *s_table, unsigned char *s_flag)
+{
+    const int tid = threadIdx.x;
+    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
+    const int total = nC + nS;
+    const size_t sb = (size_t)b * rd.cap;
+    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+
+    // ---- flags -> LDS, census (PCR:325,425) -------------------------------------------------------------------
+    {
+        int na = 0, nca = 0, nsa = 0;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const unsigned char fl = rd.blk_flag[sb + slot_of(j, nC, rd.cap_c)];
+            s_flag[j] = fl;
+            na += (fl & BLK_ACTIVE) ? 1 : 0;
+            if (fl & 8) {
+                if (j < nC) nca++; else nsa++;
+            }
+        }
+        na = block_sum_int(na, sh);
+        nca = block_sum_int(nca, sh);
+        nsa = block_sum_int(nsa, sh);
+        if (tid == 0) {
+            sh.n_active = na;
+            sh.n_corner_avail = nca;
+            sh.n_surf_avail = nsa;
+        }
+        __syncthreads();
+    }
+
+    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
+    solver_lm_fast(rd, rc, b, nC, total, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, sh);
+    int lm_iters = sh.ctl.iteration;
+
+    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers ------------------
+    double l1r[FAST_MAXK];
+    {
+        double R[9], t[3];
+        const double q[4] = {sh.ctl.x[0], sh.ctl.x[1], sh.ctl.x[2], sh.ctl.x[3]};
+        quat_to_mat(q, R);
+        t[0] = sh.ctl.x[4];
+        t[1] = sh.ctl.x[5];
+        t[2] = sh.ctl.x[6];
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++) {
+            const int j = tid + k * RS_THREADS;
+            double l1 = -1.0;  // marker: not an active block
+            if (j < total) {
+                const unsigned char fl = s_flag[j];
+                if (fl & BLK_ACTIVE) {
+                    BlkRegs br;
+                    load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), br);
+                    const double f[3] = {(double)br.f.x, (double)br.f.y, (double)br.f.z};
+                    const double a[3] = {br.a0, br.a1, br.a2};
+                    const double v[3] = {br.v0, br.v1, br.v2};
+                    l1 = block_l1(fl & 3, R, t, f, a, v, rc.huber_a, st->pose_last);
+                }
+            }
+            l1r[k] = l1;
+        }
+    }
+
+    // ---- std::set semantics (PCR:155-160): distinct values via an LDS hash table, HT_PART keys per round -----
+    unsigned long long first_mask = 0;  // bit k: block k of this thread is the first occurrence of its L1 value
+    {
+        const int rounds = (total + HT_PART - 1) / HT_PART;
+        int my = 0;
+        for (int rnd = 0; rnd < rounds; rnd++) {
+            for (int e = tid; e < HT_SIZE; e += RS_THREADS) s_table[e] = HASH_EMPTY;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < FAST_MAXK; k++) {
+                const double l1 = l1r[k];
+                if (!(l1 >= 0.0)) continue;  // inactive slot or NaN (NaN never enters the set)
+                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
+                const unsigned long long hk = hash64(key);
+                if ((int)((hk >> 40) % (unsigned long long)rounds) != rnd) continue;
+                unsigned int h = (unsigned int)hk & (HT_SIZE - 1);
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&s_table[h], HASH_EMPTY, key);
+                    if (old == HASH_EMPTY) {
+                        first_mask |= (1ull << k);
+                        my++;
+                        break;
+                    }
+                    if (old == key) break;
+                    h = (h + 1u) & (HT_SIZE - 1);
+                }
+            }
+            __syncthreads();
+        }
+        const int nu = block_sum_int(my, sh);
+        if (tid == 0) {
+            sh.n_unique = nu;
+            sh.sel_prefix = 0ull;
+            int target = (int)(rc.inlier_ratio * (double)nu);  // PCR:160
+            if (target > nu - 1) target = nu - 1;
+            sh.sel_rank = target;
+        }
+        __syncthreads();
+    }
+    if (sh.n_unique > 0) {
+        // MSB-first radix select (8 bits per pass) over the distinct keys held in registers
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            for (int e = tid; e < 256; e += RS_THREADS) sh.hist[e] = 0;
+            __syncthreads();
+            const unsigned long long prefix = sh.sel_prefix;
+#pragma unroll
+            for (int k = 0; k < FAST_MAXK; k++) {
+                if (!(first_mask & (1ull << k))) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
+                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rank = sh.sel_rank, d = 0, cum = 0;
+                for (d = 0; d < 256; d++) {
+                    if (cum + sh.hist[d] > rank) break;
+                    cum += sh.hist[d];
+                }
+                if (d > 255) d = 255;
+                sh.sel_rank = rank - cum;
+                sh.sel_prefix = (prefix << 8) | (unsigned long long)d;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sh.sel_prefix));  // PCR:485
+    } else {
+        if (tid == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
+    }
+    __syncthreads();
+    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
+    {
+        const double thr = sh.thr;
+        int na = 0;
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++) {
+            const int j = tid + k * RS_THREADS;
+            if (j >= total) continue;
+            const unsigned char fl = s_flag[j];
+            if (!(fl & BLK_ACTIVE)) continue;
+            if (l1r[k] > thr)
+                s_flag[j] = fl & ~BLK_ACTIVE;
+            else
+                na++;
+        }
+        na = block_sum_int(na, sh);
+        if (tid == 0) sh.n_active = na;
+        __syncthreads();
+    }
+
+    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
+    {
+        __shared__ double x_start_f[7];
+        if (tid < 7) x_start_f[tid] = sh.ctl.x[tid];
+        __syncthreads();
+        solver_lm_fast(rd, rc, b, nC, total, x_start_f, rc.ceres_max_iterations, sh.n_active, s_flag, sh);
+    }
+    lm_iters += sh.ctl.iteration;
+    solve_epilogue(rc, st, sh, lm_iters);
+}
+
+__global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc)
+{
+    const int b = blockIdx.x;
+    RegState *st = rd.state + b;
+    if (st->done) return;
+    __shared__ SolveShared sh;
+    __shared__ unsigned long long s_table[HT_SIZE];
+    __shared__ unsigned char s_flag[FAST_MAX_BLOCKS];
+    const int total = rd.n_corner[b] + rd.n_surf[b];
+    if (total <= FAST_MAX_BLOCKS && !rc.force_general)
+        solve_fast(rd, rc, b, st, sh, s_table, s_flag);
+    else
+        solve_general(rd, rc, b, st, sh);
 }
 
 __global__ void reg_finalize_kernel(RegDev rd, RegConst rc, int n_scans)

@@ -70,13 +70,16 @@ def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
 
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 @pytest.mark.parametrize("force", [0, 1])
-def test_registration_matches_oracle(dev_map, small_world, scans, k, force):
+@pytest.mark.parametrize("general", [False, True])
+def test_registration_matches_oracle(dev_map, small_world, scans, k, force, general):
+    """general=False: register/LDS-resident solver path; True: the HBM-resident path used by scans with more than
+    24576 residual blocks (forced here on a normal scan)."""
     sc = scans[k]
     _, _, _, _, fc, fs = oracle_features(sc)
     prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     reg = Point_cloud_registration(max_scans=1, max_features=24000)
-    reg.set_debug(True)
+    reg.set_debug(True, force_general_solver=general)
     set_params(reg, 10, 20, force)
     reg.m_pose_w_last = sc.pose_init.copy()
     reg.m_pose_w_curr = sc.pose_init.copy()
