@@ -110,7 +110,7 @@ void ll_map_destroy(ll_map *m);
 /* Replaces pcl::KdTreeFLANN::setInputCloud for the match buffers (laser_mapping.hpp:544-545,
  * point_cloud_registration.hpp:596-597): uploads the cloud and builds the device search grid.
  * xyz: m points, stride_floats apart (3 = xyz, 4 = xyzi).  cell_size <= 0 selects the default
- * (0.5 m corner / 1.0 m surface).  Point indices reported by the library refer to this input order. */
+ * (0.5 m corner / 0.6 m surface: about 1.5x the 0.4 m surface-map leaf).  Point indices reported by the library refer to this input order. */
 int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size);
 int64_t ll_map_size(const ll_map *m, int32_t kind);
 

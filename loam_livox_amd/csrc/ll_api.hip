@@ -413,7 +413,7 @@ extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t 
     if (stride_floats < 3) return set_err("ll_map_upload", "stride_floats must be >= 3");
     if (n < 0 || n > 0x7fffffffLL) return set_err("ll_map_upload", "point count out of range");
     HC(hipSetDevice(m->device));
-    if (!(cell_size > 0.f)) cell_size = (kind == LL_MAP_CORNER) ? 0.5f : 1.0f;
+    if (!(cell_size > 0.f)) cell_size = (kind == LL_MAP_CORNER) ? 0.5f : 0.6f;
     float *d_raw = nullptr;
     const size_t bytes = (size_t)(n > 0 ? n : 1) * stride_floats * sizeof(float);
     HC(hipMalloc(&d_raw, bytes));
@@ -530,6 +530,7 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(d.blk_av, B * 6 * d.cap);
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
+    DM(d.qw, B * d.cap);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -548,7 +549,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.qw, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -101,6 +101,7 @@ struct RegDev {
     int cap_c, cap_s, cap;        // cap = cap_c + cap_s
     float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
     double *blk_av;               // [B][6][cap] a'(3) then v'(3) in the frame of pose_last
+    float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     int4 *nn;                     // [B][cap]  neighbour positions (cell-sorted order) + found flag (K6a -> K6b)
     unsigned char *blk_flag;      // [B][cap]  BLK_* bits
     double *blk_l1;               // [B][cap]  scratch for the inlier threshold

@@ -105,10 +105,18 @@ LL_HD void scan_run(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of o
                     float qz, float max_d2, Knn5 &r)
 {
     const int b = g.cell_start[c_lo], e = g.cell_start[c_hi + 1];
-    for (int j = b; j < e; j++) {
-        const f4 p = g.pts[j];
-        const float d2 = dist2_xyz(qx, qy, qz, p.x, p.y, p.z);
-        if (d2 < max_d2) knn5_push(r, d2, as_int(p.w), j);
+    // four candidates per trip: the four 16-byte loads are independent, so their latencies overlap
+    for (int j = b; j < e; j += 4) {
+        const int j1 = (j + 1 < e) ? j + 1 : j, j2 = (j + 2 < e) ? j + 2 : j, j3 = (j + 3 < e) ? j + 3 : j;
+        const f4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
+        const float d0 = dist2_xyz(qx, qy, qz, p0.x, p0.y, p0.z);
+        const float d1 = dist2_xyz(qx, qy, qz, p1.x, p1.y, p1.z);
+        const float d2 = dist2_xyz(qx, qy, qz, p2.x, p2.y, p2.z);
+        const float d3 = dist2_xyz(qx, qy, qz, p3.x, p3.y, p3.z);
+        if (d0 < max_d2) knn5_push(r, d0, as_int(p0.w), j);
+        if (j1 != j && d1 < max_d2) knn5_push(r, d1, as_int(p1.w), j1);
+        if (j2 != j && d2 < max_d2) knn5_push(r, d2, as_int(p2.w), j2);
+        if (j3 != j && d3 < max_d2) knn5_push(r, d3, as_int(p3.w), j3);
     }
 }
 
@@ -140,36 +148,29 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
     const float xm2 = xm * xm, xp2 = xp * xp;
 
     // ---- phase 1: 3x3 runs, own run first, then the 4 face neighbours, then the 4 diagonal ones -----------
-#define LL_KNN_ROW(DY, DZ)                                                                            \
-    {                                                                                                 \
-        const int y = cy + (DY), z = cz + (DZ);                                                       \
-        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {                                               \
-            const float dy = (DY) < 0 ? ym : ((DY) > 0 ? yp : 0.0f);                                  \
-            const float dz = (DZ) < 0 ? zm : ((DZ) > 0 ? zp : 0.0f);                                  \
-            const float row2 = dy * dy + dz * dz;                                                     \
-            const float lim = (r.count == 5) ? r.d2[4] : max_d2;                                      \
-            if (!(row2 > lim)) {                                                                      \
-                int x0 = (xm2 + row2 > lim) ? cx : cx - 1;                                            \
-                int x1 = (xp2 + row2 > lim) ? cx : cx + 1;                                            \
-                if (x0 < 0) x0 = 0;                                                                   \
-                if (x1 >= g.nx) x1 = g.nx - 1;                                                        \
-                if (x0 <= x1) {                                                                       \
-                    const int base = (z * g.ny + y) * g.nx;                                           \
-                    scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);                         \
-                }                                                                                     \
-            }                                                                                         \
-        }                                                                                             \
+    // (dy,dz) order packed two bits per entry (0 -> -1, 1 -> 0, 2 -> +1); kept as a rolled loop so the
+    // candidate-scan code exists once (small instruction footprint, fewer live registers)
+    const unsigned int DY_CODES = 0x22161u, DZ_CODES = 0x28215u;
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int ri = 0; ri < 9; ri++) {
+        const int dyc = (int)((DY_CODES >> (2 * ri)) & 3u) - 1, dzc = (int)((DZ_CODES >> (2 * ri)) & 3u) - 1;
+        const int y = cy + dyc, z = cz + dzc;
+        if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+        const float dy = dyc < 0 ? ym : (dyc > 0 ? yp : 0.0f);
+        const float dz = dzc < 0 ? zm : (dzc > 0 ? zp : 0.0f);
+        const float row2 = dy * dy + dz * dz;
+        const float lim = (r.count == 5) ? r.d2[4] : max_d2;
+        if (row2 > lim) continue;
+        int x0 = (xm2 + row2 > lim) ? cx : cx - 1;
+        int x1 = (xp2 + row2 > lim) ? cx : cx + 1;
+        if (x0 < 0) x0 = 0;
+        if (x1 >= g.nx) x1 = g.nx - 1;
+        if (x0 > x1) continue;
+        const int base = (z * g.ny + y) * g.nx;
+        scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
     }
-    LL_KNN_ROW(0, 0)
-    LL_KNN_ROW(-1, 0)
-    LL_KNN_ROW(1, 0)
-    LL_KNN_ROW(0, -1)
-    LL_KNN_ROW(0, 1)
-    LL_KNN_ROW(-1, -1)
-    LL_KNN_ROW(1, -1)
-    LL_KNN_ROW(-1, 1)
-    LL_KNN_ROW(1, 1)
-#undef LL_KNN_ROW
 
     const float m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));  // already shrunk by slack
     const int kmax = (int)ceilf(sqrtf(max_d2) * g.inv_h) + 1;
@@ -184,15 +185,17 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
                     if (y < 0 || y >= g.ny) continue;
                     const int base = (z * g.ny + y) * g.nx;
                     const bool full_row = (dz == -k || dz == k || dy == -k || dy == k);
-                    if (full_row) {
-                        int x0 = cx - k, x1 = cx + k;
-                        if (x0 < 0) x0 = 0;
-                        if (x1 >= g.nx) x1 = g.nx - 1;
+                    // a full x-run on the shell's faces, otherwise only the two end cells of the row
+                    for (int seg = 0; seg < (full_row ? 1 : 2); seg++) {
+                        int x0 = full_row ? cx - k : (seg == 0 ? cx - k : cx + k);
+                        int x1 = full_row ? cx + k : x0;
+                        if (full_row) {  // clamp the run to the grid; single end cells must lie inside it
+                            if (x0 < 0) x0 = 0;
+                            if (x1 >= g.nx) x1 = g.nx - 1;
+                        } else if (x0 < 0 || x0 >= g.nx) {
+                            continue;
+                        }
                         if (x0 <= x1) scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
-                    } else {
-                        const int xa = cx - k, xb = cx + k;
-                        if (xa >= 0 && xa < g.nx) scan_run(g, base + xa, base + xa, qx, qy, qz, max_d2, r);
-                        if (xb >= 0 && xb < g.nx) scan_run(g, base + xb, base + xb, qx, qy, qz, max_d2, r);
                     }
                 }
             }

@@ -39,10 +39,10 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K6a: one lane per query: pose transform (fp64 -> fp32 like the reference) + exact 5-NN.  Kept free of the
-// fp64 block algebra so that the register footprint stays small (occupancy hides the gather latency).
-// Output per query: positions (cell-sorted order) of the neighbours the block needs + "5 found" flag.
-__global__ __launch_bounds__(KB_THREADS) void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+// K6t: pose transform of every query (pointAssociateToMap, fp64 math -> fp32 store like the reference).  A
+// kernel of its own so that the double-precision sin/cos of the motion-deblur branch does not set the register
+// footprint of the k-NN kernel.
+__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc)
 {
     const int b = blockIdx.y;
     const int kind = blockIdx.z;  // 0 corner / line, 1 surface / plane
@@ -54,12 +54,9 @@ __global__ __launch_bounds__(KB_THREADS) void reg_knn_kernel(RegDev rd, RegConst
     const int slot = (kind ? rd.cap_c : 0) + q;
     const size_t sb = (size_t)b * rd.cap;
     const float4 f = kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
-
-    Knn5 r;
-    knn5_init(r);
-    if (ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z)) {  // PCR:242-245 (surface: defined deviation)
+    float pw[3] = {NAN, NAN, NAN};  // non-finite features are skipped (PCR:242-245; surface: defined deviation)
+    if (ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z)) {
         const float sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
-        float pw[3];
         if (rc.if_motion_deblur == 0 || (double)sblur == 1.0) {
             point_to_map(st->pose_curr, f.x, f.y, f.z, pw);  // PCR:629
         } else {
@@ -85,8 +82,31 @@ __global__ __launch_bounds__(KB_THREADS) void reg_knn_kernel(RegDev rd, RegConst
             pw[1] = (float)(o[1] + st->pose_last[5]);
             pw[2] = (float)(o[2] + st->pose_last[6]);
         }
-        knn5_search(kind ? gs : gc, pw[0], pw[1], pw[2], kind ? rc.max_d2_plane : rc.max_d2_line, r);
     }
+    rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
+}
+
+// K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
+// occupancy hides the gather latency).  Output per query: positions (cell-sorted order) of the neighbours the
+// block needs + "5 found" flag.
+#ifndef KNN_WAVES_PER_EU
+#define KNN_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
+void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+{
+    const int b = blockIdx.y;
+    const int kind = blockIdx.z;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
+    if (q >= n) return;
+    const int slot = (kind ? rd.cap_c : 0) + q;
+    const size_t sb = (size_t)b * rd.cap;
+    const float4 pw = rd.qw[sb + slot];
+    Knn5 r;
+    knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);  // NaN query -> empty
     // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
     int4 nn;
     nn.w = (r.count == 5) ? 1 : 0;
@@ -797,6 +817,7 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
 {
     const int capq = rd.cap_c > rd.cap_s ? rd.cap_c : rd.cap_s;
     dim3 grid((capq + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
+    hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
     hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
     hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
