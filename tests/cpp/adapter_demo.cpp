@@ -1,0 +1,86 @@
+// Exercises include/loam_livox_adapter.hpp the way the reference's node shells call Livox_laser /
+// Point_cloud_registration (laser_feature_extractor.hpp:285-330, laser_mapping.hpp:1405), with a stand-in for
+// pcl::PointCloud<pcl::PointXYZI>.  argv: <scan.bin> <corner_map.bin> <surf_map.bin> <pose_init.bin> <out.txt>
+// (.bin = raw float32 xyzi rows / 7 float64).
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "../../include/loam_livox_adapter.hpp"
+
+struct PointXYZI {
+    float x, y, z, intensity;
+};
+struct Cloud {
+    std::vector<PointXYZI> points;
+    size_t size() const { return points.size(); }
+};
+struct KdTreeStub {};
+
+static Cloud load_cloud(const char *path)
+{
+    Cloud c;
+    FILE *f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    PointXYZI p;
+    while (fread(&p, sizeof(p), 1, f) == 1) c.points.push_back(p);
+    fclose(f);
+    return c;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) return 2;
+    try {
+        Cloud scan = load_cloud(argv[1]);
+        auto map_corner = std::make_shared<Cloud>(load_cloud(argv[2]));
+        auto map_surf = std::make_shared<Cloud>(load_cloud(argv[3]));
+        double pose[7];
+        FILE *f = fopen(argv[4], "rb");
+        if (!f || fread(pose, sizeof(double), 7, f) != 7) return 3;
+        fclose(f);
+
+        loam_livox_hip::Livox_laser m_livox;
+        m_livox.thr_corner_curvature = 0.05f;  // laser_feature_extractor.hpp:152-154
+        m_livox.thr_surface_curvature = 0.01f;
+        m_livox.minimum_view_angle = 10;
+        m_livox.m_livox_min_allow_dis = 0.1f;  // :854
+        m_livox.m_livox_min_sigma = 7e-4f;     // :859
+        m_livox.piecewise_number = 1;
+        m_livox.max_points = 30000;
+        std::vector<Cloud> laserCloudScans = m_livox.extract_laser_features(scan, 5.0);
+        if (laserCloudScans.size() <= 5) return 4;  // :287
+        const int m_laser_scan_number = (int)laserCloudScans.size();
+        const int end_idx = (int)laserCloudScans[m_laser_scan_number - 1].size() - 1;
+        const float piece_start = ((float)m_livox.find_pt_info(laserCloudScans[0].points[0])->idx) / m_livox.m_pts_info_vec.size();
+        const float piece_end =
+            ((float)m_livox.find_pt_info(laserCloudScans[m_laser_scan_number - 1].points[end_idx])->idx) / m_livox.m_pts_info_vec.size();
+        auto corners = std::make_shared<Cloud>(), surface = std::make_shared<Cloud>();
+        Cloud full;
+        m_livox.get_features(*corners, *surface, full, piece_start, piece_end);
+
+        loam_livox_hip::Point_cloud_registration pc_reg;
+        pc_reg.m_current_frame_index = 100;
+        pc_reg.m_mapping_init_accumulate_frames = 50;
+        pc_reg.m_para_icp_max_iterations = 5;
+        pc_reg.m_para_cere_max_iterations = 20;
+        pc_reg.m_para_max_angular_rate = 20.0f;
+        pc_reg.m_para_max_speed = 0.3f;
+        pc_reg.max_features = 30000;
+        for (int i = 0; i < 7; i++) pc_reg.m_para_buffer_RT[i] = pc_reg.m_para_buffer_RT_last[i] = pose[i];
+        KdTreeStub kd_c, kd_s;
+        const int reg_res = pc_reg.find_out_incremental_transfrom(map_corner, map_surf, kd_c, kd_s, corners, surface);
+        Cloud world;
+        pc_reg.pointcloudAssociateToMap(*corners, world);
+
+        FILE *o = fopen(argv[5], "w");
+        fprintf(o, "%d %zu %zu %zu %d\n", m_laser_scan_number, corners->size(), surface->size(), full.size(), reg_res);
+        for (int i = 0; i < 7; i++) fprintf(o, "%.17g ", pc_reg.m_para_buffer_RT[i]);
+        fprintf(o, "\n%.9g %.9g\n", piece_start, piece_end);
+        fclose(o);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "adapter_demo: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,56 @@
+"""include/loam_livox_adapter.hpp: the C++ host-side mirror of Livox_laser / Point_cloud_registration.
+CPU tier: it compiles and links against the C-ABI library.  GPU tier: the demo (written like the reference's
+node code) reproduces what the Python mirror and the oracle give."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_demo")
+
+
+def build_demo():
+    from loam_livox_amd import build
+    lib = build.build()
+    deps = [SRC, os.path.join(ROOT, "include", "loam_livox_adapter.hpp"), os.path.join(ROOT, "include", "loam_livox_hip.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-o", EXE, SRC, lib, "-Wl,-rpath," + os.path.dirname(lib),
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def test_adapter_compiles_and_links():
+    assert os.path.exists(build_demo())
+
+
+@pytest.mark.gpu
+def test_adapter_demo_matches_oracle(tmp_path, small_world, scans):
+    from loam_livox_amd import synth
+    from oracle import orc
+    exe = build_demo()
+    sc = scans[0]
+    paths = [str(tmp_path / n) for n in ("scan.bin", "corner.bin", "surf.bin", "pose.bin", "out.txt")]
+    sc.xyzi.astype(np.float32).tofile(paths[0])
+    np.c_[small_world["corner"], np.zeros(len(small_world["corner"]), np.float32)].astype(np.float32).tofile(paths[1])
+    np.c_[small_world["surf"], np.zeros(len(small_world["surf"]), np.float32)].astype(np.float32).tofile(paths[2])
+    sc.pose_init.astype(np.float64).tofile(paths[3])
+    subprocess.check_call([exe] + paths, timeout=120)
+    lines = open(paths[4]).read().split("\n")
+    n_clouds, n_c, n_s, n_f, reg_res = [int(v) for v in lines[0].split()]
+    pose = np.array([float(v) for v in lines[1].split()])
+    ps, pe = [np.float32(v) for v in lines[2].split()]
+    # oracle: first call -> current_time = stamp + 1 (LFE:731)
+    o = orc.fe_extract(sc.xyzi, 6.0)
+    S, first, last = orc.fe_split_scan(o)
+    ops, ope = orc.fe_piecewise(o, first, last, 1)
+    assert n_clouds == S and ps == ops[0] and pe == ope[0]
+    ci, si, fi = orc.fe_get_features(o, float(ops[0]), float(ope[0]))
+    assert (n_c, n_s, n_f) == (len(ci), len(si), len(fi))
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=0)
+    ret, opc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], orc.feature_cloud(o, ci), orc.feature_cloud(o, si), prm,
+                                   sc.pose_init, sc.pose_init)
+    dt, dr = synth.pose_error(pose, opc)
+    assert reg_res == ret and dt < 1e-7 and dr < 1e-7
