@@ -45,6 +45,28 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic_bytes(kernel: str, batch: int):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/r*_pmc_hbm_bytes.csv:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command at batch 256; FETCH_SIZE x2 per the
+    gfx950 note in MI355X_MICROARCH.md).  None when no matching measurement is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.csv")))
+    if not files or batch != 256:
+        return None
+    best = None
+    with open(files[-1]) as f:
+        rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+    hdr, rows = rows[0], rows[1:]
+    for r in rows:
+        d = dict(zip(hdr, r))
+        if d["kernel"] == "ll::" + kernel.replace("reg_knn_build_kernel", "reg_knn_kernel"):
+            g = int(d["grid_threads"])
+            if best is None or g > best[0]:
+                best = (g, (2.0 * float(d["fetch_kib_avg"]) + float(d["write_kib_avg"])) * 1024.0)
+    return None if best is None else int(best[1])
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -162,8 +184,9 @@ def main():
         # k-NN + block build launch: 16 B/query in, 65 B/block out (candidate gather is cache-resident)
         alg_bytes = queries * 16.0 + blocks * 65.0
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = pmc_traffic_bytes(names[dom], B)
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes)}
 
     result = {

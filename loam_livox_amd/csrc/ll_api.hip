@@ -531,6 +531,11 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
     DM(d.qw, B * d.cap);
+    DM(d.ref_q, B * d.cap);
+    DM(d.ref_p, B * d.cap);
+    DM(d.ref_p4, B * d.cap);
+    DM(d.todo, B * d.cap);
+    DM(d.todo_n, B * 2);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -549,7 +554,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.qw, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_p4, d.todo, d.todo_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -592,6 +597,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->force_all_iterations = p->force_all_iterations;
     c->debug_knn = debug & 1;
     c->force_general = (debug & 2) ? 1 : 0;
+    c->knn_reuse = (debug & 4) ? 0 : 1;
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)

@@ -31,6 +31,9 @@ struct Knn5 {
     int idx[5];  // original (upload-order) index: the tie-break key and what callers see
     int pos[5];  // position in the cell-sorted array (to fetch the coordinates again)
     int count;
+    float lb2;   // lower bound on the squared distance of every map point that is NOT in the list
+                 // (6th best seen, nearest pruned/unvisited cell, match radius) -- lets the next ICP iteration
+                 // prove that the neighbour set is unchanged without searching again
 };
 
 #define LL_KNN_EMPTY 0x7fffffff
@@ -43,6 +46,7 @@ LL_HD void knn5_init(Knn5 &r)
         r.pos[i] = -1;
     }
     r.count = 0;
+    r.lb2 = INFINITY;
 }
 
 LL_HD int as_int(float f)
@@ -61,7 +65,10 @@ LL_HD bool lex_less(float da, int ia, float db, int ib) { return da < db || (da 
 // (static indices only, so the five slots stay in registers on the GPU).
 LL_HD void knn5_push(Knn5 &r, float d2, int idx, int pos)
 {
-    if (!lex_less(d2, idx, r.d2[4], r.idx[4])) return;
+    if (!lex_less(d2, idx, r.d2[4], r.idx[4])) {
+        r.lb2 = fminf(r.lb2, d2);  // rejected: it stays outside the list
+        return;
+    }
     if (r.count < 5) r.count++;
     float cd = d2;
     int ci = idx, cp = pos;
@@ -78,6 +85,7 @@ LL_HD void knn5_push(Knn5 &r, float d2, int idx, int pos)
             cp = tp;
         }
     }
+    r.lb2 = fminf(r.lb2, cd);  // whatever fell off the end (INF while the list was not full)
 }
 
 // FLANN L2_Simple<float>: result = 0; result += diff*diff for x, y, z.  No FMA contraction.
@@ -162,9 +170,19 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
         const float dz = dzc < 0 ? zm : (dzc > 0 ? zp : 0.0f);
         const float row2 = dy * dy + dz * dz;
         const float lim = (r.count == 5) ? r.d2[4] : max_d2;
-        if (row2 > lim) continue;
-        int x0 = (xm2 + row2 > lim) ? cx : cx - 1;
-        int x1 = (xp2 + row2 > lim) ? cx : cx + 1;
+        if (row2 > lim) {
+            r.lb2 = fminf(r.lb2, row2);  // everything in this run is at least this far
+            continue;
+        }
+        int x0 = cx - 1, x1 = cx + 1;
+        if (xm2 + row2 > lim) {
+            x0 = cx;
+            r.lb2 = fminf(r.lb2, xm2 + row2);
+        }
+        if (xp2 + row2 > lim) {
+            x1 = cx;
+            r.lb2 = fminf(r.lb2, xp2 + row2);
+        }
         if (x0 < 0) x0 = 0;
         if (x1 >= g.nx) x1 = g.nx - 1;
         if (x0 > x1) continue;
@@ -202,9 +220,66 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
         }
         const float bound = (float)k * g.h + m - ((k >= 2) ? slack : 0.0f);
         const float b2 = bound * bound;
-        if (b2 >= max_d2) break;                  // every point within the match radius has been seen
-        if (r.count == 5 && r.d2[4] < b2) break;  // the 5 best cannot be displaced by an unvisited point
+        if (b2 >= max_d2 || (r.count == 5 && r.d2[4] < b2)) {
+            // done: every point within the match radius has been seen, or the 5 best cannot be displaced by an
+            // unvisited point.  Unvisited points are farther than `bound`; points beyond the radius never count.
+            r.lb2 = fminf(r.lb2, fminf(b2, max_d2));
+            return;
+        }
     }
+    r.lb2 = fminf(r.lb2, max_d2);
+}
+
+// How far the query may move before the result of knn5_search has to be recomputed (metres, conservative):
+//   5 found : the set is unchanged while  d5 + delta < lb - delta          ->  (lb - d5) / 2
+//   < 5     : still fewer than 5 inside the radius while  lb - delta >= R   ->  lb - R
+// where lb = sqrt(lb2).  fp32 rounding of the distances is covered by the subtracted slack.
+LL_HD float knn5_reuse_margin(const Knn5 &r, float max_d2)
+{
+    const float lb = sqrtf(r.lb2);
+    float mg;
+    if (r.count == 5)
+        mg = 0.5f * (lb - sqrtf(r.d2[4]));
+    else
+        mg = lb - sqrtf(max_d2);
+    mg -= 1e-5f * (1.0f + lb);
+    return (mg > 0.0f && ll_isfinite(mg)) ? mg : 0.0f;
+}
+
+
+// ---- neighbour reuse across ICP iterations (exact) -------------------------------------------------------------
+// The registrar queries the same feature again after every pose update; late iterations move a query by far less
+// than the gap between its 5th neighbour and everything else.  KnnRef remembers where the last full search was made,
+// what it found and how far the query may move (knn5_reuse_margin) before a new search is needed.
+struct KnnRef {
+    float qx, qy, qz, margin;
+    int pos[5];  // pos[4] < 0: fewer than 5 neighbours inside the match radius
+};
+
+LL_HD void knn5_make_ref(const Knn5 &r, float qx, float qy, float qz, float max_d2, KnnRef &ref)
+{
+    ref.qx = qx;
+    ref.qy = qy;
+    ref.qz = qz;
+    ref.margin = knn5_reuse_margin(r, max_d2);
+    for (int i = 0; i < 5; i++) ref.pos[i] = (r.count == 5) ? r.pos[i] : -1;
+}
+
+// true: `r` holds exactly what knn5_search would return for (qx,qy,qz) (list part only); false: search again
+LL_HD bool knn5_try_reuse(const Grid &g, const KnnRef &ref, float qx, float qy, float qz, float max_d2, Knn5 &r)
+{
+    if (!(ref.margin > 0.0f)) return false;
+    const float delta = sqrtf(dist2_xyz(qx, qy, qz, ref.qx, ref.qy, ref.qz));
+    if (!(delta * 1.000001f + 1e-7f < ref.margin)) return false;
+    knn5_init(r);
+    if (ref.pos[4] < 0) return true;  // still fewer than 5 inside the radius
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const f4 p = g.pts[ref.pos[i]];
+        const float d2 = dist2_xyz(qx, qy, qz, p.x, p.y, p.z);
+        if (d2 < max_d2) knn5_push(r, d2, as_int(p.w), ref.pos[i]);
+    }
+    return true;
 }
 
 }  // namespace ll

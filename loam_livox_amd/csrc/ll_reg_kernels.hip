@@ -88,25 +88,14 @@ __global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, Re
 
 // K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
 // occupancy hides the gather latency).  Output per query: positions (cell-sorted order) of the neighbours the
-// block needs + "5 found" flag.
-#ifndef KNN_WAVES_PER_EU
-#define KNN_WAVES_PER_EU 4
-#endif
-__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
-void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+// block needs + "5 found" flag, and the reuse record for the next ICP iteration.
+//
+// ICP iteration 0 searches every query (reg_knn_kernel, todo == nullptr).  Later iterations first run
+// reg_knn_reuse_kernel: a query whose displacement since its last search is inside its stored margin gets its
+// (re-sorted) previous neighbours -- provably what a new search would return (ll_knn_core.h) -- and the rest are
+// appended to a compact to-do list, so that the expensive search kernel runs on dense wavefronts only.
+__device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r)
 {
-    const int b = blockIdx.y;
-    const int kind = blockIdx.z;
-    const RegState *st = rd.state + b;
-    if (st->done) return;
-    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
-    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
-    if (q >= n) return;
-    const int slot = (kind ? rd.cap_c : 0) + q;
-    const size_t sb = (size_t)b * rd.cap;
-    const float4 pw = rd.qw[sb + slot];
-    Knn5 r;
-    knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);  // NaN query -> empty
     // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
     int4 nn;
     nn.w = (r.count == 5) ? 1 : 0;
@@ -120,6 +109,83 @@ void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
             rd.dbg_idx[(sb + slot) * 5 + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
             rd.dbg_d2[(sb + slot) * 5 + k] = r.d2[k];
         }
+    }
+}
+
+#ifndef KNN_WAVES_PER_EU
+#define KNN_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
+void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int use_todo)
+{
+    const int b = blockIdx.y;
+    const int kind = blockIdx.z;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int t = blockIdx.x * KB_THREADS + threadIdx.x;
+    const size_t sb = (size_t)b * rd.cap;
+    int slot;
+    if (use_todo) {
+        if (t >= rd.todo_n[2 * b + kind]) return;
+        slot = rd.todo[sb + (kind ? rd.cap_c : 0) + t];
+    } else {
+        const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+        if (t >= n) return;
+        slot = (kind ? rd.cap_c : 0) + t;
+    }
+    const float4 pw = rd.qw[sb + slot];
+    const Grid &g = kind ? gs : gc;
+    const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
+    Knn5 r;
+    knn5_search(g, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
+    if (rc.knn_reuse) {
+        KnnRef ref;
+        knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
+        rd.ref_q[sb + slot] = make_float4(ref.qx, ref.qy, ref.qz, ref.margin);
+        rd.ref_p[sb + slot] = make_int4(ref.pos[0], ref.pos[1], ref.pos[2], ref.pos[3]);
+        rd.ref_p4[sb + slot] = ref.pos[4];
+    }
+    knn_store(rd, rc, sb, slot, kind, iter, r);
+}
+
+__global__ __launch_bounds__(KB_THREADS) void reg_knn_reuse_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+{
+    const int b = blockIdx.y;
+    const int kind = blockIdx.z;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
+    if (q >= n) return;
+    const int slot = (kind ? rd.cap_c : 0) + q;
+    const size_t sb = (size_t)b * rd.cap;
+    const float4 pw = rd.qw[sb + slot];
+    const float4 rq = rd.ref_q[sb + slot];
+    KnnRef ref;
+    ref.qx = rq.x;
+    ref.qy = rq.y;
+    ref.qz = rq.z;
+    ref.margin = rq.w;
+    bool reused = false;
+    Knn5 r;
+    // cheap displacement test first; the neighbour positions are only fetched when it passes
+    if (rq.w > 0.0f) {
+        const float delta = sqrtf(dist2_xyz(pw.x, pw.y, pw.z, rq.x, rq.y, rq.z));
+        if (delta * 1.000001f + 1e-7f < rq.w) {
+            const int4 rp = rd.ref_p[sb + slot];
+            ref.pos[0] = rp.x;
+            ref.pos[1] = rp.y;
+            ref.pos[2] = rp.z;
+            ref.pos[3] = rp.w;
+            ref.pos[4] = rd.ref_p4[sb + slot];
+            reused = knn5_try_reuse(kind ? gs : gc, ref, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);
+        }
+    }
+    if (reused) {
+        knn_store(rd, rc, sb, slot, kind, iter, r);
+    } else {
+        const int at = atomicAdd(&rd.todo_n[2 * b + kind], 1);  // wave-aggregated by the compiler
+        rd.todo[sb + (kind ? rd.cap_c : 0) + at] = slot;
     }
 }
 
@@ -818,7 +884,13 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     const int capq = rd.cap_c > rd.cap_s ? rd.cap_c : rd.cap_s;
     dim3 grid((capq + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
     hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
-    hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+    if (iter > 0 && rc.knn_reuse) {
+        (void)hipMemsetAsync(rd.todo_n, 0, (size_t)n_scans * 2 * sizeof(int), s);
+        hipLaunchKernelGGL(reg_knn_reuse_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, 1);
+    } else {
+        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, 0);
+    }
     hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)

@@ -128,7 +128,7 @@ def reg_solve(gc: Grid, gs: Grid, corner, surf, prm: RegParams, pose_last, pose_
     pl = np.ascontiguousarray(pose_last, np.float64).copy()
     pc = np.ascontiguousarray(pose_curr, np.float64).copy()
     pi = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if inc is None else np.ascontiguousarray(inc, np.float64).copy()
-    rep = np.zeros(8)
+    rep = np.zeros(10)
     ret = lib().hc_reg_solve(gc.h, gs.h, _p(corner), corner.shape[0], _p(surf), surf.shape[0], C.byref(prm), _p(pl), _p(pc),
                              _p(pi), _p(rep))
     return ret, pc, pi, rep

@@ -239,9 +239,13 @@ int hc_make_block(int kind, const double *pose_last, const double *pa, const dou
 }
 
 int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int nC, const float *surf, int nS,
-                 const hc_reg_params *p, const double *pose_last, double *pose_curr, double *inc, double *report /*[8]*/)
+                 const hc_reg_params *p, const double *pose_last, double *pose_curr, double *inc, double *report /*[10]*/)
 {
     double prev_q[4] = {0, 0, 0, 1}, prev_t[3] = {0, 0, 0};
+    std::vector<KnnRef> refs[2];
+    refs[0].resize(nC);
+    refs[1].resize(nS);
+    long n_reused = 0, n_searched = 0;
     double final_cost = 0, initial_cost = 0, inlier_thr = 0, angular_diff = 0, t_diff = 0;
     int icp_iters = 0, n_blocks_last = 0, corner_avail = 0, surf_avail = 0, lm_total = 0;
     float fl = (float)p->max_d2_line, fp = (float)p->max_d2_plane;
@@ -260,7 +264,15 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                 float pw[3];
                 point_to_map(pose_curr, f[0], f[1], f[2], pw);
                 Knn5 r;
-                knn5_search(G->g, pw[0], pw[1], pw[2], kind ? fp : fl, r);
+                const float md2 = kind ? fp : fl;
+                bool reused = (it > 0) && knn5_try_reuse(G->g, refs[kind][q], pw[0], pw[1], pw[2], md2, r);
+                if (!reused) {
+                    knn5_search(G->g, pw[0], pw[1], pw[2], md2, r);
+                    knn5_make_ref(r, pw[0], pw[1], pw[2], md2, refs[kind][q]);
+                    n_searched++;
+                } else {
+                    n_reused++;
+                }
                 if (r.count != 5) continue;
                 hc_blk b;
                 b.active = 1;
@@ -354,6 +366,8 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
     report[5] = corner_avail;
     report[6] = surf_avail;
     report[7] = lm_total;
+    report[8] = (double)n_reused;
+    report[9] = (double)n_searched;
     return result;
 }
 
