@@ -642,7 +642,6 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
 {
     if (!map || !prm || !poses_last || !poses_curr) return set_err("ll_reg", "null argument");
     if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg", "n_scans out of range");
-    if (prm->if_motion_deblur) return set_err("ll_reg", "if_motion_deblur=1 is not implemented in this build");
     if (prm->icp_max_iterations < 0 || prm->ceres_max_iterations < 0 || prm->ceres_prerun_times < 0)
         return set_err("ll_reg", "negative iteration count");
     if (map->device != r->device) return set_err("ll_reg", "map lives on another device");

@@ -280,6 +280,162 @@ LL_HD void block_accumulate(int kind, const double R[9], const double t[3], cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------- motion-deblur blocks
+// ceres_icp_point2line_mb / point2plane_mb (ceres_icp.hpp:81-233):  p = q_last (slerp(I, q_inc, s) f + s t_inc) + t_last.
+// With w = Log(R_inc) (rotation vector, |w| = W, axis n, K = [n]x) the interpolated rotation is R_s = Exp(s w) and,
+// for the Ceres perturbation R_inc+ = Exp(2 d) R_inc,
+//     d(R_s f)/dd = -[R_s f]x M,   M = 2 s J_l(s w) J_l(w)^-1 = m0 (I + beta K + gamma K^2)
+// (left Jacobians of SO(3); both are polynomials in K, K^3 = -K).  d p/d t_inc = s I.
+struct MbRot {
+    double n[3];       // rotation axis of the increment
+    double W;          // rotation angle of the increment
+    double c_half, d;  // J_l(w)^-1 = I + c_half K + d K^2 : c_half = -W/2, d = 1 - (W/2) cot(W/2)
+};
+
+LL_HD void mb_prepare(const double q_in[4], MbRot &m)
+{
+    double q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
+    if (q[3] < 0.0) {  // slerp takes the shorter arc (Eigen: scale1 = -scale1 when the dot product is negative)
+        q[0] = -q[0];
+        q[1] = -q[1];
+        q[2] = -q[2];
+        q[3] = -q[3];
+    }
+    const double nv = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (nv > 0.0) {
+        m.n[0] = q[0] / nv;
+        m.n[1] = q[1] / nv;
+        m.n[2] = q[2] / nv;
+        m.W = 2.0 * atan2(nv, q[3]);
+    } else {
+        m.n[0] = 1.0;
+        m.n[1] = 0.0;
+        m.n[2] = 0.0;
+        m.W = 0.0;
+    }
+    m.c_half = -0.5 * m.W;
+    if (m.W > 1e-4) {
+        const double h = 0.5 * m.W;
+        m.d = 1.0 - h * cos(h) / sin(h);
+    } else {
+        m.d = m.W * m.W / 12.0;
+    }
+}
+
+// y = R_s f and the coefficients (m0, beta, gamma) of M for blur ratio s
+LL_HD void mb_block(const MbRot &m, double s, const double f[3], double y[3], double coef[3])
+{
+    const double sW = s * m.W;
+    const double sn = sin(sW), cs = cos(sW);
+    double nf[3], nnf[3];
+    cross3(m.n, f, nf);
+    cross3(m.n, nf, nnf);
+    y[0] = f[0] + sn * nf[0] + (1.0 - cs) * nnf[0];
+    y[1] = f[1] + sn * nf[1] + (1.0 - cs) * nnf[1];
+    y[2] = f[2] + sn * nf[2] + (1.0 - cs) * nnf[2];
+    double a, b;  // J_l(s w) = I + a K + b K^2
+    if (fabs(sW) > 1e-4) {
+        a = (1.0 - cs) / sW;
+        b = 1.0 - sn / sW;
+    } else {
+        a = 0.5 * sW;
+        b = sW * sW / 6.0;
+    }
+    const double c = m.c_half, d = m.d;
+    coef[0] = 2.0 * s;
+    coef[1] = a + c - a * d - b * c;
+    coef[2] = b + d + a * c - b * d;
+}
+
+// M^T z = m0 (z - beta K z + gamma K^2 z)
+LL_HD void mb_Mt(const MbRot &m, const double coef[3], const double z[3], double o[3])
+{
+    double kz[3], kkz[3];
+    cross3(m.n, z, kz);
+    cross3(m.n, kz, kkz);
+    o[0] = coef[0] * (z[0] - coef[1] * kz[0] + coef[2] * kkz[0]);
+    o[1] = coef[0] * (z[1] - coef[1] * kz[1] + coef[2] * kkz[1]);
+    o[2] = coef[0] * (z[2] - coef[1] * kz[2] + coef[2] * kkz[2]);
+}
+
+// residual of a deblur block (frame of pose_last): returns |r|^2
+LL_HD double block_residual_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
+                               const double v[3], double y[3], double coef[3], double r[3], double *dd_out)
+{
+    mb_block(m, s, f, y, coef);
+    const double d[3] = {y[0] + s * t[0] - a[0], y[1] + s * t[1] - a[1], y[2] + s * t[2] - a[2]};
+    const double dd = dot3(d, v);
+    *dd_out = dd;
+    if (kind == BLK_LINE) {
+        r[0] = d[0] - dd * v[0];
+        r[1] = d[1] - dd * v[1];
+        r[2] = d[2] - dd * v[2];
+    } else {
+        r[0] = dd * v[0];
+        r[1] = dd * v[1];
+        r[2] = dd * v[2];
+    }
+    return dot3(r, r);
+}
+
+LL_HD_NOINLINE void block_accumulate_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
+                               const double v[3], double huber_a, double acc[LL_NACC])
+{
+    double y[3], coef[3], r[3], dd, rho0, w;
+    const double ss = block_residual_mb(kind, m, t, s, f, a, v, y, coef, r, &dd);
+    huber(huber_a, ss, &rho0, &w);
+    acc[27] += 0.5 * rho0;
+    if (kind == BLK_PLANE) {
+        // J = n (B^T n)^T with B^T n = [M^T (y x n) ; s n]
+        double yxn[3], top[3];
+        cross3(y, v, yxn);
+        mb_Mt(m, coef, yxn, top);
+        const double cv[6] = {top[0], top[1], top[2], s * v[0], s * v[1], s * v[2]};
+        const double nn2 = dot3(v, v);
+        const double wn = w * nn2, gs = wn * dd;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc[21 + i] += gs * cv[i];
+            const double wi = wn * cv[i];
+#pragma unroll
+            for (int j = i; j < 6; j++) acc[hidx(i, j)] += wi * cv[j];
+        }
+    } else {
+        // explicit J = A B (3x6): column j of B is (M e_j) x y for the rotation part, s e_j for the translation part
+        double J[3][6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double ej[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+            double kz[3], kkz[3], me[3], bj[3];
+            cross3(m.n, ej, kz);
+            cross3(m.n, kz, kkz);
+            for (int i = 0; i < 3; i++) me[i] = coef[0] * (ej[i] + coef[1] * kz[i] + coef[2] * kkz[i]);  // M e_j
+            cross3(me, y, bj);                                                                        // -[y]x M e_j
+            const double ub = dot3(v, bj);
+            for (int i = 0; i < 3; i++) J[i][j] = bj[i] - ub * v[i];
+            const double us = s * v[j];
+            for (int i = 0; i < 3; i++) J[i][3 + j] = (i == j ? s : 0.0) - us * v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc[21 + i] += w * (J[0][i] * r[0] + J[1][i] * r[1] + J[2][i] * r[2]);
+#pragma unroll
+            for (int j = i; j < 6; j++) acc[hidx(i, j)] += w * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
+        }
+    }
+}
+
+LL_HD_NOINLINE double block_l1_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
+                         const double v[3], double huber_a, const double q_last[4])
+{
+    double y[3], coef[3], r[3], dd, rho0, w, rw[3];
+    const double ss = block_residual_mb(kind, m, t, s, f, a, v, y, coef, r, &dd);
+    huber(huber_a, ss, &rho0, &w);
+    quat_rot(q_last, r, rw);
+    const double sq = sqrt(w);
+    return fabs(sq * rw[0]) + fabs(sq * rw[1]) + fabs(sq * rw[2]);
+}
+
 // loss-corrected L1 norm of the world-frame residual (problem.Evaluate + point_cloud_registration.hpp:158,489)
 LL_HD double block_l1(int kind, const double R[9], const double t[3], const double f[3], const double a[3],
                       const double v[3], double huber_a, const double q_last[4])

@@ -234,6 +234,36 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
     rd.blk_flag[sb + slot] = flag;
 }
 
+// Evaluation context as plain locals (R_inc / t_inc for the plain blocks, axis-angle for the motion-deblur ones);
+// DEBLUR is a template constant, so the unused half disappears from each kernel instantiation.
+#define LL_CTX_DECL(x)                                   \
+    double R_[9], t_[3];                                  \
+    MbRot mb_;                                            \
+    {                                                     \
+        const double q_[4] = {(x)[0], (x)[1], (x)[2], (x)[3]}; \
+        quat_to_mat(q_, R_);                              \
+        t_[0] = (x)[4];                                   \
+        t_[1] = (x)[5];                                   \
+        t_[2] = (x)[6];                                   \
+        if (DEBLUR) mb_prepare(q_, mb_);                  \
+    }
+#define LL_CTX_ACCUM(kind, ff, a, v, huber_a, acc)                                                        \
+    do {                                                                                                  \
+        const double f_[3] = {(double)(ff).x, (double)(ff).y, (double)(ff).z};                            \
+        if (DEBLUR)                                                                                       \
+            block_accumulate_mb((kind), mb_, t_, (double)(ff).w, f_, (a), (v), (huber_a), (acc)); /* ICP:81-233 */ \
+        else                                                                                              \
+            block_accumulate((kind), R_, t_, f_, (a), (v), (huber_a), (acc)); /* ICP:238-380 */           \
+    } while (0)
+#define LL_CTX_L1(out, kind, ff, a, v, huber_a, q_last)                                                   \
+    do {                                                                                                  \
+        const double f_[3] = {(double)(ff).x, (double)(ff).y, (double)(ff).z};                            \
+        if (DEBLUR)                                                                                       \
+            (out) = block_l1_mb((kind), mb_, t_, (double)(ff).w, f_, (a), (v), (huber_a), (q_last));      \
+        else                                                                                              \
+            (out) = block_l1((kind), R_, t_, f_, (a), (v), (huber_a), (q_last));                          \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 struct SolveShared {
     LmCtl ctl;
@@ -251,19 +281,13 @@ struct SolveShared {
 __device__ __forceinline__ int slot_of(int j, int nC, int cap_c) { return j < nC ? j : cap_c + (j - nC); }
 
 // workgroup evaluation of cost / g / H at x (LDS) over the active blocks -> sh.sum
-__device__ void solver_eval(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a, SolveShared &sh)
+template <int DEBLUR>
+__device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a, int deblur, SolveShared &sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * rd.cap;
     const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    double R[9], t[3];
-    {
-        const double q[4] = {x[0], x[1], x[2], x[3]};
-        quat_to_mat(q, R);
-        t[0] = x[4];
-        t[1] = x[5];
-        t[2] = x[6];
-    }
+    LL_CTX_DECL(x)
     double acc[LL_NACC];
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
@@ -273,10 +297,9 @@ __device__ void solver_eval(const RegDev &rd, int b, int nC, int nS, const doubl
         const unsigned char fl = rd.blk_flag[sb + slot];
         if (!(fl & BLK_ACTIVE)) continue;
         const float4 ff = rd.blk_f[sb + slot];
-        const double f[3] = {(double)ff.x, (double)ff.y, (double)ff.z};
         const double a[3] = {av[slot], av[(size_t)rd.cap + slot], av[(size_t)2 * rd.cap + slot]};
         const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
-        block_accumulate(fl & 3, R, t, f, a, v, huber_a, acc);
+        LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
     }
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) {
@@ -306,17 +329,18 @@ __device__ int block_sum_int(int v, SolveShared &sh)
 }
 
 // one ceres::Solve: starts at x0 (global/LDS), leaves the result in sh.ctl
+template <int DEBLUR>
 __device__ void solver_lm(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
                           int n_active, SolveShared &sh)
 {
     const int tid = threadIdx.x;
     if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
     __syncthreads();
-    solver_eval(rd, b, nC, nS, sh.ctl.x, rc.huber_a, sh);
+    solver_eval<DEBLUR>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, DEBLUR, sh);
     if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
     __syncthreads();
     while (sh.need) {
-        solver_eval(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, sh);
+        solver_eval<DEBLUR>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, DEBLUR, sh);
         if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
         __syncthreads();
     }
@@ -410,6 +434,7 @@ __device__ void solve_epilogue(const RegConst &rc, RegState *st, SolveShared &sh
 
 
 // General path: any number of blocks per scan; flags, L1 values and the de-duplication table live in HBM.
+template <int DEBLUR>
 __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh)
 {
     const int tid = threadIdx.x;
@@ -440,28 +465,24 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
     }
 
     // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    solver_lm(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, sh);
+    solver_lm<DEBLUR>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, sh);
     int lm_iters = sh.ctl.iteration;
 
     // ---- loss-corrected L1 per block at the prerun result (PCR:476-483) -----------------------------------
     unsigned long long *table = rd.hash + (size_t)b * rd.hash_cap;
     for (int k = tid; k < rd.hash_cap; k += RS_THREADS) table[k] = HASH_EMPTY;
     {
-        double R[9], t[3];
-        const double q[4] = {sh.ctl.x[0], sh.ctl.x[1], sh.ctl.x[2], sh.ctl.x[3]};
-        quat_to_mat(q, R);
-        t[0] = sh.ctl.x[4];
-        t[1] = sh.ctl.x[5];
-        t[2] = sh.ctl.x[6];
+        LL_CTX_DECL(sh.ctl.x)
         for (int j = tid; j < total; j += RS_THREADS) {
             const int slot = slot_of(j, nC, rd.cap_c);
             const unsigned char fl = rd.blk_flag[sb + slot];
             if (!(fl & BLK_ACTIVE)) continue;
             const float4 ff = rd.blk_f[sb + slot];
-            const double f[3] = {(double)ff.x, (double)ff.y, (double)ff.z};
             const double a[3] = {av[slot], av[(size_t)rd.cap + slot], av[(size_t)2 * rd.cap + slot]};
             const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
-            rd.blk_l1[sb + slot] = block_l1(fl & 3, R, t, f, a, v, rc.huber_a, st->pose_last);
+            double l1v;
+            LL_CTX_L1(l1v, fl & 3, ff, a, v, rc.huber_a, st->pose_last);
+            rd.blk_l1[sb + slot] = l1v;
         }
     }
     __syncthreads();
@@ -557,7 +578,7 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
         __shared__ double x_start[7];
         if (tid < 7) x_start[tid] = sh.ctl.x[tid];
         __syncthreads();
-        solver_lm(rd, rc, b, nC, nS, x_start, rc.ceres_max_iterations, sh.n_active, sh);
+        solver_lm<DEBLUR>(rd, rc, b, nC, nS, x_start, rc.ceres_max_iterations, sh.n_active, sh);
     }
     lm_iters += sh.ctl.iteration;
 
@@ -591,20 +612,14 @@ __device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const doub
     r.v2 = av[(size_t)5 * rd.cap + slot];
 }
 
-__device__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a,
+template <int DEBLUR>
+__device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a, int deblur,
                                  const unsigned char *s_flag, SolveShared &sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t sb = (size_t)b * rd.cap;
     const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    double R[9], t[3];
-    {
-        const double q[4] = {x[0], x[1], x[2], x[3]};
-        quat_to_mat(q, R);
-        t[0] = x[4];
-        t[1] = x[5];
-        t[2] = x[6];
-    }
+    LL_CTX_DECL(x)
     double acc[LL_NACC];
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
@@ -617,10 +632,9 @@ __device__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, con
         if (jn < total) load_blk(rd, sb, av, slot_of(jn, nC, rd.cap_c), nxt);  // in flight while we compute
         const unsigned char fl = s_flag[j];
         if (fl & BLK_ACTIVE) {
-            const double f[3] = {(double)cur.f.x, (double)cur.f.y, (double)cur.f.z};
             const double a[3] = {cur.a0, cur.a1, cur.a2};
             const double v[3] = {cur.v0, cur.v1, cur.v2};
-            block_accumulate(fl & 3, R, t, f, a, v, huber_a, acc);
+            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
         }
         cur = nxt;
         j = jn;
@@ -631,10 +645,9 @@ __device__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, con
         load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);  // unconditional: no dependence on the flag
         const unsigned char fl = s_flag[j];
         if (fl & BLK_ACTIVE) {
-            const double f[3] = {(double)cur.f.x, (double)cur.f.y, (double)cur.f.z};
             const double a[3] = {cur.a0, cur.a1, cur.a2};
             const double v[3] = {cur.v0, cur.v1, cur.v2};
-            block_accumulate(fl & 3, R, t, f, a, v, huber_a, acc);
+            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
         }
     }
 #endif
@@ -652,22 +665,24 @@ __device__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, con
     __syncthreads();
 }
 
+template <int DEBLUR>
 __device__ void solver_lm_fast(const RegDev &rd, const RegConst &rc, int b, int nC, int total, const double *x0, int max_iter,
                                int n_active, const unsigned char *s_flag, SolveShared &sh)
 {
     const int tid = threadIdx.x;
     if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
     __syncthreads();
-    solver_eval_fast(rd, b, nC, total, sh.ctl.x, rc.huber_a, s_flag, sh);
+    solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.x, rc.huber_a, DEBLUR, s_flag, sh);
     if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
     __syncthreads();
     while (sh.need) {
-        solver_eval_fast(rd, b, nC, total, sh.ctl.cand, rc.huber_a, s_flag, sh);
+        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.cand, rc.huber_a, DEBLUR, s_flag, sh);
         if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
         __syncthreads();
     }
 }
 
+template <int DEBLUR>
 __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
                            unsigned long long *s_table, unsigned char *s_flag)
 {
@@ -700,18 +715,13 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
     }
 
     // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    solver_lm_fast(rd, rc, b, nC, total, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, sh);
+    solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, sh);
     int lm_iters = sh.ctl.iteration;
 
     // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers ------------------
     double l1r[FAST_MAXK];
     {
-        double R[9], t[3];
-        const double q[4] = {sh.ctl.x[0], sh.ctl.x[1], sh.ctl.x[2], sh.ctl.x[3]};
-        quat_to_mat(q, R);
-        t[0] = sh.ctl.x[4];
-        t[1] = sh.ctl.x[5];
-        t[2] = sh.ctl.x[6];
+        LL_CTX_DECL(sh.ctl.x)
 #pragma unroll
         for (int k = 0; k < FAST_MAXK; k++) {
             const int j = tid + k * RS_THREADS;
@@ -721,10 +731,9 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
                 if (fl & BLK_ACTIVE) {
                     BlkRegs br;
                     load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), br);
-                    const double f[3] = {(double)br.f.x, (double)br.f.y, (double)br.f.z};
                     const double a[3] = {br.a0, br.a1, br.a2};
                     const double v[3] = {br.v0, br.v1, br.v2};
-                    l1 = block_l1(fl & 3, R, t, f, a, v, rc.huber_a, st->pose_last);
+                    LL_CTX_L1(l1, fl & 3, br.f, a, v, rc.huber_a, st->pose_last);
                 }
             }
             l1r[k] = l1;
@@ -826,12 +835,13 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         __shared__ double x_start_f[7];
         if (tid < 7) x_start_f[tid] = sh.ctl.x[tid];
         __syncthreads();
-        solver_lm_fast(rd, rc, b, nC, total, x_start_f, rc.ceres_max_iterations, sh.n_active, s_flag, sh);
+        solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, x_start_f, rc.ceres_max_iterations, sh.n_active, s_flag, sh);
     }
     lm_iters += sh.ctl.iteration;
     solve_epilogue(rc, st, sh, lm_iters);
 }
 
+template <int DEBLUR>
 __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc)
 {
     const int b = blockIdx.x;
@@ -842,9 +852,9 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     __shared__ unsigned char s_flag[FAST_MAX_BLOCKS];
     const int total = rd.n_corner[b] + rd.n_surf[b];
     if (total <= FAST_MAX_BLOCKS && !rc.force_general)
-        solve_fast(rd, rc, b, st, sh, s_table, s_flag);
+        solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
     else
-        solve_general(rd, rc, b, st, sh);
+        solve_general<DEBLUR>(rd, rc, b, st, sh);
 }
 
 __global__ void reg_finalize_kernel(RegDev rd, RegConst rc, int n_scans)
@@ -895,7 +905,10 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {
-    hipLaunchKernelGGL(reg_solve_kernel, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
+    if (rc.if_motion_deblur)
+        hipLaunchKernelGGL(reg_solve_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
+    else
+        hipLaunchKernelGGL(reg_solve_kernel<0>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
 }
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {

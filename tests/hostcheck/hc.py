@@ -48,7 +48,7 @@ def lib():
         L.hc_knn5.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hc_fe_points.argtypes = [C.POINTER(FeParams), C.c_void_p, C.c_int, C.c_double] + [C.c_void_p] * 8
         L.hc_select.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 6
-        L.hc_eval_blocks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.hc_eval_blocks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
         L.hc_make_block.argtypes = [C.c_int] + [C.c_void_p] * 6
         L.hc_reg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(RegParams),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -99,12 +99,13 @@ class Grid:
         return idx, d2
 
 
-def eval_blocks(kind, f, a, v, x, huber_a=0.1):
+def eval_blocks(kind, f, a, v, x, huber_a=0.1, sblur=None):
     kind = np.ascontiguousarray(kind, np.int32)
+    sb = None if sblur is None else np.ascontiguousarray(sblur, np.float64)
     f, a, v = (np.ascontiguousarray(t, np.float64) for t in (f, a, v))
     x = np.ascontiguousarray(x, np.float64)
     acc = np.zeros(28)
-    lib().hc_eval_blocks(len(kind), _p(kind), _p(f), _p(a), _p(v), _p(x), huber_a, _p(acc))
+    lib().hc_eval_blocks(len(kind), _p(kind), _p(f), _p(a), _p(v), _p(x), huber_a, _p(acc), 0 if sb is None else 1, None if sb is None else _p(sb))
     H = np.zeros((6, 6))
     k = 0
     for i in range(6):

@@ -188,15 +188,25 @@ struct hc_blk {
     int kind;
     int active;
     double f[3], a[3], v[3];
+    double s;
 };
+
+static int g_deblur = 0;  // set by the entry points below
 
 static void eval_all(const std::vector<hc_blk> &blk, const double x[7], double huber_a, double acc[LL_NACC])
 {
     double R[9], t[3] = {x[4], x[5], x[6]};
     quat_to_mat(x, R);
+    MbRot mb;
+    if (g_deblur) mb_prepare(x, mb);
     for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
-    for (const hc_blk &b : blk)
-        if (b.active) block_accumulate(b.kind, R, t, b.f, b.a, b.v, huber_a, acc);
+    for (const hc_blk &b : blk) {
+        if (!b.active) continue;
+        if (g_deblur)
+            block_accumulate_mb(b.kind, mb, t, b.s, b.f, b.a, b.v, huber_a, acc);
+        else
+            block_accumulate(b.kind, R, t, b.f, b.a, b.v, huber_a, acc);
+    }
 }
 
 static void lm_run(const std::vector<hc_blk> &blk, const double x0[7], int max_iter, double bound, double huber_a, LmCtl &c)
@@ -215,12 +225,14 @@ static void lm_run(const std::vector<hc_blk> &blk, const double x0[7], int max_i
 
 // blocks evaluation only (for Jacobian checks): kind[], f[3n], a[3n], v[3n] in the pose_last frame
 int hc_eval_blocks(int n, const int32_t *kind, const double *f, const double *a, const double *v, const double *x, double huber_a,
-                   double *acc28)
+                   double *acc28, int deblur, const double *sblur)
 {
+    g_deblur = deblur;
     std::vector<hc_blk> blk(n);
     for (int i = 0; i < n; i++) {
         blk[i].kind = kind[i];
         blk[i].active = 1;
+        blk[i].s = sblur ? sblur[i] : 1.0;
         for (int k = 0; k < 3; k++) {
             blk[i].f[k] = f[3 * i + k];
             blk[i].a[k] = a[3 * i + k];
@@ -246,6 +258,8 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
     refs[0].resize(nC);
     refs[1].resize(nS);
     long n_reused = 0, n_searched = 0;
+    g_deblur = p->if_motion_deblur;
+    double interp_theta = 0.0, hat[9] = {0}, hat_sq[9] = {0};
     double final_cost = 0, initial_cost = 0, inlier_thr = 0, angular_diff = 0, t_diff = 0;
     int icp_iters = 0, n_blocks_last = 0, corner_avail = 0, surf_avail = 0, lm_total = 0;
     float fl = (float)p->max_d2_line, fp = (float)p->max_d2_plane;
@@ -262,7 +276,25 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                 const float *f = feat + 4 * q;
                 if (!(ll_isfinite(f[0]) && ll_isfinite(f[1]) && ll_isfinite(f[2]))) continue;
                 float pw[3];
-                point_to_map(pose_curr, f[0], f[1], f[2], pw);
+                const float sblur = refine_blur(p->if_motion_deblur, f[3], p->min_ts, p->max_ts);
+                if (p->if_motion_deblur == 0 || (double)sblur == 1.0) {
+                    point_to_map(pose_curr, f[0], f[1], f[2], pw);
+                } else {  // Rodrigues interpolation, PCR:641-646
+                    const double sd = (double)sblur;
+                    const double T[3] = {inc[4] * (sd * 1.0), inc[5] * (sd * 1.0), inc[6] * (sd * 1.0)};
+                    const double th = interp_theta * sd, sn = sin(th), cs1 = 1.0 - cos(th);
+                    const double pc3[3] = {(double)f[0], (double)f[1], (double)f[2]};
+                    double inner[3], o[3];
+                    for (int i = 0; i < 3; i++) {
+                        double acc = 0.0;
+                        for (int j = 0; j < 3; j++) acc += (((i == j) ? 1.0 : 0.0) + sn * hat[i * 3 + j] + cs1 * hat_sq[i * 3 + j]) * pc3[j];
+                        inner[i] = acc + T[i];
+                    }
+                    quat_rot(pose_last, inner, o);
+                    pw[0] = (float)(o[0] + pose_last[4]);
+                    pw[1] = (float)(o[1] + pose_last[5]);
+                    pw[2] = (float)(o[2] + pose_last[6]);
+                }
                 Knn5 r;
                 const float md2 = kind ? fp : fl;
                 bool reused = (it > 0) && knn5_try_reuse(G->g, refs[kind][q], pw[0], pw[1], pw[2], md2, r);
@@ -276,6 +308,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                 if (r.count != 5) continue;
                 hc_blk b;
                 b.active = 1;
+                b.s = p->if_motion_deblur ? (double)sblur : 1.0;
                 b.f[0] = f[0];
                 b.f[1] = f[1];
                 b.f[2] = f[2];
@@ -307,7 +340,11 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
             double R[9], t[3] = {c.x[4], c.x[5], c.x[6]};
             quat_to_mat(c.x, R);
             std::vector<double> l1(blk.size());
-            for (size_t i = 0; i < blk.size(); i++) l1[i] = block_l1(blk[i].kind, R, t, blk[i].f, blk[i].a, blk[i].v, p->huber_a, pose_last);
+            MbRot mb;
+            if (g_deblur) mb_prepare(c.x, mb);
+            for (size_t i = 0; i < blk.size(); i++)
+                l1[i] = g_deblur ? block_l1_mb(blk[i].kind, mb, t, blk[i].s, blk[i].f, blk[i].a, blk[i].v, p->huber_a, pose_last)
+                                 : block_l1(blk[i].kind, R, t, blk[i].f, blk[i].a, blk[i].v, p->huber_a, pose_last);
             std::vector<double> u;
             for (double v : l1)
                 if (v == v) u.push_back(v);
@@ -330,6 +367,28 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
         n_blocks_last = 0;
         for (const hc_blk &b : blk) n_blocks_last += b.active;
         for (int i = 0; i < 7; i++) inc[i] = c.x[i];
+        if (p->if_motion_deblur) {  // compute_interpolatation_rodrigue, PCR:607-620
+            double n = sqrt(inc[0] * inc[0] + inc[1] * inc[1] + inc[2] * inc[2]), axis[3];
+            if (inc[3] < 0) n = -n;
+            if (n != 0.0) {
+                interp_theta = 2.0 * atan2(n, fabs(inc[3]));
+                for (int i = 0; i < 3; i++) axis[i] = inc[i] / n;
+            } else {
+                interp_theta = 0.0;
+                axis[0] = 1.0;
+                axis[1] = axis[2] = 0.0;
+            }
+            const double an = sqrt(dot3(axis, axis));
+            for (int i = 0; i < 3; i++) axis[i] /= an;
+            for (int i = 0; i < 9; i++) hat[i] = 0.0;
+            hat[1] = -axis[2]; hat[3] = axis[2]; hat[2] = axis[1]; hat[6] = -axis[1]; hat[5] = -axis[0]; hat[7] = axis[0];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double sacc = 0;
+                    for (int k = 0; k < 3; k++) sacc += hat[i * 3 + k] * hat[k * 3 + j];
+                    hat_sq[i * 3 + j] = sacc;
+                }
+        }
         double tw[3], qc[4];
         quat_rot(pose_last, &inc[4], tw);
         pose_curr[4] = tw[0] + pose_last[4];

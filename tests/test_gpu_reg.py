@@ -198,10 +198,31 @@ def test_cloud_transform_bit_exact(gpu_lib):
 
 def test_errors_are_reported_not_fatal(gpu_lib, dev_map):
     reg = Point_cloud_registration(max_features=10)
-    reg.params.if_motion_deblur = 1
-    with pytest.raises(capi.LoamLivoxError):
-        reg.find_out_incremental_transfrom(dev_map, np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32))
-    reg.params.if_motion_deblur = 0
     with pytest.raises(capi.LoamLivoxError):
         reg.find_out_incremental_transfrom(dev_map, np.zeros((11, 4), np.float32), np.zeros((1, 4), np.float32))
+    reg.close()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+@pytest.mark.parametrize("general", [False, True])
+def test_motion_deblur_matches_oracle(dev_map, small_world, scans, k, general):
+    """if_motion_deblur = 1: the *_mb residuals (ceres_icp.hpp:81-233, slerp-interpolated increment) and the Rodrigues
+    query transform (PCR:641-646).  The device uses SO(3) left-Jacobians where the reference differentiates slerp."""
+    sc = scans[k]
+    fe, ci, si, fi, fc, fs = oracle_features(sc)
+    tmin, tmax = float(fe.time_stamp.min()), float(fe.time_stamp.max())
+    prm = orc.RegParams.defaults(icp_iters=6, ceres_iters=20, force_all=1, deblur=1)
+    prm.minimum_pt_time_stamp, prm.maximum_pt_time_stamp = tmin, tmax
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(False, force_general_solver=general)
+    p = set_params(reg, 6, 20, 1)
+    p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = 1, tmin, tmax
+    reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+    gret = reg.find_out_incremental_transfrom(dev_map, fc, fs)
+    dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+    assert gret == ret and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-7 and dr < 1e-7
+    g = reg.report
+    assert g.n_blocks_last == rep.n_blocks_last and g.lm_iterations_total == rep.lm_iterations_total
+    assert np.isclose(g.final_cost, rep.final_cost, rtol=1e-8)
     reg.close()

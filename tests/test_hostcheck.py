@@ -143,3 +143,40 @@ def test_rejection_matches_oracle(small_world, scans):
     ret, pc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     hret, hpc, _, _ = hc.reg_solve(gc, gs, fc, fs, hc_reg_params(2, 20, 0, 0.3, 1e-6), sc.pose_init, sc.pose_init)
     assert ret == hret == 0 and np.array_equal(pc, hpc)
+
+
+def test_motion_deblur_gauss_newton_matches_jets():
+    """SO(3)-Jacobian form of the *_mb blocks vs the oracle's dual numbers through Eigen's slerp (ceres_icp.hpp:116)."""
+    rng = np.random.default_rng(19)
+    pose_last = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), 0.8), rng.uniform(-50, 50, 3)]
+    for ang in (0.0, 1e-9, 1e-5, 0.03, 0.5):
+        x = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), ang), rng.uniform(-0.1, 0.1, 3)]
+        oblocks, kind, F, A, V, S = [], [], [], [], [], []
+        for i in range(120):
+            f, s = rng.uniform(-8, 8, 3), rng.uniform(0.0, 1.0)
+            pw = synth.quat_to_mat(pose_last[:4]) @ f + pose_last[4:]
+            a = pw + rng.normal(0, 0.04 if i % 4 else 0.4, 3)
+            b, c = a + rng.normal(size=3), a + rng.normal(size=3)
+            if i % 2:
+                oblocks.append(orc.make_block_line(f, a, b, s)); ok, aa, vv = hc.make_block(1, pose_last, a, b)
+            else:
+                oblocks.append(orc.make_block_plane(f, a, b, c, s)); ok, aa, vv = hc.make_block(2, pose_last, a, b, c)
+            kind.append(1 if i % 2 else 2); F.append(f); A.append(aa); V.append(vv); S.append(s)
+        oc, og, oH = orc.blocks_eval(oblocks, pose_last, x, deblur=1)
+        c2, g2, H2 = hc.eval_blocks(kind, np.array(F), np.array(A), np.array(V), x, sblur=S)
+        assert np.isclose(oc, c2, rtol=1e-12)
+        assert np.allclose(og, g2, rtol=1e-9, atol=1e-11) and np.allclose(oH, H2, rtol=1e-9, atol=1e-10)
+
+
+def test_motion_deblur_registration_matches_oracle(small_world, scans):
+    sc = scans[1]
+    fe, ci, si, fi, fc, fs = oracle_features(sc)
+    tmin, tmax = float(fe.time_stamp.min()), float(fe.time_stamp.max())
+    gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 0.6)
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1, deblur=1)
+    prm.minimum_pt_time_stamp, prm.maximum_pt_time_stamp = tmin, tmax
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    hp = hc.RegParams(1, 5, 20, 2, 1, 1, 1, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 0.3, 20.0, 100.0, tmin, tmax)
+    hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hp, sc.pose_init, sc.pose_init)
+    dt, dr = synth.pose_error(pc, hpc)
+    assert ret == hret and dt < 1e-9 and dr < 1e-9 and rep.lm_iterations_total == hrep[7] and rep.n_blocks_last == hrep[4]
