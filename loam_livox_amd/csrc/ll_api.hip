@@ -468,6 +468,7 @@ struct ll_reg {
     float4 *d_corner = nullptr, *d_surf = nullptr;
     int *d_nc = nullptr, *d_ns = nullptr;
     std::vector<RegState> h_state;
+    std::vector<int> h_nc, h_ns;
     int debug = 0, profiling = 0;
     int last_n_scans = 0, last_gated = 0;
     // profiling
@@ -533,9 +534,12 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(d.qw, B * d.cap);
     DM(d.ref_q, B * d.cap);
     DM(d.ref_p, B * d.cap);
-    DM(d.ref_p4, B * d.cap);
-    DM(d.todo, B * d.cap);
-    DM(d.todo_n, B * 2);
+    DM(d.ref_s, B * d.cap);
+    DM(d.blk_flag0, B * d.cap);
+    DM(d.work_search, B * d.cap);
+    DM(d.work_build, B * d.cap);
+    d.n_chunks = (int)((F + 1023) / 1024);
+    DM(d.work_n, B * 4 * (size_t)d.n_chunks);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -545,6 +549,8 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(r->d_pose_tmp, 8);
     HC(hipMemset(d.blk_flag, 0, B * d.cap));
     r->h_state.resize(B);
+    r->h_nc.assign(B, 0);
+    r->h_ns.assign(B, 0);
     *out = r;
     return 0;
 }
@@ -554,7 +560,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_p4, d.todo, d.todo_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -598,6 +604,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->debug_knn = debug & 1;
     c->force_general = (debug & 2) ? 1 : 0;
     c->knn_reuse = (debug & 4) ? 0 : 1;
+    c->knn_reuse_from = (debug & 8) ? 1 : 2;  // bit 3: also try reuse at ICP iteration 1 (test coverage)
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)
@@ -668,11 +675,26 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     r->ev.clear();
     r->ev_class.clear();
     HC(hipMemcpyAsync(r->dev.state, r->h_state.data(), (size_t)n_scans * sizeof(RegState), hipMemcpyHostToDevice, r->stream));
+    // feature counts on the host: launch geometry, and the sub-sampling precondition (the reference's random
+    // drop, PCR:232-238,339-345,438-458, is not reproduced)
+    HC(hipMemcpyAsync(r->h_nc.data(), r->dev.n_corner, (size_t)n_scans * sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    HC(hipMemcpyAsync(r->h_ns.data(), r->dev.n_surf, (size_t)n_scans * sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    HC(hipStreamSynchronize(r->stream));
+    int max_nc = 0, max_ns = 0;
+    for (int b = 0; b < n_scans; b++) {
+        max_nc = r->h_nc[b] > max_nc ? r->h_nc[b] : max_nc;
+        max_ns = r->h_ns[b] > max_ns ? r->h_ns[b] : max_ns;
+    }
+    if (max_nc > r->dev.cap_c || max_ns > r->dev.cap_s) return set_err("ll_reg", "feature count exceeds the registrar capacity");
+    if (max_nc > prm->maximum_allow_residual_block || max_ns > prm->maximum_allow_residual_block)
+        return set_err("ll_reg", "feature count exceeds maximum_allow_residual_block: the reference's random sub-sampling "
+                                 "(point_cloud_registration.hpp:232-238,339-345,438-458) is not reproduced; raise the limit");
     if (run) {
         if (!map->kind[0].pts || !map->kind[1].pts) return set_err("ll_reg", "map not uploaded");
+        HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));
         for (int it = 0; it < prm->icp_max_iterations; it++) {
             prof_begin(r, 0);
-            launch_reg_knn_build(r->dev, r->rc, map->kind[0].grid, map->kind[1].grid, n_scans, it, r->stream);
+            launch_reg_knn_build(r->dev, r->rc, map->kind[0].grid, map->kind[1].grid, n_scans, it, max_nc, max_ns, r->stream);
             prof_end(r);
             prof_begin(r, 1);
             launch_reg_solve(r->dev, r->rc, n_scans, r->stream);

@@ -83,7 +83,10 @@ struct RegState {
 struct RegConst {
     int if_motion_deblur, icp_max_iterations, ceres_max_iterations, ceres_prerun_times;
     int icp_line, icp_plane, force_all_iterations, debug_knn;
-    int force_general, knn_reuse;         // knn_reuse: exact neighbour reuse across ICP iterations (ll_knn_core.h)              // test switch: run the HBM-resident solver path even for small scans
+    int force_general;   // test switch: run the HBM-resident solver path even for small scans
+    int knn_reuse;       // exact neighbour reuse across ICP iterations (ll_knn_core.h)
+    int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)
+    int pad1;
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
     double max_d2_line_d, max_d2_plane_d;
     double huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff;
@@ -102,11 +105,14 @@ struct RegDev {
     float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
     double *blk_av;               // [B][6][cap] a'(3) then v'(3) in the frame of pose_last
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
-    float4 *ref_q;                // [B][cap]  query position of the last full search, w = reuse margin (metres)
+    float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
-    int *ref_p4;                  // [B][cap]  neighbour 4, or -1 when fewer than 5 were inside the radius
-    int *todo;                    // [B][cap]  compact list of query slots that need a full search this iteration
-    int *todo_n;                  // [B][2]    its length per (scan, kind)
+    float2 *ref_s;                // [B][cap]  x = bits(neighbour 4, -1 when fewer than 5 inside the radius), y = m_set
+    unsigned char *blk_flag0;     // [B][cap]  block flag as built; the solver prunes a copy (LDS, or blk_flag in the general path)
+    int *work_search;             // [B][cap]  slots that need a full search this iteration
+    int *work_build;              // [B][cap]  slots that were re-sorted (block must be rebuilt)
+    int *work_n;                  // [B][2 kinds][n_chunks][2] per-chunk list lengths (search, re-sorted)
+    int n_chunks;                 // chunks of 1024 queries per (scan, kind)
     int4 *nn;                     // [B][cap]  neighbour positions (cell-sorted order) + found flag (K6a -> K6b)
     unsigned char *blk_flag;      // [B][cap]  BLK_* bits
     double *blk_l1;               // [B][cap]  scratch for the inlier threshold
@@ -118,7 +124,7 @@ struct RegDev {
 };
 
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
-                          hipStream_t s);
+                          int max_nc, int max_ns, hipStream_t s);
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);

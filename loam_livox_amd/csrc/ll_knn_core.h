@@ -31,6 +31,7 @@ struct Knn5 {
     int idx[5];  // original (upload-order) index: the tie-break key and what callers see
     int pos[5];  // position in the cell-sorted array (to fetch the coordinates again)
     int count;
+    float out2;  // smallest squared distance seen among points at or beyond the match radius (INF if none)
     float lb2;   // lower bound on the squared distance of every map point that is NOT in the list
                  // (6th best seen, nearest pruned/unvisited cell, match radius) -- lets the next ICP iteration
                  // prove that the neighbour set is unchanged without searching again
@@ -47,6 +48,7 @@ LL_HD void knn5_init(Knn5 &r)
     }
     r.count = 0;
     r.lb2 = INFINITY;
+    r.out2 = INFINITY;
 }
 
 LL_HD int as_int(float f)
@@ -121,10 +123,10 @@ LL_HD void scan_run(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of o
         const float d1 = dist2_xyz(qx, qy, qz, p1.x, p1.y, p1.z);
         const float d2 = dist2_xyz(qx, qy, qz, p2.x, p2.y, p2.z);
         const float d3 = dist2_xyz(qx, qy, qz, p3.x, p3.y, p3.z);
-        if (d0 < max_d2) knn5_push(r, d0, as_int(p0.w), j);
-        if (j1 != j && d1 < max_d2) knn5_push(r, d1, as_int(p1.w), j1);
-        if (j2 != j && d2 < max_d2) knn5_push(r, d2, as_int(p2.w), j2);
-        if (j3 != j && d3 < max_d2) knn5_push(r, d3, as_int(p3.w), j3);
+        if (d0 < max_d2) knn5_push(r, d0, as_int(p0.w), j); else r.out2 = fminf(r.out2, d0);
+        if (j1 != j) { if (d1 < max_d2) knn5_push(r, d1, as_int(p1.w), j1); else r.out2 = fminf(r.out2, d1); }
+        if (j2 != j) { if (d2 < max_d2) knn5_push(r, d2, as_int(p2.w), j2); else r.out2 = fminf(r.out2, d2); }
+        if (j3 != j) { if (d3 < max_d2) knn5_push(r, d3, as_int(p3.w), j3); else r.out2 = fminf(r.out2, d3); }
     }
 }
 
@@ -172,16 +174,19 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
         const float lim = (r.count == 5) ? r.d2[4] : max_d2;
         if (row2 > lim) {
             r.lb2 = fminf(r.lb2, row2);  // everything in this run is at least this far
+            if (row2 >= max_d2) r.out2 = fminf(r.out2, row2);
             continue;
         }
         int x0 = cx - 1, x1 = cx + 1;
         if (xm2 + row2 > lim) {
             x0 = cx;
             r.lb2 = fminf(r.lb2, xm2 + row2);
+            if (xm2 + row2 >= max_d2) r.out2 = fminf(r.out2, xm2 + row2);
         }
         if (xp2 + row2 > lim) {
             x1 = cx;
             r.lb2 = fminf(r.lb2, xp2 + row2);
+            if (xp2 + row2 >= max_d2) r.out2 = fminf(r.out2, xp2 + row2);
         }
         if (x0 < 0) x0 = 0;
         if (x1 >= g.nx) x1 = g.nx - 1;
@@ -224,10 +229,13 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
             // done: every point within the match radius has been seen, or the 5 best cannot be displaced by an
             // unvisited point.  Unvisited points are farther than `bound`; points beyond the radius never count.
             r.lb2 = fminf(r.lb2, fminf(b2, max_d2));
+            r.out2 = fminf(r.out2, fmaxf(b2, max_d2));  // unvisited points are beyond `bound` (and beyond the radius
+                                                         // when the search was exhaustive inside it)
             return;
         }
     }
     r.lb2 = fminf(r.lb2, max_d2);
+    r.out2 = fminf(r.out2, max_d2);
 }
 
 // How far the query may move before the result of knn5_search has to be recomputed (metres, conservative):
@@ -236,12 +244,17 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
 // where lb = sqrt(lb2).  fp32 rounding of the distances is covered by the subtracted slack.
 LL_HD float knn5_reuse_margin(const Knn5 &r, float max_d2)
 {
-    const float lb = sqrtf(r.lb2);
+    float lb = sqrtf(r.lb2);
     float mg;
-    if (r.count == 5)
+    if (r.count == 5) {
         mg = 0.5f * (lb - sqrtf(r.d2[4]));
-    else
-        mg = lb - sqrtf(max_d2);
+    } else {
+        // every point inside the radius is in the list (the search was exhaustive there); the state "< 5 inside"
+        // persists while no outside point can enter: nearest outside point (or unvisited region) minus the radius.
+        // Only meaningful when the ring loop really covered the radius, i.e. out2 >= max_d2.
+        lb = sqrtf(r.out2);
+        mg = (r.out2 >= max_d2) ? lb - sqrtf(max_d2) : 0.0f;
+    }
     mg -= 1e-5f * (1.0f + lb);
     return (mg > 0.0f && ll_isfinite(mg)) ? mg : 0.0f;
 }
@@ -249,37 +262,72 @@ LL_HD float knn5_reuse_margin(const Knn5 &r, float max_d2)
 
 // ---- neighbour reuse across ICP iterations (exact) -------------------------------------------------------------
 // The registrar queries the same feature again after every pose update; late iterations move a query by far less
-// than the gap between its 5th neighbour and everything else.  KnnRef remembers where the last full search was made,
-// what it found and how far the query may move (knn5_reuse_margin) before a new search is needed.
+// than the gaps between its neighbours.  KnnRef remembers where the neighbour list was last established, what it was
+// and two displacement budgets (metres, conservative):
+//   m_set    : the SET of 5 neighbours is provably unchanged (knn5_reuse_margin);
+//   m_strong : additionally their ORDER is unchanged (half the smallest gap between consecutive neighbour
+//              distances), i.e. the whole result -- and therefore the residual block -- is bit-for-bit what a new
+//              search would give, and nothing has to be recomputed at all.
 struct KnnRef {
-    float qx, qy, qz, margin;
+    float qx, qy, qz;
+    float m_strong, m_set;
     int pos[5];  // pos[4] < 0: fewer than 5 neighbours inside the match radius
 };
+
+LL_HD float knn5_order_margin(const Knn5 &r)
+{
+    if (r.count != 5) return INFINITY;  // nothing to order
+    float d[5];
+    for (int i = 0; i < 5; i++) d[i] = sqrtf(r.d2[i]);
+    float g = INFINITY;
+    for (int i = 0; i < 4; i++) g = fminf(g, d[i + 1] - d[i]);
+    g = 0.5f * g - 1e-5f * (1.0f + d[4]);
+    return (g > 0.0f) ? g : 0.0f;
+}
 
 LL_HD void knn5_make_ref(const Knn5 &r, float qx, float qy, float qz, float max_d2, KnnRef &ref)
 {
     ref.qx = qx;
     ref.qy = qy;
     ref.qz = qz;
-    ref.margin = knn5_reuse_margin(r, max_d2);
+    ref.m_set = knn5_reuse_margin(r, max_d2);
+    ref.m_strong = fminf(ref.m_set, knn5_order_margin(r));
     for (int i = 0; i < 5; i++) ref.pos[i] = (r.count == 5) ? r.pos[i] : -1;
 }
 
-// true: `r` holds exactly what knn5_search would return for (qx,qy,qz) (list part only); false: search again
-LL_HD bool knn5_try_reuse(const Grid &g, const KnnRef &ref, float qx, float qy, float qz, float max_d2, Knn5 &r)
+// displacement of the query since the reference was taken, slightly over-estimated
+LL_HD float knn5_ref_delta(const KnnRef &ref, float qx, float qy, float qz)
 {
-    if (!(ref.margin > 0.0f)) return false;
-    const float delta = sqrtf(dist2_xyz(qx, qy, qz, ref.qx, ref.qy, ref.qz));
-    if (!(delta * 1.000001f + 1e-7f < ref.margin)) return false;
+    return sqrtf(dist2_xyz(qx, qy, qz, ref.qx, ref.qy, ref.qz)) * 1.000001f + 1e-7f;
+}
+
+// Set-stable path: same five neighbours, possibly in another order.  Re-evaluates and re-sorts them at the new
+// position (`r` = exactly what knn5_search would return, list part) and moves the reference to the new position
+// (budgets shrink by the distance travelled -- triangle inequality -- and the order budget is recomputed).
+LL_HD void knn5_resort(const Grid &g, KnnRef &ref, float delta, float qx, float qy, float qz, float max_d2, Knn5 &r)
+{
     knn5_init(r);
-    if (ref.pos[4] < 0) return true;  // still fewer than 5 inside the radius
+    if (ref.pos[4] >= 0) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        const f4 p = g.pts[ref.pos[i]];
-        const float d2 = dist2_xyz(qx, qy, qz, p.x, p.y, p.z);
-        if (d2 < max_d2) knn5_push(r, d2, as_int(p.w), ref.pos[i]);
+        for (int i = 0; i < 5; i++) {
+            const f4 p = g.pts[ref.pos[i]];
+            const float d2 = dist2_xyz(qx, qy, qz, p.x, p.y, p.z);
+            if (d2 < max_d2) knn5_push(r, d2, as_int(p.w), ref.pos[i]);
+        }
     }
-    return true;
+    const float m_set = fmaxf(ref.m_set - delta, 0.0f);
+    ref.qx = qx;
+    ref.qy = qy;
+    ref.qz = qz;
+    ref.m_set = m_set;
+    if (r.count == 5) {
+        for (int i = 0; i < 5; i++) ref.pos[i] = r.pos[i];
+        ref.m_strong = fminf(m_set, knn5_order_margin(r));
+    } else {
+        // a neighbour left the match radius (or there never were five): the query has no valid block; it stays so
+        // while the set budget lasts, and the stored positions are kept for the next re-sort
+        ref.m_strong = (ref.pos[4] < 0) ? m_set : 0.0f;
+    }
 }
 
 }  // namespace ll

@@ -22,6 +22,8 @@
 namespace ll {
 
 #define KB_THREADS 128
+#define RQ_THREADS 1024  // queries per requery workgroup = work-list segment size
+#define RQ_WAVES (RQ_THREADS / 64)
 #ifndef RS_THREADS
 #define RS_THREADS 512
 #endif
@@ -39,61 +41,76 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// Per-iteration query kernels.
+//
+//   ICP iteration 0 (and every iteration when neighbour reuse is disabled):
+//       reg_transform_kernel -> reg_knn_kernel(all queries) -> reg_build_kernel(all queries)
+//   ICP iteration >= 1:
+//       reg_requery_kernel : transform + displacement test of every query against its reference (ll_knn_core.h):
+//                              stable  -> nothing to do: same neighbours, same order, same residual block;
+//                              re-sort -> same five neighbours re-evaluated at the new position, appended to the
+//                                         build list;
+//                              search  -> appended to the search list
+//       reg_knn_kernel(list)   : full exact search of the search list (dense wavefronts), appends to the build list
+//       reg_build_kernel(list) : block constants for the build list
+// Lists are segmented per 1024-query chunk, filled in query order by one workgroup each (no atomics); late ICP iterations (>= 95 % stable
+// queries) cost one 32-byte read per query plus mostly-empty list launches.
+
+__device__ __forceinline__ void transform_query(const RegState *st, const RegConst &rc, const float4 &f, float pw[3])
+{
+    pw[0] = pw[1] = pw[2] = NAN;  // non-finite features are skipped (PCR:242-245; surface: defined deviation)
+    if (!(ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z))) return;
+    const float sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
+    if (rc.if_motion_deblur == 0 || (double)sblur == 1.0) {
+        point_to_map(st->pose_curr, f.x, f.y, f.z, pw);  // PCR:629
+    } else {
+        // Rodrigues interpolation, PCR:641-646
+        const double s = (double)sblur;
+        const double T[3] = {st->inc[4] * (s * 1.0), st->inc[5] * (s * 1.0), st->inc[6] * (s * 1.0)};
+        const double th = st->interp_theta * s;
+        const double sn = sin(th), cs1 = 1.0 - cos(th);
+        const double pc[3] = {(double)f.x, (double)f.y, (double)f.z};
+        double inner[3], o[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double rij = ((i == j) ? 1.0 : 0.0) + sn * st->hat[i * 3 + j] + cs1 * st->hat_sq[i * 3 + j];
+                acc += rij * pc[j];
+            }
+            inner[i] = acc + T[i];
+        }
+        quat_rot(st->pose_last, inner, o);
+        pw[0] = (float)(o[0] + st->pose_last[4]);
+        pw[1] = (float)(o[1] + st->pose_last[5]);
+        pw[2] = (float)(o[2] + st->pose_last[6]);
+    }
+}
+
+__device__ __forceinline__ float4 load_feature(const RegDev &rd, int b, int kind, int q)
+{
+    return kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
+}
+
 // K6t: pose transform of every query (pointAssociateToMap, fp64 math -> fp32 store like the reference).  A
 // kernel of its own so that the double-precision sin/cos of the motion-deblur branch does not set the register
 // footprint of the k-NN kernel.
-__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc)
+__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc, int kind)
 {
     const int b = blockIdx.y;
-    const int kind = blockIdx.z;  // 0 corner / line, 1 surface / plane
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
     const int q = blockIdx.x * KB_THREADS + threadIdx.x;
     if (q >= n) return;
     const int slot = (kind ? rd.cap_c : 0) + q;
-    const size_t sb = (size_t)b * rd.cap;
-    const float4 f = kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
-    float pw[3] = {NAN, NAN, NAN};  // non-finite features are skipped (PCR:242-245; surface: defined deviation)
-    if (ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z)) {
-        const float sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
-        if (rc.if_motion_deblur == 0 || (double)sblur == 1.0) {
-            point_to_map(st->pose_curr, f.x, f.y, f.z, pw);  // PCR:629
-        } else {
-            // Rodrigues interpolation, PCR:641-646
-            const double s = (double)sblur;
-            const double T[3] = {st->inc[4] * (s * 1.0), st->inc[5] * (s * 1.0), st->inc[6] * (s * 1.0)};
-            const double th = st->interp_theta * s;
-            const double sn = sin(th), cs1 = 1.0 - cos(th);
-            const double pc[3] = {(double)f.x, (double)f.y, (double)f.z};
-            double inner[3], o[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const double rij = ((i == j) ? 1.0 : 0.0) + sn * st->hat[i * 3 + j] + cs1 * st->hat_sq[i * 3 + j];
-                    acc += rij * pc[j];
-                }
-                inner[i] = acc + T[i];
-            }
-            quat_rot(st->pose_last, inner, o);
-            pw[0] = (float)(o[0] + st->pose_last[4]);
-            pw[1] = (float)(o[1] + st->pose_last[5]);
-            pw[2] = (float)(o[2] + st->pose_last[6]);
-        }
-    }
-    rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
+    float pw[3];
+    transform_query(st, rc, load_feature(rd, b, kind, q), pw);
+    rd.qw[(size_t)b * rd.cap + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
 }
 
-// K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
-// occupancy hides the gather latency).  Output per query: positions (cell-sorted order) of the neighbours the
-// block needs + "5 found" flag, and the reuse record for the next ICP iteration.
-//
-// ICP iteration 0 searches every query (reg_knn_kernel, todo == nullptr).  Later iterations first run
-// reg_knn_reuse_kernel: a query whose displacement since its last search is inside its stored margin gets its
-// (re-sorted) previous neighbours -- provably what a new search would return (ll_knn_core.h) -- and the rest are
-// appended to a compact to-do list, so that the expensive search kernel runs on dense wavefronts only.
 __device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r)
 {
     // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
@@ -112,94 +129,149 @@ __device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, 
     }
 }
 
-#ifndef KNN_WAVES_PER_EU
-#define KNN_WAVES_PER_EU 4
-#endif
-__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
-void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int use_todo)
+__device__ __forceinline__ void ref_store(const RegDev &rd, size_t sb, int slot, const KnnRef &ref)
 {
-    const int b = blockIdx.y;
-    const int kind = blockIdx.z;
-    const RegState *st = rd.state + b;
-    if (st->done) return;
-    const int t = blockIdx.x * KB_THREADS + threadIdx.x;
+    rd.ref_q[sb + slot] = make_float4(ref.qx, ref.qy, ref.qz, ref.m_strong);
+    rd.ref_p[sb + slot] = make_int4(ref.pos[0], ref.pos[1], ref.pos[2], ref.pos[3]);
+    rd.ref_s[sb + slot] = make_float2(__int_as_float(ref.pos[4]), ref.m_set);
+}
+
+__device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
+{
+    const int kind = slot >= rd.cap_c ? 1 : 0;
     const size_t sb = (size_t)b * rd.cap;
-    int slot;
-    if (use_todo) {
-        if (t >= rd.todo_n[2 * b + kind]) return;
-        slot = rd.todo[sb + (kind ? rd.cap_c : 0) + t];
-    } else {
-        const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
-        if (t >= n) return;
-        slot = (kind ? rd.cap_c : 0) + t;
-    }
     const float4 pw = rd.qw[sb + slot];
-    const Grid &g = kind ? gs : gc;
     const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
     Knn5 r;
-    knn5_search(g, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
+    knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
     if (rc.knn_reuse) {
         KnnRef ref;
         knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
-        rd.ref_q[sb + slot] = make_float4(ref.qx, ref.qy, ref.qz, ref.margin);
-        rd.ref_p[sb + slot] = make_int4(ref.pos[0], ref.pos[1], ref.pos[2], ref.pos[3]);
-        rd.ref_p4[sb + slot] = ref.pos[4];
+        ref_store(rd, sb, slot, ref);
     }
     knn_store(rd, rc, sb, slot, kind, iter, r);
 }
 
-__global__ __launch_bounds__(KB_THREADS) void reg_knn_reuse_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+// K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
+// occupancy hides the gather latency).  Output per query: positions (cell-sorted order) of the neighbours the
+// block needs + "5 found" flag, and the reuse record for the next ICP iteration.
+#ifndef KNN_WAVES_PER_EU
+#define KNN_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
+void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int kind)
 {
     const int b = blockIdx.y;
-    const int kind = blockIdx.z;
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
     const int q = blockIdx.x * KB_THREADS + threadIdx.x;
     if (q >= n) return;
-    const int slot = (kind ? rd.cap_c : 0) + q;
+    knn_one(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q, iter);
+}
+
+// the same search over the scan's search list (dense wavefronts)
+__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
+void reg_knn_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+{
+    const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
+    if (rd.state[b].done) return;  // the requery kernel did not refresh this scan's lists
+    const int nq = kind ? rd.n_surf[b] : rd.n_corner[b];
+    if (chunk * RQ_THREADS >= nq) return;
+    const int n = rd.work_n[(((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2];
+    const size_t seg = (size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (size_t)chunk * RQ_THREADS;
+    for (int t = threadIdx.x; t < n; t += KB_THREADS) knn_one(rd, rc, gc, gs, b, rd.work_search[seg + t], iter);
+}
+
+// K6r: transform + reuse test (ICP iteration >= 1)
+
+// ordered workgroup compaction: returns this thread's output slot (or -1) and advances *s_base by the number of
+// set predicates.  All threads of the workgroup must call it.
+__device__ __forceinline__ int rq_compact_slot(bool pred, int *s_wave_cnt, int *s_base, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long m = __ballot(pred);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = *s_base;
+    for (int w = 0; w < wave; w++) off += s_wave_cnt[w];
+    const int slot = pred ? off + before : -1;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < RQ_WAVES; w++) tot += s_wave_cnt[w];
+        *s_base += tot;
+    }
+    __syncthreads();
+    return slot;
+}
+
+// One workgroup per chunk of RQ_THREADS consecutive queries: no global atomics; each chunk owns the matching
+// RQ_THREADS-entry segment of the work lists (filled in query order) and a pair of counters, so the list kernels
+// run on spatially coherent, densely packed wavefronts.
+__global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+{
+    const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+    if (chunk * RQ_THREADS >= n) return;
     const size_t sb = (size_t)b * rd.cap;
-    const float4 pw = rd.qw[sb + slot];
-    const float4 rq = rd.ref_q[sb + slot];
-    KnnRef ref;
-    ref.qx = rq.x;
-    ref.qy = rq.y;
-    ref.qz = rq.z;
-    ref.margin = rq.w;
-    bool reused = false;
-    Knn5 r;
-    // cheap displacement test first; the neighbour positions are only fetched when it passes
-    if (rq.w > 0.0f) {
-        const float delta = sqrtf(dist2_xyz(pw.x, pw.y, pw.z, rq.x, rq.y, rq.z));
-        if (delta * 1.000001f + 1e-7f < rq.w) {
-            const int4 rp = rd.ref_p[sb + slot];
-            ref.pos[0] = rp.x;
-            ref.pos[1] = rp.y;
-            ref.pos[2] = rp.z;
-            ref.pos[3] = rp.w;
-            ref.pos[4] = rd.ref_p4[sb + slot];
-            reused = knn5_try_reuse(kind ? gs : gc, ref, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);
+    const int koff = kind ? rd.cap_c : 0;
+    const int tid = threadIdx.x;
+    __shared__ int s_wave[RQ_WAVES];
+    __shared__ int s_n[2];
+    if (tid < 2) s_n[tid] = 0;
+    __syncthreads();
+    const int q = chunk * RQ_THREADS + tid;
+    const int slot = koff + q;
+    int state = 0;  // 0 = stable or out of range, 1 = re-sorted, 2 = needs a search
+    if (q < n) {
+        float pw[3];
+        transform_query(st, rc, load_feature(rd, b, kind, q), pw);
+        const float4 rq = rd.ref_q[sb + slot];
+        KnnRef ref;
+        ref.qx = rq.x;
+        ref.qy = rq.y;
+        ref.qz = rq.z;
+        ref.m_strong = rq.w;
+        const float delta = knn5_ref_delta(ref, pw[0], pw[1], pw[2]);  // NaN for a non-finite query -> search
+        if (!(delta < ref.m_strong)) {  // else: same neighbours, same order: nn and the block are unchanged
+            const float2 rs = rd.ref_s[sb + slot];
+            ref.m_set = rs.y;
+            if (delta < ref.m_set) {
+                const int4 rp = rd.ref_p[sb + slot];
+                ref.pos[0] = rp.x;
+                ref.pos[1] = rp.y;
+                ref.pos[2] = rp.z;
+                ref.pos[3] = rp.w;
+                ref.pos[4] = __float_as_int(rs.x);
+                Knn5 r;
+                knn5_resort(kind ? gs : gc, ref, delta, pw[0], pw[1], pw[2], kind ? rc.max_d2_plane : rc.max_d2_line, r);
+                ref_store(rd, sb, slot, ref);
+                knn_store(rd, rc, sb, slot, kind, iter, r);
+                state = 1;
+            } else {
+                rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
+                state = 2;
+            }
         }
     }
-    if (reused) {
-        knn_store(rd, rc, sb, slot, kind, iter, r);
-    } else {
-        const int at = atomicAdd(&rd.todo_n[2 * b + kind], 1);  // wave-aggregated by the compiler
-        rd.todo[sb + (kind ? rd.cap_c : 0) + at] = slot;
-    }
+    const size_t seg = sb + koff + (size_t)chunk * RQ_THREADS;
+    const int a1 = rq_compact_slot(state == 1, s_wave, &s_n[1], tid);
+    if (a1 >= 0) rd.work_build[seg + a1] = slot;
+    const int a2 = rq_compact_slot(state == 2, s_wave, &s_n[0], tid);
+    if (a2 >= 0) rd.work_search[seg + a2] = slot;
+    if (tid < 2) rd.work_n[(((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2 + tid] = s_n[tid];
 }
 
 // K6b: residual-block constants (fp64) from the neighbours found by K6a.
-__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs)
+__device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot)
 {
-    const int b = blockIdx.y;
-    const int kind = blockIdx.z;
+    const int kind = slot >= rd.cap_c ? 1 : 0;
+    const int q = slot - (kind ? rd.cap_c : 0);
     const RegState *st = rd.state + b;
-    if (st->done) return;
-    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
-    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
-    if (q >= n) return;
-    const int slot = (kind ? rd.cap_c : 0) + q;
     const size_t sb = (size_t)b * rd.cap;
     const int4 nn = rd.nn[sb + slot];
     unsigned char flag = BLK_NONE;
@@ -220,7 +292,7 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
             }
         }
         if (flag & BLK_ACTIVE) {
-            const float4 f = kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
+            const float4 f = load_feature(rd, b, kind, q);
             const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
             rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
             double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
@@ -231,7 +303,32 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
             }
         }
     }
-    rd.blk_flag[sb + slot] = flag;
+    rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)
+}
+
+__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int kind)
+{
+    const int b = blockIdx.y;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
+    const int q = blockIdx.x * KB_THREADS + threadIdx.x;
+    if (q >= n) return;
+    build_one(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q);
+}
+
+// blocks of everything that was searched or re-sorted this iteration
+__global__ __launch_bounds__(KB_THREADS) void reg_build_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs)
+{
+    const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
+    if (rd.state[b].done) return;
+    const int nq = kind ? rd.n_surf[b] : rd.n_corner[b];
+    if (chunk * RQ_THREADS >= nq) return;
+    const size_t ci = (((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2;
+    const int n0 = rd.work_n[ci], n1 = rd.work_n[ci + 1];
+    const size_t seg = (size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (size_t)chunk * RQ_THREADS;
+    for (int t = threadIdx.x; t < n0 + n1; t += KB_THREADS)
+        build_one(rd, rc, gc, gs, b, t < n0 ? rd.work_search[seg + t] : rd.work_build[seg + t - n0]);
 }
 
 // Evaluation context as plain locals (R_inc / t_inc for the plain blocks, axis-angle for the motion-deblur ones);
@@ -447,7 +544,9 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
     {
         int na = 0, nca = 0, nsa = 0;
         for (int j = tid; j < total; j += RS_THREADS) {
-            const unsigned char fl = rd.blk_flag[sb + slot_of(j, nC, rd.cap_c)];
+            const int slot0 = slot_of(j, nC, rd.cap_c);
+            const unsigned char fl = rd.blk_flag0[sb + slot0];
+            rd.blk_flag[sb + slot0] = fl;  // working copy: the prune below clears BLK_ACTIVE in place
             na += (fl & BLK_ACTIVE) ? 1 : 0;
             if (fl & 8) {
                 if (j < nC) nca++; else nsa++;
@@ -696,7 +795,7 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
     {
         int na = 0, nca = 0, nsa = 0;
         for (int j = tid; j < total; j += RS_THREADS) {
-            const unsigned char fl = rd.blk_flag[sb + slot_of(j, nC, rd.cap_c)];
+            const unsigned char fl = rd.blk_flag0[sb + slot_of(j, nC, rd.cap_c)];
             s_flag[j] = fl;
             na += (fl & BLK_ACTIVE) ? 1 : 0;
             if (fl & 8) {
@@ -889,19 +988,25 @@ __global__ void cloud_transform_kernel(const float4 *in, float4 *out, int n, con
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
-                          hipStream_t s)
+                          int max_nc, int max_ns, hipStream_t s)
 {
-    const int capq = rd.cap_c > rd.cap_s ? rd.cap_c : rd.cap_s;
-    dim3 grid((capq + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
-    hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
-    if (iter > 0 && rc.knn_reuse) {
-        (void)hipMemsetAsync(rd.todo_n, 0, (size_t)n_scans * 2 * sizeof(int), s);
-        hipLaunchKernelGGL(reg_knn_reuse_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
-        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, 1);
-    } else {
-        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, 0);
+    const int maxn[2] = {max_nc, max_ns};
+    if (iter >= rc.knn_reuse_from && rc.knn_reuse) {
+        if (max_nc + max_ns <= 0) return;
+        const int mx = max_nc > max_ns ? max_nc : max_ns;
+        dim3 cgrid((mx + RQ_THREADS - 1) / RQ_THREADS, n_scans, 2);
+        hipLaunchKernelGGL(reg_requery_kernel, cgrid, dim3(RQ_THREADS), 0, s, rd, rc, gc, gs, iter);
+        hipLaunchKernelGGL(reg_knn_list_kernel, cgrid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+        hipLaunchKernelGGL(reg_build_list_kernel, cgrid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
+        return;
     }
-    hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
+    for (int kind = 0; kind < 2; kind++) {
+        if (maxn[kind] <= 0) continue;
+        dim3 grid((maxn[kind] + KB_THREADS - 1) / KB_THREADS, n_scans);
+        hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, kind);
+        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, kind);
+        hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, kind);
+    }
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {

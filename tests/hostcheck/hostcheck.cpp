@@ -8,6 +8,8 @@
 // GPU-only plumbing (LDS staging, wave reductions, hash de-duplication, radix select, stream compaction) is
 // covered by the `-m gpu` tests.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -257,6 +259,11 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
     std::vector<KnnRef> refs[2];
     refs[0].resize(nC);
     refs[1].resize(nS);
+    std::vector<hc_blk> kept[2];
+    kept[0].resize(nC);
+    kept[1].resize(nS);
+    for (auto &v : kept) for (auto &k : v) k.kind = BLK_NONE;
+    std::vector<char> kept_avail(nS, 0);
     long n_reused = 0, n_searched = 0;
     g_deblur = p->if_motion_deblur;
     double interp_theta = 0.0, hat[9] = {0}, hat_sq[9] = {0};
@@ -268,6 +275,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
     for (int it = 0; it < p->icp_max_iterations; it++) {
         std::vector<hc_blk> blk;
         corner_avail = surf_avail = 0;
+        long st_cnt[3] = {0, 0, 0};
         for (int kind = 0; kind < 2; kind++) {
             const int n = kind ? nS : nC;
             const float *feat = kind ? surf : corner;
@@ -297,14 +305,37 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                 }
                 Knn5 r;
                 const float md2 = kind ? fp : fl;
-                bool reused = (it > 0) && knn5_try_reuse(G->g, refs[kind][q], pw[0], pw[1], pw[2], md2, r);
-                if (!reused) {
+                KnnRef &ref = refs[kind][q];
+                int state = 2;  // 0 = stable (nothing recomputed), 1 = re-sorted, 2 = searched
+                if (it > 0) {
+                    const float delta = knn5_ref_delta(ref, pw[0], pw[1], pw[2]);
+                    if (delta < ref.m_strong) state = 0;
+                    else if (delta < ref.m_set) {
+                        knn5_resort(G->g, ref, delta, pw[0], pw[1], pw[2], md2, r);
+                        state = 1;
+                    }
+                }
+                if (state == 2) {
                     knn5_search(G->g, pw[0], pw[1], pw[2], md2, r);
-                    knn5_make_ref(r, pw[0], pw[1], pw[2], md2, refs[kind][q]);
+                    knn5_make_ref(r, pw[0], pw[1], pw[2], md2, ref);
                     n_searched++;
                 } else {
                     n_reused++;
                 }
+                st_cnt[state]++;
+                if (state == 0) {
+                    // unchanged: re-use the block built earlier for this query (if it had one)
+                    if (kept[kind][q].kind != BLK_NONE) {
+                        hc_blk kb = kept[kind][q];
+                        kb.active = 1;
+                        blk.push_back(kb);
+                        if (kind == 0) corner_avail++;
+                    }
+                    if (kind == 1 && kept_avail[q]) surf_avail++;
+                    continue;
+                }
+                kept[kind][q].kind = BLK_NONE;
+                if (kind == 1) kept_avail[q] = 0;
                 if (r.count != 5) continue;
                 hc_blk b;
                 b.active = 1;
@@ -319,6 +350,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                     if (!block_line(pose_last, pa, pb, b.a, b.v)) continue;
                     b.kind = BLK_LINE;
                     blk.push_back(b);
+                    kept[0][q] = b;
                     corner_avail++;
                 } else {
                     if (p->icp_plane) {
@@ -327,11 +359,14 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                         if (!block_plane(pose_last, pa, pb, pc, b.a, b.v)) continue;
                         b.kind = BLK_PLANE;
                         blk.push_back(b);
+                        kept[1][q] = b;
                     }
+                    kept_avail[q] = 1;
                     surf_avail++;
                 }
             }
         }
+        if (getenv("HC_KNN_STATS")) fprintf(stderr, "iter %d: stable %ld resort %ld search %ld\n", it, st_cnt[0], st_cnt[1], st_cnt[2]);
         LmCtl c;
         lm_run(blk, inc, p->ceres_prerun_times, p->bound, p->huber_a, c);
         int lm_iters = c.iteration;

@@ -172,6 +172,24 @@ def test_batch_pipeline_equals_single_calls(dev_map, small_world, scans):
     fe.close(); reg.close()
 
 
+@pytest.mark.parametrize("mode", ["no_reuse", "reuse_from_iter1"])
+def test_knn_reuse_is_exact(dev_map, small_world, scans, mode):
+    """the neighbour reuse across ICP iterations must not change anything: same pose bits as with a full search in
+    every iteration, whether it starts at iteration 1 or 2"""
+    sc = scans[2]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    poses = []
+    for kw in ({}, {"no_knn_reuse": True} if mode == "no_reuse" else {"reuse_from_iter1": True}):
+        reg = Point_cloud_registration()
+        reg.set_debug(False, **kw)
+        set_params(reg, 10, 20, 1)
+        reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+        reg.find_out_incremental_transfrom(dev_map, fc, fs)
+        poses.append((reg.m_pose_w_curr.copy(), reg.report.lm_iterations_total, reg.report.n_blocks_last))
+        reg.close()
+    assert np.array_equal(poses[0][0], poses[1][0]) and poses[0][1:] == poses[1][1:]
+
+
 def test_run_to_run_determinism(dev_map, scans):
     sc = scans[1]
     _, _, _, _, fc, fs = oracle_features(sc)
