@@ -538,7 +538,7 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(d.blk_flag0, B * d.cap);
     DM(d.work_search, B * d.cap);
     DM(d.work_build, B * d.cap);
-    d.n_chunks = (int)((F + 1023) / 1024);
+    d.n_chunks = (int)((F + 255) / 256);  // must match RQ_THREADS in ll_reg_kernels.hip
     DM(d.work_n, B * 4 * (size_t)d.n_chunks);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
@@ -752,6 +752,13 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
             }
         }
     }
+    return 0;
+}
+
+extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[6])
+{
+    if (!r || scan < 0 || scan >= r->max_scans) return set_err("ll_reg_debug_cycles", "bad argument");
+    for (int i = 0; i < 6; i++) out[i] = r->h_state[scan].dbg_cycles[i];
     return 0;
 }
 

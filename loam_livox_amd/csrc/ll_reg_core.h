@@ -122,7 +122,7 @@ LL_HD bool block_line(const double pose_last[7], const double pa[3], const doubl
     return true;
 }
 
-// plane block from neighbours 0, k/2, k-1 (point_cloud_registration.hpp:416-418, ceres_icp.hpp:328-334);
+// plane block from neighbours 0, k/2, k-1 (point_cloud_registration.hpp:416-418, ceres_icp.hpp:328-334); a_out[0] = n'.a';
 // n = (ab/|ab|) x (ac/|ac|) is NOT re-normalised.  Degenerate triples (a==b or a==c) are skipped (the
 // reference would produce NaN residuals).
 LL_HD bool block_plane(const double pose_last[7], const double pa[3], const double pb[3], const double pc[3],
@@ -139,8 +139,14 @@ LL_HD bool block_plane(const double pose_last[7], const double pa[3], const doub
     double n[3];
     cross3(ab, ac, n);
     const double rel[3] = {pa[0] - pose_last[4], pa[1] - pose_last[5], pa[2] - pose_last[6]};
-    quat_rot_inv(pose_last, rel, a_out);
+    double a_loc[3];
+    quat_rot_inv(pose_last, rel, a_loc);
     quat_rot_inv(pose_last, n, v_out);
+    // a plane block only ever needs n'.a' (r = ((p - a').n') n'), so it is stored as one scalar: 8 B instead of 24 B
+    // per block on every cost evaluation
+    a_out[0] = dot3(v_out, a_loc);
+    a_out[1] = 0.0;
+    a_out[2] = 0.0;
     return true;
 }
 
@@ -174,18 +180,21 @@ LL_HD double block_residual(int kind, const double R[9], const double t[3], cons
     y[0] = R[0] * f[0] + R[1] * f[1] + R[2] * f[2];
     y[1] = R[3] * f[0] + R[4] * f[1] + R[5] * f[2];
     y[2] = R[6] * f[0] + R[7] * f[1] + R[8] * f[2];
-    const double d[3] = {y[0] + t[0] - a[0], y[1] + t[1] - a[1], y[2] + t[2] - a[2]};
-    const double dd = dot3(d, v);
-    *dd_out = dd;
+    double dd;
     if (kind == BLK_LINE) {
+        const double d[3] = {y[0] + t[0] - a[0], y[1] + t[1] - a[1], y[2] + t[2] - a[2]};
+        dd = dot3(d, v);
         r[0] = d[0] - dd * v[0];
         r[1] = d[1] - dd * v[1];
         r[2] = d[2] - dd * v[2];
     } else {
+        const double p[3] = {y[0] + t[0], y[1] + t[1], y[2] + t[2]};
+        dd = dot3(p, v) - a[0];  // a[0] = n'.a'
         r[0] = dd * v[0];
         r[1] = dd * v[1];
         r[2] = dd * v[2];
     }
+    *dd_out = dd;
     return dot3(r, r);
 }
 
@@ -363,18 +372,21 @@ LL_HD double block_residual_mb(int kind, const MbRot &m, const double t[3], doub
                                const double v[3], double y[3], double coef[3], double r[3], double *dd_out)
 {
     mb_block(m, s, f, y, coef);
-    const double d[3] = {y[0] + s * t[0] - a[0], y[1] + s * t[1] - a[1], y[2] + s * t[2] - a[2]};
-    const double dd = dot3(d, v);
-    *dd_out = dd;
+    double dd;
     if (kind == BLK_LINE) {
+        const double d[3] = {y[0] + s * t[0] - a[0], y[1] + s * t[1] - a[1], y[2] + s * t[2] - a[2]};
+        dd = dot3(d, v);
         r[0] = d[0] - dd * v[0];
         r[1] = d[1] - dd * v[1];
         r[2] = d[2] - dd * v[2];
     } else {
+        const double p[3] = {y[0] + s * t[0], y[1] + s * t[1], y[2] + s * t[2]};
+        dd = dot3(p, v) - a[0];  // a[0] = n'.a'
         r[0] = dd * v[0];
         r[1] = dd * v[1];
         r[2] = dd * v[2];
     }
+    *dd_out = dd;
     return dot3(r, r);
 }
 

@@ -22,7 +22,7 @@
 namespace ll {
 
 #define KB_THREADS 128
-#define RQ_THREADS 1024  // queries per requery workgroup = work-list segment size
+#define RQ_THREADS 256  // queries per requery workgroup = work-list segment size
 #define RQ_WAVES (RQ_THREADS / 64)
 #ifndef RS_THREADS
 #define RS_THREADS 512
@@ -296,11 +296,13 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
             const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
             rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
             double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                av[(size_t)c * rd.cap + slot] = a_out[c];
-                av[(size_t)(3 + c) * rd.cap + slot] = v_out[c];
+            av[slot] = a_out[0];
+            if (kind == 0) {  // line blocks keep the full a'; plane blocks only the scalar n'.a'
+                av[(size_t)rd.cap + slot] = a_out[1];
+                av[(size_t)2 * rd.cap + slot] = a_out[2];
             }
+#pragma unroll
+            for (int c = 0; c < 3; c++) av[(size_t)(3 + c) * rd.cap + slot] = v_out[c];
         }
     }
     rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)
@@ -362,12 +364,26 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_list_kernel(RegDev rd, R
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
+#ifdef LL_SOLVE_TIMING
+#define LL_T0(var) long long var = clock64()
+#define LL_TACC(slot, var)                                   \
+    do {                                                     \
+        if (threadIdx.x == 0) sh.tcyc[slot] += clock64() - var; \
+    } while (0)
+#else
+#define LL_T0(var)
+#define LL_TACC(slot, var)
+#endif
+
 struct SolveShared {
+    long long tcyc[6];
     LmCtl ctl;
     double red[RS_WAVES][LL_NACC];
     double sum[LL_NACC];
     int need;
     int hist[256];
+    int hist_part[RS_THREADS];
+    int sel_bin, sel_cnt, n_cand;
     int isum[RS_WAVES];
     unsigned long long sel_prefix;
     int sel_rank;
@@ -394,7 +410,7 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
         const unsigned char fl = rd.blk_flag[sb + slot];
         if (!(fl & BLK_ACTIVE)) continue;
         const float4 ff = rd.blk_f[sb + slot];
-        const double a[3] = {av[slot], av[(size_t)rd.cap + slot], av[(size_t)2 * rd.cap + slot]};
+        const double a[3] = {av[slot], slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0, slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0};
         const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
         LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
     }
@@ -577,7 +593,7 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
             const unsigned char fl = rd.blk_flag[sb + slot];
             if (!(fl & BLK_ACTIVE)) continue;
             const float4 ff = rd.blk_f[sb + slot];
-            const double a[3] = {av[slot], av[(size_t)rd.cap + slot], av[(size_t)2 * rd.cap + slot]};
+            const double a[3] = {av[slot], slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0, slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0};
             const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
             double l1v;
             LL_CTX_L1(l1v, fl & 3, ff, a, v, rc.huber_a, st->pose_last);
@@ -694,6 +710,8 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
 #define FAST_MAXK (FAST_MAX_BLOCKS / RS_THREADS)
 #define HT_SIZE 16384
 #define HT_PART 6144  // keys per de-duplication round (load factor <= 0.375)
+#define SEL_BINS 4096  // value-range bins of the rank select (must be a multiple of RS_THREADS)
+#define SEL_CAND 1024  // keys of the selected bin ranked exactly; more -> radix-select fallback
 
 struct BlkRegs {
     float4 f;
@@ -704,8 +722,10 @@ __device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const doub
 {
     r.f = rd.blk_f[sb + slot];
     r.a0 = av[slot];
-    r.a1 = av[(size_t)rd.cap + slot];
-    r.a2 = av[(size_t)2 * rd.cap + slot];
+    // surface slots hold plane blocks: a' is folded into the scalar a0 = n'.a' (ll_reg_core.h block_plane)
+    const bool line = slot < rd.cap_c;
+    r.a1 = line ? av[(size_t)rd.cap + slot] : 0.0;
+    r.a2 = line ? av[(size_t)2 * rd.cap + slot] : 0.0;
     r.v0 = av[(size_t)3 * rd.cap + slot];
     r.v1 = av[(size_t)4 * rd.cap + slot];
     r.v2 = av[(size_t)5 * rd.cap + slot];
@@ -771,13 +791,25 @@ __device__ void solver_lm_fast(const RegDev &rd, const RegConst &rc, int b, int 
     const int tid = threadIdx.x;
     if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
     __syncthreads();
-    solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.x, rc.huber_a, DEBLUR, s_flag, sh);
-    if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
-    __syncthreads();
+    {
+        LL_T0(t0);
+        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.x, rc.huber_a, DEBLUR, s_flag, sh);
+        LL_TACC(0, t0);
+    }
+    {
+        LL_T0(t1);
+        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
     while (sh.need) {
+        LL_T0(t0);
         solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.cand, rc.huber_a, DEBLUR, s_flag, sh);
+        LL_TACC(0, t0);
+        LL_T0(t1);
         if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
         __syncthreads();
+        LL_TACC(1, t1);
     }
 }
 
@@ -790,6 +822,9 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
     const int total = nC + nS;
     const size_t sb = (size_t)b * rd.cap;
     const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+    if (tid < 6) sh.tcyc[tid] = 0;
+    __syncthreads();
+    LL_T0(t_total);
 
     // ---- flags -> LDS, census (PCR:325,425) -------------------------------------------------------------------
     {
@@ -819,6 +854,7 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
 
     // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers ------------------
     double l1r[FAST_MAXK];
+    LL_T0(t_l1);
     {
         LL_CTX_DECL(sh.ctl.x)
 #pragma unroll
@@ -839,6 +875,9 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         }
     }
 
+    __syncthreads();
+    LL_TACC(2, t_l1);
+    LL_T0(t_dd);
     // ---- std::set semantics (PCR:155-160): distinct values via an LDS hash table, HT_PART keys per round -----
     unsigned long long first_mask = 0;  // bit k: block k of this thread is the first occurrence of its L1 value
     {
@@ -878,31 +917,123 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         }
         __syncthreads();
     }
+    LL_TACC(3, t_dd);
+    LL_T0(t_sel);
     if (sh.n_unique > 0) {
-        // MSB-first radix select (8 bits per pass) over the distinct keys held in registers
-        for (int pass = 0; pass < 8; pass++) {
-            const int shift = 56 - 8 * pass;
-            for (int e = tid; e < 256; e += RS_THREADS) sh.hist[e] = 0;
-            __syncthreads();
-            const unsigned long long prefix = sh.sel_prefix;
+        // Rank select of the distinct values.  One histogram pass over SEL_BINS value-range bins (a monotone map, so
+        // every key in a lower bin is smaller) finds the bin that holds the wanted rank; its few keys are ranked
+        // exactly against each other.  An 8-bit radix select over the same keys is the fallback when that bin is
+        // crowded (heavily clustered values).
+        int *bins = (int *)s_table;                                      // [SEL_BINS]
+        unsigned long long *cand = s_table + SEL_BINS / 2;               // [SEL_CAND] keys of the selected bin
+        double kmin = INFINITY, kmax = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < FAST_MAXK; k++) {
-                if (!(first_mask & (1ull << k))) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
-                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
+        for (int k = 0; k < FAST_MAXK; k++)
+            if (first_mask & (1ull << k)) {
+                kmin = fmin(kmin, l1r[k]);
+                kmax = fmax(kmax, l1r[k]);
             }
+        for (int off = 32; off > 0; off >>= 1) {
+            kmin = fmin(kmin, __shfl_down(kmin, off));
+            kmax = fmax(kmax, __shfl_down(kmax, off));
+        }
+        if ((tid & 63) == 0) {
+            sh.red[tid >> 6][0] = kmin;
+            sh.red[tid >> 6][1] = kmax;
+        }
+        for (int e = tid; e < SEL_BINS; e += RS_THREADS) bins[e] = 0;
+        __syncthreads();
+        double lo = sh.red[0][0], hi = sh.red[0][1];
+        for (int w = 1; w < RS_WAVES; w++) {
+            lo = fmin(lo, sh.red[w][0]);
+            hi = fmax(hi, sh.red[w][1]);
+        }
+        const double scale = (hi > lo) ? (double)(SEL_BINS - 1) / (hi - lo) : 0.0;
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++)
+            if (first_mask & (1ull << k)) {
+                int bi = (int)((l1r[k] - lo) * scale);
+                bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
+                atomicAdd(&bins[bi], 1);
+            }
+        __syncthreads();
+        // locate the bin of the wanted rank: every thread sums SEL_BINS/RS_THREADS consecutive bins, lane 0 walks
+        // the RS_THREADS partial sums, the owning thread walks its own bins
+        {
+            const int per = SEL_BINS / RS_THREADS;
+            int part = 0;
+            for (int e = 0; e < per; e++) part += bins[tid * per + e];
+            sh.hist_part[tid] = part;
             __syncthreads();
             if (tid == 0) {
-                int rank = sh.sel_rank, d = 0, cum = 0;
-                for (d = 0; d < 256; d++) {
-                    if (cum + sh.hist[d] > rank) break;
-                    cum += sh.hist[d];
+                int rank = sh.sel_rank, cum = 0, t = 0;
+                for (t = 0; t < RS_THREADS; t++) {
+                    if (cum + sh.hist_part[t] > rank) break;
+                    cum += sh.hist_part[t];
                 }
-                if (d > 255) d = 255;
-                sh.sel_rank = rank - cum;
-                sh.sel_prefix = (prefix << 8) | (unsigned long long)d;
+                if (t >= RS_THREADS) t = RS_THREADS - 1;
+                int bi = t * per;
+                for (; bi < t * per + per - 1; bi++) {
+                    if (cum + bins[bi] > rank) break;
+                    cum += bins[bi];
+                }
+                sh.sel_bin = bi;
+                sh.sel_rank = rank - cum;  // rank inside the bin
+                sh.sel_cnt = bins[bi];
+                sh.n_cand = 0;
             }
             __syncthreads();
+        }
+        if (sh.sel_cnt <= SEL_CAND) {
+            const int sel_bin = sh.sel_bin;
+#pragma unroll
+            for (int k = 0; k < FAST_MAXK; k++)
+                if (first_mask & (1ull << k)) {
+                    int bi = (int)((l1r[k] - lo) * scale);
+                    bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
+                    if (bi == sel_bin) cand[atomicAdd(&sh.n_cand, 1)] = (unsigned long long)__double_as_longlong(l1r[k]);
+                }
+            __syncthreads();
+            const int m = sh.n_cand;  // == sel_cnt
+            for (int i = tid; i < m; i += RS_THREADS) {
+                const unsigned long long ki = cand[i];
+                int rk = 0;
+                for (int j = 0; j < m; j++) rk += (cand[j] < ki) ? 1 : 0;  // keys are distinct
+                if (rk == sh.sel_rank) sh.sel_prefix = ki;
+            }
+            __syncthreads();
+        } else {
+            // crowded bin: MSB-first radix select (8 bits per pass) restricted to the keys of that bin
+            const int sel_bin = sh.sel_bin;
+            if (tid == 0) sh.sel_prefix = 0ull;
+            __syncthreads();
+            for (int pass = 0; pass < 8; pass++) {
+                const int shift = 56 - 8 * pass;
+                for (int e = tid; e < 256; e += RS_THREADS) sh.hist[e] = 0;
+                __syncthreads();
+                const unsigned long long prefix = sh.sel_prefix;
+#pragma unroll
+                for (int k = 0; k < FAST_MAXK; k++) {
+                    if (!(first_mask & (1ull << k))) continue;
+                    int bi = (int)((l1r[k] - lo) * scale);
+                    bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
+                    if (bi != sel_bin) continue;
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
+                    if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int rank = sh.sel_rank, d = 0, cum = 0;
+                    for (d = 0; d < 256; d++) {
+                        if (cum + sh.hist[d] > rank) break;
+                        cum += sh.hist[d];
+                    }
+                    if (d > 255) d = 255;
+                    sh.sel_rank = rank - cum;
+                    sh.sel_prefix = (prefix << 8) | (unsigned long long)d;
+                }
+                __syncthreads();
+            }
         }
         if (tid == 0) sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sh.sel_prefix));  // PCR:485
     } else {
@@ -929,6 +1060,7 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         __syncthreads();
     }
 
+    LL_TACC(4, t_sel);
     // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
     {
         __shared__ double x_start_f[7];
@@ -938,6 +1070,11 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
     }
     lm_iters += sh.ctl.iteration;
     solve_epilogue(rc, st, sh, lm_iters);
+#ifdef LL_SOLVE_TIMING
+    LL_TACC(5, t_total);
+    if (tid == 0)
+        for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
+#endif
 }
 
 template <int DEBLUR>

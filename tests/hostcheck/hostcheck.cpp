@@ -240,6 +240,7 @@ int hc_eval_blocks(int n, const int32_t *kind, const double *f, const double *a,
             blk[i].a[k] = a[3 * i + k];
             blk[i].v[k] = v[3 * i + k];
         }
+        // hc_make_block already returns plane blocks in their stored form (a[0] = n'.a')
     }
     eval_all(blk, x, huber_a, acc28);
     return 0;
