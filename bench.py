@@ -60,7 +60,7 @@ def pmc_traffic_bytes(kernel: str, batch: int):
     hdr, rows = rows[0], rows[1:]
     for r in rows:
         d = dict(zip(hdr, r))
-        if d["kernel"] == "ll::" + kernel.replace("reg_knn_build_kernel", "reg_knn_kernel"):
+        if d["kernel"].split("<")[0] == "ll::" + kernel.replace("reg_knn_build_kernel", "reg_knn_kernel"):
             g = int(d["grid_threads"])
             if best is None or g > best[0]:
                 best = (g, (2.0 * float(d["fetch_kib_avg"]) + float(d["write_kib_avg"])) * 1024.0)

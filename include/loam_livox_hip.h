@@ -219,6 +219,11 @@ int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t
 int ll_reg_set_profiling(ll_reg *r, int32_t enable);
 int ll_reg_kernel_times(ll_reg *r, float ms[3], int32_t launches[3]);
 
+/* Builds compiled with -DLL_SOLVE_TIMING accumulate shader-clock counts per solver phase of scan slot `scan`:
+ * [0] cost evaluations, [1] LM controller, [2] L1 pass, [3] de-duplication, [4] rank select + prune, [5] total.
+ * Zeros in normal builds. */
+int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[6]);
+
 /* The HIP stream the handle launches on (hipStream_t), for callers that want their own events on it. */
 void *ll_reg_stream(ll_reg *r);
 void *ll_fe_stream(ll_fe *h);
