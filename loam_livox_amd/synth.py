@@ -212,7 +212,11 @@ def rosette_dirs(n: int, t0: float = 0.0) -> np.ndarray:
 
 def raycast(world: World, origin: np.ndarray, dirs_w: np.ndarray, max_range: float = 200.0,
             prefilter_range: float = 40.0) -> np.ndarray:
-    """Range along each ray to the nearest rectangle (inf if none)."""
+    """Range along each ray to the nearest rectangle (inf if none).  `origin` is one point (3,) or one per ray (n,3)
+    (a sensor that moves during the scan)."""
+    origin = np.asarray(origin, dtype=np.float64)
+    per_ray = origin.ndim == 2
+    o_ref = origin.mean(axis=0) if per_ray else origin
     r = world.rects
     # prefilter rectangles by distance from the origin to their bounding box
     lo = np.empty((r.shape[0], 3))
@@ -226,7 +230,7 @@ def raycast(world: World, origin: np.ndarray, dirs_w: np.ndarray, max_range: flo
         hi[m, others[0]] = r[m, 3]
         lo[m, others[1]] = r[m, 4]
         hi[m, others[1]] = r[m, 5]
-    dbox = np.linalg.norm(np.maximum(np.maximum(lo - origin, origin - hi), 0.0), axis=1)
+    dbox = np.linalg.norm(np.maximum(np.maximum(lo - o_ref, o_ref - hi), 0.0), axis=1)
     keep = dbox < prefilter_range
     r = r[keep]
     best = np.full(dirs_w.shape[0], np.inf)
@@ -236,10 +240,13 @@ def raycast(world: World, origin: np.ndarray, dirs_w: np.ndarray, max_range: flo
             continue
         others = [a for a in range(3) if a != axis]
         dk = dirs_w[:, axis][:, None]
+        oa = origin[:, axis][:, None] if per_ray else origin[axis]
+        ou = origin[:, others[0]][:, None] if per_ray else origin[others[0]]
+        ov = origin[:, others[1]][:, None] if per_ray else origin[others[1]]
         with np.errstate(divide="ignore", invalid="ignore"):
-            t = (ra[:, 1][None, :] - origin[axis]) / dk  # (n, R)
-        u = origin[others[0]] + t * dirs_w[:, others[0]][:, None]
-        v = origin[others[1]] + t * dirs_w[:, others[1]][:, None]
+            t = (ra[:, 1][None, :] - oa) / dk  # (n, R)
+        u = ou + t * dirs_w[:, others[0]][:, None]
+        v = ov + t * dirs_w[:, others[1]][:, None]
         ok = (t > 1e-3) & (u >= ra[:, 2][None, :]) & (u <= ra[:, 3][None, :]) & (v >= ra[:, 4][None, :]) & (
             v <= ra[:, 5][None, :])
         t = np.where(ok, t, np.inf)
@@ -304,6 +311,60 @@ def make_scan(world: World, k: int = 0, n: int = 24000, range_sigma: float = 0.0
     dt = rng.uniform(-0.1, 0.1, 3)
     pose_init = pose_compose(pose_true, np.r_[dq, dt])
     return Scan(np.ascontiguousarray(xyzi), pose_true, pose_init, seed=1000 + k)
+
+
+def quat_slerp_from_identity(q, s):
+    """Eigen's Quaterniond::Identity().slerp(s, q) for an array of ratios s -> (n,4) (x,y,z,w)."""
+    q = np.asarray(q, dtype=np.float64)
+    if q[3] < 0:
+        q = -q
+    nv = np.linalg.norm(q[:3])
+    if nv < 1e-15:
+        return np.tile(np.array([0, 0, 0, 1.0]), (len(s), 1))
+    th = np.arctan2(nv, q[3])
+    axis = q[:3] / nv
+    return np.concatenate([np.sin(s * th)[:, None] * axis[None, :], np.cos(s * th)[:, None]], axis=1)
+
+
+def make_moving_scan(world: World, k: int = 0, n: int = 24000, inc_true=None, yaw_offset: float = 0.0, t_phase: float | None = None,
+                     range_sigma: float = 0.02, p_zero: float = 0.005, p_nan: float = 0.001, pose_start=None) -> Scan:
+    """Scan taken while the sensor moves with a constant twist: point i (blur ratio s_i = i/(n-1)) is measured from
+    T(s_i) = T_start o (slerp(I, q_inc, s_i), s_i t_inc) -- exactly the motion model of the reference's *_mb residuals
+    (ceres_icp.hpp:116-121) -- and is expressed in the instantaneous sensor frame.  `yaw_offset` rotates the rosette
+    about the sensor Z axis (the three heads of a Mid-100 are ~38.4 degrees apart).  pose_true = pose at scan END,
+    pose_init = pose at scan START (what the registrar receives as pose_last / initial guess)."""
+    rng = np.random.default_rng(3000 + k)
+    if pose_start is None:
+        pose_start = sensor_pose_in_world(world, rng)
+    if inc_true is None:
+        inc_true = np.r_[quat_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0.3, 1.0))), rng.uniform(-0.08, 0.08, 3)]
+    s = np.arange(n) / max(1, n - 1)
+    dirs = rosette_dirs(n, t0=rng.uniform(0.0, 1.0) if t_phase is None else t_phase)
+    if yaw_offset != 0.0:
+        cy, sy = np.cos(yaw_offset), np.sin(yaw_offset)
+        dirs = dirs @ np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]]).T
+    qs = quat_slerp_from_identity(inc_true[:4], s)                       # (n,4) incremental rotation at ratio s
+    ts = s[:, None] * inc_true[4:][None, :]
+    R0 = quat_to_mat(pose_start[:4])
+    # rotate each direction by its own incremental rotation: v + 2w(qv x v) + 2 qv x (qv x v)
+    qv, qw = qs[:, :3], qs[:, 3:4]
+    uv = 2.0 * np.cross(qv, dirs)
+    d_inc = dirs + qw * uv + np.cross(qv, uv)
+    dirs_w = d_inc @ R0.T
+    origins = ts @ R0.T + pose_start[4:]
+    rng_m = raycast(world, origins, dirs_w)
+    hit = np.isfinite(rng_m)
+    r = np.where(hit, rng_m + rng.normal(0.0, range_sigma, n), 0.0)
+    pts = (dirs * r[:, None]).astype(np.float32)
+    pts[~hit] = 0.0
+    inten = rng.uniform(5.0, 150.0, n).astype(np.float32)
+    u = rng.uniform(0.0, 1.0, n)
+    pts[u < p_zero] = 0.0
+    pts[(u >= p_zero) & (u < p_zero + p_nan)] = np.nan
+    xyzi = np.concatenate([pts, inten[:, None]], axis=1).astype(np.float32)
+    pose_end = pose_compose(pose_start, inc_true)
+    return Scan(np.ascontiguousarray(xyzi), pose_end, np.asarray(pose_start, dtype=np.float64), seed=3000 + k,
+                meta=dict(inc_true=np.asarray(inc_true, dtype=np.float64)))
 
 
 def transform_points(pose, pts):

@@ -244,3 +244,28 @@ def test_motion_deblur_matches_oracle(dev_map, small_world, scans, k, general):
     assert g.n_blocks_last == rep.n_blocks_last and g.lm_iterations_total == rep.lm_iterations_total
     assert np.isclose(g.final_cost, rep.final_cost, rtol=1e-8)
     reg.close()
+
+
+def test_moving_sensor_deblur_matches_oracle_and_lowers_cost(dev_map, small_world):
+    """a scan taken from a moving sensor (constant twist, the motion model of the *_mb residuals): GPU == oracle with
+    and without deblur, and compensating the distortion explains the data better (lower final cost)"""
+    sc = synth.make_moving_scan(small_world["world"], 1)
+    o = orc.fe_extract(sc.xyzi, 0.0)
+    ci, si, fi = orc.fe_get_features(o, 0.0, 1.0)
+    fc, fs = orc.feature_cloud(o, ci), orc.feature_cloud(o, si)
+    tmin, tmax = float(o.time_stamp[0]), float(o.time_stamp[-1])
+    costs = {}
+    for deblur in (0, 1):
+        prm = orc.RegParams.defaults(icp_iters=8, ceres_iters=20, force_all=1, deblur=deblur)
+        prm.minimum_pt_time_stamp, prm.maximum_pt_time_stamp = tmin, tmax
+        ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+        reg = Point_cloud_registration()
+        p = set_params(reg, 8, 20, 1)
+        p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = deblur, tmin, tmax
+        reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+        assert reg.find_out_incremental_transfrom(dev_map, fc, fs) == ret
+        dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+        assert dt < 1e-7 and dr < 1e-7 and reg.report.n_blocks_last == rep.n_blocks_last
+        costs[deblur] = reg.report.final_cost
+        reg.close()
+    assert costs[1] < costs[0]
