@@ -168,6 +168,7 @@ class Point_cloud_registration {
    public:
     // configuration fields with the reference names and defaults (point_cloud_registration.hpp:45-103)
     int ICP_PLANE = 1, ICP_LINE = 1;
+    int IF_LINE_FEATURE_CHECK = 0, IF_PLANE_FEATURE_CHECK = 0;  // PCR:46,48
     int m_if_motion_deblur = 0;
     int m_current_frame_index = 0;
     int m_mapping_init_accumulate_frames = 100;
@@ -224,6 +225,8 @@ class Point_cloud_registration {
         p.ceres_prerun_times = m_para_cere_prerun_times;
         p.icp_line = ICP_LINE;
         p.icp_plane = ICP_PLANE;
+        p.if_line_feature_check = IF_LINE_FEATURE_CHECK;
+        p.if_plane_feature_check = IF_PLANE_FEATURE_CHECK;
         p.current_frame_index = m_current_frame_index;
         p.mapping_init_accumulate_frames = m_mapping_init_accumulate_frames;
         p.maximum_allow_residual_block = m_maximum_allow_residual_block;

@@ -149,6 +149,9 @@ typedef struct {
     float max_final_cost;                   /* :88  (ROS optimization/max_allow_final_cost) */
     float minimum_pt_time_stamp;            /* :92  */
     float maximum_pt_time_stamp;            /* :93  */
+    int32_t if_line_feature_check;          /* :46  IF_LINE_FEATURE_CHECK  (0): PCA test of the 5 line neighbours, :259-292  */
+    int32_t if_plane_feature_check;         /* :48  IF_PLANE_FEATURE_CHECK (0): PCA test of the 5 plane neighbours, :357-389;
+                                               uses the SURFACE cloud (the reference indexes the corner cloud, a bug) */
 } ll_reg_params;
 
 void ll_reg_default_params(ll_reg_params *p);

@@ -488,6 +488,8 @@ extern "C" void ll_reg_default_params(ll_reg_params *p)
     p->ceres_prerun_times = 2;            // PCR:91
     p->icp_line = 1;                      // PCR:50
     p->icp_plane = 1;                     // PCR:49
+    p->if_line_feature_check = 0;         // PCR:46
+    p->if_plane_feature_check = 0;        // PCR:48
     p->current_frame_index = 101;
     p->mapping_init_accumulate_frames = 100;  // PCR:84
     p->maximum_allow_residual_block = 100000; // PCR:103
@@ -600,6 +602,8 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->ceres_prerun_times = p->ceres_prerun_times;
     c->icp_line = p->icp_line;
     c->icp_plane = p->icp_plane;
+    c->check_line_pca = p->if_line_feature_check;
+    c->check_plane_pca = p->if_plane_feature_check;
     c->force_all_iterations = p->force_all_iterations;
     c->debug_knn = debug & 1;
     c->force_general = (debug & 2) ? 1 : 0;

@@ -87,6 +87,7 @@ struct RegConst {
     int force_general;   // test switch: run the HBM-resident solver path even for small scans
     int knn_reuse;       // exact neighbour reuse across ICP iterations (ll_knn_core.h)
     int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)
+    int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
     int pad1;
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
     double max_d2_line_d, max_d2_plane_d;

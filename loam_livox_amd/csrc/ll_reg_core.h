@@ -150,6 +150,71 @@ LL_HD bool block_plane(const double pose_last[7], const double pa[3], const doub
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------- K7: PCA checks
+// Optional neighbourhood checks of point_cloud_registration.hpp:259-292 (line) and :357-389 (plane), switched by
+// IF_LINE_FEATURE_CHECK / IF_PLANE_FEATURE_CHECK (:46,48; 0 in every shipped configuration).  Covariance of the
+// five neighbours (not divided by n) in double, eigenvalues ascending (Eigen::SelfAdjointEigenSolver order):
+//   line  ok  <=>  l2 > 3 l1                       (:284)
+//   plane ok  <=>  l2 > 3 l0  &&  l2 < 10 l1       (:380-381)
+// The reference's plane branch reads laser_cloud_corner_from_map with surface indices (:361-363), a bug (SURVEY
+// App. B-5); this implementation uses the surface cloud.
+LL_HD void sym3_eigenvalues(const double A_in[9], double ev[3])
+{
+    // cyclic Jacobi rotations on the symmetric 3x3 (converges to ~1 ulp in <= 6 sweeps)
+    double a[9];
+    for (int i = 0; i < 9; i++) a[i] = A_in[i];
+    for (int sweep = 0; sweep < 12; sweep++) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        const double diag = a[0] * a[0] + a[4] * a[4] + a[8] * a[8];
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+            const double apq = a[p * 3 + q];
+            if (apq == 0.0) continue;
+            const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            // A <- J^T A J for the rotation in the (p,q) plane
+            for (int k = 0; k < 3; k++) {
+                const double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                a[k * 3 + p] = c * akp - sn * akq;
+                a[k * 3 + q] = sn * akp + c * akq;
+            }
+            for (int k = 0; k < 3; k++) {
+                const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                a[p * 3 + k] = c * apk - sn * aqk;
+                a[q * 3 + k] = sn * apk + c * aqk;
+            }
+        }
+    }
+    double e0 = a[0], e1 = a[4], e2 = a[8], tmp;
+    if (e0 > e1) { tmp = e0; e0 = e1; e1 = tmp; }
+    if (e1 > e2) { tmp = e1; e1 = e2; e2 = tmp; }
+    if (e0 > e1) { tmp = e0; e0 = e1; e1 = tmp; }
+    ev[0] = e0;
+    ev[1] = e1;
+    ev[2] = e2;
+}
+
+// pts: the five neighbours (float coordinates promoted to double as at :263-265)
+LL_HD bool pca_check(int is_plane, const double pts[5][3])
+{
+    double center[3] = {0, 0, 0};
+    for (int j = 0; j < 5; j++)
+        for (int c = 0; c < 3; c++) center[c] = center[c] + pts[j][c];
+    for (int c = 0; c < 3; c++) center[c] = center[c] / 5.0;  // center / ((float) line_search_num), :270
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < 5; j++) {
+        const double z[3] = {pts[j][0] - center[0], pts[j][1] - center[1], pts[j][2] - center[2]};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) cov[r * 3 + c] = cov[r * 3 + c] + z[r] * z[c];
+    }
+    double ev[3];
+    sym3_eigenvalues(cov, ev);
+    if (is_plane) return (ev[2] > 3 * ev[0]) && (ev[2] < 10 * ev[1]);
+    return ev[2] > 3 * ev[1];
+}
+
 // ceres::HuberLoss(a): rho(s), rho'(s)
 LL_HD void huber(double a, double s, double *rho0, double *rho1)
 {

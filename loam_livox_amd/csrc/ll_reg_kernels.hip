@@ -144,7 +144,7 @@ __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, co
     const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
     Knn5 r;
     knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
-    if (rc.knn_reuse) {
+    if (rc.knn_reuse || rc.check_line_pca || rc.check_plane_pca) {  // the PCA checks need all five positions
         KnnRef ref;
         knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
         ref_store(rd, sb, slot, ref);
@@ -275,7 +275,22 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
     const size_t sb = (size_t)b * rd.cap;
     const int4 nn = rd.nn[sb + slot];
     unsigned char flag = BLK_NONE;
-    if (nn.w) {
+    bool feature_ok = true;
+    if (nn.w && (kind ? rc.check_plane_pca : rc.check_line_pca)) {
+        // K7: PCA check of the five neighbours (PCR:259-292, 357-389); their positions live in the reuse record
+        const Grid &g5 = kind ? gs : gc;
+        const int4 rp = rd.ref_p[sb + slot];
+        const int p5[5] = {rp.x, rp.y, rp.z, rp.w, __float_as_int(rd.ref_s[sb + slot].x)};
+        double pts[5][3];
+        for (int j = 0; j < 5; j++) {
+            const f4 pj = g5.pts[p5[j]];
+            pts[j][0] = (double)pj.x;
+            pts[j][1] = (double)pj.y;
+            pts[j][2] = (double)pj.z;
+        }
+        feature_ok = pca_check(kind, pts);
+    }
+    if (nn.w && feature_ok) {
         const Grid &g = kind ? gs : gc;
         double a_out[3], v_out[3];
         const f4 p0 = g.pts[nn.x], p1 = g.pts[nn.y];

@@ -154,6 +154,8 @@ typedef struct {
     float max_final_cost;           /* PCR:88 */
     float minimum_pt_time_stamp;    /* PCR:92 */
     float maximum_pt_time_stamp;    /* PCR:93 */
+    int if_line_feature_check;      /* PCR:46 (0) */
+    int if_plane_feature_check;     /* PCR:48 (0); uses the surface cloud (reference bug PCR:361-363 fixed) */
 } orc_reg_params;
 
 typedef struct {
@@ -205,6 +207,9 @@ void orc_blocks_eval(const orc_block *blocks, int nb, const double pose_last[7],
                      int deblur, double huber_a, double *cost, double g[6], double H[36]);
 
 /* pointAssociateToMap (PCR:622-661), no-deblur branch: p_w = q*p + t in double, stored float. */
+/* PCA feature checks (PCR:259-292 line, :357-389 plane): pts = 5 float points; ev_out = eigenvalues ascending; returns pass(1)/fail(0) */
+int orc_pca_check(int is_plane, const float pts[15], double ev_out[3]);
+
 void orc_point_to_map(const double pose[7], const float p[3], float out[3]);
 
 /* cloud transform, pointcloudAssociateToMap PCR:673-685 (no-deblur branch). xyzi in/out, n points. */

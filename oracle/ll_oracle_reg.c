@@ -637,6 +637,81 @@ static void lm_solve(const orc_block *blocks, const unsigned char *active, int n
     }
 }
 
+/* ------------------------------------------------------------------ PCA feature checks (PCR:259-292, 357-389) */
+
+/* eigenvalues (ascending) of a symmetric 3x3 by the trigonometric closed form (Smith 1961), refined by one
+ * Newton step per root on the characteristic polynomial; independent of the Jacobi iteration used on the device */
+static void sym3_eig(const double A[9], double ev[3])
+{
+    const double p1 = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double q = (A[0] + A[4] + A[8]) / 3.0;
+    if (p1 == 0.0) {
+        ev[0] = A[0]; ev[1] = A[4]; ev[2] = A[8];
+    } else {
+        const double p2 = (A[0] - q) * (A[0] - q) + (A[4] - q) * (A[4] - q) + (A[8] - q) * (A[8] - q) + 2.0 * p1;
+        const double p = sqrt(p2 / 6.0);
+        double B[9];
+        for (int i = 0; i < 9; i++) B[i] = (A[i] - ((i % 4 == 0) ? q : 0.0)) / p;
+        const double detB = B[0] * (B[4] * B[8] - B[5] * B[7]) - B[1] * (B[3] * B[8] - B[5] * B[6]) + B[2] * (B[3] * B[7] - B[4] * B[6]);
+        double r = detB / 2.0;
+        r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+        const double phi = acos(r) / 3.0;
+        ev[2] = q + 2.0 * p * cos(phi);
+        ev[0] = q + 2.0 * p * cos(phi + 2.0943951023931954923 /* 2 pi / 3 */);
+        ev[1] = 3.0 * q - ev[0] - ev[2];
+    }
+    /* Newton polish on det(A - x I) = 0 (characteristic cubic), keeps ~1e-16 relative accuracy near repeated roots */
+    const double c2 = -(A[0] + A[4] + A[8]);
+    const double c1 = A[0] * A[4] + A[0] * A[8] + A[4] * A[8] - A[1] * A[1] - A[2] * A[2] - A[5] * A[5];
+    const double c0 = -(A[0] * (A[4] * A[8] - A[5] * A[5]) - A[1] * (A[1] * A[8] - A[5] * A[2]) + A[2] * (A[1] * A[5] - A[4] * A[2]));
+    for (int k = 0; k < 3; k++)
+        for (int itn = 0; itn < 2; itn++) {
+            const double x = ev[k];
+            const double f = ((x + c2) * x + c1) * x + c0, df = (3.0 * x + 2.0 * c2) * x + c1;
+            if (df != 0.0 && isfinite(f / df)) ev[k] = x - f / df;
+        }
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2 - i; j++)
+            if (ev[j] > ev[j + 1]) { double t = ev[j]; ev[j] = ev[j + 1]; ev[j + 1] = t; }
+}
+
+static int pca_check(int is_plane, const float *map, int stride, const int32_t idx[5])
+{
+    double center[3] = {0, 0, 0}, pts[5][3];
+    for (int j = 0; j < 5; j++)
+        for (int c = 0; c < 3; c++) {
+            pts[j][c] = (double)map[(size_t)idx[j] * stride + c]; /* PCR:263-265 */
+            center[c] = center[c] + pts[j][c];
+        }
+    for (int c = 0; c < 3; c++) center[c] = center[c] / 5.0; /* PCR:270 */
+    double cov[9] = {0};
+    for (int j = 0; j < 5; j++) { /* PCR:274-278 */
+        double z[3] = {pts[j][0] - center[0], pts[j][1] - center[1], pts[j][2] - center[2]};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) cov[r * 3 + c] += z[r] * z[c];
+    }
+    double ev[3];
+    sym3_eig(cov, ev);
+    if (is_plane) return (ev[2] > 3 * ev[0]) && (ev[2] < 10 * ev[1]); /* PCR:380-381 */
+    return ev[2] > 3 * ev[1];                                          /* PCR:284 */
+}
+
+int orc_pca_check(int is_plane, const float pts[15], double ev_out[3])
+{
+    const int32_t idx[5] = {0, 1, 2, 3, 4};
+    double center[3] = {0, 0, 0}, cov[9] = {0};
+    for (int j = 0; j < 5; j++)
+        for (int c = 0; c < 3; c++) center[c] = center[c] + (double)pts[j * 3 + c];
+    for (int c = 0; c < 3; c++) center[c] = center[c] / 5.0;
+    for (int j = 0; j < 5; j++) {
+        double z[3] = {pts[j * 3] - center[0], pts[j * 3 + 1] - center[1], pts[j * 3 + 2] - center[2]};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) cov[r * 3 + c] += z[r] * z[c];
+    }
+    sym3_eig(cov, ev_out);
+    return pca_check(is_plane, pts, 3, idx);
+}
+
 /* ------------------------------------------------------------------ PCR helpers */
 
 /* refine_blur PCR:128-141 (float arithmetic) */
@@ -803,6 +878,7 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
             point_associate(deblur, pose_curr, pose_last, &pose_incre[4], &st, po, (double)s, sel);
             if (orc_kdtree_knn(tree_corner, sel, kl, nn_idx, nn_d2) != kl) continue; /* PCR:249 */
             if ((double)nn_d2[kl - 1] < prm->maximum_dis_line_for_match) {           /* PCR:254 */
+                if (prm->if_line_feature_check && !pca_check(0, map_corner, map_stride, nn_idx)) continue; /* PCR:259-292,328-331 */
                 if (prm->icp_line) {
                     const float *pa = &map_corner[(size_t)nn_idx[0] * map_stride];
                     const float *pb = &map_corner[(size_t)nn_idx[1] * map_stride];
@@ -823,6 +899,7 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
             point_associate(deblur, pose_curr, pose_last, &pose_incre[4], &st, po, (double)s, sel);
             if (orc_kdtree_knn(tree_surf, sel, kp, nn_idx, nn_d2) != kp) continue; /* PCR:351 */
             if ((double)nn_d2[kp - 1] < prm->maximum_dis_plane_for_match) {        /* PCR:353 */
+                if (prm->if_plane_feature_check && !pca_check(1, map_surf, map_stride, nn_idx)) continue; /* PCR:357-389,427-430 (surface cloud: bug fixed) */
                 if (prm->icp_plane) {
                     const float *pa = &map_surf[(size_t)nn_idx[0] * map_stride];
                     const float *pb = &map_surf[(size_t)nn_idx[kp / 2] * map_stride];

@@ -31,7 +31,8 @@ class RegParams(C.Structure):
                                        "ceres_prerun_times", "icp_line", "icp_plane", "force_all_iterations")] + \
                [(n, C.c_double) for n in ("max_d2_line", "max_d2_plane", "huber_a", "inliner_dis", "inlier_ratio",
                                           "minimum_icp_R_diff", "minimum_icp_T_diff", "bound")] + \
-               [(n, C.c_float) for n in ("para_max_angular_rate", "max_final_cost", "min_ts", "max_ts")]
+               [(n, C.c_float) for n in ("para_max_angular_rate", "max_final_cost", "min_ts", "max_ts")] + \
+               [(n, C.c_int) for n in ("check_line_pca", "check_plane_pca")]
 
 
 _lib = None
@@ -133,3 +134,12 @@ def reg_solve(gc: Grid, gs: Grid, corner, surf, prm: RegParams, pose_last, pose_
     ret = lib().hc_reg_solve(gc.h, gs.h, _p(corner), corner.shape[0], _p(surf), surf.shape[0], C.byref(prm), _p(pl), _p(pc),
                              _p(pi), _p(rep))
     return ret, pc, pi, rep
+
+
+def pca_check(is_plane, pts5):
+    p = np.ascontiguousarray(pts5, np.float32).reshape(15)
+    ev = np.zeros(3)
+    L = lib()
+    L.hc_pca_check.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.hc_pca_check.restype = C.c_int
+    return bool(L.hc_pca_check(int(is_plane), p.ctypes.data, ev.ctypes.data)), ev

@@ -184,6 +184,7 @@ struct hc_reg_params {
         force_all_iterations;
     double max_d2_line, max_d2_plane, huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff, bound;
     float para_max_angular_rate, max_final_cost, min_ts, max_ts;
+    int check_line_pca, check_plane_pca;
 };
 
 struct hc_blk {
@@ -251,6 +252,22 @@ int hc_make_block(int kind, const double *pose_last, const double *pa, const dou
 {
     if (kind == BLK_LINE) return block_line(pose_last, pa, pb, a_out, v_out) ? 1 : 0;
     return block_plane(pose_last, pa, pb, pc, a_out, v_out) ? 1 : 0;
+}
+
+int hc_pca_check(int is_plane, const float *pts, double *ev_out)
+{
+    double p5[5][3], center[3] = {0, 0, 0}, cov[9] = {0};
+    for (int j = 0; j < 5; j++)
+        for (int c = 0; c < 3; c++) {
+            p5[j][c] = pts[j * 3 + c];
+            center[c] += p5[j][c];
+        }
+    for (int c = 0; c < 3; c++) center[c] /= 5.0;
+    for (int j = 0; j < 5; j++)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) cov[r * 3 + c] += (p5[j][r] - center[r]) * (p5[j][c] - center[c]);
+    sym3_eigenvalues(cov, ev_out);
+    return pca_check(is_plane, p5) ? 1 : 0;
 }
 
 int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int nC, const float *surf, int nS,
@@ -338,6 +355,16 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                 kept[kind][q].kind = BLK_NONE;
                 if (kind == 1) kept_avail[q] = 0;
                 if (r.count != 5) continue;
+                if (kind ? p->check_plane_pca : p->check_line_pca) {
+                    double pts5[5][3];
+                    for (int j = 0; j < 5; j++) {
+                        const f4 pj = G->g.pts[r.pos[j]];
+                        pts5[j][0] = pj.x;
+                        pts5[j][1] = pj.y;
+                        pts5[j][2] = pj.z;
+                    }
+                    if (!pca_check(kind, pts5)) continue;
+                }
                 hc_blk b;
                 b.active = 1;
                 b.s = p->if_motion_deblur ? (double)sblur : 1.0;

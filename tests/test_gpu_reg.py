@@ -269,3 +269,41 @@ def test_moving_sensor_deblur_matches_oracle_and_lowers_cost(dev_map, small_worl
         costs[deblur] = reg.report.final_cost
         reg.close()
     assert costs[1] < costs[0]
+
+
+@pytest.mark.parametrize("checks", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("general", [False, True])
+def test_pca_feature_checks_match_oracle(gpu_lib, small_world, scans, checks, general):
+    """K7: IF_LINE_FEATURE_CHECK / IF_PLANE_FEATURE_CHECK (PCR:46,48,259-292,357-389), with the plane check on the
+    surface cloud.  A noisy corner map makes the line test reject neighbourhoods too."""
+    from tests.test_hostcheck import noisy_corner_map
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    corner = noisy_corner_map(small_world)
+    tree_c = orc.KdTree(corner)
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, corner)
+    m.setInputCloud(Map_buffer.SURF, small_world["surf"])
+    prm = orc.RegParams.defaults(icp_iters=8, ceres_iters=20, force_all=1)
+    prm.if_line_feature_check, prm.if_plane_feature_check = checks
+    ret, pc, pi, rep = orc.reg_solve(tree_c, small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    base = orc.RegParams.defaults(icp_iters=8, ceres_iters=20, force_all=1)
+    _, _, _, rep0 = orc.reg_solve(tree_c, small_world["tree_s"], fc, fs, base, sc.pose_init, sc.pose_init)
+    assert rep.corner_avail + rep.surf_avail < rep0.corner_avail + rep0.surf_avail
+    poses = []
+    for no_reuse in (False, True):
+        reg = Point_cloud_registration(max_scans=1, max_features=24000)
+        reg.set_debug(False, force_general_solver=general, no_knn_reuse=no_reuse)
+        p = set_params(reg, 8, 20, 1)
+        p.if_line_feature_check, p.if_plane_feature_check = checks
+        reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+        gret = reg.find_out_incremental_transfrom(m, fc, fs)
+        dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+        g = reg.report
+        assert gret == ret and dt < 1e-7 and dr < 1e-7
+        assert g.n_blocks_last == rep.n_blocks_last and g.corner_avail == rep.corner_avail and g.surf_avail == rep.surf_avail
+        assert g.lm_iterations_total == rep.lm_iterations_total
+        poses.append(reg.m_pose_w_curr.copy())
+        reg.close()
+    assert np.array_equal(poses[0], poses[1])
+    m.close()

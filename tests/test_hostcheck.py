@@ -180,3 +180,74 @@ def test_motion_deblur_registration_matches_oracle(small_world, scans):
     hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hp, sc.pose_init, sc.pose_init)
     dt, dr = synth.pose_error(pc, hpc)
     assert ret == hret and dt < 1e-9 and dr < 1e-9 and rep.lm_iterations_total == hrep[7] and rep.n_blocks_last == hrep[4]
+
+
+def _pca_cases(rng):
+    cases = []
+    for _ in range(200):
+        kind = rng.integers(0, 5)
+        c = rng.uniform(-50, 50, 3)
+        if kind == 0:      # blob
+            p = c + rng.normal(0, rng.uniform(0.01, 1.0), (5, 3))
+        elif kind == 1:    # noisy line
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            p = c + np.outer(rng.uniform(-1, 1, 5), d) + rng.normal(0, rng.uniform(0, 0.2), (5, 3))
+        elif kind == 2:    # noisy plane
+            u, v = rng.normal(size=3), rng.normal(size=3)
+            p = c + np.outer(rng.uniform(-1, 1, 5), u) + np.outer(rng.uniform(-1, 1, 5), v) + rng.normal(0, rng.uniform(0, 0.1), (5, 3))
+        elif kind == 3:    # exactly collinear on an axis (repeated zero eigenvalues)
+            p = c + np.outer(np.arange(5.0), [0.25, 0, 0])
+        else:              # all the same point
+            p = np.tile(c, (5, 1))
+        cases.append(p.astype(np.float32))
+    return cases
+
+
+def test_pca_feature_checks_match_oracle_and_numpy():
+    """K7 (PCR:259-292, 357-389): Jacobi eigenvalues of the device header, the oracle's closed form and LAPACK agree,
+    and so do the pass/fail decisions"""
+    rng = np.random.default_rng(77)
+    n_pass = [0, 0]
+    for p in _pca_cases(rng):
+        z = p.astype(np.float64) - p.astype(np.float64).sum(0) / 5.0
+        ev_np = np.linalg.eigvalsh(z.T @ z)
+        scale = max(ev_np[2], 1e-300)
+        for is_plane in (0, 1):
+            ok_o, ev_o = orc.pca_check(is_plane, p)
+            ok_h, ev_h = hc.pca_check(is_plane, p)
+            assert np.all(np.abs(ev_o - ev_np) <= 1e-9 * scale + 1e-300) and np.all(np.abs(ev_h - ev_np) <= 1e-12 * scale + 1e-300)
+            expect = (ev_np[2] > 3 * ev_np[0] and ev_np[2] < 10 * ev_np[1]) if is_plane else ev_np[2] > 3 * ev_np[1]
+            margin = min(abs(ev_np[2] - 3 * ev_np[0]), abs(ev_np[2] - 10 * ev_np[1])) if is_plane else abs(ev_np[2] - 3 * ev_np[1])
+            if margin > 1e-6 * scale:  # away from the decision boundary all three must agree
+                assert ok_o == expect and ok_h == expect
+            n_pass[is_plane] += ok_h
+    assert 20 < n_pass[0] < 190 and 20 < n_pass[1] < 190  # both outcomes are exercised
+
+
+def noisy_corner_map(small_world, sigma=0.12):
+    c = small_world["corner"].copy()
+    c[:, :3] += np.random.default_rng(5).normal(0, sigma, (len(c), 3)).astype(np.float32)
+    return c
+
+
+@pytest.mark.parametrize("checks", [(1, 0), (0, 1), (1, 1)])
+def test_registration_with_pca_checks_matches_oracle(small_world, scans, checks):
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    corner = noisy_corner_map(small_world)  # the clean synthetic edges always pass the line test
+    tree_c = orc.KdTree(corner)
+    gc, gs = hc.Grid(corner, 0.5), hc.Grid(small_world["surf"], 0.6)
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
+    prm.if_line_feature_check, prm.if_plane_feature_check = checks
+    ret, pc, pi, rep = orc.reg_solve(tree_c, small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    hp = hc.RegParams(0, 5, 20, 2, 1, 1, 1, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 0.3, 20.0, 100.0, 0.0, 1.0, *checks)
+    hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hp, sc.pose_init, sc.pose_init)
+    dt, dr = synth.pose_error(pc, hpc)
+    assert ret == hret and dt < 1e-9 and dr < 1e-9
+    assert rep.n_blocks_last == hrep[4] and rep.corner_avail == hrep[5] and rep.surf_avail == hrep[6]
+    base = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
+    _, _, _, rep0 = orc.reg_solve(tree_c, small_world["tree_s"], fc, fs, base, sc.pose_init, sc.pose_init)
+    if checks[0]:  # both checks reject some neighbourhoods
+        assert rep.corner_avail < rep0.corner_avail
+    if checks[1]:
+        assert rep.surf_avail < rep0.surf_avail
