@@ -110,7 +110,8 @@ void ll_map_destroy(ll_map *m);
 /* Replaces pcl::KdTreeFLANN::setInputCloud for the match buffers (laser_mapping.hpp:544-545,
  * point_cloud_registration.hpp:596-597): uploads the cloud and builds the device search grid.
  * xyz: m points, stride_floats apart (3 = xyz, 4 = xyzi).  cell_size <= 0 selects the default
- * (0.5 m corner / 0.6 m surface: about 1.5x the 0.4 m surface-map leaf).  Point indices reported by the library refer to this input order. */
+ * (1.45 m corner: the sparse edge map is searched out to the sqrt(2) m line radius, one cell ring covers it;
+ * 0.6 m surface: about 1.5x the 0.4 m surface-map leaf).  Point indices reported by the library refer to this input order. */
 int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size);
 int64_t ll_map_size(const ll_map *m, int32_t kind);
 
@@ -226,6 +227,10 @@ int ll_reg_kernel_times(ll_reg *r, float ms[3], int32_t launches[3]);
  * [0] cost evaluations, [1] LM controller, [2] L1 pass, [3] de-duplication, [4] rank select + prune, [5] total.
  * Zeros in normal builds. */
 int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[6]);
+
+/* Lengths of the neighbour-reuse work lists left by the last ICP iteration of the last solve, summed over the first
+ * n_scans slots: out[0] = queries that needed a full search, out[1] = queries whose five neighbours were re-sorted. */
+int ll_reg_debug_worklists(ll_reg *r, int32_t n_scans, int64_t out[2]);
 
 /* The HIP stream the handle launches on (hipStream_t), for callers that want their own events on it. */
 void *ll_reg_stream(ll_reg *r);

@@ -254,6 +254,11 @@ class Point_cloud_registration:
     def set_profiling(self, enable: bool = True):
         check(self.L.ll_reg_set_profiling(self.h, int(enable)), "ll_reg_set_profiling")
 
+    def debug_worklists(self, n_scans=1):
+        out = np.zeros(2, np.int64)
+        check(self.L.ll_reg_debug_worklists(self.h, int(n_scans), ptr(out)), "ll_reg_debug_worklists")
+        return int(out[0]), int(out[1])
+
     def kernel_times(self):
         ms = np.zeros(3, np.float32)
         n = np.zeros(3, np.int32)

@@ -81,6 +81,7 @@ SYMBOLS = {
     "ll_reg_set_profiling": (_i32, [_vp, _i32]),
     "ll_reg_kernel_times": (_i32, [_vp, _vp, _vp]),
     "ll_reg_debug_cycles": (_i32, [_vp, _i32, _vp]),
+    "ll_reg_debug_worklists": (_i32, [_vp, _i32, _vp]),
     "ll_reg_stream": (_vp, [_vp]),
     "ll_fe_stream": (_vp, [_vp]),
     "ll_last_error": (C.c_char_p, []),

@@ -413,7 +413,7 @@ extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t 
     if (stride_floats < 3) return set_err("ll_map_upload", "stride_floats must be >= 3");
     if (n < 0 || n > 0x7fffffffLL) return set_err("ll_map_upload", "point count out of range");
     HC(hipSetDevice(m->device));
-    if (!(cell_size > 0.f)) cell_size = (kind == LL_MAP_CORNER) ? 0.5f : 0.6f;
+    if (!(cell_size > 0.f)) cell_size = (kind == LL_MAP_CORNER) ? 1.45f : 0.6f;  // corner: just above the line match radius sqrt(2) m (PCR:89)
     float *d_raw = nullptr;
     const size_t bytes = (size_t)(n > 0 ? n : 1) * stride_floats * sizeof(float);
     HC(hipMalloc(&d_raw, bytes));
@@ -763,6 +763,19 @@ extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[6])
 {
     if (!r || scan < 0 || scan >= r->max_scans) return set_err("ll_reg_debug_cycles", "bad argument");
     for (int i = 0; i < 6; i++) out[i] = r->h_state[scan].dbg_cycles[i];
+    return 0;
+}
+
+extern "C" int ll_reg_debug_worklists(ll_reg *r, int32_t n_scans, int64_t out[2])
+{
+    if (!r || !out || n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_debug_worklists", "bad argument");
+    HC(hipSetDevice(r->device));
+    const size_t n = (size_t)n_scans * 4 * r->dev.n_chunks;
+    std::vector<int> h(n);
+    HC(hipStreamSynchronize(r->stream));
+    HC(hipMemcpy(h.data(), r->dev.work_n, n * sizeof(int), hipMemcpyDeviceToHost));
+    out[0] = out[1] = 0;
+    for (size_t i = 0; i < n; i++) out[i & 1] += h[i];
     return 0;
 }
 

@@ -97,9 +97,9 @@ __device__ __forceinline__ float4 load_feature(const RegDev &rd, int b, int kind
 // K6t: pose transform of every query (pointAssociateToMap, fp64 math -> fp32 store like the reference).  A
 // kernel of its own so that the double-precision sin/cos of the motion-deblur branch does not set the register
 // footprint of the k-NN kernel.
-__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc, int kind)
+__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc)
 {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, kind = blockIdx.z;
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
@@ -159,9 +159,9 @@ __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, co
 #define KNN_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
-void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int kind)
+void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, kind = blockIdx.z;
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
@@ -323,9 +323,9 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
     rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)
 }
 
-__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int kind)
+__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs)
 {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, kind = blockIdx.z;
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
@@ -1142,7 +1142,6 @@ __global__ void cloud_transform_kernel(const float4 *in, float4 *out, int n, con
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
                           int max_nc, int max_ns, hipStream_t s)
 {
-    const int maxn[2] = {max_nc, max_ns};
     if (iter >= rc.knn_reuse_from && rc.knn_reuse) {
         if (max_nc + max_ns <= 0) return;
         const int mx = max_nc > max_ns ? max_nc : max_ns;
@@ -1152,13 +1151,14 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         hipLaunchKernelGGL(reg_build_list_kernel, cgrid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
         return;
     }
-    for (int kind = 0; kind < 2; kind++) {
-        if (maxn[kind] <= 0) continue;
-        dim3 grid((maxn[kind] + KB_THREADS - 1) / KB_THREADS, n_scans);
-        hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, kind);
-        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, kind);
-        hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, kind);
-    }
+    // corner and surface queries share every launch (blockIdx.z = kind): the few hundred corner queries of a scan
+    // are latency-bound on their own and would otherwise serialise three more launches per iteration
+    const int mx = max_nc > max_ns ? max_nc : max_ns;
+    if (mx <= 0) return;
+    dim3 grid((mx + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
+    hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
+    hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+    hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {

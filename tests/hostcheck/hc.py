@@ -99,6 +99,14 @@ class Grid:
         lib().hc_knn5(self.h, _p(q), q.shape[0], max_d2, _p(idx), _p(d2))
         return idx, d2
 
+    def knn5_bounds(self, q, max_d2):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        out = [np.zeros(q.shape[0], np.float32) for _ in range(4)]
+        L = lib()
+        L.hc_knn5_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
+        L.hc_knn5_bounds(self.h, _p(q), q.shape[0], max_d2, *[_p(o) for o in out])
+        return out  # lb2, out2, m_set, m_strong
+
 
 def eval_blocks(kind, f, a, v, x, huber_a=0.1, sblur=None):
     kind = np.ascontiguousarray(kind, np.int32)

@@ -178,6 +178,23 @@ int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx
     return 0;
 }
 
+// the reuse bounds of the same search: lb2 (lower bound on every point outside the list), out2 (lower bound on every
+// point at or beyond the match radius) and the two displacement budgets of the reuse record
+int hc_knn5_bounds(const hc_grid *G, const float *q, int nq, float max_d2, float *lb2, float *out2, float *m_set, float *m_strong)
+{
+    for (int i = 0; i < nq; i++) {
+        Knn5 r;
+        knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
+        KnnRef ref;
+        knn5_make_ref(r, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, ref);
+        lb2[i] = r.lb2;
+        out2[i] = r.out2;
+        m_set[i] = ref.m_set;
+        m_strong[i] = ref.m_strong;
+    }
+    return 0;
+}
+
 // ---- registration (host stand-in for reg_knn_build_kernel + reg_solve_kernel + reg_finalize_kernel) ----------
 struct hc_reg_params {
     int if_motion_deblur, icp_max_iterations, ceres_max_iterations, ceres_prerun_times, icp_line, icp_plane,

@@ -86,6 +86,40 @@ def test_grid_knn_sparse_outside_and_ties():
     assert hi[500].tolist()[:4] == [100, 101, 102, 103]
 
 
+@pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500)])
+def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts):
+    """lb2 / out2 and the displacement budgets derived from them must be conservative whatever the search pruned:
+    moving the query by less than m_set keeps the neighbour set, by less than m_strong the ordered list"""
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
+    g = hc.Grid(pts, cell)
+    q = rng.uniform(-2, 32, (400, 3)).astype(np.float32)
+    hi, hd = g.knn5(q, max_d2)
+    lb2, out2, m_set, m_strong = g.knn5_bounds(q, max_d2)
+    d2_all = ((q[:, None, :].astype(np.float64) - pts[None, :, :]) ** 2).sum(-1)
+    for i in range(len(q)):
+        listed = hi[i][hi[i] >= 0]
+        full = len(listed) == 5 and hd[i][4] < max_d2
+        rest = np.delete(d2_all[i], listed) if full else d2_all[i][d2_all[i] >= max_d2]
+        bound = lb2[i] if full else out2[i]
+        assert rest.size == 0 or bound <= rest.min() * (1 + 1e-5) + 1e-6
+    assert (m_set > 0).mean() > 0.5 and np.all(m_strong <= m_set)
+    # move every query by 0.9 of its budget in a random direction and search again
+    d = rng.normal(size=q.shape); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for budget, ordered in ((m_set, False), (m_strong, True)):
+        q2 = (q + 0.9 * budget[:, None] * d).astype(np.float32)
+        hi2, hd2 = g.knn5(q2, max_d2)
+        found1 = (hi >= 0).sum(1) == 5
+        found2 = (hi2 >= 0).sum(1) == 5
+        if ordered:
+            assert np.array_equal(found1, found2) and np.array_equal(hi[found1], hi2[found1])
+        else:
+            # the set is unchanged; a neighbour may leave the radius (found -> not found) but nothing new may enter
+            assert not np.any(found2 & ~found1)
+            both = found1 & found2
+            assert np.array_equal(np.sort(hi[both], 1), np.sort(hi2[both], 1))
+
+
 def test_analytic_gauss_newton_matches_jets():
     rng = np.random.default_rng(9)
     pose_last = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), 0.8), rng.uniform(-50, 50, 3)]
