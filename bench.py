@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--distinct-scans", type=int, default=16)
     ap.add_argument("--cell-corner", type=float, default=0.0, help="grid cell size override (0 = library default)")
     ap.add_argument("--cell-surf", type=float, default=0.0)
+    ap.add_argument("--q-pipe", action="store_true", help="Q-pipe query mode (SURVEY 8d): device VoxelGrid (leaf 0.1 corner / 0.4 surface, "
+                    "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
     return ap.parse_args()
@@ -87,7 +89,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from loam_livox_amd import synth
-    from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration
+    from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration, VoxelGrid
 
     B, N = args.batch, args.scan_points
     t0 = time.time()
@@ -118,11 +120,16 @@ def main():
     p.maximum_allow_residual_block = N
     reg.set_profiling(True)
 
+    vox = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
+
     def step():
         fe.extract_batch(B)
         fe.resolve()
         fe.select_batch(B, -1, 0.0, 1.0)
-        reg.enqueue_fe(mp, fe, B, init, init)
+        if vox:
+            reg.enqueue_fe_downsampled(mp, fe, vox[0], vox[1], 0.1, 0.4, B, init, init)
+        else:
+            reg.enqueue_fe(mp, fe, B, init, init)
         return reg.collect(B)
 
     def barrier():
@@ -150,6 +157,9 @@ def main():
         elapsed = float(t.item())
     res, pc, pi, reps = out
     nc, ns, nf, n_amb = fe.counts(B)
+    nc_fe, ns_fe = nc, ns
+    if vox:  # what the registrar saw
+        nc, ns = vox[0].counts(B)[0], vox[1].counts(B)[0]
     total_scans = B * args.steps * world
     value = total_scans / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -162,11 +172,16 @@ def main():
     for f_ in ("icp_max_iterations", "ceres_max_iterations", "force_all_iterations", "para_max_angular_rate", "para_max_speed",
                "max_final_cost", "current_frame_index", "mapping_init_accumulate_frames", "maximum_allow_residual_block"):
         setattr(reg1.params, f_, getattr(p, f_))
+    vox1 = (VoxelGrid(N, 1, device=dev), VoxelGrid(N, 1, device=dev)) if vox else None
     for i in range(5):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         fe1.extract_batch(1); fe1.resolve(); fe1.select_batch(1, -1, 0.0, 1.0)
-        reg1.enqueue_fe(mp, fe1, 1, init[:1], init[:1]); reg1.collect(1)
+        if vox:
+            reg1.enqueue_fe_downsampled(mp, fe1, vox1[0], vox1[1], 0.1, 0.4, 1, init[:1], init[:1])
+        else:
+            reg1.enqueue_fe(mp, fe1, 1, init[:1], init[:1])
+        reg1.collect(1)
         lat.append(time.perf_counter() - t1)
     latency_ms = 1e3 * float(np.median(lat[1:]))
 
@@ -193,7 +208,8 @@ def main():
         "metric": "scans_per_s", "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 points / f64 solve", "data": "synthetic",
-        "config": {"workload": "C2: 24k-pt Mid-40 scan vs 5M-pt corner+surface map, 10 ICP iters (fixed), k=5, Q-full",
+        "config": {"workload": "C2: 24k-pt Mid-40 scan vs 5M-pt corner+surface map, 10 ICP iters (fixed), k=5, "
+                               + ("Q-pipe (device VoxelGrid 0.1/0.4 before registration)" if vox else "Q-full"),
                    "scan_points": N, "map_points": int(len(corner) + len(surf)), "map_corner": int(len(corner)),
                    "map_surf": int(len(surf)), "icp_iters": args.icp_iters, "batch_scans_per_step_per_gpu": B,
                    "parallelism": f"replicas x{world} (independent scans, no data-path collective)"},
@@ -222,10 +238,13 @@ def main():
             tb = time.perf_counter()
             o = orc.fe_extract(scans[b], 1.0)
             ci, si, fi = orc.fe_get_features(o, 0.0, 1.0)
-            ret, opc, _, orep = orc.reg_solve(tc, ts, orc.feature_cloud(o, ci), orc.feature_cloud(o, si), prm, init[b], init[b])
+            fc_o, fs_o = orc.feature_cloud(o, ci), orc.feature_cloud(o, si)
+            if vox:
+                fc_o, fs_o = orc.voxel_grid(fc_o, 0.1)[1], orc.voxel_grid(fs_o, 0.4)[1]
+            ret, opc, _, orep = orc.reg_solve(tc, ts, fc_o, fs_o, prm, init[b], init[b])
             t_cpu += time.perf_counter() - tb
             errs.append(synth.pose_error(pc[b], opc))
-            same_sets &= (len(ci) == nc[b] and len(si) == ns[b])
+            same_sets &= (len(ci) == nc_fe[b] and len(si) == ns_fe[b] and len(fc_o) == nc[b] and len(fs_o) == ns[b])
         result["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 4), "unit": "scans/s", "cores": 1, "kind": "port",
                                   "sample": f"{n_cpu} of the {B} scans of one step (extract + {args.icp_iters} ICP iters each) "
                                             f"vs the same {len(corner) + len(surf)}-pt map; k-d tree build {t_tree:.1f}s excluded",

@@ -164,6 +164,60 @@ class Livox_laser {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+// pcl::VoxelGrid<PointType> as the node shells use it: setLeafSize / setInputCloud / filter
+// (laser_feature_extractor.hpp:192-193,372-381; laser_mapping.hpp:742-743,1367-1373,1434-1437,533-537).
+// CloudPtr is anything that dereferences to a cloud (std::shared_ptr, boost::shared_ptr, raw pointer).
+template <class Cloud>
+class VoxelGrid {
+   public:
+    int device = 0;
+    int max_points = 0;  // 0: sized for the first cloud seen (grown on demand)
+    int status = 0;      // of the last filter(): 0 filtered, 1 leaf too small (copy of the input, like PCL), 2 no finite point
+
+    ~VoxelGrid()
+    {
+        if (h_) ll_voxel_destroy(h_);
+    }
+    void setLeafSize(float lx, float ly, float lz)
+    {
+        leaf_[0] = lx;
+        leaf_[1] = ly;
+        leaf_[2] = lz;
+    }
+    template <class CloudPtr>
+    void setInputCloud(const CloudPtr &cloud)
+    {
+        in_ = cloud_to_xyzi(*cloud);
+    }
+    void filter(Cloud &output)  // `output` may be the input cloud itself (the reference filters in place)
+    {
+        const int32_t n = (int32_t)(in_.size() / 4);
+        if (n == 0) {
+            output.points.clear();
+            status = 2;
+            return;
+        }
+        if (!h_ || n > cap_) {
+            if (h_) ll_voxel_destroy(h_);
+            h_ = nullptr;
+            cap_ = n > max_points ? n : max_points;
+            check(ll_voxel_create(device, 1, cap_, &h_), "ll_voxel_create");
+        }
+        std::vector<float> out(in_.size());
+        int32_t n_out = 0, st = 0;
+        check(ll_voxel_filter(h_, 1, in_.data(), &n, n, leaf_, out.data(), &n_out, &st), "ll_voxel_filter");
+        status = st;
+        xyzi_to_cloud(out.data(), n_out, output);
+    }
+
+   private:
+    ll_voxel *h_ = nullptr;
+    int cap_ = 0;
+    float leaf_[3] = {0.4f, 0.4f, 0.4f};
+    std::vector<float> in_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
 class Point_cloud_registration {
    public:
     // configuration fields with the reference names and defaults (point_cloud_registration.hpp:45-103)

@@ -213,6 +213,33 @@ int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corne
  * already (default: from iteration 2, the first pose update usually moves the queries too far). */
 int ll_reg_set_debug(ll_reg *r, int32_t enable);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * VoxelGrid  (SURVEY 8(f) row 1).  pcl::VoxelGrid<pcl::PointXYZI> as hku-mars/loam_livox uses it:
+ *   m_voxel_filter_for_surface / _corner     laser_feature_extractor.hpp:192-193, 372-381
+ *   m_down_sample_filter_corner / _surface   laser_mapping.hpp:742-743, 1367-1373, 1434-1437, 533-537
+ * i.e. setLeafSize(l, l, l); setInputCloud(c); filter(out).  Semantics: PCL 1.9 VoxelGrid::applyFilter with its
+ * defaults (centroid of x, y, z and intensity per leaf, float sums, output in ascending leaf index), made
+ * deterministic: the points of a leaf are summed in input order (PCL's std::sort leaves that order open), and
+ * non-finite points are always skipped.  One call filters n_clouds independent clouds.
+ * status[b]: 0 = filtered; 1 = "leaf size is too small for the input dataset" -> the output is a copy of the input,
+ * like PCL; 2 = no finite point -> empty output. */
+typedef struct ll_voxel ll_voxel;
+int ll_voxel_create(int32_t device, int32_t max_clouds, int32_t max_points_per_cloud, ll_voxel **out);
+void ll_voxel_destroy(ll_voxel *v);
+/* xyzi / out_xyzi: [n_clouds][stride_points][4] floats on the host; n_points / n_out / status: [n_clouds]. */
+int ll_voxel_filter(ll_voxel *v, int32_t n_clouds, const float *xyzi, const int32_t *n_points, int32_t stride_points,
+                    const float leaf[3], float *out_xyzi, int32_t *n_out, int32_t *status);
+
+/* m_if_input_downsample_mode (laser_mapping.hpp:1367-1373): the corner / surface clouds selected by the extractor are
+ * voxel-filtered on the device (leaf line_res / plane_res, laser_mapping.hpp:742-743) and registered, without leaving
+ * HBM.  vox_corner / vox_surf need max_clouds >= n_scans and max_points_per_cloud >= the extractor's max_points.
+ * Collect with ll_reg_collect. */
+int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe *fe, ll_voxel *vox_corner, ll_voxel *vox_surf,
+                                  float line_res, float plane_res, int32_t n_scans, const ll_reg_params *prm,
+                                  const double *poses_last, const double *poses_curr, const double *poses_incre);
+/* the filtered feature counts of the last ll_reg_enqueue_fe_downsampled (after ll_reg_collect) */
+int ll_voxel_counts(ll_voxel *v, int32_t n_clouds, int32_t *n_out, int32_t *status);
+
 /* unsigned int Point_cloud_registration::pointcloudAssociateToMap(pc_in, pc_out, if_undistore = 0)
  * (point_cloud_registration.hpp:673-685, no-deblur branch :629): p_w = q*p + t in double, stored float. */
 int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t n, const double pose[7]);

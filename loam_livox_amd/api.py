@@ -124,6 +124,63 @@ class Livox_laser:
         check(self.L.ll_fe_sync(self.h), "ll_fe_sync")
 
 
+class VoxelGrid:
+    """pcl::VoxelGrid<pcl::PointXYZI> as the reference uses it (setLeafSize / setInputCloud / filter:
+    laser_feature_extractor.hpp:192-193,372-381; laser_mapping.hpp:742-743,1367-1373,1434-1437,533-537),
+    PCL 1.9 semantics with a deterministic in-leaf order (include/loam_livox_hip.h)."""
+
+    def __init__(self, max_points: int = 100000, max_clouds: int = 1, device: int = 0):
+        self.L = capi.load()
+        self.h = C.c_void_p()
+        self.max_points, self.max_clouds = max_points, max_clouds
+        check(self.L.ll_voxel_create(device, max_clouds, max_points, C.byref(self.h)), "ll_voxel_create")
+        self.leaf = np.array([0.4, 0.4, 0.4], np.float32)
+        self._cloud = None
+        self.status = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ll_voxel_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setLeafSize(self, lx: float, ly: float, lz: float):
+        self.leaf = np.array([lx, ly, lz], np.float32)
+
+    def setInputCloud(self, cloud: np.ndarray):
+        self._cloud = capi.as_f32(cloud, 4)
+
+    def filter(self) -> np.ndarray:
+        """Returns the filtered cloud (n_out x 4); self.status: 0 filtered, 1 leaf too small (copy of the input), 2 empty."""
+        out, n_out, st = self.filter_batch(self._cloud[None], np.array([self._cloud.shape[0]], np.int32))
+        self.status = int(st[0])
+        return out[0, :n_out[0]].copy()
+
+    def filter_batch(self, clouds: np.ndarray, n_points: np.ndarray):
+        """clouds [B][stride][4], n_points [B] -> (out [B][stride][4], n_out [B], status [B])."""
+        clouds = np.ascontiguousarray(clouds, np.float32)
+        B, stride = clouds.shape[0], clouds.shape[1]
+        n_points = np.ascontiguousarray(n_points, np.int32)
+        if stride == 0:
+            return np.zeros_like(clouds), np.zeros(B, np.int32), np.full(B, 2, np.int32)
+        out = np.zeros_like(clouds)
+        n_out = np.zeros(B, np.int32)
+        st = np.zeros(B, np.int32)
+        check(self.L.ll_voxel_filter(self.h, B, ptr(clouds), ptr(n_points), stride, ptr(self.leaf), ptr(out), ptr(n_out), ptr(st)),
+              "ll_voxel_filter")
+        return out, n_out, st
+
+    def counts(self, n_clouds: int):
+        n_out, st = np.zeros(n_clouds, np.int32), np.zeros(n_clouds, np.int32)
+        check(self.L.ll_voxel_counts(self.h, n_clouds, ptr(n_out), ptr(st)), "ll_voxel_counts")
+        return n_out, st
+
+
 class Map_buffer:
     """m_laser_cloud_{corner,surf}_from_map + their kd-trees (laser_mapping.hpp:539-546) as device grids."""
 
@@ -227,6 +284,15 @@ class Point_cloud_registration:
         pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n_scans, 7)
         check(self.L.ll_reg_enqueue_fe(self.h, map_buffer.h, fe.h, n_scans, C.byref(self.params), ptr(pl), ptr(pc), None),
               "ll_reg_enqueue_fe")
+
+    def enqueue_fe_downsampled(self, map_buffer: Map_buffer, fe: Livox_laser, vox_corner: "VoxelGrid", vox_surf: "VoxelGrid",
+                               line_res: float, plane_res: float, n_scans: int, poses_last, poses_curr):
+        """m_if_input_downsample_mode (laser_mapping.hpp:1367-1373): voxel-filter the selected features on the device, then
+        register them."""
+        pl = np.ascontiguousarray(poses_last, np.float64).reshape(n_scans, 7)
+        pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n_scans, 7)
+        check(self.L.ll_reg_enqueue_fe_downsampled(self.h, map_buffer.h, fe.h, vox_corner.h, vox_surf.h, line_res, plane_res, n_scans,
+                                                   C.byref(self.params), ptr(pl), ptr(pc), None), "ll_reg_enqueue_fe_downsampled")
 
     def collect(self, n_scans: int):
         pc = np.zeros((n_scans, 7), np.float64)

@@ -82,6 +82,11 @@ SYMBOLS = {
     "ll_reg_kernel_times": (_i32, [_vp, _vp, _vp]),
     "ll_reg_debug_cycles": (_i32, [_vp, _i32, _vp]),
     "ll_reg_debug_worklists": (_i32, [_vp, _i32, _vp]),
+    "ll_voxel_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
+    "ll_voxel_destroy": (None, [_vp]),
+    "ll_voxel_filter": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ll_voxel_counts": (_i32, [_vp, _i32, _vp, _vp]),
+    "ll_reg_enqueue_fe_downsampled": (_i32, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i32, C.POINTER(RegParams), _vp, _vp, _vp]),
     "ll_reg_stream": (_vp, [_vp]),
     "ll_fe_stream": (_vp, [_vp]),
     "ll_last_error": (C.c_char_p, []),

@@ -14,6 +14,7 @@
 #include "../../include/loam_livox_hip.h"
 #include "ll_device.h"
 #include "ll_reg_core.h"
+#include "ll_voxel.h"
 
 using namespace ll;
 
@@ -806,6 +807,108 @@ extern "C" int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_
     r->dev.n_surf = fe->dev.n_surf;
     r->dev.feat_stride_c = fe->dev.stride;
     r->dev.feat_stride_s = fe->dev.stride;
+    return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
+}
+
+// ---------------------------------------------------------------------------------------------------- voxel grid
+struct ll_voxel {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    VoxelDev dev{};
+};
+
+extern "C" int ll_voxel_create(int32_t device, int32_t max_clouds, int32_t max_points_per_cloud, ll_voxel **out)
+{
+    if (!out) return set_err("ll_voxel_create", "null argument");
+    if (max_clouds < 1 || max_points_per_cloud < 1) return set_err("ll_voxel_create", "bad capacity");
+    if (check_device(device)) return -1;
+    ll_voxel *v = new ll_voxel();
+    v->device = device;
+    HC(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    HC(hipEventCreateWithFlags(&v->ev, hipEventDisableTiming));
+    const char *err = nullptr;
+    if (voxel_alloc(v->dev, max_clouds, max_points_per_cloud, &err)) {
+        voxel_free(v->dev);
+        (void)hipStreamDestroy(v->stream);
+        (void)hipEventDestroy(v->ev);
+        delete v;
+        return set_err("ll_voxel_create", err);
+    }
+    *out = v;
+    return 0;
+}
+
+extern "C" void ll_voxel_destroy(ll_voxel *v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    voxel_free(v->dev);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
+    if (v->ev) (void)hipEventDestroy(v->ev);
+    delete v;
+}
+
+extern "C" int ll_voxel_filter(ll_voxel *v, int32_t n_clouds, const float *xyzi, const int32_t *n_points, int32_t stride_points,
+                               const float leaf[3], float *out_xyzi, int32_t *n_out, int32_t *status)
+{
+    if (!v || !xyzi || !n_points || !leaf || !out_xyzi || !n_out) return set_err("ll_voxel_filter", "null argument");
+    if (n_clouds < 1 || n_clouds > v->dev.max_clouds) return set_err("ll_voxel_filter", "n_clouds out of range");
+    if (stride_points < 1 || stride_points > v->dev.stride) return set_err("ll_voxel_filter", "stride exceeds max_points_per_cloud");
+    for (int b = 0; b < n_clouds; b++)
+        if (n_points[b] < 0 || n_points[b] > stride_points) return set_err("ll_voxel_filter", "n_points out of range");
+    HC(hipSetDevice(v->device));
+    const size_t total = (size_t)n_clouds * stride_points;
+    HC(hipMemcpyAsync(v->dev.in, xyzi, total * sizeof(float4), hipMemcpyHostToDevice, v->stream));
+    HC(hipMemcpyAsync(v->dev.n, n_points, (size_t)n_clouds * sizeof(int), hipMemcpyHostToDevice, v->stream));
+    const char *err = nullptr;
+    if (voxel_filter(v->dev, v->dev.in, v->dev.n, stride_points, n_clouds, leaf, v->stream, &err)) return set_err("ll_voxel_filter", err);
+    HC(hipMemcpyAsync(out_xyzi, v->dev.out, total * sizeof(float4), hipMemcpyDeviceToHost, v->stream));
+    HC(hipMemcpyAsync(n_out, v->dev.n_out, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    std::vector<int> st(n_clouds);
+    HC(hipMemcpyAsync(st.data(), v->dev.status, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HC(hipStreamSynchronize(v->stream));
+    if (status)
+        for (int b = 0; b < n_clouds; b++) status[b] = st[b];
+    return 0;
+}
+
+extern "C" int ll_voxel_counts(ll_voxel *v, int32_t n_clouds, int32_t *n_out, int32_t *status)
+{
+    if (!v || n_clouds < 1 || n_clouds > v->dev.max_clouds) return set_err("ll_voxel_counts", "bad argument");
+    HC(hipSetDevice(v->device));
+    HC(hipStreamSynchronize(v->stream));
+    if (n_out) HC(hipMemcpy(n_out, v->dev.n_out, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost));
+    if (status) HC(hipMemcpy(status, v->dev.status, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe *fe, ll_voxel *vc, ll_voxel *vs, float line_res,
+                                             float plane_res, int32_t n_scans, const ll_reg_params *prm, const double *poses_last,
+                                             const double *poses_curr, const double *poses_incre)
+{
+    if (!r || !fe || !vc || !vs) return set_err("ll_reg_enqueue_fe_downsampled", "null handle");
+    if (fe->prm.device != r->device || vc->device != r->device || vs->device != r->device)
+        return set_err("ll_reg_enqueue_fe_downsampled", "handles live on different devices");
+    if (n_scans < 1 || n_scans > fe->prm.max_scans) return set_err("ll_reg_enqueue_fe_downsampled", "n_scans exceeds the extractor capacity");
+    if (fe->prm.max_points > r->max_feat) return set_err("ll_reg_enqueue_fe_downsampled", "registrar feature capacity < extractor max_points");
+    if (vc == vs) return set_err("ll_reg_enqueue_fe_downsampled", "corner and surface need their own voxel filter handle");
+    HC(hipSetDevice(r->device));
+    // extractor -> (voxel filters, on the registrar's stream) -> registrar
+    HC(hipEventRecord(r->ev_wait, fe->stream));
+    HC(hipStreamWaitEvent(r->stream, r->ev_wait, 0));
+    const char *err = nullptr;
+    const float lc[3] = {line_res, line_res, line_res}, ls[3] = {plane_res, plane_res, plane_res};
+    if (voxel_filter(vc->dev, fe->dev.corner_feat, fe->dev.n_corner, fe->dev.stride, n_scans, lc, r->stream, &err))
+        return set_err("ll_reg_enqueue_fe_downsampled", err);
+    if (voxel_filter(vs->dev, fe->dev.surf_feat, fe->dev.n_surf, fe->dev.stride, n_scans, ls, r->stream, &err))
+        return set_err("ll_reg_enqueue_fe_downsampled", err);
+    r->dev.corner_feat = vc->dev.out;
+    r->dev.surf_feat = vs->dev.out;
+    r->dev.n_corner = vc->dev.n_out;
+    r->dev.n_surf = vs->dev.n_out;
+    r->dev.feat_stride_c = vc->dev.out_stride;
+    r->dev.feat_stride_s = vs->dev.out_stride;
     return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
 }
 

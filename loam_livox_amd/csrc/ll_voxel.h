@@ -1,0 +1,29 @@
+// ll_voxel.h -- device buffers of the batched VoxelGrid (ll_voxel_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ll_voxel_core.h"
+
+namespace ll {
+
+struct VoxelDev {
+    int max_clouds, stride;
+    int out_stride;              // stride of `out` after the last filter call (= the input stride of that call)
+    float4 *in;                  // [max_clouds][stride]  staging for host inputs
+    float4 *out;                 // [n_clouds][out_stride] filtered clouds
+    int *n, *n_out, *status;     // [max_clouds]
+    int *n_vox, *vox_off;        // [max_clouds]
+    unsigned int *mm;            // [max_clouds][8] bounding box (ordered encoding) + finite count
+    VoxelParams *prm;            // [max_clouds]
+    unsigned long long *keys, *keys2;
+    unsigned int *vals, *vals2, *is_head, *rank;
+    void *tmp;
+    size_t tmp_bytes;
+};
+
+int voxel_alloc(VoxelDev &v, int max_clouds, int stride, const char **err);
+void voxel_free(VoxelDev &v);
+int voxel_filter(VoxelDev &v, const float4 *in, const int *n, int in_stride, int n_clouds, const float leaf[3], hipStream_t s,
+                 const char **err);
+
+}  // namespace ll

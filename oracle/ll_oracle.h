@@ -207,6 +207,10 @@ void orc_blocks_eval(const orc_block *blocks, int nb, const double pose_last[7],
                      int deblur, double huber_a, double *cost, double g[6], double H[36]);
 
 /* pointAssociateToMap (PCR:622-661), no-deblur branch: p_w = q*p + t in double, stored float. */
+/* pcl::VoxelGrid<PointXYZI>::filter, PCL 1.9 semantics with a stable in-voxel order (ll_oracle_voxel.c).
+ * out_xyzi must hold n points.  Returns 0 = filtered, 1 = leaf too small (output is a copy of the input), 2 = no finite point. */
+int orc_voxel_grid(const float *xyzi, int32_t n, const float leaf[3], float *out_xyzi, int32_t *n_out);
+
 /* PCA feature checks (PCR:259-292 line, :357-389 plane): pts = 5 float points; ev_out = eigenvalues ascending; returns pass(1)/fail(0) */
 int orc_pca_check(int is_plane, const float pts[15], double ev_out[3]);
 

@@ -294,3 +294,16 @@ def pca_check(is_plane, pts5):
     L.orc_pca_check.restype = C.c_int
     ok = L.orc_pca_check(int(is_plane), p.ctypes.data, ev.ctypes.data)
     return bool(ok), ev
+
+
+def voxel_grid(xyzi, leaf):
+    """pcl::VoxelGrid<PointXYZI> (PCL 1.9 semantics, stable in-voxel order).  Returns (status, filtered cloud)."""
+    pts = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+    lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, np.float32), (3,)))
+    out = np.zeros_like(pts)
+    n_out = C.c_int32(0)
+    L = lib()
+    L.orc_voxel_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.orc_voxel_grid.restype = C.c_int
+    st = L.orc_voxel_grid(pts.ctypes.data, pts.shape[0], lf.ctypes.data, out.ctypes.data, C.byref(n_out))
+    return st, out[:n_out.value].copy()

@@ -1,8 +1,10 @@
 // Exercises include/loam_livox_adapter.hpp the way the reference's node shells call Livox_laser /
 // Point_cloud_registration (laser_feature_extractor.hpp:285-330, laser_mapping.hpp:1405), with a stand-in for
 // pcl::PointCloud<pcl::PointXYZI>.  argv: <scan.bin> <corner_map.bin> <surf_map.bin> <pose_init.bin> <out.txt>
-// (.bin = raw float32 xyzi rows / 7 float64).
+// (.bin = raw float32 xyzi rows / 7 float64) [line_res plane_res]: with the two optional leaf sizes the features are
+// voxel-filtered before registration.
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -59,6 +61,21 @@ int main(int argc, char **argv)
         Cloud full;
         m_livox.get_features(*corners, *surface, full, piece_start, piece_end);
 
+        // m_if_input_downsample_mode (laser_mapping.hpp:742-743,1367-1373): argv[6] = line_res, argv[7] = plane_res
+        size_t n_corner_raw = corners->size(), n_surf_raw = surface->size();
+        if (argc >= 8) {
+            loam_livox_hip::VoxelGrid<Cloud> down_sample_filter_corner, down_sample_filter_surface;
+            const float line_res = (float)atof(argv[6]), plane_res = (float)atof(argv[7]);
+            down_sample_filter_corner.setLeafSize(line_res, line_res, line_res);
+            down_sample_filter_surface.setLeafSize(plane_res, plane_res, plane_res);
+            auto corner_stack = std::make_shared<Cloud>(), surf_stack = std::make_shared<Cloud>();
+            down_sample_filter_corner.setInputCloud(corners);
+            down_sample_filter_corner.filter(*corner_stack);
+            down_sample_filter_surface.setInputCloud(surface);
+            down_sample_filter_surface.filter(*surface);  // in place, like laser_feature_extractor.hpp:372-373
+            corners = corner_stack;
+        }
+
         loam_livox_hip::Point_cloud_registration pc_reg;
         pc_reg.m_current_frame_index = 100;
         pc_reg.m_mapping_init_accumulate_frames = 50;
@@ -74,7 +91,7 @@ int main(int argc, char **argv)
         pc_reg.pointcloudAssociateToMap(*corners, world);
 
         FILE *o = fopen(argv[5], "w");
-        fprintf(o, "%d %zu %zu %zu %d\n", m_laser_scan_number, corners->size(), surface->size(), full.size(), reg_res);
+        fprintf(o, "%d %zu %zu %zu %d %zu %zu\n", m_laser_scan_number, n_corner_raw, n_surf_raw, full.size(), reg_res, corners->size(), surface->size());
         for (int i = 0; i < 7; i++) fprintf(o, "%.17g ", pc_reg.m_para_buffer_RT[i]);
         fprintf(o, "\n%.9g %.9g\n", piece_start, piece_end);
         fclose(o);

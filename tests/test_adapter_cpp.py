@@ -27,7 +27,8 @@ def test_adapter_compiles_and_links():
 
 
 @pytest.mark.gpu
-def test_adapter_demo_matches_oracle(tmp_path, small_world, scans):
+@pytest.mark.parametrize("downsample", [False, True])
+def test_adapter_demo_matches_oracle(tmp_path, small_world, scans, downsample):
     from loam_livox_amd import synth
     from oracle import orc
     exe = build_demo()
@@ -37,9 +38,9 @@ def test_adapter_demo_matches_oracle(tmp_path, small_world, scans):
     np.c_[small_world["corner"], np.zeros(len(small_world["corner"]), np.float32)].astype(np.float32).tofile(paths[1])
     np.c_[small_world["surf"], np.zeros(len(small_world["surf"]), np.float32)].astype(np.float32).tofile(paths[2])
     sc.pose_init.astype(np.float64).tofile(paths[3])
-    subprocess.check_call([exe] + paths, timeout=120)
+    subprocess.check_call([exe] + paths + (["0.1", "0.4"] if downsample else []), timeout=120)
     lines = open(paths[4]).read().split("\n")
-    n_clouds, n_c, n_s, n_f, reg_res = [int(v) for v in lines[0].split()]
+    n_clouds, n_c, n_s, n_f, reg_res, n_c_used, n_s_used = [int(v) for v in lines[0].split()]
     pose = np.array([float(v) for v in lines[1].split()])
     ps, pe = [np.float32(v) for v in lines[2].split()]
     # oracle: first call -> current_time = stamp + 1 (LFE:731)
@@ -50,7 +51,10 @@ def test_adapter_demo_matches_oracle(tmp_path, small_world, scans):
     ci, si, fi = orc.fe_get_features(o, float(ops[0]), float(ope[0]))
     assert (n_c, n_s, n_f) == (len(ci), len(si), len(fi))
     prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=0)
-    ret, opc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], orc.feature_cloud(o, ci), orc.feature_cloud(o, si), prm,
-                                   sc.pose_init, sc.pose_init)
+    fc, fs = orc.feature_cloud(o, ci), orc.feature_cloud(o, si)
+    if downsample:
+        fc, fs = orc.voxel_grid(fc, 0.1)[1], orc.voxel_grid(fs, 0.4)[1]
+    assert (n_c_used, n_s_used) == (len(fc), len(fs))
+    ret, opc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     dt, dr = synth.pose_error(pose, opc)
     assert reg_res == ret and dt < 1e-7 and dr < 1e-7

@@ -1,0 +1,143 @@
+"""-m gpu: device VoxelGrid (through the C ABI) against the oracle -- bit-exact: the leaf of every point is integer
+work, and the centroid sums run in the same (input) order in float."""
+import numpy as np
+import pytest
+
+from loam_livox_amd import synth
+from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration, VoxelGrid
+from oracle import orc
+from tests.conftest import oracle_features
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,span,leaf", [(24000, 30.0, 0.4), (24000, 30.0, 0.1), (5000, 8.0, (0.2, 0.4, 0.8)), (1, 1.0, 0.4),
+                                         (100000, 200.0, 0.5), (7, 0.01, 1.0)])
+def test_filter_bit_exact_vs_oracle(gpu_lib, n, span, leaf):
+    rng = np.random.default_rng(n)
+    p = rng.uniform(-span, span, (n, 4)).astype(np.float32)
+    p[rng.random(n) < 0.01, rng.integers(0, 3)] = np.nan
+    vg = VoxelGrid(max_points=100000)
+    vg.setLeafSize(*np.broadcast_to(np.asarray(leaf, np.float32), (3,)))
+    vg.setInputCloud(p)
+    out = vg.filter()
+    st, ref = orc.voxel_grid(p, leaf)
+    assert vg.status == st == 0 and out.shape == ref.shape and np.array_equal(bits(out), bits(ref))
+    vg.close()
+
+
+def test_edge_cases(gpu_lib):
+    vg = VoxelGrid(max_points=1000)
+    vg.setLeafSize(1.0, 1.0, 1.0)
+    # order-sensitive float sum, -0/+0, exact leaf boundaries
+    a, b, c = np.float32(1e8), np.float32(-1e8), np.float32(0.3)
+    p = np.array([[0.1, 0.1, 0.1, a], [0.2, 0.2, 0.2, b], [0.3, 0.3, 0.3, c], [1.0, 0, 0, 1], [0.99999994, 0, 0, 1], [-0.0, 0, 0, 5]], np.float32)
+    for perm in ([0, 1, 2, 3, 4, 5], [2, 1, 0, 5, 4, 3]):
+        vg.setInputCloud(p[perm])
+        out = vg.filter()
+        st, ref = orc.voxel_grid(p[perm], 1.0)
+        assert np.array_equal(bits(out), bits(ref))
+    # no finite point / empty input
+    vg.setInputCloud(np.full((5, 4), np.nan, np.float32))
+    assert vg.filter().shape == (0, 4) and vg.status == 2
+    vg.setInputCloud(np.zeros((0, 4), np.float32))
+    assert vg.filter().shape == (0, 4) and vg.status == 2
+    # leaf too small for the extent: PCL copies the input
+    rng = np.random.default_rng(1)
+    q = rng.uniform(-100, 100, (50, 4)).astype(np.float32)
+    q[3, 1] = np.nan
+    vg.setLeafSize(0.01, 0.01, 0.01)
+    vg.setInputCloud(q)
+    out = vg.filter()
+    assert vg.status == 1 and np.array_equal(bits(out), bits(q))
+    # errors are reported, not fatal
+    with pytest.raises(Exception):
+        vg.setLeafSize(0.0, 1.0, 1.0); vg.filter()
+    with pytest.raises(Exception):
+        vg.setLeafSize(1.0, 1.0, 1.0); vg.setInputCloud(np.zeros((2000, 4), np.float32)); vg.filter()
+    vg.close()
+
+
+def test_batch_of_ragged_clouds(gpu_lib):
+    rng = np.random.default_rng(5)
+    B, stride = 7, 6000
+    n = np.array([6000, 0, 1, 3333, 5999, 17, 6000], np.int32)
+    clouds = rng.uniform(-15, 15, (B, stride, 4)).astype(np.float32)
+    clouds[2, 0, 0] = np.nan          # its only point is invalid -> empty
+    clouds[6] *= 1e4                  # 300 km extent at leaf 0.3: too many leafs -> pass-through
+    vg = VoxelGrid(max_points=stride, max_clouds=B)
+    vg.setLeafSize(0.3, 0.3, 0.3)
+    out, n_out, st = vg.filter_batch(clouds, n)
+    for b in range(B):
+        s, ref = orc.voxel_grid(clouds[b, :n[b]], 0.3)
+        assert st[b] == s and n_out[b] == len(ref)
+        assert np.array_equal(bits(out[b, :n_out[b]]), bits(ref))
+    assert list(st) == [0, 2, 2, 0, 0, 0, 1]
+    # run to run identical
+    out2, n_out2, _ = vg.filter_batch(clouds, n)
+    assert np.array_equal(n_out, n_out2) and np.array_equal(bits(out), bits(out2))
+    vg.close()
+
+
+def test_properties_at_map_scale(gpu_lib):
+    """1 M points (a map refresh, LM:533-537): count conservation, centroids inside their leaf, ascending leaf order"""
+    rng = np.random.default_rng(6)
+    n = 1_000_000
+    p = rng.uniform(-40, 40, (n, 4)).astype(np.float32)
+    vg = VoxelGrid(max_points=n)
+    vg.setLeafSize(0.4, 0.4, 0.4)
+    vg.setInputCloud(p)
+    out = vg.filter()
+    inv = np.float32(1.0) / np.float32(0.4)
+    mn = p[:, :3].min(0)
+    min_b = np.floor(mn * inv).astype(np.int64)
+    div = np.floor(p[:, :3].max(0) * inv).astype(np.int64) - min_b + 1
+    ijk_in = (np.floor(p[:, :3] * inv) - min_b).astype(np.int64)
+    idx_in = ijk_in[:, 0] + ijk_in[:, 1] * div[0] + ijk_in[:, 2] * div[0] * div[1]
+    uniq, counts = np.unique(idx_in, return_counts=True)
+    assert len(out) == len(uniq)
+    # intensity-weighted conservation: sum(count * centroid) == sum(points) up to float rounding
+    assert np.allclose((out * counts[:, None]).sum(0, dtype=np.float64), p.sum(0, dtype=np.float64), rtol=1e-4, atol=1.0)
+    ijk_out = (np.floor(out[:, :3] * inv) - min_b).astype(np.int64)
+    idx_out = ijk_out[:, 0] + ijk_out[:, 1] * div[0] + ijk_out[:, 2] * div[0] * div[1]
+    assert (idx_out == uniq).mean() > 0.999   # a centroid can round onto a leaf wall, otherwise it stays in its leaf
+    vg.close()
+
+
+def test_downsampled_registration_matches_oracle(gpu_lib, small_world, scans):
+    """m_if_input_downsample_mode (LM:1367-1373): extractor -> device VoxelGrid (line_res 0.1 / plane_res 0.4) -> registrar,
+    against oracle extraction -> oracle VoxelGrid -> oracle registration"""
+    B = 4
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, small_world["corner"])
+    m.setInputCloud(Map_buffer.SURF, small_world["surf"])
+    fe = Livox_laser(max_points=24000, max_scans=B, piecewise_number=1)
+    fe.upload(np.stack([s.xyzi for s in scans]), np.full(B, 1.0))
+    fe.extract_batch(B); fe.resolve(); fe.select_batch(B, -1, 0.0, 1.0)
+    vc, vs = VoxelGrid(24000, B), VoxelGrid(24000, B)
+    reg = Point_cloud_registration(max_scans=B, max_features=24000)
+    p = reg.params
+    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = 10, 20, 1
+    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 100.0
+    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+    init = np.stack([s.pose_init for s in scans])
+    reg.enqueue_fe_downsampled(m, fe, vc, vs, 0.1, 0.4, B, init, init)
+    res, pc, pi, reps = reg.collect(B)
+    nc, _ = vc.counts(B)
+    ns, _ = vs.counts(B)
+    for b, sc in enumerate(scans):
+        _, _, _, _, fc, fs = oracle_features(sc)
+        _, fc_ds = orc.voxel_grid(fc, 0.1)
+        _, fs_ds = orc.voxel_grid(fs, 0.4)
+        assert nc[b] == len(fc_ds) and ns[b] == len(fs_ds) and len(fs_ds) < len(fs)
+        prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=1)
+        ret, opc, opi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc_ds, fs_ds, prm, sc.pose_init, sc.pose_init)
+        dt, dr = synth.pose_error(pc[b], opc)
+        assert res[b] == ret and dt < 1e-7 and dr < 1e-7
+        assert reps[b].n_blocks_last == rep.n_blocks_last and reps[b].lm_iterations_total == rep.lm_iterations_total
+    for h in (fe, vc, vs, reg, m):
+        h.close()
