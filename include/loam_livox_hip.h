@@ -240,6 +240,37 @@ int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe *fe, ll_vo
 /* the filtered feature counts of the last ll_reg_enqueue_fe_downsampled (after ll_reg_collect) */
 int ll_voxel_counts(ll_voxel *v, int32_t n_clouds, int32_t *n_out, int32_t *status);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Match buffer, history mode  (m_matching_mode == 0).  Device-resident stand-in for
+ *   m_laser_cloud_corner_history / m_laser_cloud_surface_history      laser_mapping.hpp:1443-1478
+ *   update_buff_for_matching(), history branch                        laser_mapping.hpp:517-546
+ * ll_history_add = "Add new frame" (laser_mapping.hpp:1417-1478): the scan's corner / surface features (sensor frame)
+ * are moved to the map frame with `pose` (pointAssociateToMap without undistortion, g_if_undistore = 0), voxel-filtered
+ * (leaf line_res / plane_res) and pushed onto the two FIFO histories when
+ *     history.size() < maximum_history_size  ||  t_diff > history_add_t_step  ||  r_diff > history_add_angle_step * 57.3
+ * with t_diff / r_diff measured from the pose of the last frame that was pushed; the oldest frame is dropped when the
+ * history is longer than maximum_history_size.  *added = 1 when the frame was pushed.
+ * ll_history_refresh = update_buff_for_matching: concatenation of the history frames (oldest first) -> VoxelGrid
+ * (line_res / plane_res) -> the two search structures of `map` (device grids instead of two k-d tree builds).
+ * Everything stays in HBM; only the counts come back. */
+typedef struct ll_history ll_history;
+int ll_history_create(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res, float plane_res,
+                      ll_history **out);
+void ll_history_destroy(ll_history *h);
+int ll_history_add(ll_history *h, const float *corner_xyzi, int32_t n_corner, const float *surf_xyzi, int32_t n_surf,
+                   const double pose[7], double history_add_t_step, double history_add_angle_step, int32_t *added);
+/* same, taking the clouds selected by the extractor for scan slot `scan` (device to device) */
+int ll_history_add_fe(ll_history *h, ll_fe *fe, int32_t scan, const double pose[7], double history_add_t_step,
+                      double history_add_angle_step, int32_t *added);
+/* same, taking cloud `cloud` of the last ll_reg_enqueue_fe_downsampled (the down-sampled stacks the reference pushes,
+ * laser_mapping.hpp:1367-1373,1421-1431) */
+int ll_history_add_voxel(ll_history *h, ll_voxel *vox_corner, ll_voxel *vox_surf, int32_t cloud, const double pose[7],
+                         double history_add_t_step, double history_add_angle_step, int32_t *added);
+int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_corner, int64_t *n_map_surf);
+int32_t ll_history_size(const ll_history *h);
+/* the match buffer clouds of the last refresh (host copy, for inspection / tests): returns the number of points written */
+int64_t ll_history_map_cloud(ll_history *h, int32_t kind, float *xyzi, int64_t capacity_points);
+
 /* unsigned int Point_cloud_registration::pointcloudAssociateToMap(pc_in, pc_out, if_undistore = 0)
  * (point_cloud_registration.hpp:673-685, no-deblur branch :629): p_w = q*p + t in double, stored float. */
 int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t n, const double pose[7]);

@@ -181,6 +181,67 @@ class VoxelGrid:
         return n_out, st
 
 
+class History_buffer:
+    """m_laser_cloud_{corner,surface}_history + update_buff_for_matching (history mode), laser_mapping.hpp:1417-1478,
+    517-546, resident on the device (include/loam_livox_hip.h, ll_history_*)."""
+
+    def __init__(self, maximum_history_size: int = 100, max_points_per_frame: int = 24000, line_res: float = 0.1,
+                 plane_res: float = 0.4, device: int = 0):
+        self.L = capi.load()
+        self.h = C.c_void_p()
+        check(self.L.ll_history_create(device, maximum_history_size, max_points_per_frame, line_res, plane_res, C.byref(self.h)),
+              "ll_history_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ll_history_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self.L.ll_history_size(self.h))
+
+    def add(self, corner, surf, pose, history_add_t_step: float = 0.0, history_add_angle_step: float = 0.0) -> bool:
+        corner, surf = capi.as_f32(corner, 4), capi.as_f32(surf, 4)
+        pose = np.ascontiguousarray(pose, np.float64)
+        added = C.c_int32(0)
+        check(self.L.ll_history_add(self.h, ptr(corner), corner.shape[0], ptr(surf), surf.shape[0], ptr(pose), history_add_t_step,
+                                    history_add_angle_step, C.byref(added)), "ll_history_add")
+        return bool(added.value)
+
+    def add_fe(self, fe: "Livox_laser", scan: int, pose, history_add_t_step: float = 0.0, history_add_angle_step: float = 0.0) -> bool:
+        pose = np.ascontiguousarray(pose, np.float64)
+        added = C.c_int32(0)
+        check(self.L.ll_history_add_fe(self.h, fe.h, scan, ptr(pose), history_add_t_step, history_add_angle_step, C.byref(added)),
+              "ll_history_add_fe")
+        return bool(added.value)
+
+    def add_voxel(self, vox_corner: "VoxelGrid", vox_surf: "VoxelGrid", cloud: int, pose, history_add_t_step: float = 0.0,
+                  history_add_angle_step: float = 0.0) -> bool:
+        pose = np.ascontiguousarray(pose, np.float64)
+        added = C.c_int32(0)
+        check(self.L.ll_history_add_voxel(self.h, vox_corner.h, vox_surf.h, cloud, ptr(pose), history_add_t_step,
+                                          history_add_angle_step, C.byref(added)), "ll_history_add_voxel")
+        return bool(added.value)
+
+    def refresh(self, map_buffer: "Map_buffer"):
+        nc, ns = C.c_int64(0), C.c_int64(0)
+        check(self.L.ll_history_refresh(self.h, map_buffer.h, C.byref(nc), C.byref(ns)), "ll_history_refresh")
+        return nc.value, ns.value
+
+    def map_cloud(self, kind: int) -> np.ndarray:
+        n = self.L.ll_history_map_cloud(self.h, kind, None, 0)
+        out = np.zeros((max(n, 0), 4), np.float32)
+        if n > 0:
+            check(min(0, self.L.ll_history_map_cloud(self.h, kind, ptr(out), n)), "ll_history_map_cloud")
+        return out
+
+
 class Map_buffer:
     """m_laser_cloud_{corner,surf}_from_map + their kd-trees (laser_mapping.hpp:539-546) as device grids."""
 

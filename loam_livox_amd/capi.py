@@ -87,6 +87,14 @@ SYMBOLS = {
     "ll_voxel_filter": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ll_voxel_counts": (_i32, [_vp, _i32, _vp, _vp]),
     "ll_reg_enqueue_fe_downsampled": (_i32, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i32, C.POINTER(RegParams), _vp, _vp, _vp]),
+    "ll_history_create": (_i32, [_i32, _i32, _i32, _f, _f, C.POINTER(_vp)]),
+    "ll_history_destroy": (None, [_vp]),
+    "ll_history_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, C.c_double, C.c_double, _vp]),
+    "ll_history_add_fe": (_i32, [_vp, _vp, _i32, _vp, C.c_double, C.c_double, _vp]),
+    "ll_history_add_voxel": (_i32, [_vp, _vp, _vp, _i32, _vp, C.c_double, C.c_double, _vp]),
+    "ll_history_refresh": (_i32, [_vp, _vp, _vp, _vp]),
+    "ll_history_size": (_i32, [_vp]),
+    "ll_history_map_cloud": (_i64, [_vp, _i32, _vp, _i64]),
     "ll_reg_stream": (_vp, [_vp]),
     "ll_fe_stream": (_vp, [_vp]),
     "ll_last_error": (C.c_char_p, []),

@@ -912,6 +912,213 @@ extern "C" int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe
     return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
 }
 
+// ---------------------------------------------------------------------------------------------------- history
+struct ll_history {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_hist = 0, max_pts = 0;
+    float res[2] = {0.1f, 0.4f};       // line_res, plane_res
+    float4 *frames[2] = {nullptr, nullptr};  // [max_hist + 1][max_pts] ring per kind
+    std::vector<int> count[2];         // points per ring slot
+    int head = 0, size = 0;            // FIFO window over the ring slots
+    float4 *d_in = nullptr, *d_xf = nullptr, *d_concat = nullptr;
+    int *d_n = nullptr;
+    double *d_pose = nullptr;
+    VoxelDev vox_frame{}, vox_map{};
+    double last_q[4] = {0, 0, 0, 1}, last_t[3] = {0, 0, 0};  // m_last_his_add_q / m_last_his_add_t
+    int64_t n_map[2] = {0, 0};
+    float4 *d_map[2] = {nullptr, nullptr};   // filtered match buffer of the last refresh
+};
+
+extern "C" int ll_history_create(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res,
+                                 float plane_res, ll_history **out)
+{
+    if (!out) return set_err("ll_history_create", "null argument");
+    if (maximum_history_size < 1 || max_points_per_frame < 1) return set_err("ll_history_create", "bad capacity");
+    if (!(line_res > 0.f) || !(plane_res > 0.f)) return set_err("ll_history_create", "resolutions must be positive");
+    if ((int64_t)(maximum_history_size + 1) * max_points_per_frame >= 0x7fffffffLL) return set_err("ll_history_create", "history too large");
+    if (check_device(device)) return -1;
+    ll_history *h = new ll_history();
+    h->device = device;
+    h->max_hist = maximum_history_size;
+    h->max_pts = max_points_per_frame;
+    h->res[0] = line_res;
+    h->res[1] = plane_res;
+    HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t slots = (size_t)maximum_history_size + 1, cap = slots * max_points_per_frame;
+    for (int k = 0; k < 2; k++) {
+        DM(h->frames[k], cap);
+        DM(h->d_map[k], cap);
+        h->count[k].assign(slots, 0);
+    }
+    DM(h->d_in, (size_t)max_points_per_frame);
+    DM(h->d_xf, (size_t)max_points_per_frame);
+    DM(h->d_concat, cap);
+    DM(h->d_n, 1);
+    DM(h->d_pose, 8);
+    const char *err = nullptr;
+    if (voxel_alloc(h->vox_frame, 1, max_points_per_frame, &err) || voxel_alloc(h->vox_map, 1, (int)cap, &err)) {
+        ll_history_destroy(h);
+        return set_err("ll_history_create", err);
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void ll_history_destroy(ll_history *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    voxel_free(h->vox_frame);
+    voxel_free(h->vox_map);
+    void *ptrs[] = {h->frames[0], h->frames[1], h->d_map[0], h->d_map[1], h->d_in, h->d_xf, h->d_concat, h->d_n, h->d_pose};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int32_t ll_history_size(const ll_history *h) { return h ? h->size : -1; }
+
+// one kind of one frame: d_src (sensor frame, n points on the device) -> map frame -> VoxelGrid -> ring slot
+static int history_push_kind(ll_history *h, int kind, const float4 *d_src, int n, int slot)
+{
+    h->count[kind][slot] = 0;
+    if (n <= 0) return 0;
+    launch_cloud_transform(d_src, h->d_xf, n, h->d_pose, h->stream);  // laser_mapping.hpp:1421-1431
+    HC(hipMemcpyAsync(h->d_n, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const float leaf[3] = {h->res[kind], h->res[kind], h->res[kind]};
+    const char *err = nullptr;
+    if (voxel_filter(h->vox_frame, h->d_xf, h->d_n, n, 1, leaf, h->stream, &err)) return set_err("ll_history_add", err);  // :1434-1437
+    int n_out = 0;
+    HC(hipMemcpyAsync(&n_out, h->vox_frame.n_out, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HC(hipStreamSynchronize(h->stream));
+    HC(hipMemcpyAsync(h->frames[kind] + (size_t)slot * h->max_pts, h->vox_frame.out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice,
+                      h->stream));
+    h->count[kind][slot] = n_out;
+    return 0;
+}
+
+static int history_add_common(ll_history *h, const float4 *d_corner, int n_corner, const float4 *d_surf, int n_surf, const double pose[7],
+                              double t_step, double angle_step, int32_t *added)
+{
+    if (n_corner > h->max_pts || n_surf > h->max_pts) return set_err("ll_history_add", "frame exceeds max_points_per_frame");
+    // laser_mapping.hpp:1439-1440: distance from the pose of the last pushed frame
+    const double r_diff = quat_angular_distance(pose, h->last_q) * 57.3;
+    const double dt[3] = {pose[4] - h->last_t[0], pose[5] - h->last_t[1], pose[6] - h->last_t[2]};
+    const double t_diff = sqrt(dot3(dt, dt));
+    const bool push = h->size < h->max_hist || t_diff > t_step || r_diff > angle_step * 57.3;  // :1446-1448
+    if (added) *added = push ? 1 : 0;
+    if (!push) return 0;
+    for (int i = 0; i < 4; i++) h->last_q[i] = pose[i];
+    for (int i = 0; i < 3; i++) h->last_t[i] = pose[4 + i];
+    const int slots = h->max_hist + 1;
+    const int slot = (h->head + h->size) % slots;
+    HC(hipMemcpyAsync(h->d_pose, pose, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (history_push_kind(h, 0, d_corner, n_corner, slot)) return -1;
+    if (history_push_kind(h, 1, d_surf, n_surf, slot)) return -1;
+    h->size++;
+    if (h->size > h->max_hist) {  // :1463-1473 pop_front
+        h->head = (h->head + 1) % slots;
+        h->size--;
+    }
+    HC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int ll_history_add(ll_history *h, const float *corner_xyzi, int32_t n_corner, const float *surf_xyzi, int32_t n_surf,
+                              const double pose[7], double history_add_t_step, double history_add_angle_step, int32_t *added)
+{
+    if (!h || !pose || (n_corner > 0 && !corner_xyzi) || (n_surf > 0 && !surf_xyzi)) return set_err("ll_history_add", "null argument");
+    if (n_corner < 0 || n_surf < 0 || n_corner > h->max_pts || n_surf > h->max_pts) return set_err("ll_history_add", "frame exceeds max_points_per_frame");
+    HC(hipSetDevice(h->device));
+    // the two kinds are staged one after the other through d_in: copy the surface cloud to the concat scratch first
+    if (n_corner > 0) HC(hipMemcpyAsync(h->d_in, corner_xyzi, (size_t)n_corner * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    if (n_surf > 0) HC(hipMemcpyAsync(h->d_concat, surf_xyzi, (size_t)n_surf * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    return history_add_common(h, h->d_in, n_corner, h->d_concat, n_surf, pose, history_add_t_step, history_add_angle_step, added);
+}
+
+extern "C" int ll_history_add_fe(ll_history *h, ll_fe *fe, int32_t scan, const double pose[7], double history_add_t_step,
+                                 double history_add_angle_step, int32_t *added)
+{
+    if (!h || !fe || !pose) return set_err("ll_history_add_fe", "null argument");
+    if (fe->prm.device != h->device) return set_err("ll_history_add_fe", "extractor lives on another device");
+    if (scan < 0 || scan >= fe->prm.max_scans) return set_err("ll_history_add_fe", "scan slot out of range");
+    HC(hipSetDevice(h->device));
+    HC(hipStreamSynchronize(fe->stream));
+    int nc = 0, ns = 0;
+    HC(hipMemcpy(&nc, fe->dev.n_corner + scan, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&ns, fe->dev.n_surf + scan, sizeof(int), hipMemcpyDeviceToHost));
+    return history_add_common(h, fe->dev.corner_feat + (size_t)scan * fe->dev.stride, nc, fe->dev.surf_feat + (size_t)scan * fe->dev.stride, ns,
+                              pose, history_add_t_step, history_add_angle_step, added);
+}
+
+extern "C" int ll_history_add_voxel(ll_history *h, ll_voxel *vc, ll_voxel *vs, int32_t cloud, const double pose[7],
+                                    double history_add_t_step, double history_add_angle_step, int32_t *added)
+{
+    if (!h || !vc || !vs || !pose) return set_err("ll_history_add_voxel", "null argument");
+    if (vc->device != h->device || vs->device != h->device) return set_err("ll_history_add_voxel", "handles live on different devices");
+    if (cloud < 0 || cloud >= vc->dev.max_clouds || cloud >= vs->dev.max_clouds) return set_err("ll_history_add_voxel", "cloud index out of range");
+    HC(hipSetDevice(h->device));
+    HC(hipDeviceSynchronize());
+    int nc = 0, ns = 0;
+    HC(hipMemcpy(&nc, vc->dev.n_out + cloud, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&ns, vs->dev.n_out + cloud, sizeof(int), hipMemcpyDeviceToHost));
+    return history_add_common(h, vc->dev.out + (size_t)cloud * vc->dev.out_stride, nc, vs->dev.out + (size_t)cloud * vs->dev.out_stride, ns, pose,
+                              history_add_t_step, history_add_angle_step, added);
+}
+
+extern "C" int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_corner, int64_t *n_map_surf)
+{
+    if (!h || !map) return set_err("ll_history_refresh", "null argument");
+    if (map->device != h->device) return set_err("ll_history_refresh", "map lives on another device");
+    HC(hipSetDevice(h->device));
+    const int slots = h->max_hist + 1;
+    for (int kind = 0; kind < 2; kind++) {
+        // laser_mapping.hpp:519-530: concatenate the history, oldest frame first
+        int total = 0;
+        for (int i = 0; i < h->size; i++) {
+            const int slot = (h->head + i) % slots;
+            const int c = h->count[kind][slot];
+            if (c > 0)
+                HC(hipMemcpyAsync(h->d_concat + total, h->frames[kind] + (size_t)slot * h->max_pts, (size_t)c * sizeof(float4),
+                                  hipMemcpyDeviceToDevice, h->stream));
+            total += c;
+        }
+        int n_out = 0;
+        if (total > 0) {
+            HC(hipMemcpyAsync(h->d_n, &total, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            const float leaf[3] = {h->res[kind], h->res[kind], h->res[kind]};
+            const char *err = nullptr;
+            if (voxel_filter(h->vox_map, h->d_concat, h->d_n, total, 1, leaf, h->stream, &err)) return set_err("ll_history_refresh", err);  // :533-537
+            HC(hipMemcpyAsync(&n_out, h->vox_map.n_out, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HC(hipStreamSynchronize(h->stream));
+            HC(hipMemcpyAsync(h->d_map[kind], h->vox_map.out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->n_map[kind] = n_out;
+        // the search structure (laser_mapping.hpp:539-546: two KdTreeFLANN::setInputCloud) is the device grid
+        const char *err = nullptr;
+        const float cell = (kind == LL_MAP_CORNER) ? 1.45f : 0.6f;
+        if (map_build(map->kind[kind], (const float *)h->d_map[kind], 4, n_out, cell, h->stream, &err)) return set_err("map_build", err ? err : "failed");
+    }
+    HC(hipStreamSynchronize(h->stream));
+    if (n_map_corner) *n_map_corner = h->n_map[0];
+    if (n_map_surf) *n_map_surf = h->n_map[1];
+    return 0;
+}
+
+extern "C" int64_t ll_history_map_cloud(ll_history *h, int32_t kind, float *xyzi, int64_t capacity_points)
+{
+    if (!h || kind < 0 || kind > 1) return set_err("ll_history_map_cloud", "bad argument");
+    const int64_t n = h->n_map[kind];
+    if (!xyzi) return n;
+    if (capacity_points < n) return set_err("ll_history_map_cloud", "buffer too small");
+    if (hipSetDevice(h->device) != hipSuccess) return set_err("ll_history_map_cloud", "hipSetDevice failed");
+    if (n > 0 && hipMemcpy(xyzi, h->d_map[kind], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err("ll_history_map_cloud", "copy failed");
+    return n;
+}
+
 extern "C" int ll_reg_solve_batch_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
                                      const double *poses_last, double *poses_curr, double *poses_incre, ll_reg_report *reports,
                                      int32_t *results)

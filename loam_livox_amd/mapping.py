@@ -1,0 +1,69 @@
+"""Host-side mirror of Laser_mapping::process_new_scan for the history match mode (m_matching_mode == 0),
+hku-mars/loam_livox source/laser_mapping.hpp:1311-1520, on top of the C ABI: extractor -> (VoxelGrid) -> registrar
+-> history -> match-buffer refresh, everything resident on one device.
+
+This is the unit of BASELINE config C4 (one sequence per GPU, local map growth).  Differences from the node, by design:
+  * the match buffer is refreshed synchronously after every accepted frame; the node refreshes it on a service thread
+    and registers against whichever buffer is newest (laser_mapping.hpp:568-594, 1395-1403), which makes its output
+    depend on thread timing;
+  * no ROS, logging, cell maps, key frames or loop closure (out of scope).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .api import History_buffer, Livox_laser, Map_buffer, Point_cloud_registration, VoxelGrid
+
+
+class Laser_mapping:
+    def __init__(self, scan_points: int = 24000, device: int = 0, maximum_history_size: int = 100, line_res: float = 0.1,
+                 plane_res: float = 0.4, init_accumulate_frames: int = 50, input_downsample_mode: int = 1, icp_max_iterations: int = 20,
+                 ceres_max_iterations: int = 100, max_allow_incre_R: float = 200.0 / 50.0, max_allow_incre_T: float = 100.0 / 50.0,
+                 max_allow_final_cost: float = 100.0, history_add_t_step: float = 0.0, history_add_angle_step: float = 0.0):
+        self.fe = Livox_laser(max_points=scan_points, max_scans=1, device=device, piecewise_number=1)
+        self.reg = Point_cloud_registration(max_scans=1, max_features=scan_points, device=device)
+        self.map = Map_buffer(device=device)
+        self.vox = (VoxelGrid(scan_points, 1, device=device), VoxelGrid(scan_points, 1, device=device))
+        self.history = History_buffer(maximum_history_size, scan_points, line_res, plane_res, device=device)
+        self.line_res, self.plane_res = line_res, plane_res
+        self.m_if_input_downsample_mode = input_downsample_mode
+        self.history_add_t_step, self.history_add_angle_step = history_add_t_step, history_add_angle_step
+        p = self.reg.params
+        p.icp_max_iterations, p.ceres_max_iterations = icp_max_iterations, ceres_max_iterations
+        p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = max_allow_incre_R, max_allow_incre_T, max_allow_final_cost
+        p.mapping_init_accumulate_frames = init_accumulate_frames
+        p.maximum_allow_residual_block = scan_points
+        self.m_current_frame_index = 0
+        self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)  # m_q_w_curr / m_t_w_curr
+        self.map_sizes = (0, 0)
+        self.last_report = None
+
+    def close(self):
+        for h in (self.fe, self.reg, self.map, self.vox[0], self.vox[1], self.history):
+            h.close()
+
+    def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0) -> int:
+        """One frame (laser_mapping.hpp:1311-1520).  Returns the registration result (1 accepted, 0 rejected)."""
+        fe, reg = self.fe, self.reg
+        fe.upload(xyzi[None], np.full(1, time_stamp))
+        fe.extract_batch(1)
+        fe.resolve()
+        fe.select_batch(1, -1, 0.0, 1.0)
+        reg.params.current_frame_index = self.m_current_frame_index  # init_pointcloud_registration runs before the increment
+        self.m_current_frame_index += 1
+        pose = self.pose[None]
+        if self.m_if_input_downsample_mode:  # :1367-1373
+            reg.enqueue_fe_downsampled(self.map, fe, self.vox[0], self.vox[1], self.line_res, self.plane_res, 1, pose, pose)
+        else:
+            reg.enqueue_fe(self.map, fe, 1, pose, pose)
+        res, pc, _, reps = reg.collect(1)
+        self.last_report = reps[0]
+        if not res[0]:  # :1413-1416
+            return 0
+        if self.m_if_input_downsample_mode:
+            self.history.add_voxel(self.vox[0], self.vox[1], 0, pc[0], self.history_add_t_step, self.history_add_angle_step)
+        else:
+            self.history.add_fe(fe, 0, pc[0], self.history_add_t_step, self.history_add_angle_step)
+        self.pose = pc[0].copy()  # :1496-1500
+        self.map_sizes = self.history.refresh(self.map)  # service_update_buff_for_matching, synchronous here
+        return 1

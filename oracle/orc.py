@@ -240,6 +240,10 @@ def reg_solve(tree_c: KdTree, tree_s: KdTree, scan_corner: np.ndarray, scan_surf
     pi = np.array([0, 0, 0, 1, 0, 0, 0], np.float64) if pose_incre is None else np.ascontiguousarray(
         pose_incre, np.float64).copy()
     rep = RegReport()
+    if tree_c is None or tree_s is None:  # an empty map: only the PCR:199 gate can be reached
+        ret = L.orc_reg_solve(None, None, 0, None, None, 0, 4, _fp(sc), sc.shape[0], _fp(ss), ss.shape[0],
+                              C.byref(prm), _dp(pl), _dp(pc), _dp(pi), C.byref(rep))
+        return ret, pc, pi, rep
     assert tree_c.stride == tree_s.stride
     ret = L.orc_reg_solve(tree_c.h, _fp(tree_c.xyz), tree_c.xyz.shape[0], tree_s.h, _fp(tree_s.xyz),
                           tree_s.xyz.shape[0], tree_c.stride, _fp(sc), sc.shape[0], _fp(ss), ss.shape[0],
