@@ -51,13 +51,15 @@ class History:
 
 class LaserMapping:
     def __init__(self, maximum_history_size=100, line_res=0.1, plane_res=0.4, init_accumulate_frames=50, input_downsample_mode=1,
-                 icp_max_iterations=20, ceres_max_iterations=100, max_allow_incre_R=4.0, max_allow_incre_T=2.0, max_allow_final_cost=100.0):
+                 icp_max_iterations=20, ceres_max_iterations=100, max_allow_incre_R=4.0, max_allow_incre_T=2.0, max_allow_final_cost=100.0,
+                 minimum_icp_R_diff=0.01, minimum_icp_T_diff=0.01):
         self.hist = History(maximum_history_size, line_res, plane_res)
         self.res = (line_res, plane_res)
         self.ds = input_downsample_mode
         self.prm = orc.RegParams.defaults(icp_iters=icp_max_iterations, ceres_iters=ceres_max_iterations, force_all=0)
         self.prm.para_max_angular_rate, self.prm.para_max_speed, self.prm.max_final_cost = max_allow_incre_R, max_allow_incre_T, max_allow_final_cost
         self.prm.mapping_init_accumulate_frames = init_accumulate_frames
+        self.prm.minimum_icp_R_diff, self.prm.minimum_icp_T_diff = minimum_icp_R_diff, minimum_icp_T_diff
         self.frame = 0
         self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
         self.maps = [np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)]
