@@ -386,6 +386,11 @@ class Point_cloud_registration:
         check(self.L.ll_reg_debug_worklists(self.h, int(n_scans), ptr(out)), "ll_reg_debug_worklists")
         return int(out[0]), int(out[1])
 
+    def debug_cycles(self, scan: int = 0):
+        out = np.zeros(6, np.int64)
+        check(self.L.ll_reg_debug_cycles(self.h, scan, ptr(out)), "ll_reg_debug_cycles")
+        return out
+
     def kernel_times(self):
         ms = np.zeros(3, np.float32)
         n = np.zeros(3, np.int32)

@@ -9,6 +9,12 @@
 #include <math.h>
 #include <stdint.h>
 
+#if defined(__clang__)
+#define LL_UNROLL _Pragma("unroll")
+#else
+#define LL_UNROLL
+#endif
+
 #if defined(__HIPCC__)
 #define LL_HD __host__ __device__ __forceinline__
 #define LL_HD_NOINLINE __host__ __device__ __noinline__ inline

@@ -551,16 +551,25 @@ LL_HD void state_plus(const double x[7], const double d[6], double bound, double
     }
 }
 
+// Every loop is fully unrolled so that the factor lives in registers on the GPU (with rolled loops the 6x6 arrays are
+// indexed dynamically and end up in scratch memory: ~250 dependent memory round trips per LM iteration on the one lane
+// that runs the controller).  A failed pivot clears `ok` instead of returning early; the arithmetic of a successful
+// factorisation is unchanged.
 LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
 {
     double L[36];
-    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    int ok = 1;
+    LL_UNROLL
     for (int i = 0; i < 6; i++) {
-        for (int j = 0; j <= i; j++) {
+        LL_UNROLL
+        for (int j = 0; j < 6; j++) {
+            if (j > i) continue;
             double s = A[i * 6 + j];
-            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            LL_UNROLL
+            for (int k = 0; k < 6; k++)
+                if (k < j) s -= L[i * 6 + k] * L[j * 6 + k];
             if (i == j) {
-                if (!(s > 0.0)) return 0;
+                if (!(s > 0.0)) ok = 0;
                 L[i * 6 + i] = sqrt(s);
             } else {
                 L[i * 6 + j] = s / L[j * 6 + j];
@@ -568,19 +577,26 @@ LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
         }
     }
     double y[6];
+    LL_UNROLL
     for (int i = 0; i < 6; i++) {
         double s = b[i];
-        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
+        LL_UNROLL
+        for (int k = 0; k < 6; k++)
+            if (k < i) s -= L[i * 6 + k] * y[k];
         y[i] = s / L[i * 6 + i];
     }
+    LL_UNROLL
     for (int i = 5; i >= 0; i--) {
         double s = y[i];
-        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
+        LL_UNROLL
+        for (int k = 0; k < 6; k++)
+            if (k > i) s -= L[k * 6 + i] * x[k];
         x[i] = s / L[i * 6 + i];
     }
+    LL_UNROLL
     for (int i = 0; i < 6; i++)
-        if (!((x[i] - x[i]) == 0.0)) return 0;
-    return 1;
+        if (!((x[i] - x[i]) == 0.0)) ok = 0;
+    return ok;
 }
 
 // Trust-region Levenberg-Marquardt step controller with Ceres' default options (see oracle/ll_oracle_reg.c
@@ -677,26 +693,35 @@ LL_HD_NOINLINE int lm_propose(LmCtl &c)
         }
         c.iteration++;
         double Hs[36], gs[6], A[36], y[6], step[6];
+        LL_UNROLL
         for (int a = 0; a < 6; a++) {
             gs[a] = c.g[a] * c.scale[a];
+            LL_UNROLL
             for (int b = 0; b < 6; b++) {
                 const double h = (a <= b) ? c.H[hidx(a, b)] : c.H[hidx(b, a)];
                 Hs[a * 6 + b] = h * c.scale[a] * c.scale[b];
             }
         }
-        if (!c.reuse_diagonal)
+        if (!c.reuse_diagonal) {
+            LL_UNROLL
             for (int j = 0; j < 6; j++) c.diag[j] = fmin(fmax(Hs[j * 6 + j], 1e-6), 1e32);
+        }
+        LL_UNROLL
         for (int i = 0; i < 36; i++) A[i] = Hs[i];
+        LL_UNROLL
         for (int j = 0; j < 6; j++) A[j * 6 + j] += c.diag[j] / c.radius;
         const int ok = chol_solve6(A, gs, y);
         c.reuse_diagonal = 1;
         double mcc = 0.0;
         if (ok) {
             double sg = 0.0, sHs = 0.0;
+            LL_UNROLL
             for (int a = 0; a < 6; a++) step[a] = -y[a];
+            LL_UNROLL
             for (int a = 0; a < 6; a++) {
                 sg += step[a] * gs[a];
                 double t = 0.0;
+                LL_UNROLL
                 for (int b = 0; b < 6; b++) t += Hs[a * 6 + b] * step[b];
                 sHs += step[a] * t;
             }
@@ -715,6 +740,7 @@ LL_HD_NOINLINE int lm_propose(LmCtl &c)
         c.model_cost_change = mcc;
         c.gd = 0.0;
         c.dmax = 0.0;
+        LL_UNROLL
         for (int j = 0; j < 6; j++) {
             c.delta[j] = step[j] * c.scale[j];
             c.gd += c.g[j] * c.delta[j];

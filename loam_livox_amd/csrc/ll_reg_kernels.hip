@@ -33,12 +33,30 @@ namespace ll {
 #define RS_WAVES (RS_THREADS / 64)
 #define HASH_EMPTY 0xffffffffffffffffull
 
+// Wave-wide sum of a double, result valid in lane 63.  Data-parallel-primitive moves (row shifts inside each row of 16
+// lanes, then row broadcasts) instead of ds_bpermute shuffles: no LDS crossbar round trip per step, which is what a
+// 28-value reduction per cost evaluation spends its time on when a scan has only a few hundred residual blocks.
+// The addition tree is fixed, so results are reproducible run to run.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shifted(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    // lanes that receive nothing (row start, masked rows) add the `old` operand of update_dpp: +0.0
+    v += dpp_shifted<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_shifted<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_shifted<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_shifted<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_shifted<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold the half sums
+    v += dpp_shifted<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
     return v;
 }
+#define WAVE_SUM_LANE 63
 
 // ---------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------
@@ -432,7 +450,7 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) {
         const double s = wave_sum(acc[i]);
-        if (lane == 0) sh.red[wave][i] = s;
+        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
     }
     __syncthreads();
     if (tid < LL_NACC) {
@@ -788,7 +806,7 @@ __device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, i
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) {
         const double s = wave_sum(acc[i]);
-        if (lane == 0) sh.red[wave][i] = s;
+        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
     }
     __syncthreads();
     if (tid < LL_NACC) {
@@ -972,30 +990,37 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
                 atomicAdd(&bins[bi], 1);
             }
         __syncthreads();
-        // locate the bin of the wanted rank: every thread sums SEL_BINS/RS_THREADS consecutive bins, lane 0 walks
-        // the RS_THREADS partial sums, the owning thread walks its own bins
+        // locate the bin of the wanted rank: every thread sums its SEL_BINS/RS_THREADS consecutive bins, a workgroup
+        // prefix sum (wave scan + the eight wave totals) gives each thread the count below its first bin, and the one
+        // thread whose range holds the rank walks its own few bins
         {
             const int per = SEL_BINS / RS_THREADS;
+            const int lane = tid & 63, wave = tid >> 6;
             int part = 0;
             for (int e = 0; e < per; e++) part += bins[tid * per + e];
-            sh.hist_part[tid] = part;
+            int incl = part;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off) incl += y;
+            }
+            if (lane == 63) sh.isum[wave] = incl;
+            if (tid == 0) sh.n_cand = 0;
             __syncthreads();
-            if (tid == 0) {
-                int rank = sh.sel_rank, cum = 0, t = 0;
-                for (t = 0; t < RS_THREADS; t++) {
-                    if (cum + sh.hist_part[t] > rank) break;
-                    cum += sh.hist_part[t];
-                }
-                if (t >= RS_THREADS) t = RS_THREADS - 1;
-                int bi = t * per;
-                for (; bi < t * per + per - 1; bi++) {
+            int below = incl - part;
+            for (int w = 0; w < wave; w++) below += sh.isum[w];
+            const int rank = sh.sel_rank;
+            __syncthreads();  // everyone has read sel_rank / isum before the owner overwrites sel_rank
+            const bool last_thread = tid == RS_THREADS - 1;
+            if ((rank >= below && rank < below + part) || (last_thread && rank >= below + part)) {
+                int cum = below, bi = tid * per;
+                for (; bi < tid * per + per - 1; bi++) {
                     if (cum + bins[bi] > rank) break;
                     cum += bins[bi];
                 }
                 sh.sel_bin = bi;
                 sh.sel_rank = rank - cum;  // rank inside the bin
                 sh.sel_cnt = bins[bi];
-                sh.n_cand = 0;
             }
             __syncthreads();
         }
