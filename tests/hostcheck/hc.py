@@ -101,11 +101,23 @@ class Grid:
 
     def knn5_bounds(self, q, max_d2):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        cand = np.zeros((q.shape[0], lib().hc_knn_k()), np.int32)
         out = [np.zeros(q.shape[0], np.float32) for _ in range(4)]
         L = lib()
-        L.hc_knn5_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
-        L.hc_knn5_bounds(self.h, _p(q), q.shape[0], max_d2, *[_p(o) for o in out])
-        return out  # lb2, out2, m_set, m_strong
+        L.hc_knn5_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5
+        L.hc_knn5_bounds(self.h, _p(q), q.shape[0], max_d2, _p(cand), *[_p(o) for o in out])
+        return [cand] + out  # candidates, lb2, out2, m_set, m_strong
+
+    def knn5_reuse_chain(self, path, max_d2):
+        """path [n_hops][nq][3] -> (idx5 [n_hops][nq][5], state [n_hops][nq]); state 0 kept, 1 re-sorted, 2 searched"""
+        path = np.ascontiguousarray(path, np.float32)
+        n_hops, nq = path.shape[0], path.shape[1]
+        idx = np.zeros((n_hops, nq, 5), np.int32)
+        st = np.zeros((n_hops, nq), np.int32)
+        L = lib()
+        L.hc_knn5_reuse_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.hc_knn5_reuse_chain(self.h, _p(path), n_hops, nq, max_d2, _p(idx), _p(st))
+        return idx, st
 
 
 def eval_blocks(kind, f, a, v, x, huber_a=0.1, sblur=None):

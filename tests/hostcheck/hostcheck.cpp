@@ -178,19 +178,55 @@ int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx
     return 0;
 }
 
-// the reuse bounds of the same search: lb2 (lower bound on every point outside the list), out2 (lower bound on every
-// point at or beyond the match radius) and the two displacement budgets of the reuse record
-int hc_knn5_bounds(const hc_grid *G, const float *q, int nq, float max_d2, float *lb2, float *out2, float *m_set, float *m_strong)
+#define HC_KNN_K 5  // candidates the search keeps (ll_knn_core.h, Knn5)
+int hc_knn_k(void) { return HC_KNN_K; }
+
+// the reuse bounds of the same search: the full candidate list, lb2 (lower bound on every point outside the list), out2
+// (lower bound on every point at or beyond the match radius) and the two displacement budgets of the reuse record
+int hc_knn5_bounds(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *cand, float *lb2, float *out2, float *m_set,
+                   float *m_strong)
 {
     for (int i = 0; i < nq; i++) {
         Knn5 r;
         knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
         KnnRef ref;
         knn5_make_ref(r, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, ref);
+        for (int k = 0; k < HC_KNN_K; k++) cand[HC_KNN_K * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
         lb2[i] = r.lb2;
         out2[i] = r.out2;
         m_set[i] = ref.m_set;
         m_strong[i] = ref.m_strong;
+    }
+    return 0;
+}
+
+// The registrar's reuse logic over a chain of query positions (reg_requery_kernel): path[h][i] = position of query i at
+// hop h.  Hop 0 searches; every later hop keeps the result (state 0), re-sorts the stored candidates (1) or searches
+// again (2).  idx5 / state: [n_hops][nq][5] / [n_hops][nq]; idx -1 when fewer than five neighbours are inside the radius.
+int hc_knn5_reuse_chain(const hc_grid *G, const float *path, int n_hops, int nq, float max_d2, int32_t *idx5, int32_t *state)
+{
+    for (int i = 0; i < nq; i++) {
+        KnnRef ref{};
+        int cur[5] = {-1, -1, -1, -1, -1};
+        for (int h = 0; h < n_hops; h++) {
+            const float *p = path + ((size_t)h * nq + i) * 3;
+            int st = 2;
+            Knn5 r;
+            if (h > 0) {
+                const float delta = knn5_ref_delta(ref, p[0], p[1], p[2]);
+                if (delta < ref.m_strong) st = 0;
+                else if (delta < ref.m_set) st = 1;
+                if (st == 1) knn5_resort(G->g, ref, delta, p[0], p[1], p[2], max_d2, r);
+            }
+            if (st == 2) {
+                knn5_search(G->g, p[0], p[1], p[2], max_d2, r);
+                knn5_make_ref(r, p[0], p[1], p[2], max_d2, ref);
+            }
+            if (st != 0)
+                for (int k = 0; k < 5; k++) cur[k] = (r.count >= 5) ? r.idx[k] : -1;
+            for (int k = 0; k < 5; k++) idx5[((size_t)h * nq + i) * 5 + k] = cur[k];
+            state[(size_t)h * nq + i] = st;
+        }
     }
     return 0;
 }

@@ -88,36 +88,50 @@ def test_grid_knn_sparse_outside_and_ties():
 
 @pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500)])
 def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts):
-    """lb2 / out2 and the displacement budgets derived from them must be conservative whatever the search pruned:
-    moving the query by less than m_set keeps the neighbour set, by less than m_strong the ordered list"""
+    """the search keeps LL_KNN_K candidates; lb2 / out2 must bound every point outside that list whatever was pruned"""
     rng = np.random.default_rng(11)
     pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
     g = hc.Grid(pts, cell)
     q = rng.uniform(-2, 32, (400, 3)).astype(np.float32)
     hi, hd = g.knn5(q, max_d2)
-    lb2, out2, m_set, m_strong = g.knn5_bounds(q, max_d2)
+    cand, lb2, out2, m_set, m_strong = g.knn5_bounds(q, max_d2)
+    assert np.array_equal(cand[:, :5], hi)
     d2_all = ((q[:, None, :].astype(np.float64) - pts[None, :, :]) ** 2).sum(-1)
     for i in range(len(q)):
-        listed = hi[i][hi[i] >= 0]
-        full = len(listed) == 5 and hd[i][4] < max_d2
-        rest = np.delete(d2_all[i], listed) if full else d2_all[i][d2_all[i] >= max_d2]
-        bound = lb2[i] if full else out2[i]
-        assert rest.size == 0 or bound <= rest.min() * (1 + 1e-5) + 1e-6
+        listed = cand[i][cand[i] >= 0]
+        if len(listed) >= 5:
+            rest = np.delete(d2_all[i], listed)
+            assert rest.size == 0 or lb2[i] <= rest.min() * (1 + 1e-5) + 1e-6
+        far = d2_all[i][d2_all[i] >= max_d2]
+        assert far.size == 0 or out2[i] <= far.min() * (1 + 1e-5) + 1e-6
+        inside = np.sort(d2_all[i][d2_all[i] < max_d2])
+        assert len(listed) == min(cand.shape[1], len(inside))
     assert (m_set > 0).mean() > 0.5 and np.all(m_strong <= m_set)
-    # move every query by 0.9 of its budget in a random direction and search again
-    d = rng.normal(size=q.shape); d /= np.linalg.norm(d, axis=1, keepdims=True)
-    for budget, ordered in ((m_set, False), (m_strong, True)):
-        q2 = (q + 0.9 * budget[:, None] * d).astype(np.float32)
-        hi2, hd2 = g.knn5(q2, max_d2)
-        found1 = (hi >= 0).sum(1) == 5
-        found2 = (hi2 >= 0).sum(1) == 5
-        if ordered:
-            assert np.array_equal(found1, found2) and np.array_equal(hi[found1], hi2[found1])
-        else:
-            # the set is unchanged; a neighbour may leave the radius (found -> not found) but nothing new may enter
-            assert not np.any(found2 & ~found1)
-            both = found1 & found2
-            assert np.array_equal(np.sort(hi[both], 1), np.sort(hi2[both], 1))
+
+
+@pytest.mark.parametrize("cell,max_d2,npts,step", [(0.7, 50.0, 4000, 0.05), (0.5, 2.0, 30000, 0.02), (1.3, 9.0, 1500, 0.3),
+                                                   (0.6, 50.0, 60000, 0.01)])
+def test_knn_reuse_chain_is_exact(cell, max_d2, npts, step):
+    """the registrar's reuse over a chain of moves (keep / re-sort the 8 candidates / search) returns at every hop exactly
+    what a fresh search returns"""
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
+    g = hc.Grid(pts, cell)
+    nq, n_hops = 600, 6
+    path = np.zeros((n_hops, nq, 3), np.float32)
+    path[0] = rng.uniform(-1, 31, (nq, 3))
+    for h in range(1, n_hops):  # shrinking moves, like successive ICP iterations
+        d = rng.normal(size=(nq, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        path[h] = path[h - 1] + (step / h) * rng.uniform(0.2, 1.0, (nq, 1)) * d
+    idx, st = g.knn5_reuse_chain(path, max_d2)
+    for h in range(n_hops):
+        hi, hd = g.knn5(path[h], max_d2)
+        fresh = np.where(((hi >= 0).sum(1) == 5)[:, None], hi, -1)
+        assert np.array_equal(idx[h], fresh), f"hop {h}"
+    assert np.all(st[0] == 2)
+    assert (st[1:] == 2).mean() < 0.6 and (st[1:] < 2).any()
+    if step <= 0.02 and hc.lib().hc_knn_k() >= 8:
+        assert (st[2:] == 2).mean() < 0.05   # small moves: 8 candidates almost always cover the answer
 
 
 def test_analytic_gauss_newton_matches_jets():
