@@ -307,3 +307,32 @@ def test_pca_feature_checks_match_oracle(gpu_lib, small_world, scans, checks, ge
         reg.close()
     assert np.array_equal(poses[0], poses[1])
     m.close()
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_duplicate_residuals_follow_std_set_semantics(dev_map, small_world, scans, general):
+    """compute_inlier_residual_threshold (PCR:155-160) ranks the DISTINCT loss-corrected residuals (it inserts them into a
+    std::set).  Repeating features verbatim produces exact duplicates, which shift the rank of the 80 % threshold; the device
+    de-duplication (LDS hash table / HBM table) has to land on the same value as the oracle's set."""
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    rng = np.random.default_rng(3)
+    rep = rng.choice(len(fs), len(fs) // 3, replace=False)
+    fs2 = np.concatenate([fs, fs[rep], fs[rep[: len(rep) // 2]]])          # some features twice, some three times
+    fc2 = np.concatenate([fc, fc[: len(fc) // 2]])
+    prm = orc.RegParams.defaults(icp_iters=6, ceres_iters=20, force_all=1)
+    ret, pc, pi, orep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc2, fs2, prm, sc.pose_init, sc.pose_init)
+    _, pc_plain, _, orep_plain = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    assert orep.inlier_threshold != orep_plain.inlier_threshold            # the duplicates do matter
+    reg = Point_cloud_registration(max_scans=1, max_features=40000)
+    reg.set_debug(False, force_general_solver=general)
+    set_params(reg, 6, 20, 1)
+    reg.params.maximum_allow_residual_block = 40000
+    reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+    gret = reg.find_out_incremental_transfrom(dev_map, fc2, fs2)
+    g = reg.report
+    dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+    assert gret == ret and dt < 1e-7 and dr < 1e-7
+    assert g.n_blocks_last == orep.n_blocks_last and g.lm_iterations_total == orep.lm_iterations_total
+    assert np.isclose(g.inlier_threshold, orep.inlier_threshold, rtol=1e-9)
+    reg.close()
