@@ -743,6 +743,12 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
 #define FAST_MAXK (FAST_MAX_BLOCKS / RS_THREADS)
 #define HT_SIZE 16384
 #define HT_PART 6144  // keys per de-duplication round (load factor <= 0.375)
+// set de-duplication, common case: bitmap + contested-bit set + exact table of the contested keys (all inside s_table)
+#define DD_BM_WORDS 16384  // 512 Kbit
+#define DD_CB_LOG2 11
+#define DD_CB_SIZE (1 << DD_CB_LOG2)
+#define DD_EX_SIZE 4096
+#define DD_MAX_COLL 900    // contested keys beyond this (heavily duplicated input): hash every key instead
 #define SEL_BINS 4096  // value-range bins of the rank select (must be a multiple of RS_THREADS)
 #define SEL_CAND 1024  // keys of the selected bin ranked exactly; more -> radix-select fallback
 
@@ -911,34 +917,109 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
     __syncthreads();
     LL_TACC(2, t_l1);
     LL_T0(t_dd);
-    // ---- std::set semantics (PCR:155-160): distinct values via an LDS hash table, HT_PART keys per round -----
+    // ---- std::set semantics (PCR:155-160): which values are distinct, and how many ---------------------------------
+    // Exact duplicates among the residuals are rare, so the common case is made cheap: every key sets one bit of a
+    // 512 Kbit LDS bitmap (atomicOr); only keys whose bit was already set -- true duplicates or hash collisions, a few
+    // hundred of ~17 k -- and the keys that share a bit with them go through an exact compare-and-swap table.  Heavily
+    // duplicated inputs (more than DD_MAX_COLL such keys) fall back to hashing every key, HT_PART keys per round.
     unsigned long long first_mask = 0;  // bit k: block k of this thread is the first occurrence of its L1 value
     {
-        const int rounds = (total + HT_PART - 1) / HT_PART;
         int my = 0;
-        for (int rnd = 0; rnd < rounds; rnd++) {
-            for (int e = tid; e < HT_SIZE; e += RS_THREADS) s_table[e] = HASH_EMPTY;
+        unsigned int *bm = (unsigned int *)s_table;                      // [DD_BM_WORDS] bitmap
+        unsigned int *cb = bm + DD_BM_WORDS;                             // [DD_CB_SIZE] set of contested bit indices
+        unsigned long long *ex = (unsigned long long *)(cb + DD_CB_SIZE); // [DD_EX_SIZE] exact table of the contested keys
+        for (int e = tid; e < DD_BM_WORDS; e += RS_THREADS) bm[e] = 0u;
+        for (int e = tid; e < DD_CB_SIZE; e += RS_THREADS) cb[e] = 0xffffffffu;
+        for (int e = tid; e < DD_EX_SIZE; e += RS_THREADS) ex[e] = HASH_EMPTY;
+        __syncthreads();
+        unsigned long long coll = 0;
+        int ncoll = 0;
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++) {
+            const double l1 = l1r[k];
+            if (!(l1 >= 0.0)) continue;  // inactive slot or NaN (NaN never enters the set)
+            const unsigned int hb = (unsigned int)hash64((unsigned long long)__double_as_longlong(l1)) & (DD_BM_WORDS * 32 - 1);
+            const unsigned int bit = 1u << (hb & 31);
+            if (atomicOr(&bm[hb >> 5], bit) & bit) {
+                coll |= 1ull << k;
+                ncoll++;
+            }
+        }
+        const int total_coll = block_sum_int(ncoll, sh);
+        if (total_coll <= DD_MAX_COLL) {
+#pragma unroll
+            for (int k = 0; k < FAST_MAXK; k++) {
+                if (!(coll & (1ull << k))) continue;
+                const unsigned int hb = (unsigned int)hash64((unsigned long long)__double_as_longlong(l1r[k])) & (DD_BM_WORDS * 32 - 1);
+                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
+                for (;;) {
+                    const unsigned int old = atomicCAS(&cb[h], 0xffffffffu, hb);
+                    if (old == 0xffffffffu || old == hb) break;
+                    h = (h + 1u) & (DD_CB_SIZE - 1);
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < FAST_MAXK; k++) {
                 const double l1 = l1r[k];
-                if (!(l1 >= 0.0)) continue;  // inactive slot or NaN (NaN never enters the set)
+                if (!(l1 >= 0.0)) continue;
                 const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
                 const unsigned long long hk = hash64(key);
-                if ((int)((hk >> 40) % (unsigned long long)rounds) != rnd) continue;
-                unsigned int h = (unsigned int)hk & (HT_SIZE - 1);
+                const unsigned int hb = (unsigned int)hk & (DD_BM_WORDS * 32 - 1);
+                bool contested = false;
+                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
                 for (;;) {
-                    const unsigned long long old = atomicCAS(&s_table[h], HASH_EMPTY, key);
+                    const unsigned int c = cb[h];
+                    if (c == 0xffffffffu) break;
+                    if (c == hb) {
+                        contested = true;
+                        break;
+                    }
+                    h = (h + 1u) & (DD_CB_SIZE - 1);
+                }
+                if (!contested) {  // the only key on its bit: distinct from every other key
+                    first_mask |= (1ull << k);
+                    my++;
+                    continue;
+                }
+                unsigned int h2 = (unsigned int)(hk >> 24) & (DD_EX_SIZE - 1);
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&ex[h2], HASH_EMPTY, key);
                     if (old == HASH_EMPTY) {
                         first_mask |= (1ull << k);
                         my++;
                         break;
                     }
                     if (old == key) break;
-                    h = (h + 1u) & (HT_SIZE - 1);
+                    h2 = (h2 + 1u) & (DD_EX_SIZE - 1);
                 }
             }
-            __syncthreads();
+        } else {
+            const int rounds = (total + HT_PART - 1) / HT_PART;
+            for (int rnd = 0; rnd < rounds; rnd++) {
+                __syncthreads();
+                for (int e = tid; e < HT_SIZE; e += RS_THREADS) s_table[e] = HASH_EMPTY;
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < FAST_MAXK; k++) {
+                    const double l1 = l1r[k];
+                    if (!(l1 >= 0.0)) continue;
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
+                    const unsigned long long hk = hash64(key);
+                    if ((int)((hk >> 40) % (unsigned long long)rounds) != rnd) continue;
+                    unsigned int h = (unsigned int)hk & (HT_SIZE - 1);
+                    for (;;) {
+                        const unsigned long long old = atomicCAS(&s_table[h], HASH_EMPTY, key);
+                        if (old == HASH_EMPTY) {
+                            first_mask |= (1ull << k);
+                            my++;
+                            break;
+                        }
+                        if (old == key) break;
+                        h = (h + 1u) & (HT_SIZE - 1);
+                    }
+                }
+            }
         }
         const int nu = block_sum_int(my, sh);
         if (tid == 0) {
