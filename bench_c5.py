@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config C5 on one MI355X: the exact 5-NN kernel against a 50 M-point map -- the configuration whose map
 (640 MB of 16-byte records + the cell table) no longer fits the 256 MB Infinity Cache, i.e. the honest HBM run of the
-k-NN.  fp32 points; the fp16-point variant of the config is not built yet.
+k-NN.  fp32 points by default; --f16 switches the map to 8-byte fp16-in-cell records (ll_map_to_f16).
 
   python bench_c5.py [--map-points 50000000] [--queries 4000000]
   rocprofv3 --kernel-trace --stats ... / --pmc FETCH_SIZE ... -- python bench_c5.py   (profiles/README.md)
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--queries", type=int, default=4_000_000)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--parity-queries", type=int, default=64)
+    ap.add_argument("--f16", action="store_true", help="fp16-point records (8 B per point), fp32 accumulate: the literal C5 configuration")
     args = ap.parse_args()
     import torch
     from loam_livox_amd import synth
@@ -39,6 +40,8 @@ def main():
     mp = Map_buffer()
     t0 = time.time()
     mp.setInputCloud(Map_buffer.SURF, surf)
+    if args.f16:
+        mp.to_f16(Map_buffer.SURF)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     # queries: surface features of a few scans, replicated with distinct initial-guess perturbations
@@ -67,13 +70,13 @@ def main():
     from oracle import orc
     sel = rng.choice(len(q), args.parity_queries, replace=False)
     t0 = time.time()
-    bi, bd = orc.bruteforce_knn(surf, q[sel], 5)
+    bi, bd = orc.bruteforce_knn(mp.dequantized(Map_buffer.SURF) if args.f16 else surf, q[sel], 5)
     t_bf = time.time() - t0
     same = bool(np.array_equal(np.where(bd < max_d2, bi, -1), idx[sel]) and np.array_equal(np.where(bd < max_d2, bd, np.inf), d2[sel]))
     found = float(((idx >= 0).sum(1) == 5).mean())
     print(json.dumps({
         "metric": "knn_queries_per_s", "value": round(len(q) / wall, 1), "unit": "5-NN queries/s through ll_map_knn5 (host buffers in and out)",
-        "config": {"workload": "C5: exact 5-NN, fp32 points, 50M-pt map (surface part), Mid-40 surface features as queries",
+        "config": {"workload": "C5: exact 5-NN, " + ("fp16 points (8-byte records) / fp32 accumulate" if args.f16 else "fp32 points") + ", 50M-pt map (surface part), Mid-40 surface features as queries",
                    "map_surface_points": int(len(surf)), "queries": int(len(q)), "max_sq_dis": max_d2},
         "ms_per_call": round(1e3 * wall, 2), "found_frac": found,
         "setup_s": {"synthetic_map": round(t_map_gen, 1), "upload_and_grid_build": round(t_build, 2)},

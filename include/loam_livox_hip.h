@@ -114,6 +114,13 @@ void ll_map_destroy(ll_map *m);
  * 0.6 m surface: about 1.5x the 0.4 m surface-map leaf).  Point indices reported by the library refer to this input order. */
 int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size);
 int64_t ll_map_size(const ll_map *m, int32_t kind);
+/* BASELINE config C5 ("fp16 points / fp32 accumulate k-NN"): replaces the 16-byte fp32 records of an uploaded map kind by
+ * 8-byte records -- the point's position inside its grid cell in binary16 (<= 2^-11 cell sizes off) + the cell index
+ * bits -- and ll_map_knn5 then returns the exact 5-NN of that dequantised cloud, distances accumulated in fp32.  The
+ * registrar refuses such a map (its parity contract is fp32 points, like pcl::KdTreeFLANN<PointXYZI>).
+ * ll_map_dequantized: the cloud the fp16 records stand for, in upload order (NaN rows for dropped points). */
+int ll_map_to_f16(ll_map *m, int32_t kind);
+int ll_map_dequantized(ll_map *m, int32_t kind, float *xyz, int64_t capacity_points);
 
 /* pcl::KdTreeFLANN::nearestKSearch(pt, 5, idx, sq_dis) (point_cloud_registration.hpp:249,351) for a batch of
  * host query points: exact 5-NN among map points with squared distance < max_sq_dis, ascending (d2, idx);

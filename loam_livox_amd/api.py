@@ -271,6 +271,16 @@ class Map_buffer:
     def size(self, kind: int) -> int:
         return int(self.L.ll_map_size(self.h, kind))
 
+    def to_f16(self, kind: int):
+        """fp16-point records for this kind (BASELINE config C5); the registrar cannot use the map afterwards"""
+        check(self.L.ll_map_to_f16(self.h, kind), "ll_map_to_f16")
+
+    def dequantized(self, kind: int) -> np.ndarray:
+        n = self.size(kind)
+        out = np.zeros((n, 3), np.float32)
+        check(self.L.ll_map_dequantized(self.h, kind, ptr(out), n), "ll_map_dequantized")
+        return out
+
     def nearestKSearch(self, kind: int, queries: np.ndarray, max_sq_dis: float):
         q = capi.as_f32(queries, 3)
         idx = np.zeros((q.shape[0], 5), np.int32)

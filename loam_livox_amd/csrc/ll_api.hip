@@ -426,6 +426,33 @@ extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t 
     return 0;
 }
 
+extern "C" int ll_map_to_f16(ll_map *m, int32_t kind)
+{
+    if (!m || kind < 0 || kind > 1) return set_err("ll_map_to_f16", "bad argument");
+    HC(hipSetDevice(m->device));
+    const char *err = nullptr;
+    if (map_to_f16(m->kind[kind], m->stream, &err)) return set_err("ll_map_to_f16", err ? err : "failed");
+    return 0;
+}
+
+extern "C" int ll_map_dequantized(ll_map *m, int32_t kind, float *xyz, int64_t capacity_points)
+{
+    if (!m || kind < 0 || kind > 1 || !xyz) return set_err("ll_map_dequantized", "bad argument");
+    const MapKind &mk = m->kind[kind];
+    if (capacity_points < mk.n) return set_err("ll_map_dequantized", "buffer too small");
+    HC(hipSetDevice(m->device));
+    float *d_out = nullptr;
+    const size_t bytes = (size_t)(mk.n > 0 ? mk.n : 1) * 3 * sizeof(float);
+    HC(hipMalloc(&d_out, bytes));
+    HC(hipMemsetAsync(d_out, 0xff, bytes, m->stream));  // NaN pattern for points that were dropped (non-finite input)
+    const char *err = nullptr;
+    const int rc = map_f16_dequant(mk, d_out, m->stream, &err);
+    if (rc == 0 && mk.n > 0) HC(hipMemcpy(xyz, d_out, (size_t)mk.n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_out);
+    if (rc) return set_err("ll_map_dequantized", err ? err : "failed");
+    return 0;
+}
+
 extern "C" int64_t ll_map_size(const ll_map *m, int32_t kind)
 {
     if (!m || kind < 0 || kind > 1) return -1;
@@ -436,7 +463,7 @@ extern "C" int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, in
                            float *sq_dis5)
 {
     if (!m || !queries_xyz || !idx5 || !sq_dis5) return set_err("ll_map_knn5", "null argument");
-    if (kind < 0 || kind > 1 || !m->kind[kind].pts) return set_err("ll_map_knn5", "map kind not uploaded");
+    if (kind < 0 || kind > 1 || (!m->kind[kind].pts && !m->kind[kind].pts16)) return set_err("ll_map_knn5", "map kind not uploaded");
     if (n_queries <= 0) return 0;
     HC(hipSetDevice(m->device));
     float *d_q = nullptr, *d_d2 = nullptr;
@@ -695,7 +722,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         return set_err("ll_reg", "feature count exceeds maximum_allow_residual_block: the reference's random sub-sampling "
                                  "(point_cloud_registration.hpp:232-238,339-345,438-458) is not reproduced; raise the limit");
     if (run) {
-        if (!map->kind[0].pts || !map->kind[1].pts) return set_err("ll_reg", "map not uploaded");
+        if (!map->kind[0].pts || !map->kind[1].pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
         HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));
         for (int it = 0; it < prm->icp_max_iterations; it++) {
             prof_begin(r, 0);

@@ -54,8 +54,10 @@ void launch_fe_select(const FeDev &fb, int n_scans, int piece, float min_blur, f
 // ------------------------------------------------------------------------------------------------ map grid
 
 struct MapKind {
-    f4 *pts = nullptr;          // sorted by cell, w = original index bits
+    f4 *pts = nullptr;          // sorted by cell, w = original index bits (nullptr for an fp16-point map)
     int *cell_start = nullptr;  // [ncell + 1]
+    unsigned long long *pts16 = nullptr;  // fp16-point records (ll_knn_core.h, Grid::pts16), same order as pts
+    int *perm = nullptr;        // original index of every fp16 record
     int64_t n = 0;              // points given
     int64_t n_valid = 0;        // finite points stored in the grid
     Grid grid{};                // device pointers + geometry
@@ -65,6 +67,10 @@ struct MapKind {
 // builds the grid for `n` device-resident raw points (stride floats apart); fills mk. Returns 0 or a HIP error.
 int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err);
 void map_free(MapKind &mk);
+// replaces the fp32 records of a built map by fp16-point records (BASELINE config C5); returns 0 or -1 with *err set
+int map_to_f16(MapKind &mk, hipStream_t s, const char **err);
+// dequantised coordinates of an fp16-point map in ORIGINAL index order (d_out: n_valid... n points x 3 floats, NaN where dropped)
+int map_f16_dequant(const MapKind &mk, float *d_out_xyz, hipStream_t s, const char **err);
 void launch_knn5(const Grid &g, const float *d_q, int nq, float max_d2, int *d_idx, float *d_d2, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ registrar

@@ -20,6 +20,11 @@ struct alignas(16) f4 {
 struct Grid {
     const f4 *pts;
     const int *cell_start;
+    // fp16-point variant (BASELINE config C5, ll_map_upload_f16): 8-byte records {half fx, fy, fz, uint16 cx} = position of
+    // the point inside its cell as a fraction of the cell size + the cell's x index, and the original index of every
+    // record.  Only the map k-NN entry point reads them; the registrar needs the fp32 records.
+    const unsigned long long *pts16;
+    const int *perm;
     float ox, oy, oz;  // origin (min corner)
     float inv_h, h;
     float slack;  // conservative allowance for fp32 rounding of cell assignment (metres)
@@ -111,23 +116,50 @@ LL_HD int cell_coord(float v, float o, float inv_h)
     return (int)floorf((v - o) * inv_h);
 }
 
-LL_HD void scan_run(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of one x-run*/, float qx, float qy,
-                    float qz, float max_d2, Knn5 &r)
+// How the candidate records are read.  PtF32: the 16-byte {x, y, z, index} records every production path uses.
+struct PtF32 {
+    struct Row {};
+    static LL_HD Row row(const Grid &, int) { return Row(); }
+    static LL_HD void load(const Grid &g, const Row &, int j, float &x, float &y, float &z, int &tok)
+    {
+        const f4 p = g.pts[j];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+        tok = as_int(p.w);
+    }
+    static LL_HD void push(const Grid &, Knn5 &r, float d2, int j, int tok) { knn5_push(r, d2, tok, j); }
+};
+
+template <class PT>
+LL_HD void scan_run_t(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of one x-run*/, float qx, float qy, float qz,
+                      float max_d2, Knn5 &r)
 {
     const int b = g.cell_start[c_lo], e = g.cell_start[c_hi + 1];
-    // four candidates per trip: the four 16-byte loads are independent, so their latencies overlap
+    const typename PT::Row row = PT::row(g, c_lo);
+    // four candidates per trip: the four record loads are independent, so their latencies overlap
     for (int j = b; j < e; j += 4) {
         const int j1 = (j + 1 < e) ? j + 1 : j, j2 = (j + 2 < e) ? j + 2 : j, j3 = (j + 3 < e) ? j + 3 : j;
-        const f4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
-        const float d0 = dist2_xyz(qx, qy, qz, p0.x, p0.y, p0.z);
-        const float d1 = dist2_xyz(qx, qy, qz, p1.x, p1.y, p1.z);
-        const float d2 = dist2_xyz(qx, qy, qz, p2.x, p2.y, p2.z);
-        const float d3 = dist2_xyz(qx, qy, qz, p3.x, p3.y, p3.z);
-        if (d0 < max_d2) knn5_push(r, d0, as_int(p0.w), j); else r.out2 = fminf(r.out2, d0);
-        if (j1 != j) { if (d1 < max_d2) knn5_push(r, d1, as_int(p1.w), j1); else r.out2 = fminf(r.out2, d1); }
-        if (j2 != j) { if (d2 < max_d2) knn5_push(r, d2, as_int(p2.w), j2); else r.out2 = fminf(r.out2, d2); }
-        if (j3 != j) { if (d3 < max_d2) knn5_push(r, d3, as_int(p3.w), j3); else r.out2 = fminf(r.out2, d3); }
+        float x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
+        int t0, t1, t2, t3;
+        PT::load(g, row, j, x0, y0, z0, t0);
+        PT::load(g, row, j1, x1, y1, z1, t1);
+        PT::load(g, row, j2, x2, y2, z2, t2);
+        PT::load(g, row, j3, x3, y3, z3, t3);
+        const float d0 = dist2_xyz(qx, qy, qz, x0, y0, z0);
+        const float d1 = dist2_xyz(qx, qy, qz, x1, y1, z1);
+        const float d2 = dist2_xyz(qx, qy, qz, x2, y2, z2);
+        const float d3 = dist2_xyz(qx, qy, qz, x3, y3, z3);
+        if (d0 < max_d2) PT::push(g, r, d0, j, t0); else r.out2 = fminf(r.out2, d0);
+        if (j1 != j) { if (d1 < max_d2) PT::push(g, r, d1, j1, t1); else r.out2 = fminf(r.out2, d1); }
+        if (j2 != j) { if (d2 < max_d2) PT::push(g, r, d2, j2, t2); else r.out2 = fminf(r.out2, d2); }
+        if (j3 != j) { if (d3 < max_d2) PT::push(g, r, d3, j3, t3); else r.out2 = fminf(r.out2, d3); }
     }
+}
+
+LL_HD void scan_run(const Grid &g, int c_lo, int c_hi, float qx, float qy, float qz, float max_d2, Knn5 &r)
+{
+    scan_run_t<PtF32>(g, c_lo, c_hi, qx, qy, qz, max_d2, r);
 }
 
 // Exact 5-NN of (qx,qy,qz) among points with squared distance < max_d2.
@@ -139,7 +171,8 @@ LL_HD void scan_run(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of o
 // After phase 1 every unvisited point is farther than  bound_1 = h + m  (m = distance from the query to the
 // nearest wall of its own cell); if the 5th best is not inside that bound, phase 2 grows Chebyshev rings
 // k = 2, 3, ... until it is, or until the bound passes the match radius.
-LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2, Knn5 &r)
+template <class PT>
+LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_d2, Knn5 &r)
 {
     knn5_init(r);
     if (!ll_isfinite(qx) || !ll_isfinite(qy) || !ll_isfinite(qz)) return;
@@ -192,7 +225,7 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
         if (x1 >= g.nx) x1 = g.nx - 1;
         if (x0 > x1) continue;
         const int base = (z * g.ny + y) * g.nx;
-        scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
+        scan_run_t<PT>(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
     }
 
     const float m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));  // already shrunk by slack
@@ -218,7 +251,7 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
                         } else if (x0 < 0 || x0 >= g.nx) {
                             continue;
                         }
-                        if (x0 <= x1) scan_run(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
+                        if (x0 <= x1) scan_run_t<PT>(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
                     }
                 }
             }
@@ -236,6 +269,11 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
     }
     r.lb2 = fminf(r.lb2, max_d2);
     r.out2 = fminf(r.out2, max_d2);
+}
+
+LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2, Knn5 &r)
+{
+    knn5_search_t<PtF32>(g, qx, qy, qz, max_d2, r);
 }
 
 // How far the query may move before the result of knn5_search has to be recomputed (metres, conservative):

@@ -141,3 +141,37 @@ def test_downsampled_registration_matches_oracle(gpu_lib, small_world, scans):
         assert reps[b].n_blocks_last == rep.n_blocks_last and reps[b].lm_iterations_total == rep.lm_iterations_total
     for h in (fe, vc, vs, reg, m):
         h.close()
+
+
+def test_fp16_point_map_knn_is_exact_on_the_dequantised_cloud(gpu_lib, small_world):
+    """BASELINE config C5: 8-byte fp16-in-cell records, fp32 distance accumulation.  The device returns the exact 5-NN of
+    the cloud its records stand for (ll_map_dequantized), which differs from the input by at most 2^-11 cell sizes."""
+    rng = np.random.default_rng(21)
+    surf = small_world["surf"][:, :3].copy()
+    surf[5] = surf[9]                       # an exact duplicate: ties by original index survive the quantisation
+    surf[17, 1] = np.nan                    # dropped point
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.SURF, surf)
+    q = (surf[rng.choice(len(surf), 3000)] + rng.normal(0, 0.3, (3000, 3))).astype(np.float32)
+    q[0] = surf[5]
+    i32, d32 = m.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    m.to_f16(Map_buffer.SURF)
+    deq = m.dequantized(Map_buffer.SURF)
+    ok = np.isfinite(surf).all(1)
+    assert np.isnan(deq[~ok]).all() and np.isfinite(deq[ok]).all()
+    err = np.abs(deq[ok].astype(np.float64) - surf[ok].astype(np.float64)).max()
+    assert err <= 0.6 * 2.0 ** -11 * 1.01 + 1e-5       # cell 0.6 m: <= 0.3 mm
+    i16, d16 = m.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    tree = orc.KdTree(np.where(np.isfinite(deq), deq, 1e9).astype(np.float32))
+    oi, od = tree.knn(q, 5)
+    assert np.array_equal(oi, i16) and np.array_equal(bits(od), bits(d16))
+    assert i16[0, 0] == 5 and i16[0, 1] == 9 and d16[0, 0] == d16[0, 1]
+    # the quantisation moves points by less than a millimetre: the neighbour sets barely change
+    assert (np.sort(i16, 1) == np.sort(i32, 1)).all(1).mean() > 0.95
+    # the registrar refuses an fp16-point map
+    reg = Point_cloud_registration(max_scans=1, max_features=1000)
+    reg.params.current_frame_index, reg.params.mapping_init_accumulate_frames = 100, 50
+    m.setInputCloud(Map_buffer.CORNER, small_world["corner"])
+    with pytest.raises(Exception):
+        reg.find_out_incremental_transfrom(m, small_world["corner"][:100], small_world["surf"][:500])
+    reg.close(); m.close()
