@@ -213,20 +213,26 @@ def main():
     names = ["reg_knn_build_kernel", "reg_solve_kernel", "reg_finalize_kernel"]
     dom = int(np.argmax(k_ms))
     avg_ms = float(k_ms[dom] / max(1.0, k_n[dom]))
-    blocks = float(sum(r.corner_avail + r.surf_avail for r in reps))
+    line_blocks = float(sum(r.corner_avail for r in reps))
+    plane_blocks = float(sum(r.surf_avail for r in reps))
     queries = float(nc.sum() + ns.sum())
+    # residual-block constants as stored (data layout): 16 B point + 1 B flag + 48 B (line: a', u') or
+    # 32 B (plane: n', n'.a')
+    block_bytes = line_blocks * 65.0 + plane_blocks * 49.0
     if dom == 1:
-        # algorithmic bytes of one solver launch: every residual block's constants read once (16 B point + 48 B
-        # a',v' + 1 B flag) + the 28 reduced doubles per scan (DESIGN.md "roofline")
-        alg_bytes = blocks * 65.0 + B * 224.0
+        # algorithmic bytes of one solver launch: every residual block's constants read once + the 28 reduced doubles
+        # per scan (DESIGN.md "roofline")
+        alg_bytes = block_bytes + B * 224.0
     else:
-        # k-NN + block build launch: 16 B/query in, 65 B/block out (candidate gather is cache-resident)
-        alg_bytes = queries * 16.0 + blocks * 65.0
+        # k-NN + block build launch: 16 B/query in, the block constants out (candidate gather is cache-resident)
+        alg_bytes = queries * 16.0 + block_bytes
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = pmc_traffic_bytes(names[dom], B)
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": int(alg_bytes)}
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                # what the kernel really moves (PMC, profiles/) against the same peak: how close the sweeps run to HBM speed
+                "traffic_frac": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 8e12, 4)}
 
     result = {
         "metric": "scans_per_s", "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
