@@ -249,7 +249,8 @@ def main():
         "per_iter_knn_jtj_ms_per_batch": round(float((k_ms[0] + k_ms[1]) / args.steps / max(1, args.icp_iters)), 4),
         "single_scan_latency_ms": round(latency_ms, 3),
         "features_per_scan": {"corner": float(nc.mean()), "surface": float(ns.mean())},
-        "knn_reuse_last_iter": dict(zip(("searched", "resorted"), reg.debug_worklists(B)), queries=int(nc.sum() + ns.sum())),
+        "knn_reuse_last_iter": dict(zip(("searched", "resorted"), reg.debug_worklists(B)), queries=int(nc.sum() + ns.sum()),
+                                    corner_searched_resorted=reg.debug_worklists_by_kind(B)[0], corner_queries=int(nc.sum())),
         "solver_phase_cycles_scan0": [int(v) for v in reg.debug_cycles(0)],
         "accepted_frac": float(np.mean(res)), "lm_iters_per_scan": float(np.mean([r.lm_iterations_total for r in reps])),
         "ambiguous_labels": int(n_amb), "setup_s": {"synthetic_data": round(t_data, 1), "map_upload_grid_build": round(t_map, 2)},

@@ -294,8 +294,9 @@ int ll_reg_kernel_times(ll_reg *r, float ms[3], int32_t launches[3]);
 int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[6]);
 
 /* Lengths of the neighbour-reuse work lists left by the last ICP iteration of the last solve, summed over the first
- * n_scans slots: out[0] = queries that needed a full search, out[1] = queries whose five neighbours were re-sorted. */
-int ll_reg_debug_worklists(ll_reg *r, int32_t n_scans, int64_t out[2]);
+ * n_scans slots: out[0] / out[1] = corner queries that needed a full search / whose five neighbours were re-sorted,
+ * out[2] / out[3] = the same for surface queries. */
+int ll_reg_debug_worklists(ll_reg *r, int32_t n_scans, int64_t out[4]);
 
 /* The HIP stream the handle launches on (hipStream_t), for callers that want their own events on it. */
 void *ll_reg_stream(ll_reg *r);

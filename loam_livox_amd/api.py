@@ -392,9 +392,15 @@ class Point_cloud_registration:
         check(self.L.ll_reg_set_profiling(self.h, int(enable)), "ll_reg_set_profiling")
 
     def debug_worklists(self, n_scans=1):
-        out = np.zeros(2, np.int64)
+        out = np.zeros(4, np.int64)
         check(self.L.ll_reg_debug_worklists(self.h, int(n_scans), ptr(out)), "ll_reg_debug_worklists")
-        return int(out[0]), int(out[1])
+        return int(out[0] + out[2]), int(out[1] + out[3])
+
+    def debug_worklists_by_kind(self, n_scans=1):
+        """((corner searched, corner re-sorted), (surface searched, surface re-sorted)) of the last ICP iteration"""
+        out = np.zeros(4, np.int64)
+        check(self.L.ll_reg_debug_worklists(self.h, int(n_scans), ptr(out)), "ll_reg_debug_worklists")
+        return (int(out[0]), int(out[1])), (int(out[2]), int(out[3]))
 
     def debug_cycles(self, scan: int = 0):
         out = np.zeros(6, np.int64)
