@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--cpu-scans", type=int, default=1)
+    ap.add_argument("--no-deblur", action="store_true", help="A/B: register the same scans without the motion-deblur residuals")
     args = ap.parse_args()
     from loam_livox_amd import synth
     from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration
@@ -61,7 +62,7 @@ def main():
     t_map = time.time() - t0
     reg = Point_cloud_registration(max_scans=B, max_features=nfeat)
     p = reg.params
-    p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = 1, 0.0, float((N - 1) * np.float32(1e-5))
+    p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = (0 if args.no_deblur else 1), 0.0, float((N - 1) * np.float32(1e-5))
     p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = args.icp_iters, 20, 1
     p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
     p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50

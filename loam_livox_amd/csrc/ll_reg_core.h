@@ -455,7 +455,7 @@ LL_HD double block_residual_mb(int kind, const MbRot &m, const double t[3], doub
     return dot3(r, r);
 }
 
-LL_HD_NOINLINE void block_accumulate_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
+LL_HD void block_accumulate_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
                                const double v[3], double huber_a, double acc[LL_NACC])
 {
     double y[3], coef[3], r[3], dd, rho0, w;
@@ -502,7 +502,7 @@ LL_HD_NOINLINE void block_accumulate_mb(int kind, const MbRot &m, const double t
     }
 }
 
-LL_HD_NOINLINE double block_l1_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
+LL_HD double block_l1_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
                          const double v[3], double huber_a, const double q_last[4])
 {
     double y[3], coef[3], r[3], dd, rho0, w, rw[3];
