@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cell-surf", type=float, default=0.0)
     ap.add_argument("--q-pipe", action="store_true", help="Q-pipe query mode (SURVEY 8d): device VoxelGrid (leaf 0.1 corner / 0.4 surface, "
                     "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
+    ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
     return ap.parse_args()
@@ -119,6 +120,8 @@ def main():
     p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
     p.maximum_allow_residual_block = N
     reg.set_profiling(True)
+    if args.force_general:
+        reg.set_debug(False, force_general_solver=True)
 
     vox = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
 

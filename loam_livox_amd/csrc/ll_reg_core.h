@@ -396,11 +396,43 @@ LL_HD void mb_prepare(const double q_in[4], MbRot &m)
     }
 }
 
+// sin and cos of a small angle by their Taylor polynomials (|x| < 0.25: the first neglected terms, x^19/19! and
+// x^18/18!, are below 1e-27 -- far under one ulp).  The interpolated rotation angle s W of a scan-to-scan increment is a
+// fraction of a degree, and the library sincos with its full range reduction was a third of the instructions of a
+// motion-deblur block evaluation.
+LL_HD void sincos_small(double x, double *sn, double *cs)
+{
+    const double z = x * x;
+    double p = -1.0 / 1307674368000.0;            // -1/15!
+    p = p * z + 1.0 / 6227020800.0;               //  1/13!
+    p = p * z - 1.0 / 39916800.0;                 // -1/11!
+    p = p * z + 1.0 / 362880.0;                   //  1/9!
+    p = p * z - 1.0 / 5040.0;                     // -1/7!
+    p = p * z + 1.0 / 120.0;                      //  1/5!
+    p = p * z - 1.0 / 6.0;                        // -1/3!
+    *sn = x + x * (z * p);
+    double q = 1.0 / 20922789888000.0;            //  1/16!
+    q = q * z - 1.0 / 87178291200.0;              // -1/14!
+    q = q * z + 1.0 / 479001600.0;                //  1/12!
+    q = q * z - 1.0 / 3628800.0;                  // -1/10!
+    q = q * z + 1.0 / 40320.0;                    //  1/8!
+    q = q * z - 1.0 / 720.0;                      // -1/6!
+    q = q * z + 1.0 / 24.0;                       //  1/4!
+    q = q * z - 0.5;                              // -1/2!
+    *cs = 1.0 + z * q;
+}
+
 // y = R_s f and the coefficients (m0, beta, gamma) of M for blur ratio s
 LL_HD void mb_block(const MbRot &m, double s, const double f[3], double y[3], double coef[3])
 {
     const double sW = s * m.W;
-    const double sn = sin(sW), cs = cos(sW);
+    double sn, cs;
+    if (fabs(sW) < 0.25) {
+        sincos_small(sW, &sn, &cs);
+    } else {
+        sn = sin(sW);
+        cs = cos(sW);
+    }
     double nf[3], nnf[3];
     cross3(m.n, f, nf);
     cross3(m.n, nf, nnf);

@@ -438,14 +438,40 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
     const int total = nC + nS;
-    for (int j = tid; j < total; j += RS_THREADS) {
+    // software-pipelined one block ahead (flag included): with two waves per SIMD nothing else hides the loads
+    int j = tid;
+    float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
+    double na0 = 0, na1 = 0, na2 = 0, nv0 = 0, nv1 = 0, nv2 = 0;
+    unsigned char nfl = 0;
+    if (j < total) {
         const int slot = slot_of(j, nC, rd.cap_c);
-        const unsigned char fl = rd.blk_flag[sb + slot];
-        if (!(fl & BLK_ACTIVE)) continue;
-        const float4 ff = rd.blk_f[sb + slot];
-        const double a[3] = {av[slot], slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0, slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0};
-        const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
-        LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
+        nfl = rd.blk_flag[sb + slot];
+        nf = rd.blk_f[sb + slot];
+        na0 = av[slot];
+        na1 = slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0;
+        na2 = slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0;
+        nv0 = av[(size_t)3 * rd.cap + slot];
+        nv1 = av[(size_t)4 * rd.cap + slot];
+        nv2 = av[(size_t)5 * rd.cap + slot];
+    }
+    while (j < total) {
+        const unsigned char fl = nfl;
+        const float4 ff = nf;
+        const double a[3] = {na0, na1, na2}, v[3] = {nv0, nv1, nv2};
+        const int jn = j + RS_THREADS;
+        if (jn < total) {
+            const int slot = slot_of(jn, nC, rd.cap_c);
+            nfl = rd.blk_flag[sb + slot];
+            nf = rd.blk_f[sb + slot];
+            na0 = av[slot];
+            na1 = slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0;
+            na2 = slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0;
+            nv0 = av[(size_t)3 * rd.cap + slot];
+            nv1 = av[(size_t)4 * rd.cap + slot];
+            nv2 = av[(size_t)5 * rd.cap + slot];
+        }
+        if (fl & BLK_ACTIVE) LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
+        j = jn;
     }
 #pragma unroll
     for (int i = 0; i < LL_NACC; i++) {
@@ -579,9 +605,24 @@ __device__ void solve_epilogue(const RegConst &rc, RegState *st, SolveShared &sh
 }
 
 
+// capacities shared by the two solver paths (the fast path is described further down)
+#define FAST_MAX_BLOCKS 24576
+#define FAST_MAXK (FAST_MAX_BLOCKS / RS_THREADS)
+#define HT_SIZE 16384
+#define HT_PART 6144  // keys per de-duplication round (load factor <= 0.375)
+// set de-duplication, common case: bitmap + contested-bit set + exact table of the contested keys (all inside s_table)
+#define DD_BM_WORDS 16384  // 512 Kbit
+#define DD_CB_LOG2 11
+#define DD_CB_SIZE (1 << DD_CB_LOG2)
+#define DD_EX_SIZE 4096
+#define DD_MAX_COLL 900    // contested keys beyond this (heavily duplicated input): hash every key instead
+#define SEL_BINS 4096  // value-range bins of the rank select (must be a multiple of RS_THREADS)
+#define SEL_CAND 1024  // keys of the selected bin ranked exactly; more -> radix-select fallback
+
+
 // General path: any number of blocks per scan; flags, L1 values and the de-duplication table live in HBM.
 template <int DEBLUR>
-__device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh)
+__device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, unsigned long long *s_table)
 {
     const int tid = threadIdx.x;
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
@@ -612,13 +653,19 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
         __syncthreads();
     }
 
+    if (tid < 6) sh.tcyc[tid] = 0;
+    __syncthreads();
+    LL_T0(t_total);
     // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    solver_lm<DEBLUR>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, sh);
+    {
+        LL_T0(t_e);
+        solver_lm<DEBLUR>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, sh);
+        LL_TACC(0, t_e);
+    }
     int lm_iters = sh.ctl.iteration;
+    LL_T0(t_l1);
 
     // ---- loss-corrected L1 per block at the prerun result (PCR:476-483) -----------------------------------
-    unsigned long long *table = rd.hash + (size_t)b * rd.hash_cap;
-    for (int k = tid; k < rd.hash_cap; k += RS_THREADS) table[k] = HASH_EMPTY;
     {
         LL_CTX_DECL(sh.ctl.x)
         for (int j = tid; j < total; j += RS_THREADS) {
@@ -635,28 +682,126 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
     }
     __syncthreads();
 
-    // ---- std::set semantics: count distinct L1 values, select the one of rank (int)(ratio * n_distinct) ----
-    // (first occurrences are tagged with flag bit 16)
+    LL_TACC(2, t_l1);
+    LL_T0(t_dd);
+    // ---- std::set semantics: which L1 values are distinct (first occurrences get flag bit 16), how many ------------
+    // Same scheme as the fast path -- LDS bitmap, contested keys through an exact table -- with the keys read back
+    // from HBM and split by hash into partitions of at most ~FAST_MAX_BLOCKS keys, so the LDS tables keep their size.
+    // Heavily duplicated inputs fall back to one compare-and-swap table in HBM.
     {
+        unsigned int *bm = (unsigned int *)s_table;
+        unsigned int *cb = bm + DD_BM_WORDS;
+        unsigned long long *ex = (unsigned long long *)(cb + DD_CB_SIZE);
+        const int parts = (total + FAST_MAX_BLOCKS - 1) / FAST_MAX_BLOCKS;
         int my = 0;
-        const unsigned long long mask = (unsigned long long)rd.hash_cap - 1ull;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const int slot = slot_of(j, nC, rd.cap_c);
-            const unsigned char fl0 = rd.blk_flag[sb + slot];
-            if (!(fl0 & BLK_ACTIVE)) continue;
-            const double l1 = rd.blk_l1[sb + slot];
-            if (!(l1 == l1)) continue;  // NaN never enters the set
-            const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
-            unsigned long long h = hash64(key) & mask;
-            for (;;) {
-                const unsigned long long old = atomicCAS(&table[h], HASH_EMPTY, key);
-                if (old == HASH_EMPTY) {
-                    rd.blk_flag[sb + slot] = fl0 | 16;
-                    my++;
-                    break;
+        bool overflow = false;
+        for (int part = 0; part < parts && !overflow; part++) {
+            __syncthreads();
+            for (int e = tid; e < DD_BM_WORDS; e += RS_THREADS) bm[e] = 0u;
+            for (int e = tid; e < DD_CB_SIZE; e += RS_THREADS) cb[e] = 0xffffffffu;
+            for (int e = tid; e < DD_EX_SIZE; e += RS_THREADS) ex[e] = HASH_EMPTY;
+            __syncthreads();
+            int ncoll = 0;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot = slot_of(j, nC, rd.cap_c);
+                const unsigned char fl = rd.blk_flag[sb + slot];
+                if (!(fl & BLK_ACTIVE)) continue;
+                const double l1 = rd.blk_l1[sb + slot];
+                if (!(l1 == l1)) continue;  // NaN never enters the set
+                const unsigned long long hk = hash64((unsigned long long)__double_as_longlong(l1));
+                if ((int)((hk >> 44) % (unsigned long long)parts) != part) continue;
+                const unsigned int hb = (unsigned int)hk & (DD_BM_WORDS * 32 - 1);
+                const unsigned int bit = 1u << (hb & 31);
+                if (atomicOr(&bm[hb >> 5], bit) & bit) {
+                    rd.blk_flag[sb + slot] = fl | 32;  // contested bit: its index goes to the set below
+                    ncoll++;
                 }
-                if (old == key) break;
-                h = (h + 1ull) & mask;
+            }
+            const int total_coll = block_sum_int(ncoll, sh);
+            if (total_coll > DD_MAX_COLL) {
+                overflow = true;
+                break;
+            }
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot = slot_of(j, nC, rd.cap_c);
+                const unsigned char fl = rd.blk_flag[sb + slot];
+                if (!(fl & 32)) continue;
+                rd.blk_flag[sb + slot] = fl & ~32;
+                const unsigned int hb = (unsigned int)hash64((unsigned long long)__double_as_longlong(rd.blk_l1[sb + slot])) & (DD_BM_WORDS * 32 - 1);
+                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
+                for (;;) {
+                    const unsigned int old = atomicCAS(&cb[h], 0xffffffffu, hb);
+                    if (old == 0xffffffffu || old == hb) break;
+                    h = (h + 1u) & (DD_CB_SIZE - 1);
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot = slot_of(j, nC, rd.cap_c);
+                const unsigned char fl = rd.blk_flag[sb + slot];
+                if (!(fl & BLK_ACTIVE)) continue;
+                const double l1 = rd.blk_l1[sb + slot];
+                if (!(l1 == l1)) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
+                const unsigned long long hk = hash64(key);
+                if ((int)((hk >> 44) % (unsigned long long)parts) != part) continue;
+                const unsigned int hb = (unsigned int)hk & (DD_BM_WORDS * 32 - 1);
+                bool contested = false;
+                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
+                for (;;) {
+                    const unsigned int c = cb[h];
+                    if (c == 0xffffffffu) break;
+                    if (c == hb) {
+                        contested = true;
+                        break;
+                    }
+                    h = (h + 1u) & (DD_CB_SIZE - 1);
+                }
+                bool first = !contested;
+                if (contested) {
+                    unsigned int h2 = (unsigned int)(hk >> 24) & (DD_EX_SIZE - 1);
+                    for (;;) {
+                        const unsigned long long old = atomicCAS(&ex[h2], HASH_EMPTY, key);
+                        if (old == HASH_EMPTY) {
+                            first = true;
+                            break;
+                        }
+                        if (old == key) break;
+                        h2 = (h2 + 1u) & (DD_EX_SIZE - 1);
+                    }
+                }
+                if (first) {
+                    rd.blk_flag[sb + slot] = fl | 16;
+                    my++;
+                }
+            }
+        }
+        if (overflow) {  // uniform: every thread saw the same total_coll
+            __syncthreads();
+            my = 0;
+            unsigned long long *table = rd.hash + (size_t)b * rd.hash_cap;
+            for (int k = tid; k < rd.hash_cap; k += RS_THREADS) table[k] = HASH_EMPTY;
+            __syncthreads();
+            const unsigned long long mask = (unsigned long long)rd.hash_cap - 1ull;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot = slot_of(j, nC, rd.cap_c);
+                const unsigned char fl0 = rd.blk_flag[sb + slot] & ~(16 | 32);
+                rd.blk_flag[sb + slot] = fl0;
+                if (!(fl0 & BLK_ACTIVE)) continue;
+                const double l1 = rd.blk_l1[sb + slot];
+                if (!(l1 == l1)) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
+                unsigned long long h = hash64(key) & mask;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&table[h], HASH_EMPTY, key);
+                    if (old == HASH_EMPTY) {
+                        rd.blk_flag[sb + slot] = fl0 | 16;
+                        my++;
+                        break;
+                    }
+                    if (old == key) break;
+                    h = (h + 1ull) & mask;
+                }
             }
         }
         const int nu = block_sum_int(my, sh);
@@ -669,8 +814,101 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
         }
         __syncthreads();
     }
+    LL_TACC(3, t_dd);
+    LL_T0(t_sel);
     if (sh.n_unique > 0) {
-        // MSB-first radix select (8 bits per pass) over the distinct keys; non-negative doubles order like uint64
+        // rank select of the distinct values: value-range bins in LDS, then an exact ranking of the selected bin's keys
+        // (the fast path's scheme, keys read from HBM); a crowded bin falls back to the radix select below
+        int *bins = (int *)s_table;
+        unsigned long long *cand = s_table + SEL_BINS / 2;
+        const int lane = tid & 63, wave = tid >> 6;
+        double kmin = INFINITY, kmax = -INFINITY;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const int slot = slot_of(j, nC, rd.cap_c);
+            if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
+            const double l1 = rd.blk_l1[sb + slot];
+            kmin = fmin(kmin, l1);
+            kmax = fmax(kmax, l1);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            kmin = fmin(kmin, __shfl_down(kmin, off));
+            kmax = fmax(kmax, __shfl_down(kmax, off));
+        }
+        __syncthreads();
+        if (lane == 0) {
+            sh.red[wave][0] = kmin;
+            sh.red[wave][1] = kmax;
+        }
+        for (int e = tid; e < SEL_BINS; e += RS_THREADS) bins[e] = 0;
+        __syncthreads();
+        double lo = sh.red[0][0], hi = sh.red[0][1];
+        for (int w = 1; w < RS_WAVES; w++) {
+            lo = fmin(lo, sh.red[w][0]);
+            hi = fmax(hi, sh.red[w][1]);
+        }
+        const double scale = (hi > lo) ? (double)(SEL_BINS - 1) / (hi - lo) : 0.0;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const int slot = slot_of(j, nC, rd.cap_c);
+            if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
+            int bi = (int)((rd.blk_l1[sb + slot] - lo) * scale);
+            bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
+            atomicAdd(&bins[bi], 1);
+        }
+        __syncthreads();
+        {
+            const int per = SEL_BINS / RS_THREADS;
+            int part = 0;
+            for (int e = 0; e < per; e++) part += bins[tid * per + e];
+            int incl = part;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off) incl += y;
+            }
+            if (lane == 63) sh.isum[wave] = incl;
+            if (tid == 0) sh.n_cand = 0;
+            __syncthreads();
+            int below = incl - part;
+            for (int w = 0; w < wave; w++) below += sh.isum[w];
+            const int rank = sh.sel_rank;
+            __syncthreads();
+            const bool last_thread = tid == RS_THREADS - 1;
+            if ((rank >= below && rank < below + part) || (last_thread && rank >= below + part)) {
+                int cum = below, bi = tid * per;
+                for (; bi < tid * per + per - 1; bi++) {
+                    if (cum + bins[bi] > rank) break;
+                    cum += bins[bi];
+                }
+                sh.sel_bin = bi;
+                sh.sel_rank = rank - cum;
+                sh.sel_cnt = bins[bi];
+            }
+            __syncthreads();
+        }
+        if (sh.sel_cnt <= SEL_CAND) {
+            const int sel_bin = sh.sel_bin;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot = slot_of(j, nC, rd.cap_c);
+                if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
+                const double l1 = rd.blk_l1[sb + slot];
+                int bi = (int)((l1 - lo) * scale);
+                bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
+                if (bi == sel_bin) cand[atomicAdd(&sh.n_cand, 1)] = (unsigned long long)__double_as_longlong(l1);
+            }
+            __syncthreads();
+            const int m = sh.n_cand;
+            for (int i = tid; i < m; i += RS_THREADS) {
+                const unsigned long long ki = cand[i];
+                int rk = 0;
+                for (int jj = 0; jj < m; jj++) rk += (cand[jj] < ki) ? 1 : 0;  // keys are distinct
+                if (rk == sh.sel_rank) sh.sel_prefix = ki;
+            }
+            __syncthreads();
+        } else {
+        // MSB-first radix select (8 bits per pass) over the distinct keys of that bin; non-negative doubles order like uint64
+        const int sel_bin = sh.sel_bin;
+        if (tid == 0) sh.sel_prefix = 0ull;
+        __syncthreads();
         for (int pass = 0; pass < 8; pass++) {
             const int shift = 56 - 8 * pass;
             for (int k = tid; k < 256; k += RS_THREADS) sh.hist[k] = 0;
@@ -679,7 +917,11 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
             for (int j = tid; j < total; j += RS_THREADS) {
                 const int slot = slot_of(j, nC, rd.cap_c);
                 if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(rd.blk_l1[sb + slot]);
+                const double l1 = rd.blk_l1[sb + slot];
+                int bi = (int)((l1 - lo) * scale);
+                bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
+                if (bi != sel_bin) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
                 if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
             }
             __syncthreads();
@@ -694,6 +936,7 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
                 sh.sel_prefix = (prefix << 8) | (unsigned long long)d;
             }
             __syncthreads();
+        }
         }
         if (tid == 0) sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sh.sel_prefix));  // PCR:485
     } else {
@@ -726,11 +969,19 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
         __shared__ double x_start[7];
         if (tid < 7) x_start[tid] = sh.ctl.x[tid];
         __syncthreads();
+        LL_TACC(4, t_sel);
+        LL_T0(t_e);
         solver_lm<DEBLUR>(rd, rc, b, nC, nS, x_start, rc.ceres_max_iterations, sh.n_active, sh);
+        LL_TACC(0, t_e);
     }
     lm_iters += sh.ctl.iteration;
 
     solve_epilogue(rc, st, sh, lm_iters);
+#ifdef LL_SOLVE_TIMING
+    LL_TACC(5, t_total);
+    if (tid == 0)
+        for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
+#endif
 }
 
 
@@ -739,19 +990,6 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
 // flags live in LDS, the per-block L1 values of the inlier test live in registers, the std::set
 // de-duplication runs in an LDS hash table and the rank select reads registers -- the only HBM traffic left is
 // one coalesced sweep over the block constants per cost evaluation, software-pipelined one block ahead.
-#define FAST_MAX_BLOCKS 24576
-#define FAST_MAXK (FAST_MAX_BLOCKS / RS_THREADS)
-#define HT_SIZE 16384
-#define HT_PART 6144  // keys per de-duplication round (load factor <= 0.375)
-// set de-duplication, common case: bitmap + contested-bit set + exact table of the contested keys (all inside s_table)
-#define DD_BM_WORDS 16384  // 512 Kbit
-#define DD_CB_LOG2 11
-#define DD_CB_SIZE (1 << DD_CB_LOG2)
-#define DD_EX_SIZE 4096
-#define DD_MAX_COLL 900    // contested keys beyond this (heavily duplicated input): hash every key instead
-#define SEL_BINS 4096  // value-range bins of the rank select (must be a multiple of RS_THREADS)
-#define SEL_CAND 1024  // keys of the selected bin ranked exactly; more -> radix-select fallback
-
 struct BlkRegs {
     float4 f;
     double a0, a1, a2, v0, v1, v2;
@@ -1211,7 +1449,7 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     if (total <= FAST_MAX_BLOCKS && !rc.force_general)
         solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
     else
-        solve_general<DEBLUR>(rd, rc, b, st, sh);
+        solve_general<DEBLUR>(rd, rc, b, st, sh, s_table);
 }
 
 __global__ void reg_finalize_kernel(RegDev rd, RegConst rc, int n_scans)
