@@ -197,6 +197,14 @@ int ll_reg_solve(ll_reg *r, const ll_map *map, const float *scan_corner_xyzi, in
 int ll_reg_solve_batch_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
                           const double *poses_last, double *poses_curr, double *poses_incre, ll_reg_report *reports,
                           int32_t *results);
+/* The two halves of ll_reg_solve_batch for callers that register the same host-provided feature clouds more than once
+ * (or want the upload outside a timed region): upload the per-scan corner / surface clouds into the registrar's own
+ * HBM buffers, then enqueue registrations of the first n_scans of them (collect with ll_reg_collect). */
+int ll_reg_upload_features(ll_reg *r, int32_t n_scans, const float *corner_xyzi, const int32_t *n_corner, int32_t stride_corner,
+                           const float *surf_xyzi, const int32_t *n_surf, int32_t stride_surf);
+int ll_reg_enqueue_uploaded(ll_reg *r, const ll_map *map, int32_t n_scans, const ll_reg_params *prm, const double *poses_last,
+                            const double *poses_curr, const double *poses_incre);
+
 /* Same with host feature clouds: corner_xyzi [n_scans][stride_c][4] with counts n_corner[n_scans], etc. */
 int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans, const float *corner_xyzi,
                        const int32_t *n_corner, int32_t stride_corner, const float *surf_xyzi, const int32_t *n_surf,

@@ -350,6 +350,26 @@ class Point_cloud_registration:
                                         C.byref(self.params), ptr(pl), ptr(pc), ptr(pi), reps, ptr(res)), "ll_reg_solve_batch")
         return res, pc, pi, list(reps)
 
+    def upload_features(self, corners: list, surfs: list):
+        """Host feature clouds -> the registrar's HBM buffers (the upload half of solve_batch)."""
+        n = len(corners)
+        nc = np.array([len(c) for c in corners], np.int32)
+        ns = np.array([len(s) for s in surfs], np.int32)
+        sc, ss = max(1, int(nc.max())), max(1, int(ns.max()))
+        cbuf = np.zeros((n, sc, 4), np.float32)
+        sbuf = np.zeros((n, ss, 4), np.float32)
+        for i in range(n):
+            cbuf[i, :nc[i]] = corners[i]
+            sbuf[i, :ns[i]] = surfs[i]
+        check(self.L.ll_reg_upload_features(self.h, n, ptr(cbuf), ptr(nc), sc, ptr(sbuf), ptr(ns), ss), "ll_reg_upload_features")
+        return n
+
+    def enqueue_uploaded(self, map_buffer: Map_buffer, n_scans: int, poses_last, poses_curr):
+        pl = np.ascontiguousarray(poses_last, np.float64).reshape(n_scans, 7)
+        pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n_scans, 7)
+        check(self.L.ll_reg_enqueue_uploaded(self.h, map_buffer.h, n_scans, C.byref(self.params), ptr(pl), ptr(pc), None),
+              "ll_reg_enqueue_uploaded")
+
     def enqueue_fe(self, map_buffer: Map_buffer, fe: Livox_laser, n_scans: int, poses_last, poses_curr):
         pl = np.ascontiguousarray(poses_last, np.float64).reshape(n_scans, 7)
         pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n_scans, 7)

@@ -505,6 +505,7 @@ struct ll_reg {
     float prof_ms[3] = {0, 0, 0};
     int prof_launches[3] = {0, 0, 0};
     double *d_pose_tmp = nullptr;
+    int uploaded_scans = 0;  // scans covered by the last ll_reg_upload_features
 };
 
 extern "C" void ll_reg_default_params(ll_reg_params *p)
@@ -1155,22 +1156,16 @@ extern "C" int ll_reg_solve_batch_fe(ll_reg *r, const ll_map *map, ll_fe *fe, in
     return ll_reg_collect(r, n_scans, poses_curr, poses_incre, reports, results);
 }
 
-extern "C" int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans, const float *corner_xyzi, const int32_t *n_corner,
-                                  int32_t stride_corner, const float *surf_xyzi, const int32_t *n_surf, int32_t stride_surf,
-                                  const ll_reg_params *prm, const double *poses_last, double *poses_curr, double *poses_incre,
-                                  ll_reg_report *reports, int32_t *results)
+extern "C" int ll_reg_upload_features(ll_reg *r, int32_t n_scans, const float *corner_xyzi, const int32_t *n_corner, int32_t stride_corner,
+                                      const float *surf_xyzi, const int32_t *n_surf, int32_t stride_surf)
 {
-    if (!r || !n_corner || !n_surf) return set_err("ll_reg_solve_batch", "null argument");
-    if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_solve_batch", "n_scans out of range");
+    if (!r || !n_corner || !n_surf) return set_err("ll_reg_upload_features", "null argument");
+    if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_upload_features", "n_scans out of range");
     HC(hipSetDevice(r->device));
     const size_t F = r->max_feat;
     for (int b = 0; b < n_scans; b++) {
         if (n_corner[b] < 0 || n_corner[b] > r->max_feat || n_surf[b] < 0 || n_surf[b] > r->max_feat)
-            return set_err("ll_reg_solve_batch", "feature count exceeds capacity");
-        if (prm && (n_corner[b] > prm->maximum_allow_residual_block || n_surf[b] > prm->maximum_allow_residual_block))
-            return set_err("ll_reg_solve_batch",
-                           "feature count exceeds maximum_allow_residual_block: the reference's random sub-sampling "
-                           "(point_cloud_registration.hpp:232-238,339-345,438-458) is not reproduced; raise the limit");
+            return set_err("ll_reg_upload_features", "feature count exceeds capacity");
         if (n_corner[b] > 0)
             HC(hipMemcpyAsync(r->d_corner + b * F, corner_xyzi + (size_t)b * stride_corner * 4, (size_t)n_corner[b] * sizeof(float4),
                               hipMemcpyHostToDevice, r->stream));
@@ -1181,13 +1176,33 @@ extern "C" int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans,
     HC(hipMemcpyAsync(r->d_nc, n_corner, n_scans * sizeof(int), hipMemcpyHostToDevice, r->stream));
     HC(hipMemcpyAsync(r->d_ns, n_surf, n_scans * sizeof(int), hipMemcpyHostToDevice, r->stream));
     HC(hipStreamSynchronize(r->stream));
+    r->uploaded_scans = n_scans;
+    return 0;
+}
+
+extern "C" int ll_reg_enqueue_uploaded(ll_reg *r, const ll_map *map, int32_t n_scans, const ll_reg_params *prm, const double *poses_last,
+                                       const double *poses_curr, const double *poses_incre)
+{
+    if (!r) return set_err("ll_reg_enqueue_uploaded", "null handle");
+    if (n_scans < 1 || n_scans > r->uploaded_scans) return set_err("ll_reg_enqueue_uploaded", "no features uploaded for that many scans");
+    HC(hipSetDevice(r->device));
+    const size_t F = r->max_feat;
     r->dev.corner_feat = r->d_corner;
     r->dev.surf_feat = r->d_surf;
     r->dev.n_corner = r->d_nc;
     r->dev.n_surf = r->d_ns;
     r->dev.feat_stride_c = (int)F;
     r->dev.feat_stride_s = (int)F;
-    if (reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre)) return -1;
+    return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
+}
+
+extern "C" int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans, const float *corner_xyzi, const int32_t *n_corner,
+                                  int32_t stride_corner, const float *surf_xyzi, const int32_t *n_surf, int32_t stride_surf,
+                                  const ll_reg_params *prm, const double *poses_last, double *poses_curr, double *poses_incre,
+                                  ll_reg_report *reports, int32_t *results)
+{
+    if (ll_reg_upload_features(r, n_scans, corner_xyzi, n_corner, stride_corner, surf_xyzi, n_surf, stride_surf)) return -1;
+    if (ll_reg_enqueue_uploaded(r, map, n_scans, prm, poses_last, poses_curr, poses_incre)) return -1;
     return ll_reg_collect(r, n_scans, poses_curr, poses_incre, reports, results);
 }
 
