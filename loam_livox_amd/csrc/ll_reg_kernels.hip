@@ -60,20 +60,21 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // ---------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------
-// Per-iteration query kernels.
+// Per-iteration query kernels (corner and surface queries share every launch, blockIdx.z = kind).
 //
-//   ICP iteration 0 (and every iteration when neighbour reuse is disabled):
-//       reg_transform_kernel -> reg_knn_kernel(all queries) -> reg_build_kernel(all queries)
-//   ICP iteration >= 1:
-//       reg_requery_kernel : transform + displacement test of every query against its reference (ll_knn_core.h):
-//                              stable  -> nothing to do: same neighbours, same order, same residual block;
-//                              re-sort -> same five neighbours re-evaluated at the new position, appended to the
-//                                         build list;
-//                              search  -> appended to the search list
-//       reg_knn_kernel(list)   : full exact search of the search list (dense wavefronts), appends to the build list
-//       reg_build_kernel(list) : block constants for the build list
-// Lists are segmented per 1024-query chunk, filled in query order by one workgroup each (no atomics); late ICP iterations (>= 95 % stable
-// queries) cost one 32-byte read per query plus mostly-empty list launches.
+//   ICP iterations 0 and 1 (and every iteration when neighbour reuse is disabled):
+//       reg_transform_kernel -> reg_knn_kernel (all queries) -> reg_build_kernel (all queries)
+//   ICP iteration >= 2:
+//       reg_requery_kernel    : transform + displacement test of every query against its reuse record (ll_knn_core.h):
+//                                 stable  -> nothing to do: same neighbours, same order, same residual block;
+//                                 re-sort -> the same five neighbours re-evaluated at the new position, slot appended
+//                                            to the chunk's re-sort list;
+//                                 search  -> slot appended to the chunk's search list
+//       reg_knn_list_kernel   : full exact search of the search lists
+//       reg_build_list_kernel : block constants of everything searched or re-sorted
+// Lists are segmented per chunk of RQ_THREADS queries and filled in query order by one workgroup each (no atomics).  In
+// the late iterations a per cent or two of the queries are still searched; the list launch then costs about one
+// search's chain of dependent gathers through caches the solver has just flushed (~100 us), see DESIGN.md.
 
 __device__ __forceinline__ void transform_query(const RegState *st, const RegConst &rc, const float4 &f, float pw[3])
 {
@@ -415,7 +416,6 @@ struct SolveShared {
     double sum[LL_NACC];
     int need;
     int hist[256];
-    int hist_part[RS_THREADS];
     int sel_bin, sel_cnt, n_cand;
     int isum[RS_WAVES];
     unsigned long long sel_prefix;
