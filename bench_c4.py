@@ -102,6 +102,8 @@ def main():
         "accepted": accepted, "final_drift_m": float(errs[-1][0]), "final_drift_rad": float(errs[-1][1]),
         "max_drift_m": float(max(e[0] for e in errs)), "submap_points_per_rank": counts, "gather_s": round(t_gather, 4),
         "match_buffer": {"corner": lm.map_sizes[0], "surface": lm.map_sizes[1]},
+        "ms_per_frame_by_stage": dict(zip(("extract_register", "history_add", "match_buffer_refresh"), [round(1e3 * float(v) / F, 3) for v in lm.stage_s[:3]])),
+        "icp_iterations_last_frame": int(lm.last_report.icp_iterations),
     }
     if rank == 0 and args.cpu_frames > 0:
         from oracle.orc_mapping import LaserMapping  # the checker, timed beside the device loop

@@ -39,6 +39,7 @@ class Laser_mapping:
         self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)  # m_q_w_curr / m_t_w_curr
         self.map_sizes = (0, 0)
         self.last_report = None
+        self.stage_s = np.zeros(4)  # cumulative wall time: extract+register, history add, match-buffer refresh, frames
 
     def close(self):
         for h in (self.fe, self.reg, self.map, self.vox[0], self.vox[1], self.history):
@@ -46,6 +47,8 @@ class Laser_mapping:
 
     def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0) -> int:
         """One frame (laser_mapping.hpp:1311-1520).  Returns the registration result (1 accepted, 0 rejected)."""
+        import time
+        t0 = time.perf_counter()
         fe, reg = self.fe, self.reg
         fe.upload(xyzi[None], np.full(1, time_stamp))
         fe.extract_batch(1)
@@ -60,6 +63,9 @@ class Laser_mapping:
             reg.enqueue_fe(self.map, fe, 1, pose, pose)
         res, pc, _, reps = reg.collect(1)
         self.last_report = reps[0]
+        t1 = time.perf_counter()
+        self.stage_s[0] += t1 - t0
+        self.stage_s[3] += 1
         if not res[0]:  # :1413-1416
             return 0
         if self.m_if_input_downsample_mode:
@@ -67,5 +73,9 @@ class Laser_mapping:
         else:
             self.history.add_fe(fe, 0, pc[0], self.history_add_t_step, self.history_add_angle_step)
         self.pose = pc[0].copy()  # :1496-1500
+        t2 = time.perf_counter()
         self.map_sizes = self.history.refresh(self.map)  # service_update_buff_for_matching, synchronous here
+        t3 = time.perf_counter()
+        self.stage_s[1] += t2 - t1
+        self.stage_s[2] += t3 - t2
         return 1
