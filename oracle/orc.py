@@ -39,6 +39,21 @@ class Timebase(C.Structure):
                 ("last_maximum_time_stamp", C.c_double)]
 
 
+class FeTimebase:
+    """The time base of one Livox_laser instance across messages (LFE:722-735): next(stamp) -> m_current_time."""
+
+    def __init__(self):
+        self.tb = Timebase()
+        lib().orc_fe_timebase_init(C.byref(self.tb))
+
+    def next(self, stamp: float) -> float:
+        return float(lib().orc_fe_timebase_next(C.byref(self.tb), float(stamp)))
+
+    def done(self, result) -> None:
+        """after the extraction: m_last_maximum_time_stamp = time stamp of the scan's last point (LFE:482)"""
+        self.tb.last_maximum_time_stamp = result.last_time_stamp
+
+
 class RegParams(C.Structure):
     _fields_ = [("if_motion_deblur", C.c_int), ("icp_max_iterations", C.c_int), ("ceres_max_iterations", C.c_int),
                 ("ceres_prerun_times", C.c_int), ("line_search_num", C.c_int), ("plane_search_num", C.c_int),
