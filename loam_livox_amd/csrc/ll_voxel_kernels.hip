@@ -133,13 +133,33 @@ __global__ __launch_bounds__(256) void vox_centroid_kernel(const float4 *in, int
     const float4 *src = in + (size_t)b * stride;
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // CentroidPoint<PointXYZI>: AccumulatorXYZ + AccumulatorIntensity
     int cnt = 0;
-    for (size_t j = i; j < total && keys[j] == k; j++) {
-        const float4 p = src[vals[j]];
-        sx = sx + p.x;
-        sy = sy + p.y;
-        sz = sz + p.z;
-        si = si + p.w;
-        cnt++;
+    // The additions must run in input order, the loads need not: eight keys, then the matching eight indices, then the
+    // eight points are fetched as independent loads, so a crowded voxel (hundreds of points on one thread) costs three
+    // dependent round trips per eight points instead of per point.
+    bool more = true;
+    for (size_t j = i; more && j < total; j += 8) {
+        bool ok[8];
+        unsigned int v[8];
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) ok[u] = (j + u < total) && keys[j + u] == k;
+#pragma unroll
+        for (int u = 1; u < 8; u++) ok[u] = ok[u] && ok[u - 1];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = ok[u] ? vals[j + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = src[v[u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (ok[u]) {
+                sx = sx + p[u].x;
+                sy = sy + p[u].y;
+                sz = sz + p[u].z;
+                si = si + p[u].w;
+                cnt++;
+            }
+        }
+        more = ok[7];
     }
     const float c = (float)cnt;
     const int v = (int)rank[i] - vox_off[b];
