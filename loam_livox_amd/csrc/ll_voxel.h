@@ -16,7 +16,8 @@ struct VoxelDev {
     unsigned int *mm;            // [max_clouds][8] bounding box (ordered encoding) + finite count
     VoxelParams *prm;            // [max_clouds]
     unsigned long long *keys, *keys2;
-    unsigned int *vals, *vals2, *is_head, *rank;
+    unsigned int *vals, *vals2, *is_head, *rank, *head_pos;
+    int *n_vox_total;
     void *tmp;
     size_t tmp_bytes;
 };

@@ -121,13 +121,23 @@ __global__ __launch_bounds__(256) void vox_head_kernel(const unsigned long long 
     if (head) atomicAdd(&n_vox[(int)(k >> 32)], 1);  // integer count: order-independent
 }
 
-// rank[i] = exclusive prefix of is_head = global voxel id of the head at i; off[b] = voxels of the clouds before b
-__global__ __launch_bounds__(256) void vox_centroid_kernel(const float4 *in, int stride, const unsigned long long *keys,
-                                                           const unsigned int *vals, const unsigned int *is_head,
-                                                           const unsigned int *rank, const int *vox_off, size_t total, float4 *out)
+// rank[i] = exclusive prefix of is_head = global voxel id of the head at i
+__global__ __launch_bounds__(256) void vox_headpos_kernel(const unsigned int *is_head, const unsigned int *rank, size_t total,
+                                                          unsigned int *head_pos)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total || !is_head[i]) return;
+    if (i < total && is_head[i]) head_pos[rank[i]] = (unsigned int)i;
+}
+
+// One thread per VOXEL (dense: thread t takes the t-th head), not per sorted point: with ~100 points per voxel the latter
+// leaves one working lane per wavefront.  vox_off[b] = voxels of the clouds before b; *n_vox_total = all voxels.
+__global__ __launch_bounds__(256) void vox_centroid_kernel(const float4 *in, int stride, const unsigned long long *keys,
+                                                           const unsigned int *vals, const unsigned int *head_pos,
+                                                           const int *vox_off, const int *n_vox_total, size_t total, float4 *out)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)*n_vox_total) return;
+    const size_t i = head_pos[t];
     const unsigned long long k = keys[i];
     const int b = (int)(k >> 32);
     const float4 *src = in + (size_t)b * stride;
@@ -162,22 +172,42 @@ __global__ __launch_bounds__(256) void vox_centroid_kernel(const float4 *in, int
         more = ok[7];
     }
     const float c = (float)cnt;
-    const int v = (int)rank[i] - vox_off[b];
-    out[(size_t)b * stride + v] = make_float4(sx / c, sy / c, sz / c, si / c);
+    out[(size_t)b * stride + ((int)t - vox_off[b])] = make_float4(sx / c, sy / c, sz / c, si / c);
 }
 
-// per-cloud voxel offsets (exclusive scan over a handful of clouds) and the output counts
-__global__ void vox_offsets_kernel(const int *n_vox, const int *n, const VoxelParams *prm, int n_clouds, int *vox_off, int *n_out, int *status)
+// per-cloud voxel offsets (exclusive scan over the clouds, one workgroup), the output counts and the voxel total
+__global__ __launch_bounds__(256) void vox_offsets_kernel(const int *n_vox, const int *n, const VoxelParams *prm, int n_clouds, int *vox_off,
+                                                          int *n_out, int *status, int *n_vox_total)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int acc = 0;
-    for (int b = 0; b < n_clouds; b++) {
-        vox_off[b] = acc;
-        acc += n_vox[b];
-        const int st = prm[b].status;
-        status[b] = st;
-        n_out[b] = st == VOX_PASSTHROUGH ? n[b] : n_vox[b];
+    __shared__ int s_w[4];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_clouds; base += 256) {
+        const int b = base + tid;
+        const int c = b < n_clouds ? n_vox[b] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int excl = s_carry + incl - c;
+        for (int w = 0; w < wave; w++) excl += s_w[w];
+        if (b < n_clouds) {
+            vox_off[b] = excl;
+            const int st = prm[b].status;
+            status[b] = st;
+            n_out[b] = st == VOX_PASSTHROUGH ? n[b] : c;
+        }
+        __syncthreads();
+        if (tid == 255) s_carry = excl + c;
+        __syncthreads();
     }
+    if (tid == 0) *n_vox_total = s_carry;
 }
 
 __global__ __launch_bounds__(256) void vox_copy_kernel(const float4 *in, const int *n, int stride, const VoxelParams *prm, float4 *out)
@@ -221,6 +251,8 @@ int voxel_alloc(VoxelDev &v, int max_clouds, int stride, const char **err)
     VXCHK(hipMalloc(&v.vals2, total * sizeof(unsigned int)));
     VXCHK(hipMalloc(&v.is_head, total * sizeof(unsigned int)));
     VXCHK(hipMalloc(&v.rank, total * sizeof(unsigned int)));
+    VXCHK(hipMalloc(&v.head_pos, total * sizeof(unsigned int)));
+    VXCHK(hipMalloc(&v.n_vox_total, sizeof(int)));
     size_t t1 = 0, t2 = 0;
     VXCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, v.keys, v.keys2, v.vals, v.vals2, (int)total, 0, 64));
     VXCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, v.is_head, v.rank, (int)total));
@@ -231,7 +263,7 @@ int voxel_alloc(VoxelDev &v, int max_clouds, int stride, const char **err)
 
 void voxel_free(VoxelDev &v)
 {
-    void *ptrs[] = {v.in, v.out, v.n, v.n_out, v.status, v.n_vox, v.vox_off, v.mm, v.prm, v.keys, v.keys2, v.vals, v.vals2, v.is_head, v.rank, v.tmp};
+    void *ptrs[] = {v.in, v.out, v.n, v.n_out, v.status, v.n_vox, v.vox_off, v.mm, v.prm, v.keys, v.keys2, v.vals, v.vals2, v.is_head, v.rank, v.head_pos, v.n_vox_total, v.tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     memset(&v, 0, sizeof(v));
@@ -268,8 +300,10 @@ int voxel_filter(VoxelDev &v, const float4 *in, const int *n, int in_stride, int
     hipLaunchKernelGGL(vox_head_kernel, dim3(gt), dim3(256), 0, s, v.keys2, total, v.n_vox, v.is_head);
     tb = v.tmp_bytes;
     VXCHK(hipcub::DeviceScan::ExclusiveSum(v.tmp, tb, v.is_head, v.rank, (int)total, s));
-    hipLaunchKernelGGL(vox_offsets_kernel, dim3(1), dim3(1), 0, s, v.n_vox, n, v.prm, n_clouds, v.vox_off, v.n_out, v.status);
-    hipLaunchKernelGGL(vox_centroid_kernel, dim3(gt), dim3(256), 0, s, in, in_stride, v.keys2, v.vals2, v.is_head, v.rank, v.vox_off, total, v.out);
+    hipLaunchKernelGGL(vox_headpos_kernel, dim3(gt), dim3(256), 0, s, v.is_head, v.rank, total, v.head_pos);
+    hipLaunchKernelGGL(vox_offsets_kernel, dim3(1), dim3(256), 0, s, v.n_vox, n, v.prm, n_clouds, v.vox_off, v.n_out, v.status, v.n_vox_total);
+    hipLaunchKernelGGL(vox_centroid_kernel, dim3(gt), dim3(256), 0, s, in, in_stride, v.keys2, v.vals2, v.head_pos, v.vox_off, v.n_vox_total, total,
+                       v.out);
     hipLaunchKernelGGL(vox_copy_kernel, dim3(gmm, n_clouds), dim3(256), 0, s, in, n, in_stride, v.prm, v.out);
     VXCHK(hipGetLastError());
     v.out_stride = in_stride;
