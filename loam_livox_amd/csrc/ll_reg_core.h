@@ -569,8 +569,15 @@ LL_HD void state_plus(const double x[7], const double d[6], double bound, double
         out[2] = x[2];
         out[3] = x[3];
     } else {
-        const double sn = sin(nd) / nd;
-        const double dq[4] = {sn * d[0], sn * d[1], sn * d[2], cos(nd)};
+        double sv, cv;
+        if (nd < 0.25) {  // LM steps are a fraction of a degree: Taylor polynomials, exact to the last ulp or two
+            sincos_small(nd, &sv, &cv);
+        } else {
+            sv = sin(nd);
+            cv = cos(nd);
+        }
+        const double sn = sv / nd;
+        const double dq[4] = {sn * d[0], sn * d[1], sn * d[2], cv};
         quat_mul(dq, x, out);
     }
     for (int i = 0; i < 3; i++) {
