@@ -268,7 +268,7 @@ def main():
         t_tree = time.perf_counter() - tb
         prm = orc.RegParams.defaults(icp_iters=args.icp_iters, ceres_iters=20, force_all=1)
         prm.max_final_cost = 1000.0
-        t_cpu, errs, same_sets = 0.0, [], True
+        t_cpu, errs, same_sets, same_lm, same_blocks, same_res = 0.0, [], True, True, True, True
         n_cpu = min(args.cpu_scans, B)
         for b in range(n_cpu):
             tb = time.perf_counter()
@@ -281,12 +281,17 @@ def main():
             t_cpu += time.perf_counter() - tb
             errs.append(synth.pose_error(pc[b], opc))
             same_sets &= (len(ci) == nc_fe[b] and len(si) == ns_fe[b] and len(fc_o) == nc[b] and len(fs_o) == ns[b])
+            same_lm &= (orep.lm_iterations_total == reps[b].lm_iterations_total and orep.icp_iterations == reps[b].icp_iterations)
+            same_blocks &= (orep.n_blocks_last == reps[b].n_blocks_last and orep.corner_avail == reps[b].corner_avail and orep.surf_avail == reps[b].surf_avail)
+            same_res &= (ret == res[b])
         result["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 4), "unit": "scans/s", "cores": 1, "kind": "port",
                                   "sample": f"{n_cpu} of the {B} scans of one step (extract + {args.icp_iters} ICP iters each) "
                                             f"vs the same {len(corner) + len(surf)}-pt map; k-d tree build {t_tree:.1f}s excluded",
                                   "host_cores_available": os.cpu_count()}
         result["parity_vs_cpu"] = {"max_pose_err_m": float(max(e[0] for e in errs)), "max_pose_err_rad": float(max(e[1] for e in errs)),
-                                   "feature_counts_identical": bool(same_sets)}
+                                   "feature_counts_identical": bool(same_sets), "lm_and_icp_iteration_counts_identical": bool(same_lm),
+                                   "residual_block_counts_identical": bool(same_blocks), "accept_reject_identical": bool(same_res),
+                                   "scans_compared": int(n_cpu)}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
