@@ -218,6 +218,57 @@ class VoxelGrid {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+// The history match buffer of Laser_mapping (m_matching_mode == 0): m_laser_cloud_corner_history /
+// m_laser_cloud_surface_history with the add-frame rule and FIFO of laser_mapping.hpp:1417-1478, and
+// update_buff_for_matching's history branch (laser_mapping.hpp:517-546), resident on the device.  refresh() rebuilds the
+// search grids of the ll_map the registrar uses, so the two KdTreeFLANN::setInputCloud calls (:544-545) disappear.
+class History_buffer {
+   public:
+    History_buffer(int maximum_history_size, int max_points_per_frame, float line_res, float plane_res, int device = 0)
+    {
+        check(ll_history_create(device, maximum_history_size, max_points_per_frame, line_res, plane_res, &h_), "ll_history_create");
+    }
+    ~History_buffer()
+    {
+        if (h_) ll_history_destroy(h_);
+    }
+    History_buffer(const History_buffer &) = delete;
+    History_buffer &operator=(const History_buffer &) = delete;
+
+    // "Add new frame" (laser_mapping.hpp:1417-1478): features in the sensor frame, pose = {qx,qy,qz,qw,tx,ty,tz} of the
+    // accepted registration.  Returns true when the frame was pushed (false: "Reject add history").
+    template <class Cloud>
+    bool add(const Cloud &corner_stack, const Cloud &surf_stack, const double pose[7], double history_add_t_step = 0.0,
+             double history_add_angle_step = 0.0)
+    {
+        const std::vector<float> c = cloud_to_xyzi(corner_stack), s = cloud_to_xyzi(surf_stack);
+        int32_t added = 0;
+        check(ll_history_add(h_, c.data(), (int32_t)(c.size() / 4), s.data(), (int32_t)(s.size() / 4), pose, history_add_t_step,
+                             history_add_angle_step, &added),
+              "ll_history_add");
+        return added != 0;
+    }
+    // update_buff_for_matching(): concatenation of the history -> VoxelGrid -> search grids of `map`
+    void refresh(ll_map *map, int64_t *n_corner = nullptr, int64_t *n_surf = nullptr)
+    {
+        check(ll_history_refresh(h_, map, n_corner, n_surf), "ll_history_refresh");
+    }
+    // m_laser_cloud_corner_from_map_last / m_laser_cloud_surf_from_map_last of the last refresh (for publishing / saving)
+    template <class Cloud>
+    void map_cloud(int kind, Cloud &out)
+    {
+        const int64_t n = ll_history_map_cloud(h_, kind, nullptr, 0);
+        std::vector<float> v((size_t)(n > 0 ? n : 0) * 4);
+        if (n > 0 && ll_history_map_cloud(h_, kind, v.data(), n) < 0) check(-1, "ll_history_map_cloud");
+        xyzi_to_cloud(v.data(), (int)n, out);
+    }
+    int size() const { return ll_history_size(h_); }
+
+   private:
+    ll_history *h_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------------------
 class Point_cloud_registration {
    public:
     // configuration fields with the reference names and defaults (point_cloud_registration.hpp:45-103)

@@ -90,10 +90,29 @@ int main(int argc, char **argv)
         Cloud world;
         pc_reg.pointcloudAssociateToMap(*corners, world);
 
+        // "Add new frame" + match-buffer refresh through the adapter (laser_mapping.hpp:1417-1478, 517-546)
+        size_t n_hist_corner = 0, n_hist_surf = 0;
+        if (reg_res) {
+            loam_livox_hip::History_buffer history(4, 30000, 0.1f, 0.4f);
+            const bool pushed = history.add(*corners, *surface, pc_reg.m_para_buffer_RT);
+            ll_map *scratch_map = nullptr;
+            loam_livox_hip::check(ll_map_create(0, &scratch_map), "ll_map_create");
+            int64_t nc = 0, ns = 0;
+            history.refresh(scratch_map, &nc, &ns);
+            Cloud buf_c, buf_s;
+            history.map_cloud(0, buf_c);
+            history.map_cloud(1, buf_s);
+            ll_map_destroy(scratch_map);
+            if (!pushed || (int64_t)buf_c.size() != nc || (int64_t)buf_s.size() != ns) return 5;
+            n_hist_corner = buf_c.size();
+            n_hist_surf = buf_s.size();
+        }
+
         FILE *o = fopen(argv[5], "w");
         fprintf(o, "%d %zu %zu %zu %d %zu %zu\n", m_laser_scan_number, n_corner_raw, n_surf_raw, full.size(), reg_res, corners->size(), surface->size());
         for (int i = 0; i < 7; i++) fprintf(o, "%.17g ", pc_reg.m_para_buffer_RT[i]);
         fprintf(o, "\n%.9g %.9g\n", piece_start, piece_end);
+        fprintf(o, "%zu %zu\n", n_hist_corner, n_hist_surf);
         fclose(o);
     } catch (const std::exception &e) {
         fprintf(stderr, "adapter_demo: %s\n", e.what());

@@ -58,3 +58,9 @@ def test_adapter_demo_matches_oracle(tmp_path, small_world, scans, downsample):
     ret, opc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     dt, dr = synth.pose_error(pose, opc)
     assert reg_res == ret and dt < 1e-7 and dr < 1e-7
+    # the history buffer through the adapter: one frame pushed with the registered pose, refreshed into a map
+    from oracle.orc_mapping import History
+    h = History(4, 0.1, 0.4)
+    assert h.add(fc, fs, pose)
+    mc, ms = h.refresh()
+    assert [int(v) for v in lines[3].split()] == [len(mc), len(ms)]
