@@ -288,6 +288,7 @@ class Point_cloud_registration {
     double m_inliner_dis = 0.02, m_inlier_ratio = 0.80;
     double m_maximum_dis_plane_for_match = 50.0, m_maximum_dis_line_for_match = 2.0;
     int m_maximum_allow_residual_block = 100000;
+    int m_subsample_seed = 1;  // seed of the reproducible stand-in for m_rand_float (PCR:104); 0 = refuse to sub-sample
     // state: {qx,qy,qz,qw,tx,ty,tz}
     double m_para_buffer_RT[7] = {0, 0, 0, 1, 0, 0, 0};        // m_q_w_curr / m_t_w_curr
     double m_para_buffer_RT_last[7] = {0, 0, 0, 1, 0, 0, 0};   // m_q_w_last / m_t_w_last
@@ -335,6 +336,7 @@ class Point_cloud_registration {
         p.current_frame_index = m_current_frame_index;
         p.mapping_init_accumulate_frames = m_mapping_init_accumulate_frames;
         p.maximum_allow_residual_block = m_maximum_allow_residual_block;
+        p.subsample_seed = m_subsample_seed;
         p.maximum_dis_line_for_match = m_maximum_dis_line_for_match;
         p.maximum_dis_plane_for_match = m_maximum_dis_plane_for_match;
         p.inliner_dis = m_inliner_dis;

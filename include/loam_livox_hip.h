@@ -160,6 +160,9 @@ typedef struct {
     int32_t if_line_feature_check;          /* :46  IF_LINE_FEATURE_CHECK  (0): PCA test of the 5 line neighbours, :259-292  */
     int32_t if_plane_feature_check;         /* :48  IF_PLANE_FEATURE_CHECK (0): PCA test of the 5 plane neighbours, :357-389;
                                                uses the SURFACE cloud (the reference indexes the corner cloud, a bug) */
+    int32_t subsample_seed;                 /* a13: 0 = refuse scans with more features than maximum_allow_residual_block (strict
+                                               parity mode); otherwise the reference's random sub-sampling (:232-238,339-345,
+                                               438-458) with a reproducible counter-based stream seeded by this value          */
 } ll_reg_params;
 
 void ll_reg_default_params(ll_reg_params *p);

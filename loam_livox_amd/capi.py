@@ -35,7 +35,7 @@ class RegParams(C.Structure):
                 ("minimum_icp_R_diff", C.c_double), ("minimum_icp_T_diff", C.c_double),
                 ("para_max_angular_rate", C.c_float), ("para_max_speed", C.c_float), ("max_final_cost", C.c_float),
                 ("minimum_pt_time_stamp", C.c_float), ("maximum_pt_time_stamp", C.c_float),
-                ("if_line_feature_check", C.c_int32), ("if_plane_feature_check", C.c_int32)]
+                ("if_line_feature_check", C.c_int32), ("if_plane_feature_check", C.c_int32), ("subsample_seed", C.c_int32)]
 
 
 class RegReport(C.Structure):

@@ -519,6 +519,7 @@ extern "C" void ll_reg_default_params(ll_reg_params *p)
     p->icp_plane = 1;                     // PCR:49
     p->if_line_feature_check = 0;         // PCR:46
     p->if_plane_feature_check = 0;        // PCR:48
+    p->subsample_seed = 0;                // strict: no sub-sampling, too many features is an error
     p->current_frame_index = 101;
     p->mapping_init_accumulate_frames = 100;  // PCR:84
     p->maximum_allow_residual_block = 100000; // PCR:103
@@ -633,6 +634,8 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->icp_plane = p->icp_plane;
     c->check_line_pca = p->if_line_feature_check;
     c->check_plane_pca = p->if_plane_feature_check;
+    c->subsample_seed = (unsigned int)p->subsample_seed;
+    c->max_blocks = p->maximum_allow_residual_block;
     c->force_all_iterations = p->force_all_iterations;
     c->debug_knn = debug & 1;
     c->force_general = (debug & 2) ? 1 : 0;
@@ -719,9 +722,12 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         max_ns = r->h_ns[b] > max_ns ? r->h_ns[b] : max_ns;
     }
     if (max_nc > r->dev.cap_c || max_ns > r->dev.cap_s) return set_err("ll_reg", "feature count exceeds the registrar capacity");
-    if (max_nc > prm->maximum_allow_residual_block || max_ns > prm->maximum_allow_residual_block)
-        return set_err("ll_reg", "feature count exceeds maximum_allow_residual_block: the reference's random sub-sampling "
-                                 "(point_cloud_registration.hpp:232-238,339-345,438-458) is not reproduced; raise the limit");
+    if (!prm->subsample_seed && (max_nc > prm->maximum_allow_residual_block || max_ns > prm->maximum_allow_residual_block))
+        return set_err("ll_reg", "feature count exceeds maximum_allow_residual_block and subsample_seed is 0 (strict mode): raise the "
+                                 "limit, or set a seed to get the reference's sub-sampling (point_cloud_registration.hpp:232-238,"
+                                 "339-345,438-458) with a reproducible random stream");
+    if (prm->subsample_seed && (max_nc > 2 * prm->maximum_allow_residual_block || max_ns > 2 * prm->maximum_allow_residual_block))
+        r->rc.knn_reuse = 0;  // skipped features change from iteration to iteration: every iteration searches
     if (run) {
         if (!map->kind[0].pts || !map->kind[1].pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
         HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));

@@ -95,6 +95,8 @@ struct RegConst {
     int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
     int pad1;
+    unsigned int subsample_seed;  // a13 (0 = off)
+    int max_blocks;               // maximum_allow_residual_block
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
     double max_d2_line_d, max_d2_plane_d;
     double huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff;

@@ -101,6 +101,37 @@ LL_HD float refine_blur(int deblur, float in_blur, float min_blur, float max_blu
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------- a13: sub-sampling
+// point_cloud_registration.hpp:232-238, 339-345 (features) and :438-458 (residual blocks) drop work at random when a scan
+// has more than 2 x / 1 x maximum_allow_residual_block of it.  The reference draws from mt19937(random_device), which
+// nobody can reproduce; here the uniform numbers come from a counter-based hash of (seed, stream, ICP iteration, item
+// index), so the same keep / drop rules give the same result on every run and on the oracle:
+//   feature i of a kind with n > 2 M features is skipped when        u * n > 2 M            (:234, :341)
+//   block i of a problem with n_blocks > M blocks is removed when    u > (float)M / n_blocks (:442-449)
+// streams: 0 = corner features, 1 = surface features, 2 = residual blocks (index = position of the block's query in the
+// corner-then-surface order).
+LL_HD float subsample_uniform(unsigned int seed, unsigned int stream, unsigned int iter, unsigned int index)
+{
+    unsigned int h = seed ^ (stream * 0x9E3779B9u) ^ (iter * 0x85EBCA6Bu) ^ (index * 0xC2B2AE35u);
+    h ^= h >> 16;
+    h *= 0x7feb352du;
+    h ^= h >> 15;
+    h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+LL_HD bool subsample_skip_feature(unsigned int seed, int kind, int iter, int i, int n, int max_blocks)
+{
+    if (!seed || n <= 2 * max_blocks) return false;
+    return subsample_uniform(seed, (unsigned int)kind, (unsigned int)iter, (unsigned int)i) * (float)n > (float)(2 * max_blocks);
+}
+LL_HD bool subsample_drop_block(unsigned int seed, int iter, int j, int n_blocks, int max_blocks)
+{
+    if (!seed || n_blocks <= max_blocks) return false;
+    const float threshold_to_reserve = (float)max_blocks / (float)n_blocks;
+    return subsample_uniform(seed, 2u, (unsigned int)iter, (unsigned int)j) > threshold_to_reserve;
+}
+
 // ---------------------------------------------------------------------------------------------- residual blocks
 
 enum : int { BLK_NONE = 0, BLK_LINE = 1, BLK_PLANE = 2, BLK_ACTIVE = 4 };

@@ -127,6 +127,8 @@ __global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, Re
     const int slot = (kind ? rd.cap_c : 0) + q;
     float pw[3];
     transform_query(st, rc, load_feature(rd, b, kind, q), pw);
+    // a13: a skipped feature is handed on as a non-finite query -- no neighbours, no block (PCR:232-238, 339-345)
+    if (subsample_skip_feature(rc.subsample_seed, kind, st->icp_iters, q, n, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
     rd.qw[(size_t)b * rd.cap + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
 }
 
@@ -645,6 +647,19 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
         na = block_sum_int(na, sh);
         nca = block_sum_int(nca, sh);
         nsa = block_sum_int(nsa, sh);
+        if (rc.subsample_seed && na > rc.max_blocks) {  // a13: "Number of residual blocks too Large, drop them" (PCR:438-458)
+            int kept = 0;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const int slot0 = slot_of(j, nC, rd.cap_c);
+                const unsigned char fl = rd.blk_flag[sb + slot0];
+                if (!(fl & BLK_ACTIVE)) continue;
+                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, j, na, rc.max_blocks))
+                    rd.blk_flag[sb + slot0] = fl & ~BLK_ACTIVE;
+                else
+                    kept++;
+            }
+            na = block_sum_int(kept, sh);
+        }
         if (tid == 0) {
             sh.n_active = na;
             sh.n_corner_avail = nca;
@@ -1117,6 +1132,18 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         na = block_sum_int(na, sh);
         nca = block_sum_int(nca, sh);
         nsa = block_sum_int(nsa, sh);
+        if (rc.subsample_seed && na > rc.max_blocks) {  // a13: "Number of residual blocks too Large, drop them" (PCR:438-458)
+            int kept = 0;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const unsigned char fl = s_flag[j];
+                if (!(fl & BLK_ACTIVE)) continue;
+                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, j, na, rc.max_blocks))
+                    s_flag[j] = fl & ~BLK_ACTIVE;
+                else
+                    kept++;
+            }
+            na = block_sum_int(kept, sh);
+        }
         if (tid == 0) {
             sh.n_active = na;
             sh.n_corner_avail = nca;

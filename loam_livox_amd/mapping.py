@@ -20,7 +20,8 @@ class Laser_mapping:
                  plane_res: float = 0.4, init_accumulate_frames: int = 50, input_downsample_mode: int = 1, icp_max_iterations: int = 20,
                  ceres_max_iterations: int = 100, max_allow_incre_R: float = 200.0 / 50.0, max_allow_incre_T: float = 100.0 / 50.0,
                  max_allow_final_cost: float = 100.0, history_add_t_step: float = 0.0, history_add_angle_step: float = 0.0,
-                 minimum_icp_R_diff: float = 0.01, minimum_icp_T_diff: float = 0.01):
+                 minimum_icp_R_diff: float = 0.01, minimum_icp_T_diff: float = 0.01, maximum_residual_blocks: int = 0,
+                 subsample_seed: int = 1):
         self.fe = Livox_laser(max_points=scan_points, max_scans=1, device=device, piecewise_number=1)
         self.reg = Point_cloud_registration(max_scans=1, max_features=scan_points, device=device)
         self.map = Map_buffer(device=device)
@@ -34,7 +35,9 @@ class Laser_mapping:
         p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = max_allow_incre_R, max_allow_incre_T, max_allow_final_cost
         p.mapping_init_accumulate_frames = init_accumulate_frames
         p.minimum_icp_R_diff, p.minimum_icp_T_diff = minimum_icp_R_diff, minimum_icp_T_diff  # PCR:94-95
-        p.maximum_allow_residual_block = scan_points
+        # optimization/maximum_residual_blocks (200 in the shipped configs): sub-sampling on a reproducible stream; 0 = keep all
+        p.maximum_allow_residual_block = maximum_residual_blocks if maximum_residual_blocks > 0 else scan_points
+        p.subsample_seed = subsample_seed if maximum_residual_blocks > 0 else 0
         self.m_current_frame_index = 0
         self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)  # m_q_w_curr / m_t_w_curr
         self.map_sizes = (0, 0)

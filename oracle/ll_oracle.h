@@ -156,6 +156,10 @@ typedef struct {
     float maximum_pt_time_stamp;    /* PCR:93 */
     int if_line_feature_check;      /* PCR:46 (0) */
     int if_plane_feature_check;     /* PCR:48 (0); uses the surface cloud (reference bug PCR:361-363 fixed) */
+    int maximum_allow_residual_block; /* PCR:103 */
+    int subsample_seed;             /* 0: the sub-sampling branches (PCR:232-238,339-345,438-458) are dead; else they run on the
+                                       counter-based uniform stream defined in ll_oracle_reg.c (the reference's mt19937 seeded from
+                                       random_device cannot be reproduced) */
 } orc_reg_params;
 
 typedef struct {

@@ -712,6 +712,20 @@ int orc_pca_check(int is_plane, const float pts[15], double ev_out[3])
     return pca_check(is_plane, pts, 3, idx);
 }
 
+/* ------------------------------------------------------------------ sub-sampling (PCR:232-238, 339-345, 438-458) */
+
+/* uniform [0,1) from (seed, stream, ICP iteration, item index); stream 0 corner features, 1 surface features, 2 blocks */
+static float subsample_uniform(uint32_t seed, uint32_t stream, uint32_t iter, uint32_t index)
+{
+    uint32_t h = seed ^ (stream * 0x9E3779B9u) ^ (iter * 0x85EBCA6Bu) ^ (index * 0xC2B2AE35u);
+    h ^= h >> 16;
+    h *= 0x7feb352du;
+    h ^= h >> 15;
+    h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
 /* ------------------------------------------------------------------ PCR helpers */
 
 /* refine_blur PCR:128-141 (float arithmetic) */
@@ -852,6 +866,7 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
     unsigned char *active = (unsigned char *)malloc((size_t)(cap > 0 ? cap : 1));
     double *resid = (double *)malloc(sizeof(double) * 3 * (size_t)(cap > 0 ? cap : 1));
     double *l1 = (double *)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1));
+    int32_t *blk_query = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1)); /* position of the block's feature: corner i, or n_corner + surface i */
     int32_t nn_idx[16];
     float nn_d2[16];
     quat q_last_opt = {0, 0, 0, 1};
@@ -870,7 +885,11 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
         int nb = 0;
         corner_avail = 0;
         surf_avail = 0;
+        const uint32_t seed = (uint32_t)prm->subsample_seed;
+        const int max_blk = prm->maximum_allow_residual_block;
         for (int i = 0; i < n_corner; i++) { /* PCR:230-333 */
+            if (seed && n_corner > 2 * max_blk && subsample_uniform(seed, 0u, (uint32_t)it, (uint32_t)i) * (float)n_corner > (float)(2 * max_blk))
+                continue; /* PCR:232-238 */
             const float *po = &scan_corner[4 * i];
             if (!isfinite(po[0]) || !isfinite(po[1]) || !isfinite(po[2])) continue;
             float s = refine_blur(deblur, po[3], prm->minimum_pt_time_stamp, prm->maximum_pt_time_stamp);
@@ -886,12 +905,15 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
                     double d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
                     if (norm3(d) < 0.0001) continue; /* PCR:302 */
                     double f[3] = {po[0], po[1], po[2]};
+                    blk_query[nb] = i;
                     orc_block_line(&blocks[nb++], f, a, b, deblur ? (double)s * 1.0 : 1.0);
                     corner_avail++;
                 }
             }
         }
         for (int i = 0; i < n_surf; i++) { /* PCR:336-432 */
+            if (seed && n_surf > 2 * max_blk && subsample_uniform(seed, 1u, (uint32_t)it, (uint32_t)i) * (float)n_surf > (float)(2 * max_blk))
+                continue; /* PCR:339-345 */
             const float *po = &scan_surf[4 * i];
             if (!isfinite(po[0]) || !isfinite(po[1]) || !isfinite(po[2])) continue; /* defined deviation */
             float s = refine_blur(deblur, po[3], prm->minimum_pt_time_stamp, prm->maximum_pt_time_stamp);
@@ -908,12 +930,18 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
                     double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
                     if (norm3(ab) == 0.0 || norm3(ac) == 0.0) continue; /* defined deviation: NaN normal */
                     double f[3] = {po[0], po[1], po[2]};
+                    blk_query[nb] = n_corner + i;
                     orc_block_plane(&blocks[nb++], f, a, b, c, deblur ? (double)s * 1.0 : 1.0);
                 }
                 surf_avail++; /* PCR:425 */
             }
         }
         for (int k = 0; k < nb; k++) active[k] = 1;
+        if (seed && nb > max_blk) { /* PCR:438-458: "Number of residual blocks too Large, drop them" */
+            const float threshold_to_reserve = (float)max_blk / (float)nb;
+            for (int k = 0; k < nb; k++)
+                if (subsample_uniform(seed, 2u, (uint32_t)it, (uint32_t)blk_query[k]) > threshold_to_reserve) active[k] = 0;
+        }
 
         /* prerun solve, PCR:463-474 */
         lm_summary pre;
@@ -925,12 +953,18 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
         {
             double c;
             eval_blocks(blocks, active, nb, pose_last, pose_incre, deblur, prm->huber_a, &c, NULL, NULL, resid);
-            for (int k = 0; k < nb; k++)
+            /* only the blocks still in the problem are evaluated (residual_block_ids after the drop of PCR:438-458) */
+            int na = 0;
+            double *l1a = (double *)malloc(sizeof(double) * (size_t)(nb > 0 ? nb : 1));
+            for (int k = 0; k < nb; k++) {
                 l1[k] = fabs(resid[3 * k]) + fabs(resid[3 * k + 1]) + fabs(resid[3 * k + 2]);
-            double thr = inlier_threshold(l1, nb, prm->inlier_ratio, prm->inliner_dis);
+                if (active[k]) l1a[na++] = l1[k];
+            }
+            double thr = inlier_threshold(l1a, na, prm->inlier_ratio, prm->inliner_dis);
+            free(l1a);
             inlier_thr = fmax(prm->inliner_dis, thr);
             for (int k = 0; k < nb; k++)
-                if (l1[k] > inlier_thr) active[k] = 0;
+                if (active[k] && l1[k] > inlier_thr) active[k] = 0;
         }
 
         /* final solve, PCR:501-508 */
@@ -982,6 +1016,7 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
     free(active);
     free(resid);
     free(l1);
+    free(blk_query);
 
     /* PCR:561-573; minimize_cost is a float (PCR:192,519) */
     float minimize_cost = (float)sum.final_cost;

@@ -64,14 +64,15 @@ class RegParams(C.Structure):
                 ("minimum_icp_R_diff", C.c_double), ("minimum_icp_T_diff", C.c_double),
                 ("para_max_angular_rate", C.c_float), ("para_max_speed", C.c_float), ("max_final_cost", C.c_float),
                 ("minimum_pt_time_stamp", C.c_float), ("maximum_pt_time_stamp", C.c_float),
-                ("if_line_feature_check", C.c_int), ("if_plane_feature_check", C.c_int)]
+                ("if_line_feature_check", C.c_int), ("if_plane_feature_check", C.c_int),
+                ("maximum_allow_residual_block", C.c_int), ("subsample_seed", C.c_int)]
 
     @staticmethod
     def defaults(icp_iters=10, ceres_iters=20, force_all=0, deblur=0):
         """Code defaults (PCR:45-98; max_final_cost = class default 100, PCR:88) with launch/rosbag.launch
         bounds (max_allow_incre_R 20, max_allow_incre_T 0.3); sub-sampling disabled."""
         return RegParams(deblur, icp_iters, ceres_iters, 2, 5, 5, 1, 1, 100, 50, force_all,
-                         2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 20.0, 0.3, 100.0, 0.0, 1.0, 0, 0)
+                         2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 20.0, 0.3, 100.0, 0.0, 1.0, 0, 0, 99999, 0)
 
 
 class RegReport(C.Structure):

@@ -32,7 +32,7 @@ class RegParams(C.Structure):
                [(n, C.c_double) for n in ("max_d2_line", "max_d2_plane", "huber_a", "inliner_dis", "inlier_ratio",
                                           "minimum_icp_R_diff", "minimum_icp_T_diff", "bound")] + \
                [(n, C.c_float) for n in ("para_max_angular_rate", "max_final_cost", "min_ts", "max_ts")] + \
-               [(n, C.c_int) for n in ("check_line_pca", "check_plane_pca")]
+               [(n, C.c_int) for n in ("check_line_pca", "check_plane_pca", "max_blocks", "subsample_seed")]
 
 
 _lib = None

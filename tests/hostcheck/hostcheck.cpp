@@ -238,11 +238,13 @@ struct hc_reg_params {
     double max_d2_line, max_d2_plane, huber_a, inliner_dis, inlier_ratio, minimum_icp_R_diff, minimum_icp_T_diff, bound;
     float para_max_angular_rate, max_final_cost, min_ts, max_ts;
     int check_line_pca, check_plane_pca;
+    int max_blocks, subsample_seed;  // a13
 };
 
 struct hc_blk {
     int kind;
     int active;
+    int qidx;  // position of the block's feature in the corner-then-surface order (a13 block stream)
     double f[3], a[3], v[3];
     double s;
 };
@@ -354,6 +356,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
             for (int q = 0; q < n; q++) {
                 const float *f = feat + 4 * q;
                 if (!(ll_isfinite(f[0]) && ll_isfinite(f[1]) && ll_isfinite(f[2]))) continue;
+                if (subsample_skip_feature((unsigned int)p->subsample_seed, kind, it, q, n, p->max_blocks)) continue;  // PCR:232-238, 339-345
                 float pw[3];
                 const float sblur = refine_blur(p->if_motion_deblur, f[3], p->min_ts, p->max_ts);
                 if (p->if_motion_deblur == 0 || (double)sblur == 1.0) {
@@ -399,6 +402,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                     if (kept[kind][q].kind != BLK_NONE) {
                         hc_blk kb = kept[kind][q];
                         kb.active = 1;
+                        kb.qidx = (kind ? nC : 0) + q;
                         blk.push_back(kb);
                         if (kind == 0) corner_avail++;
                     }
@@ -420,6 +424,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                 }
                 hc_blk b;
                 b.active = 1;
+                b.qidx = (kind ? nC : 0) + q;
                 b.s = p->if_motion_deblur ? (double)sblur : 1.0;
                 b.f[0] = f[0];
                 b.f[1] = f[1];
@@ -448,6 +453,11 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
             }
         }
         if (getenv("HC_KNN_STATS")) fprintf(stderr, "iter %d: stable %ld resort %ld search %ld\n", it, st_cnt[0], st_cnt[1], st_cnt[2]);
+        if (p->subsample_seed && (int)blk.size() > p->max_blocks) {  // PCR:438-458
+            const int nb = (int)blk.size();
+            for (hc_blk &b : blk)
+                if (subsample_drop_block((unsigned int)p->subsample_seed, it, b.qidx, nb, p->max_blocks)) b.active = 0;
+        }
         LmCtl c;
         lm_run(blk, inc, p->ceres_prerun_times, p->bound, p->huber_a, c);
         int lm_iters = c.iteration;
@@ -461,9 +471,9 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
             for (size_t i = 0; i < blk.size(); i++)
                 l1[i] = g_deblur ? block_l1_mb(blk[i].kind, mb, t, blk[i].s, blk[i].f, blk[i].a, blk[i].v, p->huber_a, pose_last)
                                  : block_l1(blk[i].kind, R, t, blk[i].f, blk[i].a, blk[i].v, p->huber_a, pose_last);
-            std::vector<double> u;
-            for (double v : l1)
-                if (v == v) u.push_back(v);
+            std::vector<double> u;  // blocks dropped by the sub-sampling are no longer part of the problem
+            for (size_t i = 0; i < blk.size(); i++)
+                if (blk[i].active && l1[i] == l1[i]) u.push_back(l1[i]);
             std::sort(u.begin(), u.end());
             u.erase(std::unique(u.begin(), u.end()), u.end());
             double thr = p->inliner_dis;
@@ -474,7 +484,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
             }
             inlier_thr = thr;
             for (size_t i = 0; i < blk.size(); i++)
-                if (l1[i] > thr) blk[i].active = 0;
+                if (blk[i].active && l1[i] > thr) blk[i].active = 0;
         }
         double xs[7];
         for (int i = 0; i < 7; i++) xs[i] = c.x[i];

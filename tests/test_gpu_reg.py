@@ -336,3 +336,32 @@ def test_duplicate_residuals_follow_std_set_semantics(dev_map, small_world, scan
     assert g.n_blocks_last == orep.n_blocks_last and g.lm_iterations_total == orep.lm_iterations_total
     assert np.isclose(g.inlier_threshold, orep.inlier_threshold, rtol=1e-9)
     reg.close()
+
+
+@pytest.mark.parametrize("max_blocks,general", [(200, False), (3000, False), (200, True), (6000, False)])
+def test_subsampling_matches_oracle(dev_map, small_world, scans, max_blocks, general):
+    """a13: maximum_allow_residual_block below the feature count (200 in the shipped configs).  With a seed the library
+    sub-samples like the reference does (feature skip when n > 2 M, block drop when blocks > M) on a reproducible stream;
+    the oracle makes the same choices.  6000: only the block drop fires, so the neighbour reuse stays on."""
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    prm = orc.RegParams.defaults(icp_iters=8, ceres_iters=20, force_all=1)
+    prm.maximum_allow_residual_block, prm.subsample_seed = max_blocks, 11
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(False, force_general_solver=general)
+    p = set_params(reg, 8, 20, 1)
+    p.maximum_allow_residual_block, p.subsample_seed = max_blocks, 11
+    reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
+    gret = reg.find_out_incremental_transfrom(dev_map, fc, fs)
+    g = reg.report
+    dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+    assert gret == ret and dt < 1e-7 and dr < 1e-7
+    assert g.n_blocks_last == rep.n_blocks_last and g.corner_avail == rep.corner_avail and g.surf_avail == rep.surf_avail
+    assert g.lm_iterations_total == rep.lm_iterations_total
+    assert g.n_blocks_last < 1.3 * max_blocks
+    # strict mode (seed 0) refuses instead
+    p.subsample_seed = 0
+    with pytest.raises(Exception):
+        reg.find_out_incremental_transfrom(dev_map, fc, fs)
+    reg.close()

@@ -299,3 +299,36 @@ def test_registration_with_pca_checks_matches_oracle(small_world, scans, checks)
         assert rep.corner_avail < rep0.corner_avail
     if checks[1]:
         assert rep.surf_avail < rep0.surf_avail
+
+
+@pytest.mark.parametrize("max_blocks", [200, 3000])
+def test_registration_with_subsampling_matches_oracle(small_world, scans, max_blocks):
+    """a13 (PCR:232-238, 339-345, 438-458): with a seed the keep / drop rules run on the shared counter-based stream; the host
+    build of the device math and the oracle make identical choices.  200 = the shipped configs' maximum_residual_blocks
+    (both the feature skip and the block drop fire), 3000 exercises the block drop alone for the corner-poor scan."""
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    gc, gs = hc.Grid(small_world["corner"], 1.45), hc.Grid(small_world["surf"], 0.6)
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
+    prm.maximum_allow_residual_block, prm.subsample_seed = max_blocks, 7
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    hp = hc.RegParams(0, 5, 20, 2, 1, 1, 1, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 0.3, 20.0, 100.0, 0.0, 1.0, 0, 0, max_blocks, 7)
+    hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hp, sc.pose_init, sc.pose_init)
+    dt, dr = synth.pose_error(pc, hpc)
+    assert ret == hret and dt < 1e-9 and dr < 1e-9
+    assert rep.n_blocks_last == hrep[4] and rep.corner_avail == hrep[5] and rep.surf_avail == hrep[6] and rep.lm_iterations_total == hrep[7]
+    assert rep.n_blocks_last <= max_blocks * 1.3                      # ~M blocks survive the drop (then 20 % are pruned)
+    base = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
+    _, pc0, _, rep0 = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, base, sc.pose_init, sc.pose_init)
+    assert rep0.n_blocks_last > 3 * rep.n_blocks_last
+    if max_blocks == 200:
+        assert rep.surf_avail < 0.1 * rep0.surf_avail                 # the feature skip fired (n > 2 M): ~400 of 17 k kept
+    dt, dr = synth.pose_error(pc, pc0)
+    if max_blocks == 3000:
+        assert dt < 0.05 and dr < 0.01                                # a fifth of the blocks, nearly the same pose
+    else:
+        assert dt < 0.5                                               # ~180 blocks constrain this room view only loosely
+    # another seed makes other choices
+    prm.subsample_seed = 8
+    _, pc2, _, rep2 = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    assert not np.array_equal(pc2, pc)
