@@ -1133,7 +1133,12 @@ extern "C" int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_cor
         h->n_map[kind] = n_out;
         // the search structure (laser_mapping.hpp:539-546: two KdTreeFLANN::setInputCloud) is the device grid
         const char *err = nullptr;
-        const float cell = (kind == LL_MAP_CORNER) ? 1.45f : 0.6f;
+        // Cell size from the voxel leaf the buffer has just been filtered with: the points are about one leaf apart (along
+        // the edges for the corner cloud, across the surfaces for the other), and a search is fastest with a handful of
+        // points per cell.  The default corner cell (1.45 m, sized for a sparse edge map and the sqrt(2) m line radius)
+        // would put hundreds of candidates of a dense local edge map into the query's own cells.
+        const float leaf = h->res[kind];
+        const float cell = (kind == LL_MAP_CORNER) ? fminf(fmaxf(4.0f * leaf, 0.4f), 1.45f) : fminf(fmaxf(3.0f * leaf, 0.45f), 1.2f);
         if (map_build(map->kind[kind], (const float *)h->d_map[kind], 4, n_out, cell, h->stream, &err)) return set_err("map_build", err ? err : "failed");
     }
     HC(hipStreamSynchronize(h->stream));

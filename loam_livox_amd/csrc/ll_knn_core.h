@@ -36,13 +36,15 @@ struct Knn5 {
     int idx[5];  // original (upload-order) index: the tie-break key and what callers see
     int pos[5];  // position in the cell-sorted array (to fetch the coordinates again)
     int count;
-    float out2;  // smallest squared distance seen among points at or beyond the match radius (INF if none)
+    float out2;  // lower bound on the squared distance of every point at or beyond the match radius (INF if none);
+                 // used only while fewer than five neighbours are inside the radius (knn5_reuse_margin)
     float lb2;   // lower bound on the squared distance of every map point that is NOT in the list
                  // (6th best seen, nearest pruned/unvisited cell, match radius) -- lets the next ICP iteration
                  // prove that the neighbour set is unchanged without searching again
 };
 
 #define LL_KNN_EMPTY 0x7fffffff
+#define LL_KNN_CUBE_FROM 5  // ring at which the search stops growing shells and sweeps the remaining cube (knn5_search_t)
 
 LL_HD void knn5_init(Knn5 &r)
 {
@@ -231,14 +233,46 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
     const float m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));  // already shrunk by slack
     const int kmax = (int)ceilf(sqrtf(max_d2) * g.inv_h) + 1;
     for (int k = 1; k <= kmax; k++) {
-        if (k >= 2) {
-            // ---- phase 2 (rare): the full shell at Chebyshev distance k ------------------------------------
-            for (int dz = -k; dz <= k; dz++) {
+        if (k == LL_KNN_CUBE_FROM) {
+            // ---- phase 3 (sparse surroundings): four rings have not settled the answer -- the query looks into a part
+            // of the map with next to no points (the frontier of a growing local map, a sparse voxel-filtered cloud).
+            // Shell by shell, the remaining rings would look up the two end cells of every interior row again and
+            // again (~11 k cell lookups out to a 7 m radius at 0.6 m cells); one sweep over the rows of the whole cube
+            // that is still needed costs two lookups per row (~1.5 k).  The order of the visits is irrelevant to the
+            // result, and the cells of rings 1 .. LL_KNN_CUBE_FROM-1 are left out, so no point is offered twice.
+            int K = kmax;
+            if (r.count == 5) {
+                const int kd = (int)ceilf(sqrtf(r.d2[4]) * g.inv_h) + 1;  // the 5th best can only come closer
+                K = kd < kmax ? kd : kmax;
+            }
+            if (K < LL_KNN_CUBE_FROM) K = LL_KNN_CUBE_FROM;
+            const int in = LL_KNN_CUBE_FROM - 1;  // half-width of the cube already scanned
+            const int dz_lo = -K > -cz ? -K : -cz, dz_hi = K < g.nz - 1 - cz ? K : g.nz - 1 - cz;
+            const int dy_lo = -K > -cy ? -K : -cy, dy_hi = K < g.ny - 1 - cy ? K : g.ny - 1 - cy;
+            for (int dz = dz_lo; dz <= dz_hi; dz++) {
+                for (int dy = dy_lo; dy <= dy_hi; dy++) {
+                    const int base = ((cz + dz) * g.ny + (cy + dy)) * g.nx;
+                    const bool inner_row = dz >= -in && dz <= in && dy >= -in && dy <= in;
+                    for (int seg = 0; seg < (inner_row ? 2 : 1); seg++) {
+                        int x0 = (inner_row && seg == 1) ? cx + in + 1 : cx - K;
+                        int x1 = (inner_row && seg == 0) ? cx - in - 1 : cx + K;
+                        if (x0 < 0) x0 = 0;
+                        if (x1 >= g.nx) x1 = g.nx - 1;
+                        if (x0 <= x1) scan_run_t<PT>(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
+                    }
+                }
+            }
+            k = K;  // the cube of half-width K has been seen: fall through to the termination test of ring K
+        } else if (k >= 2) {
+            // ---- phase 2 (rare on dense maps): the full shell at Chebyshev distance k --------------------------
+            // The loops only run over the part of the shell that lies inside the grid: a query at the edge of a small
+            // local map would otherwise spend its time on (2k+1)^2 empty iterations per ring.
+            const int dz_lo = -k > -cz ? -k : -cz, dz_hi = k < g.nz - 1 - cz ? k : g.nz - 1 - cz;
+            const int dy_lo = -k > -cy ? -k : -cy, dy_hi = k < g.ny - 1 - cy ? k : g.ny - 1 - cy;
+            for (int dz = dz_lo; dz <= dz_hi; dz++) {
                 const int z = cz + dz;
-                if (z < 0 || z >= g.nz) continue;
-                for (int dy = -k; dy <= k; dy++) {
+                for (int dy = dy_lo; dy <= dy_hi; dy++) {
                     const int y = cy + dy;
-                    if (y < 0 || y >= g.ny) continue;
                     const int base = (z * g.ny + y) * g.nx;
                     const bool full_row = (dz == -k || dz == k || dy == -k || dy == k);
                     // a full x-run on the shell's faces, otherwise only the two end cells of the row
@@ -256,6 +290,8 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
                 }
             }
         }
+        // the cube of ring k covers the whole grid: every point has been seen, nothing is left to bound
+        if (cx - k <= 0 && cx + k >= g.nx - 1 && cy - k <= 0 && cy + k >= g.ny - 1 && cz - k <= 0 && cz + k >= g.nz - 1) return;
         const float bound = (float)k * g.h + m - ((k >= 2) ? slack : 0.0f);
         const float b2 = bound * bound;
         if (b2 >= max_d2 || (r.count == 5 && r.d2[4] < b2)) {

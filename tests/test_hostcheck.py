@@ -102,8 +102,9 @@ def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts):
         if len(listed) >= 5:
             rest = np.delete(d2_all[i], listed)
             assert rest.size == 0 or lb2[i] <= rest.min() * (1 + 1e-5) + 1e-6
-        far = d2_all[i][d2_all[i] >= max_d2]
-        assert far.size == 0 or out2[i] <= far.min() * (1 + 1e-5) + 1e-6
+        else:  # out2 only has to hold while fewer than five neighbours are inside the radius (knn5_reuse_margin)
+            far = d2_all[i][d2_all[i] >= max_d2]
+            assert far.size == 0 or out2[i] <= far.min() * (1 + 1e-5) + 1e-6
         inside = np.sort(d2_all[i][d2_all[i] < max_d2])
         assert len(listed) == min(cand.shape[1], len(inside))
     assert (m_set > 0).mean() > 0.5 and np.all(m_strong <= m_set)
