@@ -111,7 +111,10 @@ void ll_map_destroy(ll_map *m);
  * point_cloud_registration.hpp:596-597): uploads the cloud and builds the device search grid.
  * xyz: m points, stride_floats apart (3 = xyz, 4 = xyzi).  cell_size <= 0 selects the default
  * (1.45 m corner: the sparse edge map is searched out to the sqrt(2) m line radius, one cell ring covers it;
- * 0.6 m surface: about 1.5x the 0.4 m surface-map leaf).  Point indices reported by the library refer to this input order. */
+ * 0.6 m surface: about 1.5x the 0.4 m surface-map leaf).  The results do not depend on it, the speed does: a search reads
+ * every point of the query's own cells before it can prune, so a cloud that was voxel-filtered at leaf l wants cells of
+ * about 3-4 l (ll_history_refresh picks that itself); a 1.45 m cell on an edge map with 0.1 m spacing costs 10x.
+ * Point indices reported by the library refer to this input order. */
 int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size);
 int64_t ll_map_size(const ll_map *m, int32_t kind);
 /* BASELINE config C5 ("fp16 points / fp32 accumulate k-NN"): replaces the 16-byte fp32 records of an uploaded map kind by
