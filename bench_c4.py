@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--history", type=int, default=20)
     ap.add_argument("--plane-res", type=float, default=0.15)
     ap.add_argument("--line-res", type=float, default=0.1)
+    ap.add_argument("--matching-mode", type=int, default=0, help="0 = history match buffer (shipped configs), 1 = cell maps (laser_mapping.hpp:689)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of rank 0's sequence also run through the CPU oracle (0 = skip)")
     args = ap.parse_args()
     import torch
@@ -68,7 +69,8 @@ def main():
 
     args_map = dict(maximum_history_size=args.history, init_accumulate_frames=2, line_res=args.line_res, plane_res=args.plane_res,
                     icp_max_iterations=10, ceres_max_iterations=20, max_allow_incre_R=20.0, max_allow_incre_T=0.3,
-                    minimum_icp_R_diff=1e-3, minimum_icp_T_diff=1e-4)  # the defaults (0.01 deg / 1 cm, PCR:94-95) stop the ICP a
+                    minimum_icp_R_diff=1e-3, minimum_icp_T_diff=1e-4, matching_mode=args.matching_mode,
+                    maximum_in_fov_angle=45.0)  # the ICP-diff defaults (0.01 deg / 1 cm, PCR:94-95) stop the ICP a
     # centimetre short of convergence every frame, and the lag accumulates in a map grown from those poses
     lm = Laser_mapping(scan_points=N, device=local_rank, **args_map)
     lm.process_new_scan(scans[0])  # warm-up of every kernel; the sequence restarts below
@@ -97,7 +99,7 @@ def main():
     result = {
         "metric": "frames_per_s", "value": round(F * world / elapsed, 2), "unit": "frames/s (sequential mapping loop with local map growth, all ranks)",
         "n_gpus": world, "frames_per_sequence": F, "ms_per_frame": round(1e3 * elapsed / F, 3), "scaling": "weak",
-        "config": {"workload": "C4 unit: one sequence per GPU, 24k-pt scans, history match buffer (local growth), VoxelGrid "
+        "config": {"workload": "C4 unit: one sequence per GPU, 24k-pt scans, " + ("cell-map" if args.matching_mode else "history") + " match buffer (local growth), VoxelGrid "
                                f"{args.line_res}/{args.plane_res}, 10 ICP iters max", "history": args.history},
         "accepted": accepted, "final_drift_m": float(errs[-1][0]), "final_drift_rad": float(errs[-1][1]),
         "max_drift_m": float(max(e[0] for e in errs)), "submap_points_per_rank": counts, "gather_s": round(t_gather, 4),

@@ -264,6 +264,29 @@ class History_buffer {
     }
     int size() const { return ll_history_size(h_); }
 
+    // m_pt_cell_map_corners / m_pt_cell_map_planes (laser_mapping.hpp:274-275, 617-624) for m_matching_mode == 1: once
+    // enabled, every add() also appends the frame to the two cell maps (laser_mapping.hpp:1492-1493)
+    void enable_cell_map(int64_t max_points, float m_pt_cell_resolution = 1.0f, int m_para_threshold_cell_revisit = 5000)
+    {
+        check(ll_history_enable_cell_map(h_, max_points, m_pt_cell_resolution, m_para_threshold_cell_revisit), "ll_history_enable_cell_map");
+    }
+    // update_buff_for_matching(), cell branch (laser_mapping.hpp:471-546): pose = m_q_w_curr / m_t_w_curr
+    void refresh_cells(ll_map *map, const double pose[7], float m_maximum_search_range_corner = 100.0f,
+                       float m_maximum_search_range_surface = 100.0f, float m_maximum_in_fov_angle = 30.0f, int m_down_sample_replace = 1,
+                       int64_t *n_corner = nullptr, int64_t *n_surf = nullptr)
+    {
+        check(ll_history_refresh_cells(h_, map, pose, m_maximum_search_range_corner, m_maximum_search_range_surface, m_maximum_in_fov_angle,
+                                       m_down_sample_replace, n_corner, n_surf),
+              "ll_history_refresh_cells");
+    }
+    // Points_cloud_map::get_cells_size() and the number of points held, per feature kind (0 corner, 1 surface)
+    void cell_map_size(int kind, int64_t *n_cells, int64_t *n_points)
+    {
+        ll_cellmap *c = ll_history_cell_map(h_, kind);
+        if (!c) check(-1, "ll_history_cell_map");
+        check(ll_cellmap_stats(c, n_cells, n_points, nullptr), "ll_cellmap_stats");
+    }
+
    private:
     ll_history *h_ = nullptr;
 };

@@ -292,6 +292,46 @@ int32_t ll_history_size(const ll_history *h);
 /* the match buffer clouds of the last refresh (host copy, for inspection / tests): returns the number of points written */
 int64_t ll_history_map_cloud(ll_history *h, int32_t kind, float *xyzi, int64_t capacity_points);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Match buffer, cell ("cube") mode  (m_matching_mode == 1, the default in code,
+ * laser_mapping.hpp:689).  Device-resident stand-in for
+ *   Points_cloud_map<float> m_pt_cell_map_corners / m_pt_cell_map_planes   laser_mapping.hpp:274-275, 617-624
+ *   Points_cloud_map::append_cloud / find_cell / find_cell_center          cell_map_keyframe.hpp:619-672, 716-759, 556-571
+ *   Points_cloud_map::find_cells_in_radius                                 cell_map_keyframe.hpp:761-788
+ *   Laser_mapping::if_pt_in_fov                                            laser_mapping.hpp:310-324
+ *   update_buff_for_matching(), cell branch                                laser_mapping.hpp:471-513
+ * A cell map bins xyz points (intensity is not kept, cell_map_keyframe.hpp:82) into cubes of edge resolution / 2
+ * (set_resolution halves it, cell_map_keyframe.hpp:675-680); a cell that is hit again after not being updated for
+ * minimum_revisit_threshold appended clouds starts over empty (cell_map_keyframe.hpp:735-756).
+ * ll_cellmap_query_filter: the cells whose centre lies within `radius` of the pose's translation and within
+ * maximum_in_fov_angle degrees of its x axis, each passed through pcl::VoxelGrid(leaf) on its own, concatenated;
+ * down_sample_replace != 0 stores the filtered points back into the cells (laser_mapping.hpp:492-495).
+ * Order of the result: cells ascending by (ix, iy, iz) -- the reference's order is that of a PCL octree traversal and
+ * is not reproducible; within a cell, PCL's leaf order.  Non-finite points and points beyond +-2^20 cells are dropped. */
+typedef struct ll_cellmap ll_cellmap;
+int ll_cellmap_create(int32_t device, int64_t max_points, float resolution, int32_t minimum_revisit_threshold, ll_cellmap **out);
+void ll_cellmap_destroy(ll_cellmap *c);
+int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n);
+int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], float radius, float maximum_in_fov_angle, float leaf,
+                            int32_t down_sample_replace, int64_t *n_cells_selected, int64_t *n_out);
+/* the concatenated cloud of the last query (host copy); xyzi == NULL returns its size */
+int64_t ll_cellmap_result(ll_cellmap *c, float *xyzi, int64_t capacity_points);
+int ll_cellmap_stats(const ll_cellmap *c, int64_t *n_cells, int64_t *n_points, int32_t *frame_idx);
+/* the whole map for inspection / tests: points in (cell, insertion) order, cell indices [n_cells][3], first point of
+ * each cell [n_cells + 1], m_last_update_frame_idx [n_cells]; any output may be NULL */
+int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_points, int32_t *cell_ijk, int32_t *cell_start,
+                    int32_t *cell_last_update, int64_t capacity_cells);
+
+/* The two cell maps of the mapping node, fed by every frame ll_history_add* receives (laser_mapping.hpp:1492-1493: the
+ * voxel-filtered map-frame features, whether or not the frame enters the history), and the cell branch of
+ * update_buff_for_matching: query + per-cell VoxelGrid (leaf line_res / plane_res) -> VoxelGrid of the concatenation ->
+ * the two search structures of `map`.  ll_history_cell_map returns a borrowed handle (stats / dump). */
+int ll_history_enable_cell_map(ll_history *h, int64_t max_points, float cell_resolution, int32_t threshold_cell_revisit);
+ll_cellmap *ll_history_cell_map(ll_history *h, int32_t kind);
+int ll_history_refresh_cells(ll_history *h, ll_map *map, const double pose[7], float maximum_search_range_corner,
+                             float maximum_search_range_surface, float maximum_in_fov_angle, int32_t down_sample_replace,
+                             int64_t *n_map_corner, int64_t *n_map_surf);
+
 /* unsigned int Point_cloud_registration::pointcloudAssociateToMap(pc_in, pc_out, if_undistore = 0)
  * (point_cloud_registration.hpp:673-685, no-deblur branch :629): p_w = q*p + t in double, stored float. */
 int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t n, const double pose[7]);

@@ -234,12 +234,90 @@ class History_buffer:
         check(self.L.ll_history_refresh(self.h, map_buffer.h, C.byref(nc), C.byref(ns)), "ll_history_refresh")
         return nc.value, ns.value
 
+    def enable_cell_map(self, max_points: int = 1 << 20, cell_resolution: float = 1.0, threshold_cell_revisit: int = 5000) -> None:
+        """m_pt_cell_map_corners / m_pt_cell_map_planes (laser_mapping.hpp:274-275, 617-624): fed by every add*()."""
+        check(self.L.ll_history_enable_cell_map(self.h, max_points, cell_resolution, threshold_cell_revisit), "ll_history_enable_cell_map")
+
+    def cell_map(self, kind: int) -> "Cell_map":
+        h = self.L.ll_history_cell_map(self.h, kind)
+        if not h:
+            raise RuntimeError("cell maps are not enabled")
+        return Cell_map(_borrowed=h)
+
+    def refresh_cells(self, map_buffer: "Map_buffer", pose, maximum_search_range_corner: float = 100.0,
+                      maximum_search_range_surface: float = 100.0, maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1):
+        """update_buff_for_matching with m_matching_mode == 1 (laser_mapping.hpp:471-546)."""
+        pose = np.ascontiguousarray(pose, np.float64)
+        nc, ns = C.c_int64(0), C.c_int64(0)
+        check(self.L.ll_history_refresh_cells(self.h, map_buffer.h, ptr(pose), maximum_search_range_corner, maximum_search_range_surface,
+                                              maximum_in_fov_angle, int(down_sample_replace), C.byref(nc), C.byref(ns)),
+              "ll_history_refresh_cells")
+        return nc.value, ns.value
+
     def map_cloud(self, kind: int) -> np.ndarray:
         n = self.L.ll_history_map_cloud(self.h, kind, None, 0)
         out = np.zeros((max(n, 0), 4), np.float32)
         if n > 0:
             check(min(0, self.L.ll_history_map_cloud(self.h, kind, ptr(out), n)), "ll_history_map_cloud")
         return out
+
+
+class Cell_map:
+    """Points_cloud_map<float> (cell_map_keyframe.hpp:477-790) as used by the "cube" matching mode, resident on the
+    device (include/loam_livox_hip.h, ll_cellmap_*): append_cloud, find_cells_in_radius + if_pt_in_fov + per-cell
+    VoxelGrid (laser_mapping.hpp:475-513)."""
+
+    def __init__(self, max_points: int = 1 << 20, resolution: float = 1.0, minimum_revisit_threshold: int = 2**31 - 1, device: int = 0,
+                 _borrowed=None):
+        self.L = capi.load()
+        self.owned = _borrowed is None
+        if self.owned:
+            self.h = C.c_void_p()
+            check(self.L.ll_cellmap_create(device, max_points, resolution, minimum_revisit_threshold, C.byref(self.h)), "ll_cellmap_create")
+        else:
+            self.h = C.c_void_p(_borrowed)
+
+    def close(self):
+        if getattr(self, "h", None) and self.owned:
+            self.L.ll_cellmap_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def append_cloud(self, cloud) -> None:
+        cloud = capi.as_f32(cloud, 4)
+        check(self.L.ll_cellmap_append(self.h, ptr(cloud), cloud.shape[0]), "ll_cellmap_append")
+
+    def stats(self):
+        """(cells, points, m_current_frame_idx)"""
+        nc, npts, fr = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        check(self.L.ll_cellmap_stats(self.h, C.byref(nc), C.byref(npts), C.byref(fr)), "ll_cellmap_stats")
+        return nc.value, npts.value, fr.value
+
+    def query_filter(self, pose, radius: float, maximum_in_fov_angle: float, leaf: float, down_sample_replace: int = 1):
+        """Returns (concatenated per-cell filtered cloud [n,4], number of selected cells)."""
+        pose = np.ascontiguousarray(pose, np.float64)
+        nsel, nout = C.c_int64(0), C.c_int64(0)
+        check(self.L.ll_cellmap_query_filter(self.h, ptr(pose), radius, maximum_in_fov_angle, leaf, int(down_sample_replace), C.byref(nsel),
+                                             C.byref(nout)), "ll_cellmap_query_filter")
+        out = np.zeros((nout.value, 4), np.float32)
+        if nout.value > 0:
+            check(min(0, self.L.ll_cellmap_result(self.h, ptr(out), nout.value)), "ll_cellmap_result")
+        return out, nsel.value
+
+    def dump(self):
+        """(xyz [n,3] in (cell, insertion) order, cell indices [c,3], first point of each cell [c+1], last-update frame [c])"""
+        nc, npts, _ = self.stats()
+        xyzi = np.zeros((max(npts, 1), 4), np.float32)
+        ijk = np.zeros((max(nc, 1), 3), np.int32)
+        start = np.zeros(nc + 1, np.int32)
+        last = np.zeros(max(nc, 1), np.int32)
+        check(self.L.ll_cellmap_dump(self.h, ptr(xyzi), xyzi.shape[0], ptr(ijk), ptr(start), ptr(last), ijk.shape[0]), "ll_cellmap_dump")
+        return xyzi[:npts, :3].copy(), ijk[:nc].copy(), start, last[:nc].copy()
 
 
 class Map_buffer:

@@ -99,6 +99,16 @@ SYMBOLS = {
     "ll_history_refresh": (_i32, [_vp, _vp, _vp, _vp]),
     "ll_history_size": (_i32, [_vp]),
     "ll_history_map_cloud": (_i64, [_vp, _i32, _vp, _i64]),
+    "ll_cellmap_create": (_i32, [_i32, _i64, C.c_float, _i32, _vp]),
+    "ll_cellmap_destroy": (None, [_vp]),
+    "ll_cellmap_append": (_i32, [_vp, _vp, _i32]),
+    "ll_cellmap_query_filter": (_i32, [_vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),
+    "ll_cellmap_result": (_i64, [_vp, _vp, _i64]),
+    "ll_cellmap_stats": (_i32, [_vp, _vp, _vp, _vp]),
+    "ll_cellmap_dump": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "ll_history_enable_cell_map": (_i32, [_vp, _i64, C.c_float, _i32]),
+    "ll_history_cell_map": (_vp, [_vp, _i32]),
+    "ll_history_refresh_cells": (_i32, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),
     "ll_reg_stream": (_vp, [_vp]),
     "ll_fe_stream": (_vp, [_vp]),
     "ll_last_error": (C.c_char_p, []),

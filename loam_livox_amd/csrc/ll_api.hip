@@ -14,6 +14,7 @@
 #include "../../include/loam_livox_hip.h"
 #include "ll_device.h"
 #include "ll_reg_core.h"
+#include "ll_cellmap.h"
 #include "ll_voxel.h"
 
 using namespace ll;
@@ -947,6 +948,119 @@ extern "C" int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe
     return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
 }
 
+// ---------------------------------------------------------------------------------------------------- cell map
+struct ll_cellmap {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    CellMapDev dev{};
+    float4 *d_in = nullptr;   // staging of host clouds (max_points)
+    double *d_pose = nullptr;
+};
+
+static void cellmap_release(ll_cellmap *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    cellmap_free(c->dev);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_pose) (void)hipFree(c->d_pose);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int ll_cellmap_create(int32_t device, int64_t max_points, float resolution, int32_t minimum_revisit_threshold, ll_cellmap **out)
+{
+    if (!out) return set_err("ll_cellmap_create", "null argument");
+    if (max_points < 1 || max_points >= 0x3fffffffLL) return set_err("ll_cellmap_create", "max_points out of range");
+    if (!(resolution > 0.f)) return set_err("ll_cellmap_create", "resolution must be positive");
+    if (check_device(device)) return -1;
+    ll_cellmap *c = new ll_cellmap();
+    c->device = device;
+    const char *err = nullptr;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || cellmap_alloc(c->dev, (int)max_points, resolution, minimum_revisit_threshold, &err) ||
+        hipMalloc((void **)&c->d_in, (size_t)max_points * sizeof(float4)) != hipSuccess || hipMalloc((void **)&c->d_pose, 8 * sizeof(double)) != hipSuccess) {
+        cellmap_release(c);
+        return set_err("ll_cellmap_create", err ? err : "allocation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void ll_cellmap_destroy(ll_cellmap *c) { cellmap_release(c); }
+
+extern "C" int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n)
+{
+    if (!c || (n > 0 && !xyzi)) return set_err("ll_cellmap_append", "null argument");
+    if (n < 0 || n > c->dev.cap) return set_err("ll_cellmap_append", "cloud exceeds max_points");
+    HC(hipSetDevice(c->device));
+    if (n > 0) HC(hipMemcpyAsync(c->d_in, xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    const char *err = nullptr;
+    if (cellmap_append(c->dev, c->d_in, n, c->stream, &err)) return set_err("ll_cellmap_append", err);
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], float radius, float maximum_in_fov_angle, float leaf,
+                                       int32_t down_sample_replace, int64_t *n_cells_selected, int64_t *n_out)
+{
+    if (!c || !pose) return set_err("ll_cellmap_query_filter", "null argument");
+    if (!(radius >= 0.f)) return set_err("ll_cellmap_query_filter", "radius must not be negative");
+    HC(hipSetDevice(c->device));
+    HC(hipMemcpyAsync(c->d_pose, pose, 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const char *err = nullptr;
+    if (cellmap_query_filter(c->dev, c->d_pose, radius, maximum_in_fov_angle, leaf, down_sample_replace, c->stream, &err))
+        return set_err("ll_cellmap_query_filter", err);
+    HC(hipStreamSynchronize(c->stream));
+    if (n_cells_selected) *n_cells_selected = c->dev.n_sel;
+    if (n_out) *n_out = c->dev.n_filt;
+    return 0;
+}
+
+extern "C" int64_t ll_cellmap_result(ll_cellmap *c, float *xyzi, int64_t capacity_points)
+{
+    if (!c) return set_err("ll_cellmap_result", "null argument");
+    const int64_t n = c->dev.n_filt;
+    if (!xyzi) return n;
+    if (capacity_points < n) return set_err("ll_cellmap_result", "buffer too small");
+    if (hipSetDevice(c->device) != hipSuccess) return set_err("ll_cellmap_result", "hipSetDevice failed");
+    if (n > 0 && hipMemcpy(xyzi, c->dev.filt, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err("ll_cellmap_result", "copy failed");
+    return n;
+}
+
+extern "C" int ll_cellmap_stats(const ll_cellmap *c, int64_t *n_cells, int64_t *n_points, int32_t *frame_idx)
+{
+    if (!c) return set_err("ll_cellmap_stats", "null argument");
+    if (n_cells) *n_cells = c->dev.n_cells;
+    if (n_points) *n_points = c->dev.n_pts;
+    if (frame_idx) *frame_idx = c->dev.frame;
+    return 0;
+}
+
+extern "C" int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_points, int32_t *cell_ijk, int32_t *cell_start,
+                               int32_t *cell_last_update, int64_t capacity_cells)
+{
+    if (!c) return set_err("ll_cellmap_dump", "null argument");
+    const int np = c->dev.n_pts, nc = c->dev.n_cells;
+    if ((xyzi && capacity_points < np) || ((cell_ijk || cell_start || cell_last_update) && capacity_cells < nc))
+        return set_err("ll_cellmap_dump", "buffer too small");
+    HC(hipSetDevice(c->device));
+    if (xyzi && np > 0) HC(hipMemcpy(xyzi, c->dev.pts, (size_t)np * sizeof(float4), hipMemcpyDeviceToHost));
+    if (cell_start) {
+        if (nc > 0)
+            HC(hipMemcpy(cell_start, c->dev.cstart, (size_t)(nc + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        else
+            cell_start[0] = 0;
+    }
+    if (cell_last_update && nc > 0) HC(hipMemcpy(cell_last_update, c->dev.clast, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost));
+    if (cell_ijk && nc > 0) {
+        std::vector<unsigned long long> keys(nc);
+        HC(hipMemcpy(keys.data(), c->dev.ckey, (size_t)nc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nc; i++) cell_unpack(keys[i], cell_ijk + 3 * (size_t)i);
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------- history
 struct ll_history {
     int device = 0;
@@ -963,6 +1077,11 @@ struct ll_history {
     double last_q[4] = {0, 0, 0, 1}, last_t[3] = {0, 0, 0};  // m_last_his_add_q / m_last_his_add_t
     int64_t n_map[2] = {0, 0};
     float4 *d_map[2] = {nullptr, nullptr};   // filtered match buffer of the last refresh
+    // m_pt_cell_map_corners / m_pt_cell_map_planes (laser_mapping.hpp:274-275), ll_history_enable_cell_map
+    ll_cellmap *cells[2] = {nullptr, nullptr};
+    VoxelDev vox_cells{};
+    float4 *d_cmap[2] = {nullptr, nullptr};  // match buffer of the last ll_history_refresh_cells
+    const float4 *map_src[2] = {nullptr, nullptr};
 };
 
 extern "C" int ll_history_create(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res,
@@ -1006,7 +1125,9 @@ extern "C" void ll_history_destroy(ll_history *h)
     (void)hipSetDevice(h->device);
     voxel_free(h->vox_frame);
     voxel_free(h->vox_map);
-    void *ptrs[] = {h->frames[0], h->frames[1], h->d_map[0], h->d_map[1], h->d_in, h->d_xf, h->d_concat, h->d_n, h->d_pose};
+    voxel_free(h->vox_cells);
+    for (int k = 0; k < 2; k++) cellmap_release(h->cells[k]);
+    void *ptrs[] = {h->frames[0], h->frames[1], h->d_map[0], h->d_map[1], h->d_in, h->d_xf, h->d_concat, h->d_n, h->d_pose, h->d_cmap[0], h->d_cmap[1]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1015,22 +1136,40 @@ extern "C" void ll_history_destroy(ll_history *h)
 
 extern "C" int32_t ll_history_size(const ll_history *h) { return h ? h->size : -1; }
 
-// one kind of one frame: d_src (sensor frame, n points on the device) -> map frame -> VoxelGrid -> ring slot
-static int history_push_kind(ll_history *h, int kind, const float4 *d_src, int n, int slot)
+// one kind of one frame: d_src (sensor frame, n points on the device) -> map frame -> VoxelGrid.  The filtered frame stays
+// in h->vox_frame.out; *n_out = its size.
+static int history_filter_kind(ll_history *h, int kind, const float4 *d_src, int n, int *n_out)
 {
-    h->count[kind][slot] = 0;
+    *n_out = 0;
     if (n <= 0) return 0;
     launch_cloud_transform(d_src, h->d_xf, n, h->d_pose, h->stream);  // laser_mapping.hpp:1421-1431
     HC(hipMemcpyAsync(h->d_n, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
     const float leaf[3] = {h->res[kind], h->res[kind], h->res[kind]};
     const char *err = nullptr;
     if (voxel_filter(h->vox_frame, h->d_xf, h->d_n, n, 1, leaf, h->stream, &err)) return set_err("ll_history_add", err);  // :1434-1437
-    int n_out = 0;
-    HC(hipMemcpyAsync(&n_out, h->vox_frame.n_out, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HC(hipMemcpyAsync(n_out, h->vox_frame.n_out, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HC(hipStreamSynchronize(h->stream));
-    HC(hipMemcpyAsync(h->frames[kind] + (size_t)slot * h->max_pts, h->vox_frame.out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice,
-                      h->stream));
-    h->count[kind][slot] = n_out;
+    return 0;
+}
+
+// ... -> ring slot (when the frame is pushed) and -> cell map (when enabled; every registered frame, :1492-1493)
+static int history_push_kind(ll_history *h, int kind, const float4 *d_src, int n, int slot, bool push)
+{
+    int n_out = 0;
+    if (history_filter_kind(h, kind, d_src, n, &n_out)) return -1;
+    if (push) {
+        if (n_out > 0)
+            HC(hipMemcpyAsync(h->frames[kind] + (size_t)slot * h->max_pts, h->vox_frame.out, (size_t)n_out * sizeof(float4),
+                              hipMemcpyDeviceToDevice, h->stream));
+        h->count[kind][slot] = n_out;
+    }
+    if (h->cells[kind]) {
+        ll_cellmap *c = h->cells[kind];
+        const char *err = nullptr;
+        if (cellmap_append(c->dev, h->vox_frame.out, n_out, c->stream, &err)) return set_err("ll_history_add (cell map)", err);
+        HC(hipStreamSynchronize(c->stream));
+    }
+    HC(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -1044,14 +1183,15 @@ static int history_add_common(ll_history *h, const float4 *d_corner, int n_corne
     const double t_diff = sqrt(dot3(dt, dt));
     const bool push = h->size < h->max_hist || t_diff > t_step || r_diff > angle_step * 57.3;  // :1446-1448
     if (added) *added = push ? 1 : 0;
-    if (!push) return 0;
-    for (int i = 0; i < 4; i++) h->last_q[i] = pose[i];
-    for (int i = 0; i < 3; i++) h->last_t[i] = pose[4 + i];
+    if (!push && !h->cells[0]) return 0;
     const int slots = h->max_hist + 1;
     const int slot = (h->head + h->size) % slots;
     HC(hipMemcpyAsync(h->d_pose, pose, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (history_push_kind(h, 0, d_corner, n_corner, slot)) return -1;
-    if (history_push_kind(h, 1, d_surf, n_surf, slot)) return -1;
+    if (history_push_kind(h, 0, d_corner, n_corner, slot, push)) return -1;
+    if (history_push_kind(h, 1, d_surf, n_surf, slot, push)) return -1;
+    if (!push) return 0;
+    for (int i = 0; i < 4; i++) h->last_q[i] = pose[i];
+    for (int i = 0; i < 3; i++) h->last_t[i] = pose[4 + i];
     h->size++;
     if (h->size > h->max_hist) {  // :1463-1473 pop_front
         h->head = (h->head + 1) % slots;
@@ -1103,6 +1243,8 @@ extern "C" int ll_history_add_voxel(ll_history *h, ll_voxel *vc, ll_voxel *vs, i
                               history_add_t_step, history_add_angle_step, added);
 }
 
+static float match_cell_size(int kind, float leaf);
+
 extern "C" int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_corner, int64_t *n_map_surf)
 {
     if (!h || !map) return set_err("ll_history_refresh", "null argument");
@@ -1131,14 +1273,10 @@ extern "C" int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_cor
             HC(hipMemcpyAsync(h->d_map[kind], h->vox_map.out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
         }
         h->n_map[kind] = n_out;
+        h->map_src[kind] = h->d_map[kind];
         // the search structure (laser_mapping.hpp:539-546: two KdTreeFLANN::setInputCloud) is the device grid
         const char *err = nullptr;
-        // Cell size from the voxel leaf the buffer has just been filtered with: the points are about one leaf apart (along
-        // the edges for the corner cloud, across the surfaces for the other), and a search is fastest with a handful of
-        // points per cell.  The default corner cell (1.45 m, sized for a sparse edge map and the sqrt(2) m line radius)
-        // would put hundreds of candidates of a dense local edge map into the query's own cells.
-        const float leaf = h->res[kind];
-        const float cell = (kind == LL_MAP_CORNER) ? fminf(fmaxf(4.0f * leaf, 0.4f), 1.45f) : fminf(fmaxf(3.0f * leaf, 0.45f), 1.2f);
+        const float cell = match_cell_size(kind, h->res[kind]);
         if (map_build(map->kind[kind], (const float *)h->d_map[kind], 4, n_out, cell, h->stream, &err)) return set_err("map_build", err ? err : "failed");
     }
     HC(hipStreamSynchronize(h->stream));
@@ -1154,9 +1292,81 @@ extern "C" int64_t ll_history_map_cloud(ll_history *h, int32_t kind, float *xyzi
     if (!xyzi) return n;
     if (capacity_points < n) return set_err("ll_history_map_cloud", "buffer too small");
     if (hipSetDevice(h->device) != hipSuccess) return set_err("ll_history_map_cloud", "hipSetDevice failed");
-    if (n > 0 && hipMemcpy(xyzi, h->d_map[kind], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess)
+    if (n > 0 && hipMemcpy(xyzi, h->map_src[kind], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess)
         return set_err("ll_history_map_cloud", "copy failed");
     return n;
+}
+
+static float match_cell_size(int kind, float leaf)
+{
+    // Cell size from the voxel leaf the buffer has just been filtered with: the points are about one leaf apart (along
+    // the edges for the corner cloud, across the surfaces for the other), and a search is fastest with a handful of
+    // points per cell.  The default corner cell (1.45 m, sized for a sparse edge map and the sqrt(2) m line radius)
+    // would put hundreds of candidates of a dense local edge map into the query's own cells.
+    return (kind == LL_MAP_CORNER) ? fminf(fmaxf(4.0f * leaf, 0.4f), 1.45f) : fminf(fmaxf(3.0f * leaf, 0.45f), 1.2f);
+}
+
+extern "C" int ll_history_enable_cell_map(ll_history *h, int64_t max_points, float cell_resolution, int32_t threshold_cell_revisit)
+{
+    if (!h) return set_err("ll_history_enable_cell_map", "null argument");
+    if (h->cells[0]) return set_err("ll_history_enable_cell_map", "already enabled");
+    if (max_points < h->max_pts) return set_err("ll_history_enable_cell_map", "max_points below max_points_per_frame");
+    HC(hipSetDevice(h->device));
+    for (int k = 0; k < 2; k++) {
+        // laser_mapping.hpp:620-624: set_resolution( m_pt_cell_resolution ), m_minimum_revisit_threshold
+        if (ll_cellmap_create(h->device, max_points, cell_resolution, threshold_cell_revisit, &h->cells[k])) return -1;
+        DM(h->d_cmap[k], (size_t)max_points);
+    }
+    const char *err = nullptr;
+    if (voxel_alloc(h->vox_cells, 1, (int)max_points, &err)) return set_err("ll_history_enable_cell_map", err);
+    return 0;
+}
+
+extern "C" ll_cellmap *ll_history_cell_map(ll_history *h, int32_t kind)
+{
+    if (!h || kind < 0 || kind > 1) {
+        set_err("ll_history_cell_map", "bad argument");
+        return nullptr;
+    }
+    return h->cells[kind];
+}
+
+// update_buff_for_matching with m_matching_mode == 1 (laser_mapping.hpp:471-546)
+extern "C" int ll_history_refresh_cells(ll_history *h, ll_map *map, const double pose[7], float maximum_search_range_corner,
+                                        float maximum_search_range_surface, float maximum_in_fov_angle, int32_t down_sample_replace,
+                                        int64_t *n_map_corner, int64_t *n_map_surf)
+{
+    if (!h || !map || !pose) return set_err("ll_history_refresh_cells", "null argument");
+    if (!h->cells[0]) return set_err("ll_history_refresh_cells", "cell maps are not enabled (ll_history_enable_cell_map)");
+    if (map->device != h->device) return set_err("ll_history_refresh_cells", "map lives on another device");
+    HC(hipSetDevice(h->device));
+    const float range[2] = {maximum_search_range_corner, maximum_search_range_surface};
+    for (int kind = 0; kind < 2; kind++) {
+        ll_cellmap *c = h->cells[kind];
+        const float leaf1 = h->res[kind];
+        // :475-513: cells in range and in the field of view, each through the VoxelGrid, concatenated
+        if (ll_cellmap_query_filter(c, pose, range[kind], maximum_in_fov_angle, leaf1, down_sample_replace, nullptr, nullptr)) return -1;
+        const int total = c->dev.n_filt;
+        int n_out = 0;
+        if (total > 0) {
+            HC(hipMemcpyAsync(h->d_n, &total, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            const float leaf[3] = {leaf1, leaf1, leaf1};
+            const char *err = nullptr;
+            if (voxel_filter(h->vox_cells, c->dev.filt, h->d_n, total, 1, leaf, h->stream, &err)) return set_err("ll_history_refresh_cells", err);  // :533-537
+            HC(hipMemcpyAsync(&n_out, h->vox_cells.n_out, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HC(hipStreamSynchronize(h->stream));
+            HC(hipMemcpyAsync(h->d_cmap[kind], h->vox_cells.out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->n_map[kind] = n_out;
+        h->map_src[kind] = h->d_cmap[kind];
+        const char *err = nullptr;
+        if (map_build(map->kind[kind], (const float *)h->d_cmap[kind], 4, n_out, match_cell_size(kind, leaf1), h->stream, &err))
+            return set_err("map_build", err ? err : "failed");
+    }
+    HC(hipStreamSynchronize(h->stream));
+    if (n_map_corner) *n_map_corner = h->n_map[0];
+    if (n_map_surf) *n_map_surf = h->n_map[1];
+    return 0;
 }
 
 extern "C" int ll_reg_solve_batch_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,

@@ -1,0 +1,44 @@
+// ll_cellmap.h -- device buffers of the cell map (ll_cellmap_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ll_cellmap_core.h"
+
+namespace ll {
+
+// Points of all cells in one array, ordered by (cell key, insertion order); a table of the occupied cells beside it.
+struct CellMapDev {
+    int cap;                 // points the map can hold; the arrays below are 2 * cap long (append / replace scratch)
+    CellGeom geom;
+    float resolution;
+    int revisit_threshold;   // m_minimum_revisit_threshold (CMK:506)
+    int frame;               // m_current_frame_idx (CMK:505)
+    int n_pts, n_cells;      // host mirrors of the device state
+    float4 *pts, *pts2;                    // {x, y, z, 0}: the reference's cells hold xyz only (CMK:82, pcl_tools.hpp:94-101)
+    unsigned long long *pkey, *pkey2;      // cell key of every stored point
+    unsigned int *val, *val2;
+    unsigned long long *ckey, *ckey2;      // occupied cells, ascending
+    int *cstart, *cstart2;                 // [n_cells + 1] first point of each cell
+    int *clast, *clast2;                   // m_last_update_frame_idx (CMK:75)
+    unsigned int *flag, *rank;             // head flags / prefix sums over points or cells
+    unsigned int *csel, *csel_rank;        // per cell: selected by the last query / its rank among the selected
+    unsigned long long *skey, *skey2;      // (selected cell rank, leaf) sort keys of the per-cell VoxelGrid
+    unsigned int *head_pos;
+    float4 *filt;                          // per-cell filtered clouds, concatenated in cell order
+    unsigned long long *filt_key;          // cell key of every filtered point
+    int *counts;                           // device scalars: [0] valid points, [1] cells, [2] selected cells, [3] voxels
+    int n_filt, n_sel;                     // result of the last query
+    void *tmp;
+    size_t tmp_bytes;
+};
+
+int cellmap_alloc(CellMapDev &m, int cap, float resolution, int revisit_threshold, const char **err);
+void cellmap_free(CellMapDev &m);
+// append_cloud (CMK:619-672): n points at d_src (device)
+int cellmap_append(CellMapDev &m, const float4 *d_src, int n, hipStream_t s, const char **err);
+// find_cells_in_radius + if_pt_in_fov + per-cell VoxelGrid (+ set_pointcloud), LM:475-513 for one feature kind;
+// d_pose: device copy of {qx, qy, qz, qw, tx, ty, tz}.  Result in m.filt[0 .. m.n_filt)
+int cellmap_query_filter(CellMapDev &m, const double *d_pose, float radius, float max_fov_deg, float leaf, int replace, hipStream_t s,
+                         const char **err);
+
+}  // namespace ll

@@ -1,12 +1,12 @@
-"""Host-side mirror of Laser_mapping::process_new_scan for the history match mode (m_matching_mode == 0),
-hku-mars/loam_livox source/laser_mapping.hpp:1311-1520, on top of the C ABI: extractor -> (VoxelGrid) -> registrar
--> history -> match-buffer refresh, everything resident on one device.
+"""Host-side mirror of Laser_mapping::process_new_scan for both match modes (m_matching_mode == 0: history,
+1: cell map), hku-mars/loam_livox source/laser_mapping.hpp:1311-1520, on top of the C ABI: extractor -> (VoxelGrid)
+-> registrar -> history / cell maps -> match-buffer refresh, everything resident on one device.
 
 This is the unit of BASELINE config C4 (one sequence per GPU, local map growth).  Differences from the node, by design:
   * the match buffer is refreshed synchronously after every accepted frame; the node refreshes it on a service thread
     and registers against whichever buffer is newest (laser_mapping.hpp:568-594, 1395-1403), which makes its output
     depend on thread timing;
-  * no ROS, logging, cell maps, key frames or loop closure (out of scope).
+  * no ROS, logging, full-cloud cell map, key frames or loop closure (out of scope).
 """
 from __future__ import annotations
 
@@ -21,13 +21,22 @@ class Laser_mapping:
                  ceres_max_iterations: int = 100, max_allow_incre_R: float = 200.0 / 50.0, max_allow_incre_T: float = 100.0 / 50.0,
                  max_allow_final_cost: float = 100.0, history_add_t_step: float = 0.0, history_add_angle_step: float = 0.0,
                  minimum_icp_R_diff: float = 0.01, minimum_icp_T_diff: float = 0.01, maximum_residual_blocks: int = 0,
-                 subsample_seed: int = 1):
+                 subsample_seed: int = 1, matching_mode: int = 0, cell_resolution: float = 1.0, threshold_cell_revisit: int = 5000,
+                 maximum_search_range_corner: float = 100.0, maximum_search_range_surface: float = 100.0,
+                 maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1, cell_map_max_points: int = 1 << 21):
         self.fe = Livox_laser(max_points=scan_points, max_scans=1, device=device, piecewise_number=1)
         self.reg = Point_cloud_registration(max_scans=1, max_features=scan_points, device=device)
         self.map = Map_buffer(device=device)
         self.vox = (VoxelGrid(scan_points, 1, device=device), VoxelGrid(scan_points, 1, device=device))
         self.history = History_buffer(maximum_history_size, scan_points, line_res, plane_res, device=device)
         self.line_res, self.plane_res = line_res, plane_res
+        # mapping/matching_mode (laser_mapping.hpp:689; 0 in the shipped configs): 1 = match against the cell maps
+        self.m_matching_mode = matching_mode
+        self.m_maximum_search_range = (maximum_search_range_corner, maximum_search_range_surface)  # :694-695
+        self.m_maximum_in_fov_angle = maximum_in_fov_angle                                           # :691
+        self.m_down_sample_replace = down_sample_replace                                             # :277
+        if matching_mode:
+            self.history.enable_cell_map(cell_map_max_points, cell_resolution, threshold_cell_revisit)  # :620-624
         self.m_if_input_downsample_mode = input_downsample_mode
         self.history_add_t_step, self.history_add_angle_step = history_add_t_step, history_add_angle_step
         p = self.reg.params
@@ -77,7 +86,11 @@ class Laser_mapping:
             self.history.add_fe(fe, 0, pc[0], self.history_add_t_step, self.history_add_angle_step)
         self.pose = pc[0].copy()  # :1496-1500
         t2 = time.perf_counter()
-        self.map_sizes = self.history.refresh(self.map)  # service_update_buff_for_matching, synchronous here
+        if self.m_matching_mode:  # update_buff_for_matching (service thread in the node), synchronous here
+            self.map_sizes = self.history.refresh_cells(self.map, self.pose, self.m_maximum_search_range[0], self.m_maximum_search_range[1],
+                                                        self.m_maximum_in_fov_angle, self.m_down_sample_replace)
+        else:
+            self.map_sizes = self.history.refresh(self.map)
         t3 = time.perf_counter()
         self.stage_s[1] += t2 - t1
         self.stage_s[2] += t3 - t2

@@ -1,11 +1,12 @@
-"""CPU ORACLE (test infrastructure only, see ll_oracle.h) for the host logic around the hot path in the history match
-mode: a restatement of Laser_mapping::process_new_scan / update_buff_for_matching of hku-mars/loam_livox
-(source/laser_mapping.hpp:1311-1520, 460-566 with m_matching_mode == 0), composed from the oracle's extraction,
+"""CPU ORACLE (test infrastructure only, see ll_oracle.h) for the host logic around the hot path: a restatement of
+Laser_mapping::process_new_scan / update_buff_for_matching of hku-mars/loam_livox (source/laser_mapping.hpp:1311-1520,
+460-566; m_matching_mode 0 = history, 1 = cell maps via orc_cellmap), composed from the oracle's extraction,
 VoxelGrid, k-d tree and registration.  PARITY UNPINNED.  Synchronous refresh after every accepted frame (the node's
 service-thread timing is not reproducible)."""
 import numpy as np
 
 from . import orc
+from .orc_cellmap import CellMap
 
 
 def _angular_distance(a, b):
@@ -26,20 +27,36 @@ class History:
         self.max_hist, self.res = maximum_history_size, (line_res, plane_res)
         self.frames = ([], [])
         self.last_q, self.last_t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+        self.cells = None
+
+    def enable_cell_map(self, cell_resolution=1.0, threshold_cell_revisit=5000):      # LM:620-624
+        self.cells = (CellMap(cell_resolution, threshold_cell_revisit), CellMap(cell_resolution, threshold_cell_revisit))
 
     def add(self, corner, surf, pose, t_step=0.0, angle_step=0.0):
         r_diff = _angular_distance(pose[:4], self.last_q) * 57.3          # LM:1439
         t_diff = np.linalg.norm(pose[4:] - self.last_t)                  # LM:1440
-        if not (len(self.frames[0]) < self.max_hist or t_diff > t_step or r_diff > angle_step * 57.3):  # LM:1446-1448
+        push = len(self.frames[0]) < self.max_hist or t_diff > t_step or r_diff > angle_step * 57.3   # LM:1446-1448
+        if not push and self.cells is None:
             return False
-        self.last_q, self.last_t = np.array(pose[:4], np.float64), np.array(pose[4:], np.float64)
+        if push:
+            self.last_q, self.last_t = np.array(pose[:4], np.float64), np.array(pose[4:], np.float64)
         for kind, cloud in enumerate((corner, surf)):
             w = orc.cloud_transform(pose, cloud) if len(cloud) else np.zeros((0, 4), np.float32)  # LM:1421-1431
             w = orc.voxel_grid(w, self.res[kind])[1] if len(w) else w                               # LM:1434-1437
-            self.frames[kind].append(w)
-            if len(self.frames[kind]) > self.max_hist:                                               # LM:1468-1478
-                self.frames[kind].pop(0)
-        return True
+            if push:
+                self.frames[kind].append(w)
+                if len(self.frames[kind]) > self.max_hist:                                           # LM:1468-1478
+                    self.frames[kind].pop(0)
+            if self.cells is not None:                                                               # LM:1492-1493
+                self.cells[kind].append(w)
+        return push
+
+    def refresh_cells(self, pose, ranges=(100.0, 100.0), maximum_in_fov_angle=30.0, down_sample_replace=1):
+        out = []
+        for kind in range(2):                                                                        # LM:471-513
+            cat, _ = self.cells[kind].query_filter(pose, ranges[kind], maximum_in_fov_angle, self.res[kind], down_sample_replace)
+            out.append(orc.voxel_grid(cat, self.res[kind])[1] if len(cat) else cat)                  # LM:533-537
+        return out
 
     def refresh(self):
         out = []
@@ -52,8 +69,13 @@ class History:
 class LaserMapping:
     def __init__(self, maximum_history_size=100, line_res=0.1, plane_res=0.4, init_accumulate_frames=50, input_downsample_mode=1,
                  icp_max_iterations=20, ceres_max_iterations=100, max_allow_incre_R=4.0, max_allow_incre_T=2.0, max_allow_final_cost=100.0,
-                 minimum_icp_R_diff=0.01, minimum_icp_T_diff=0.01):
+                 minimum_icp_R_diff=0.01, minimum_icp_T_diff=0.01, matching_mode=0, cell_resolution=1.0, threshold_cell_revisit=5000,
+                 maximum_search_range_corner=100.0, maximum_search_range_surface=100.0, maximum_in_fov_angle=30.0, down_sample_replace=1):
         self.hist = History(maximum_history_size, line_res, plane_res)
+        self.mode = matching_mode
+        self.cell_args = ((maximum_search_range_corner, maximum_search_range_surface), maximum_in_fov_angle, down_sample_replace)
+        if matching_mode:
+            self.hist.enable_cell_map(cell_resolution, threshold_cell_revisit)
         self.res = (line_res, plane_res)
         self.ds = input_downsample_mode
         self.prm = orc.RegParams.defaults(icp_iters=icp_max_iterations, ceres_iters=ceres_max_iterations, force_all=0)
@@ -81,6 +103,6 @@ class LaserMapping:
             return 0
         self.hist.add(fc, fs, pc)
         self.pose = pc.copy()
-        self.maps = self.hist.refresh()
+        self.maps = self.hist.refresh_cells(self.pose, *self.cell_args) if self.mode else self.hist.refresh()
         self.trees = [orc.KdTree(m) if len(m) else None for m in self.maps]
         return 1

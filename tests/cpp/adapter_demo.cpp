@@ -92,8 +92,10 @@ int main(int argc, char **argv)
 
         // "Add new frame" + match-buffer refresh through the adapter (laser_mapping.hpp:1417-1478, 517-546)
         size_t n_hist_corner = 0, n_hist_surf = 0;
+        int64_t n_cell_corner = 0, n_cell_surf = 0, n_cells = 0, n_cell_pts = 0;
         if (reg_res) {
             loam_livox_hip::History_buffer history(4, 30000, 0.1f, 0.4f);
+            history.enable_cell_map(1 << 16, 1.0f, 5000);
             const bool pushed = history.add(*corners, *surface, pc_reg.m_para_buffer_RT);
             ll_map *scratch_map = nullptr;
             loam_livox_hip::check(ll_map_create(0, &scratch_map), "ll_map_create");
@@ -102,6 +104,9 @@ int main(int argc, char **argv)
             Cloud buf_c, buf_s;
             history.map_cloud(0, buf_c);
             history.map_cloud(1, buf_s);
+            // the same frame through the cell maps (m_matching_mode == 1, laser_mapping.hpp:471-546)
+            history.refresh_cells(scratch_map, pc_reg.m_para_buffer_RT, 100.0f, 100.0f, 45.0f, 1, &n_cell_corner, &n_cell_surf);
+            history.cell_map_size(1, &n_cells, &n_cell_pts);
             ll_map_destroy(scratch_map);
             if (!pushed || (int64_t)buf_c.size() != nc || (int64_t)buf_s.size() != ns) return 5;
             n_hist_corner = buf_c.size();
@@ -113,6 +118,7 @@ int main(int argc, char **argv)
         for (int i = 0; i < 7; i++) fprintf(o, "%.17g ", pc_reg.m_para_buffer_RT[i]);
         fprintf(o, "\n%.9g %.9g\n", piece_start, piece_end);
         fprintf(o, "%zu %zu\n", n_hist_corner, n_hist_surf);
+        fprintf(o, "%lld %lld %lld %lld\n", (long long)n_cell_corner, (long long)n_cell_surf, (long long)n_cells, (long long)n_cell_pts);
         fclose(o);
     } catch (const std::exception &e) {
         fprintf(stderr, "adapter_demo: %s\n", e.what());

@@ -14,7 +14,7 @@ _CSRC = os.path.join(_HERE, "..", "..", "loam_livox_amd", "csrc")
 
 
 def build():
-    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("ll_fe_core.h", "ll_knn_core.h", "ll_reg_core.h")]
+    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("ll_fe_core.h", "ll_knn_core.h", "ll_reg_core.h", "ll_cellmap_core.h", "ll_voxel_core.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
                                "-o", _LIB, _SRC])
@@ -163,3 +163,51 @@ def pca_check(is_plane, pts5):
     L.hc_pca_check.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     L.hc_pca_check.restype = C.c_int
     return bool(L.hc_pca_check(int(is_plane), p.ctypes.data, ev.ctypes.data)), ev
+
+
+class CellMap:
+    """Serial stand-in for the device cell map (hostcheck.cpp, hc_cellmap_*)."""
+
+    def __init__(self, resolution=1.0, minimum_revisit_threshold=2**31 - 1):
+        L = lib()
+        L.hc_cellmap_create.restype = C.c_void_p
+        L.hc_cellmap_create.argtypes = [C.c_float, C.c_int]
+        L.hc_cellmap_free.argtypes = [C.c_void_p]
+        L.hc_cellmap_append.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hc_cellmap_query_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.hc_cellmap_sizes.argtypes = [C.c_void_p] * 4
+        L.hc_cellmap_dump.argtypes = [C.c_void_p] * 5
+        self.L, self.h = L, L.hc_cellmap_create(resolution, int(minimum_revisit_threshold))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hc_cellmap_free(self.h)
+            self.h = None
+
+    def append(self, cloud):
+        c = np.ascontiguousarray(cloud, np.float32).reshape(-1, 4)
+        self.L.hc_cellmap_append(self.h, c.ctypes.data, c.shape[0])
+
+    def sizes(self):
+        a, b, f = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.L.hc_cellmap_sizes(self.h, C.byref(a), C.byref(b), C.byref(f))
+        return a.value, b.value, f.value
+
+    def query_filter(self, pose, radius, max_fov, leaf, replace=1):
+        pose = np.ascontiguousarray(pose, np.float64)
+        cap = self.sizes()[1]
+        out = np.zeros((max(cap, 1), 4), np.float32)
+        nsel = C.c_int(0)
+        n = self.L.hc_cellmap_query_filter(self.h, pose.ctypes.data, radius, max_fov, leaf, int(replace), out.ctypes.data, cap, C.byref(nsel))
+        if n < 0:
+            raise ValueError("leaf too small")
+        return out[:n].copy(), nsel.value
+
+    def dump(self):
+        nc, npts, _ = self.sizes()
+        xyzi = np.zeros((max(npts, 1), 4), np.float32)
+        ijk = np.zeros((max(nc, 1), 3), np.int32)
+        start = np.zeros(nc + 1, np.int32)
+        last = np.zeros(max(nc, 1), np.int32)
+        self.L.hc_cellmap_dump(self.h, xyzi.ctypes.data, ijk.ctypes.data, start.ctypes.data, last.ctypes.data)
+        return xyzi[:npts, :3].copy(), ijk[:nc].copy(), start, last[:nc].copy()

@@ -17,6 +17,8 @@
 #include "../../loam_livox_amd/csrc/ll_fe_core.h"
 #include "../../loam_livox_amd/csrc/ll_knn_core.h"
 #include "../../loam_livox_amd/csrc/ll_reg_core.h"
+#include "../../loam_livox_amd/csrc/ll_cellmap_core.h"
+#include "../../loam_livox_amd/csrc/ll_voxel_core.h"
 
 using namespace ll;
 
@@ -554,6 +556,201 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
     report[8] = (double)n_reused;
     report[9] = (double)n_searched;
     return result;
+}
+
+// ------------------------------------------------------------------------------------------------------ cell map
+// Serial stand-in for ll_cellmap_kernels.hip: the same store (points ordered by cell key, insertion order), the same
+// key constructions and the same per-thread functions of ll_cellmap_core.h; std::stable_sort plays the radix sort.
+struct hc_cellmap {
+    CellGeom g;
+    int thr, frame;
+    std::vector<float> pts;  // xyz0 per point
+    std::vector<unsigned long long> pkey, ckey;
+    std::vector<int> cstart, clast;
+    std::vector<float> filt;
+    int n_sel;
+};
+
+hc_cellmap *hc_cellmap_create(float resolution, int thr)
+{
+    hc_cellmap *m = new hc_cellmap();
+    m->g = cell_geom(resolution);
+    m->thr = thr;
+    m->frame = 0;
+    m->n_sel = 0;
+    m->cstart.push_back(0);
+    return m;
+}
+void hc_cellmap_free(hc_cellmap *m) { delete m; }
+
+static int hc_cell_find(const std::vector<unsigned long long> &ckey, unsigned long long k)
+{
+    auto it = std::lower_bound(ckey.begin(), ckey.end(), k);
+    return (it != ckey.end() && *it == k) ? (int)(it - ckey.begin()) : -1;
+}
+
+// cellmap_resort: stable sort by key, drop NONE, rebuild the table; the last n_appended entries stamp their cells
+static void hc_cellmap_resort(hc_cellmap *m, std::vector<float> &pts, std::vector<unsigned long long> &pkey, int n_appended)
+{
+    const int total = (int)pkey.size();
+    std::vector<int> order(total);
+    for (int i = 0; i < total; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pkey[a] < pkey[b]; });
+    std::vector<float> p2;
+    std::vector<unsigned long long> k2, ck;
+    std::vector<int> cs, cl;
+    for (int i = 0; i < total; i++) {
+        const int o = order[i];
+        if (pkey[o] == LL_CELL_KEY_NONE) break;
+        if (k2.empty() || k2.back() != pkey[o]) {
+            ck.push_back(pkey[o]);
+            cs.push_back((int)k2.size());
+            const int j = hc_cell_find(m->ckey, pkey[o]);
+            cl.push_back(j >= 0 ? m->clast[j] : m->frame);
+        }
+        k2.push_back(pkey[o]);
+        for (int d = 0; d < 4; d++) p2.push_back(pts[4 * (size_t)o + d]);
+    }
+    cs.push_back((int)k2.size());
+    for (int i = total - n_appended; i < total; i++) {
+        if (pkey[i] == LL_CELL_KEY_NONE) continue;
+        const int c = hc_cell_find(ck, pkey[i]);
+        if (c >= 0) cl[c] = m->frame;
+    }
+    m->pts.swap(p2);
+    m->pkey.swap(k2);
+    m->ckey.swap(ck);
+    m->cstart.swap(cs);
+    m->clast.swap(cl);
+}
+
+int hc_cellmap_append(hc_cellmap *m, const float *xyzi, int n)
+{
+    std::vector<float> pts = m->pts;
+    std::vector<unsigned long long> pkey = m->pkey;
+    std::vector<char> reset(m->ckey.size(), 0);
+    const int n_old = (int)pkey.size();
+    for (int i = 0; i < n; i++) {
+        const float *p = xyzi + 4 * (size_t)i;
+        int k[3];
+        unsigned long long key = LL_CELL_KEY_NONE;
+        if (ll_isfinite(p[0]) && ll_isfinite(p[1]) && ll_isfinite(p[2]) && cell_index(p[0], p[1], p[2], m->g, k)) {
+            key = cell_pack(k);
+            const int c = hc_cell_find(m->ckey, key);
+            if (c >= 0 && !(m->frame - m->clast[c] < m->thr)) reset[c] = 1;
+        }
+        pts.push_back(p[0]);
+        pts.push_back(p[1]);
+        pts.push_back(p[2]);
+        pts.push_back(0.0f);
+        pkey.push_back(key);
+    }
+    for (int i = 0; i < n_old; i++) {
+        const int c = hc_cell_find(m->ckey, pkey[i]);
+        if (c >= 0 && reset[c]) pkey[i] = LL_CELL_KEY_NONE;
+    }
+    if (n > 0) hc_cellmap_resort(m, pts, pkey, n);
+    m->frame++;
+    return 0;
+}
+
+// returns the number of filtered points (written to out_xyzi when it fits), -1 on a bad leaf
+int hc_cellmap_query_filter(hc_cellmap *m, const double *pose, float radius, float max_fov, float leaf, int replace, float *out_xyzi, int cap,
+                            int *n_sel_out)
+{
+    const float inv_leaf = 1.0f / leaf;
+    if (!(cell_leaf_span(m->g, inv_leaf) < 1024.0f)) return -1;
+    const int nc = (int)m->ckey.size(), np = (int)m->pkey.size();
+    std::vector<unsigned> csel(nc), crank(nc);
+    const double q[4] = {pose[0], pose[1], pose[2], pose[3]}, t[3] = {pose[4], pose[5], pose[6]};
+    const float sp[3] = {(float)t[0], (float)t[1], (float)t[2]};
+    unsigned acc = 0;
+    for (int c = 0; c < nc; c++) {
+        int k[3];
+        cell_unpack(m->ckey[c], k);
+        float ctr[3];
+        cell_centre(k, m->g, ctr);
+        csel[c] = (cell_in_radius(ctr, sp, radius) && cell_in_fov(ctr, q, t, (double)max_fov)) ? 1u : 0u;
+        crank[c] = acc;
+        acc += csel[c];
+    }
+    m->n_sel = (int)acc;
+    if (n_sel_out) *n_sel_out = (int)acc;
+    std::vector<unsigned long long> skey(np);
+    std::vector<int> order(np);
+    for (int i = 0; i < np; i++) {
+        order[i] = i;
+        unsigned long long key = LL_CELL_KEY_NONE;
+        const int c = hc_cell_find(m->ckey, m->pkey[i]);
+        if (c >= 0 && csel[c]) {
+            int k[3];
+            cell_unpack(m->pkey[i], k);
+            int l[3];
+            for (int d = 0; d < 3; d++) {
+                l[d] = cell_leaf_local(m->pts[4 * (size_t)i + d], k[d], m->g, inv_leaf);
+                l[d] = l[d] < 0 ? 0 : (l[d] > 1023 ? 1023 : l[d]);
+            }
+            key = ((unsigned long long)crank[c] << 30) | ((unsigned long long)l[2] << 20) | ((unsigned long long)l[1] << 10) | (unsigned long long)l[0];
+        }
+        skey[i] = key;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return skey[a] < skey[b]; });
+    std::vector<float> filt;
+    std::vector<unsigned long long> fkey;
+    for (int i = 0; i < np;) {
+        const unsigned long long k = skey[order[i]];
+        if (k == LL_CELL_KEY_NONE) break;
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        int cnt = 0, j = i;
+        for (; j < np && skey[order[j]] == k; j++) {
+            const float *p = &m->pts[4 * (size_t)order[j]];
+            sx = sx + p[0];
+            sy = sy + p[1];
+            sz = sz + p[2];
+            si = si + p[3];
+            cnt++;
+        }
+        const float c = (float)cnt;
+        filt.push_back(sx / c);
+        filt.push_back(sy / c);
+        filt.push_back(sz / c);
+        filt.push_back(si / c);
+        fkey.push_back(m->pkey[order[i]]);
+        i = j;
+    }
+    const int nf = (int)fkey.size();
+    if (out_xyzi && cap >= nf) memcpy(out_xyzi, filt.data(), filt.size() * sizeof(float));
+    if (replace && nf > 0) {
+        std::vector<float> pts = m->pts;
+        std::vector<unsigned long long> pkey = m->pkey;
+        for (int i = 0; i < np; i++) {
+            const int c = hc_cell_find(m->ckey, pkey[i]);
+            if (c >= 0 && csel[c]) pkey[i] = LL_CELL_KEY_NONE;
+        }
+        pts.insert(pts.end(), filt.begin(), filt.end());
+        pkey.insert(pkey.end(), fkey.begin(), fkey.end());
+        hc_cellmap_resort(m, pts, pkey, 0);
+    }
+    return nf;
+}
+
+int hc_cellmap_sizes(const hc_cellmap *m, int *n_cells, int *n_pts, int *frame)
+{
+    *n_cells = (int)m->ckey.size();
+    *n_pts = (int)m->pkey.size();
+    *frame = m->frame;
+    return 0;
+}
+
+int hc_cellmap_dump(const hc_cellmap *m, float *xyzi, int32_t *ijk, int32_t *start, int32_t *last)
+{
+    memcpy(xyzi, m->pts.data(), m->pts.size() * sizeof(float));
+    for (size_t c = 0; c < m->ckey.size(); c++) {
+        cell_unpack(m->ckey[c], ijk + 3 * c);
+        last[c] = m->clast[c];
+    }
+    for (size_t c = 0; c < m->cstart.size(); c++) start[c] = m->cstart[c];
+    return 0;
 }
 
 }  // extern "C"

@@ -64,3 +64,10 @@ def test_adapter_demo_matches_oracle(tmp_path, small_world, scans, downsample):
     assert h.add(fc, fs, pose)
     mc, ms = h.refresh()
     assert [int(v) for v in lines[3].split()] == [len(mc), len(ms)]
+    # ... and the cell maps (m_matching_mode == 1) fed by the same add()
+    h = History(4, 0.1, 0.4)
+    h.enable_cell_map(1.0, 5000)
+    h.add(fc, fs, pose)
+    cc, cs = h.refresh_cells(pose, (100.0, 100.0), 45.0, 1)
+    assert [int(v) for v in lines[4].split()] == [len(cc), len(cs), len(h.cells[1].cells), h.cells[1].n_points()]
+    assert len(cs) > 0.5 * len(ms)

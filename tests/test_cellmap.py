@@ -1,0 +1,261 @@
+"""Cell ("cube") match mode, SURVEY 8(f) row 2: Points_cloud_map<float> (cell_map_keyframe.hpp:477-790) and the cell
+branch of update_buff_for_matching (laser_mapping.hpp:471-513).
+CPU tier: the oracle restatement (oracle/orc_cellmap.py) against hand-checked cases, and against the serial host build of
+the device arithmetic and store layout (tests/hostcheck).  GPU tier: the device cell map, the history integration and
+the mapping loop in mode 1 against the oracle -- stores and match buffers bit-identical."""
+import numpy as np
+import pytest
+
+from loam_livox_amd import synth
+from oracle import orc
+from oracle.orc_cellmap import CellMap
+from oracle.orc_mapping import History, LaserMapping
+
+IDENT = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def clouds(seed=0, n_frames=8, n=2000, span=3.0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for f in range(n_frames):
+        c = rng.uniform(-span, span, (n, 4)).astype(np.float32)
+        if f in (4, 5, 6):
+            c[:, 0] += 10.0      # the sensor looks elsewhere for three frames: the first cells go stale
+        out.append(c)
+    return out
+
+
+def some_pose(k=0):
+    q = synth.quat_from_axis_angle(np.array([0.2, -0.1, 1.0]), np.deg2rad(25.0 + 40.0 * k))
+    return np.r_[q, [0.2, 0.1, -0.3]]
+
+
+def same_store(a, b):
+    for x, y, name in zip(a, b, ("xyz", "ijk", "start", "last")):
+        assert x.shape == y.shape, name
+        assert np.array_equal(bits(x), bits(y)) if x.dtype == np.float32 else np.array_equal(x, y), name
+
+
+# ------------------------------------------------------------------------------------------------------ CPU tier
+def test_cell_geometry_and_rounding():
+    m = CellMap(1.0)
+    assert m.box == np.float32(0.5) and m.half == np.float32(0.25)   # set_resolution halves (CMK:675-677), then CMK:559-560
+    # round((p - 0.25) / 0.5): 0.0 -> -0.5 -> -1 (half away from zero), 0.5 -> 0.5 -> 1, 0.49 -> 0
+    k, ok = m.cell_index(np.array([[0.0, 0.5, 0.49], [-0.5, 0.26, 1.0], [np.nan, 0, 0], [1e9, 0, 0]], np.float32))
+    assert ok.tolist() == [True, True, False, False]
+    assert k[0].tolist() == [-1, 1, 0] and k[1].tolist() == [-2, 0, 2]
+    assert np.array_equal(m.centre((1, 0, -1)), np.array([0.75, 0.25, -0.25], np.float32))
+
+
+def test_append_revisit_rule():
+    m = CellMap(1.0, minimum_revisit_threshold=3)
+    a = np.array([[0.3, 0.3, 0.3, 9.0]], np.float32)
+    b = np.array([[5.3, 0.3, 0.3, 9.0]], np.float32)
+    m.append(a); m.append(a)                      # frames 0, 1: same cell, refreshed
+    assert len(m.cells) == 1 and len(m.cell_points((0, 0, 0))) == 2 and m.cells[(0, 0, 0)]["last"] == 1
+    m.append(b); m.append(b)                      # frames 2, 3
+    m.append(np.r_[a, a])                         # frame 4: 4 - 1 >= 3 -> a fresh cell replaces the old one (CMK:742-754)
+    assert len(m.cell_points((0, 0, 0))) == 2 and m.cells[(0, 0, 0)]["last"] == 4 and m.frame == 5
+    m.append(np.zeros((0, 4), np.float32))        # an empty cloud still advances m_current_frame_idx (CMK:667)
+    assert m.frame == 6
+
+
+def test_fov_and_radius_selection():
+    m = CellMap(1.0)
+    pts = np.array([[5.1, 0.1, 0.1], [-5.1, 0.1, 0.1], [5.1, 4.1, 0.1], [5.1, 6.1, 0.1], [30.1, 0.1, 0.1]], np.float32)
+    m.append(np.c_[pts, np.zeros(5, np.float32)])
+    keys = m.select(IDENT, 20.0, 45.0)
+    # behind the sensor: out; atan(4.25/5.25) = 39 deg: in; atan(6.25/5.25) = 50 deg: out; 30 m: out of range
+    assert keys == [(10, 0, 0), (10, 8, 0)]
+    yaw180 = np.r_[synth.quat_from_axis_angle(np.array([0, 0, 1.0]), np.pi), [0, 0, 0]]
+    assert m.select(yaw180, 20.0, 45.0) == [(-11, 0, 0)]
+    assert len(m.select(IDENT, 100.0, 45.0)) == 3
+
+
+def test_query_filter_is_a_voxel_grid_per_cell():
+    m = CellMap(2.0)
+    rng = np.random.default_rng(3)
+    c = rng.uniform(0, 4, (3000, 4)).astype(np.float32)
+    m.append(c)
+    n_before = m.n_points()
+    cat, keys = m.query_filter(np.r_[0, 0, 0, 1, -5.0, 2.0, 2.0], 50.0, 60.0, 0.25, down_sample_replace=0)
+    assert m.n_points() == n_before
+    k, _ = m.cell_index(c[:, :3])
+    off = 0
+    for key in keys:
+        sel = np.all(k == np.array(key), axis=1)
+        want = orc.voxel_grid(np.c_[c[sel, :3], np.zeros(sel.sum(), np.float32)], 0.25)[1]
+        assert np.array_equal(bits(cat[off:off + len(want)]), bits(want))
+        off += len(want)
+    assert off == len(cat) and np.all(cat[:, 3] == 0)
+    cat2, _ = m.query_filter(np.r_[0, 0, 0, 1, -5.0, 2.0, 2.0], 50.0, 60.0, 0.25, down_sample_replace=1)
+    assert np.array_equal(bits(cat2), bits(cat)) and m.n_points() < n_before          # set_pointcloud (LM:492-495)
+
+
+@pytest.mark.parametrize("replace", [1, 0])
+def test_host_build_of_device_store_matches_oracle(replace):
+    from tests.hostcheck import hc
+    o, h = CellMap(1.0, 3), hc.CellMap(1.0, 3)
+    for f, c in enumerate(clouds()):
+        o.append(c); h.append(c)
+        same_store(o.dump(), h.dump())
+        assert h.sizes() == (len(o.cells), o.n_points(), o.frame)
+        if f % 2 == 1:
+            pose = some_pose(f)
+            ca, keys = o.query_filter(pose, 4.0, 45.0, 0.2, replace)
+            cb, nsel = h.query_filter(pose, 4.0, 45.0, 0.2, replace)
+            assert nsel == len(keys) > 20 and len(ca) > 100
+            assert np.array_equal(bits(ca), bits(cb))
+            same_store(o.dump(), h.dump())
+    # frame 7 came back to the first region after three frames away: those cells started over
+    assert o.n_points() < 8 * 2000 - 3000
+
+
+def test_host_build_large_coordinates_and_fine_leaf():
+    from tests.hostcheck import hc
+    rng = np.random.default_rng(9)
+    o, h = CellMap(0.6), hc.CellMap(0.6)
+    c = (rng.uniform(-2, 2, (4000, 4)) + np.array([4321.0, -987.0, 55.0, 0])).astype(np.float32)
+    o.append(c); h.append(c)
+    same_store(o.dump(), h.dump())
+    pose = np.r_[0, 0, 0, 1, 4315.0, -987.0, 55.0]
+    ca, keys = o.query_filter(pose, 30.0, 50.0, 0.05, 1)
+    cb, nsel = h.query_filter(pose, 30.0, 50.0, 0.05, 1)
+    assert nsel == len(keys) > 50 and np.array_equal(bits(ca), bits(cb))
+    same_store(o.dump(), h.dump())
+    with pytest.raises(ValueError):
+        h.query_filter(pose, 30.0, 50.0, 0.0002, 0)   # more than 1020 leaves across one cell
+
+
+def test_history_feeds_cell_maps_every_frame():
+    rng = np.random.default_rng(4)
+    h = History(maximum_history_size=2, line_res=0.2, plane_res=0.5)
+    h.enable_cell_map(1.0, 5000)
+    for k in range(4):
+        c = rng.uniform(-3, 3, (200, 4)).astype(np.float32)
+        s = rng.uniform(-3, 3, (800, 4)).astype(np.float32)
+        assert h.add(c, s, IDENT, t_step=0.5, angle_step=0.1) == (k < 2)   # history full and no motion -> not pushed ...
+    assert h.cells[0].frame == 4 and h.cells[1].frame == 4                # ... but appended to the cell maps (LM:1492-1493)
+    mc, ms = h.refresh_cells(np.r_[0, 0, 0, 1, -6.0, 0, 0], (100.0, 100.0), 45.0, 1)
+    assert 0 < len(mc) <= 800 and 0 < len(ms) <= 3200
+
+
+# ------------------------------------------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+@pytest.mark.parametrize("replace", [1, 0])
+def test_device_cell_map_bit_exact(gpu_lib, replace):
+    from loam_livox_amd.api import Cell_map
+    o, d = CellMap(1.0, 3), Cell_map(max_points=40000, resolution=1.0, minimum_revisit_threshold=3)
+    for f, c in enumerate(clouds()):
+        if f == 2:
+            c = c.copy(); c[5, 1] = np.nan; c[6, 2] = np.inf; c[7, 0] = 3.0e6   # dropped: non-finite / beyond the key range
+        o.append(c); d.append_cloud(c)
+        assert d.stats() == (len(o.cells), o.n_points(), o.frame)
+        same_store(o.dump(), d.dump())
+        if f % 2 == 1:
+            pose = some_pose(f)
+            ca, keys = o.query_filter(pose, 4.0, 45.0, 0.2, replace)
+            cb, nsel = d.query_filter(pose, 4.0, 45.0, 0.2, replace)
+            assert nsel == len(keys) > 20
+            assert np.array_equal(bits(ca), bits(cb))
+            same_store(o.dump(), d.dump())
+    d.append_cloud(np.zeros((0, 4), np.float32)); o.append(np.zeros((0, 4), np.float32))
+    assert d.stats()[2] == o.frame
+    with pytest.raises(RuntimeError):
+        d.query_filter(IDENT, 4.0, 45.0, 0.0002, 0)
+    with pytest.raises(RuntimeError):
+        d.append_cloud(np.zeros((50000, 4), np.float32))      # exceeds max_points
+    d.close()
+
+
+@pytest.mark.gpu
+def test_device_cell_map_large(gpu_lib):
+    """1.2 M points in ~10^5 cells: size-independent properties (every point lands in its own cell, order, counts)."""
+    from loam_livox_amd.api import Cell_map
+    rng = np.random.default_rng(11)
+    d = Cell_map(max_points=1 << 21, resolution=1.0)
+    o = CellMap(1.0)
+    total = 0
+    for f in range(3):
+        c = rng.uniform(-12, 12, (400000, 4)).astype(np.float32)
+        d.append_cloud(c)
+        total += len(c)
+    nc, npts, fr = d.stats()
+    assert npts == total and fr == 3
+    xyz, ijk, start, last = d.dump()
+    k, ok = o.cell_index(xyz)
+    assert ok.all()
+    cell_of_point = np.repeat(np.arange(nc), np.diff(start))
+    assert np.array_equal(k, ijk[cell_of_point].astype(np.int64))             # grouped by cell
+    key = ((ijk[:, 0].astype(np.int64) + (1 << 20)) << 42) + ((ijk[:, 1].astype(np.int64) + (1 << 20)) << 21) + ijk[:, 2] + (1 << 20)
+    assert np.all(np.diff(key) > 0) and last.max() == 2 and np.mean(last == 2) > 0.9   # cells ascending, most touched by the last cloud
+    o.cells = {tuple(k3): {"pts": [], "last": 0} for k3 in ijk.tolist()}
+    selected = set(o.select(IDENT, 8.0, 40.0))
+    n_selected_points = int(sum(start[i + 1] - start[i] for i, k3 in enumerate(map(tuple, ijk.tolist())) if k3 in selected))
+    cat, nsel = d.query_filter(IDENT, 8.0, 40.0, 0.25, 1)
+    nc2, npts2, _ = d.stats()
+    assert nsel == len(selected) and 0 < nsel < nc and nc2 == nc
+    assert npts2 == npts - n_selected_points + len(cat) and len(cat) < n_selected_points   # the leaves replaced the points
+    assert np.all(cat[:, 3] == 0)
+    kc, _ = o.cell_index(cat[:, :3])
+    assert all(tuple(r) in selected for r in kc.tolist())                     # a centroid stays inside its cell
+    cat2, nsel2 = d.query_filter(IDENT, 8.0, 40.0, 0.25, 1)                   # idempotent: already one point per leaf
+    assert nsel2 == nsel and np.array_equal(bits(cat2), bits(cat)) and d.stats()[1] == npts2
+    d.close()
+
+
+@pytest.mark.gpu
+def test_device_history_cell_mode_bit_exact(gpu_lib):
+    from loam_livox_amd.api import History_buffer, Map_buffer
+    rng = np.random.default_rng(4)
+    dev, ora = History_buffer(3, 4000, 0.2, 0.5), History(3, 0.2, 0.5)
+    dev.enable_cell_map(1 << 16, 1.0, 4)
+    ora.enable_cell_map(1.0, 4)
+    m = Map_buffer()
+    pose = IDENT.copy()
+    for k in range(7):
+        c = rng.uniform(-6, 6, (300 + 50 * k, 4)).astype(np.float32)
+        s = rng.uniform(-6, 6, (3000 + 100 * k, 4)).astype(np.float32)
+        if k == 2:
+            c = np.zeros((0, 4), np.float32)
+        if k in (4, 5):
+            pose = synth.pose_compose(pose, np.r_[synth.quat_from_axis_angle(np.array([0, 0, 1.0]), np.deg2rad(1.0 if k == 4 else 8.0)), [0.1, 0, 0]])
+        assert dev.add(c, s, pose, 0.5, 0.1) == ora.add(c, s, pose, 0.5, 0.1)
+        for kind in range(2):
+            same_store(ora.cells[kind].dump(), dev.cell_map(kind).dump())
+        view = synth.pose_compose(pose, np.r_[0, 0, 0, 1, -9.0, 0, 0])     # stand back so that the cloud is in the field of view
+        nc, ns = dev.refresh_cells(m, view, 12.0, 14.0, 50.0, 1)
+        mc, ms = ora.refresh_cells(view, (12.0, 14.0), 50.0, 1)
+        assert (nc, ns) == (len(mc), len(ms)) and ns > 500
+        assert np.array_equal(bits(dev.map_cloud(0)), bits(mc)) and np.array_equal(bits(dev.map_cloud(1)), bits(ms))
+    q = rng.uniform(-6, 6, (500, 3)).astype(np.float32)
+    idx, d2 = m.nearestKSearch(1, q, 50.0)
+    oi, od = orc.KdTree(ms).knn(q, 5)
+    assert np.array_equal(np.where(od < 50.0, oi, -1), idx)
+    dev.close(); m.close()
+
+
+@pytest.mark.gpu
+def test_device_mapping_loop_cell_mode_matches_oracle(gpu_lib, small_world):
+    from loam_livox_amd.mapping import Laser_mapping
+    from tests.test_mapping_sequence import MAP_ARGS, N_PTS, make_sequence
+    scans, truth = make_sequence(small_world["world"], n_frames=7)
+    args = dict(MAP_ARGS, matching_mode=1, maximum_in_fov_angle=50.0, threshold_cell_revisit=2000)
+    om = LaserMapping(**args)
+    lm = Laser_mapping(scan_points=N_PTS, cell_map_max_points=1 << 18, **args)
+    for k, xyzi in enumerate(scans):
+        ro = om.process_new_scan(xyzi)
+        rd = lm.process_new_scan(xyzi)
+        dt, dr = synth.pose_error(lm.pose, om.pose)
+        assert rd == ro == 1 and dt < 1e-7 and dr < 1e-7
+        assert lm.map_sizes == (len(om.maps[0]), len(om.maps[1]))
+        assert lm.last_report.n_blocks_last == om.report.n_blocks_last
+        if dt == 0.0 and dr == 0.0:
+            assert np.array_equal(bits(lm.history.map_cloud(1)), bits(om.maps[1]))
+    dt, dr = synth.pose_error(lm.pose, truth[len(scans) - 1])
+    assert dt < 0.03 and dr < 0.006 and lm.map_sizes[1] > 300
+    lm.close()
