@@ -322,6 +322,41 @@ int ll_cellmap_stats(const ll_cellmap *c, int64_t *n_cells, int64_t *n_points, i
 int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_points, int32_t *cell_ijk, int32_t *cell_start,
                     int32_t *cell_last_update, int64_t capacity_cells);
 
+/* Points_cloud_cell::determine_feature( if_recompute = 1 ) for every cell (cell_map_keyframe.hpp:436-473 with get_mean
+ * :225-237, get_covmat :280-315, covmat_eig_decompose :239-249; SURVEY 8(f) row 4, first half): float sums and second
+ * moments over the cell's points in insertion order (COMP_TYPE = float, :41), cov = (sum p p^T - n mean mean^T) / (n - 1),
+ * eigen decomposition, then  < 5 points or |centre - mean| > 0.75 cell edge -> sphere;  l1 / 3 > l0 -> plane, vector =
+ * eigenvector of l0;  l2 / 3 > l1 -> line, vector = eigenvector of l2;  otherwise sphere (vector reported as zero).
+ * feature_type: 0 sphere, 1 line, 2 plane (Feature_type, :46-51).  Outputs in the cell order of ll_cellmap_dump:
+ * feature_vector / mean / eigen_val [n_cells][3] (eigenvalues ascending), cov [n_cells][6] (xx xy xz yy yz zz); any may
+ * be NULL.  The eigen decomposition is a double-precision Jacobi iteration of the float covariance; eigenvectors are
+ * reported with their first non-zero component positive (Eigen's signs are arbitrary). */
+int ll_cellmap_features(ll_cellmap *c, int32_t *feature_type, float *feature_vector, float *mean, float *cov, float *eigen_val,
+                        int64_t capacity_cells);
+
+/* Key-frame descriptors over the cells of a cell map: Maps_keyframe::analyze ->
+ * extract_feature_mapping_new -> generate_feature_img (cell_map_keyframe.hpp:1486-1493, 1429-1484, 1385-1427) with the map
+ * standing for the key frame's cell set.  Every line / plane cell contributes its feature vector, rotated into the
+ * principal axes of the plane normals (eigen_decompose_of_featurevector, :1554-1567; largest eigenvalue first, third axis =
+ * first x second), to a 60 x 60 (phi, theta) direction histogram (feature_direction, :1071-1089), which is then blurred
+ * with a 9 x 9, sigma 4 Gaussian on the wrap-padded image (apply_guassian_blur, :1360-1372).
+ *   images[4][60*60]   m_feature_img_line, m_feature_img_plane, then the same two over the cells closer to the key-frame
+ *                      centre than m_roi_range (row = phi index, column = theta index)
+ *   ratio_nonzero[4]   ratio_of_nonzero_in_img of the four histograms before the blur (:1142-1152)
+ *   eigen_R[2][9]      the two rotations, row-major          n_vectors[4]   feature vectors per image
+ *   centre_and_range   get_center() (:1291-1301) and m_roi_range = element ceil((k - 1) * roi_ratio) of the k distinct
+ *                      centre distances (get_ratio_range_of_cell, :1303-1319; roi_ratio 0.9 in the reference, :1438);
+ *                      roi_ratio = 0 skips the two ROI images
+ * The reference iterates a std::set of cell pointers (address order) and takes Eigen's eigenvector signs; here cells come
+ * in cell-index order and eigenvectors have their first non-zero component positive.  OpenCV's float summation order in
+ * cv::GaussianBlur is not reproduced (kernel coefficients are cv::getGaussianKernel's). */
+int ll_cellmap_keyframe_images(ll_cellmap *c, float roi_ratio, float *images, float *ratio_nonzero, float *eigen_R, int32_t *n_vectors,
+                               float *centre_and_range);
+/* Maps_keyframe::max_similiarity_of_two_image (cell_map_keyframe.hpp:1155-1224, minimum_zero_ratio = 0): the maximum of
+ * cv::matchTemplate( wrap-padded img_b, img_a, CV_TM_CCORR_NORMED ), i.e. of the normalised correlation over circular
+ * shifts of -30 .. +30 bins along both axes.  img_a, img_b: 60 x 60 host images. */
+int ll_keyframe_similarity(int32_t device, const float *img_a, const float *img_b, float *similarity);
+
 /* The two cell maps of the mapping node, fed by every frame ll_history_add* receives (laser_mapping.hpp:1492-1493: the
  * voxel-filtered map-frame features, whether or not the frame enters the history), and the cell branch of
  * update_buff_for_matching: query + per-cell VoxelGrid (leaf line_res / plane_res) -> VoxelGrid of the concatenation ->

@@ -309,6 +309,25 @@ class Cell_map:
             check(min(0, self.L.ll_cellmap_result(self.h, ptr(out), nout.value)), "ll_cellmap_result")
         return out, nsel.value
 
+    def features(self):
+        """determine_feature for every cell (cell_map_keyframe.hpp:436-473), in the cell order of dump():
+        dict(type [c] (0 sphere, 1 line, 2 plane), vector [c,3], mean [c,3], cov [c,6], eigen_val [c,3])."""
+        nc = self.stats()[0]
+        out = dict(type=np.zeros(nc, np.int32), vector=np.zeros((nc, 3), np.float32), mean=np.zeros((nc, 3), np.float32),
+                   cov=np.zeros((nc, 6), np.float32), eigen_val=np.zeros((nc, 3), np.float32))
+        if nc > 0:
+            check(self.L.ll_cellmap_features(self.h, ptr(out["type"]), ptr(out["vector"]), ptr(out["mean"]), ptr(out["cov"]),
+                                             ptr(out["eigen_val"]), nc), "ll_cellmap_features")
+        return out
+
+    def keyframe_images(self, roi_ratio: float = 0.9):
+        """Maps_keyframe::analyze over the cells of this map (cell_map_keyframe.hpp:1385-1493): dict(images [4,60,60] =
+        line, plane, line_roi, plane_roi; ratio_nonzero [4]; eigen_R [2,3,3]; n_vectors [4]; centre [3]; roi_range)."""
+        img = np.zeros((4, 60, 60), np.float32)
+        ratio, R, nv, cr = np.zeros(4, np.float32), np.zeros((2, 3, 3), np.float32), np.zeros(4, np.int32), np.zeros(4, np.float32)
+        check(self.L.ll_cellmap_keyframe_images(self.h, roi_ratio, ptr(img), ptr(ratio), ptr(R), ptr(nv), ptr(cr)), "ll_cellmap_keyframe_images")
+        return dict(images=img, ratio_nonzero=ratio, eigen_R=R, n_vectors=nv, centre=cr[:3].copy(), roi_range=float(cr[3]))
+
     def dump(self):
         """(xyz [n,3] in (cell, insertion) order, cell indices [c,3], first point of each cell [c+1], last-update frame [c])"""
         nc, npts, _ = self.stats()
@@ -318,6 +337,16 @@ class Cell_map:
         last = np.zeros(max(nc, 1), np.int32)
         check(self.L.ll_cellmap_dump(self.h, ptr(xyzi), xyzi.shape[0], ptr(ijk), ptr(start), ptr(last), ijk.shape[0]), "ll_cellmap_dump")
         return xyzi[:npts, :3].copy(), ijk[:nc].copy(), start, last[:nc].copy()
+
+
+def keyframe_similarity(img_a, img_b, device: int = 0) -> float:
+    """Maps_keyframe::max_similiarity_of_two_image (cell_map_keyframe.hpp:1155-1224) of two 60 x 60 direction images."""
+    a, b = np.ascontiguousarray(img_a, np.float32), np.ascontiguousarray(img_b, np.float32)
+    if a.shape != (60, 60) or b.shape != (60, 60):
+        raise ValueError("direction images are 60 x 60")
+    out = C.c_float(0)
+    check(capi.load().ll_keyframe_similarity(device, ptr(a), ptr(b), C.byref(out)), "ll_keyframe_similarity")
+    return float(out.value)
 
 
 class Map_buffer:

@@ -106,6 +106,9 @@ SYMBOLS = {
     "ll_cellmap_result": (_i64, [_vp, _vp, _i64]),
     "ll_cellmap_stats": (_i32, [_vp, _vp, _vp, _vp]),
     "ll_cellmap_dump": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "ll_cellmap_features": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "ll_cellmap_keyframe_images": (_i32, [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "ll_keyframe_similarity": (_i32, [_i32, _vp, _vp, _vp]),
     "ll_history_enable_cell_map": (_i32, [_vp, _i64, C.c_float, _i32]),
     "ll_history_cell_map": (_vp, [_vp, _i32]),
     "ll_history_refresh_cells": (_i32, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),

@@ -955,6 +955,8 @@ struct ll_cellmap {
     CellMapDev dev{};
     float4 *d_in = nullptr;   // staging of host clouds (max_points)
     double *d_pose = nullptr;
+    CellStats *d_stats = nullptr;  // allocated by the first ll_cellmap_features / ll_cellmap_keyframe_images
+    KfOut *d_kf = nullptr;
 };
 
 static void cellmap_release(ll_cellmap *c)
@@ -964,6 +966,8 @@ static void cellmap_release(ll_cellmap *c)
     cellmap_free(c->dev);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_pose) (void)hipFree(c->d_pose);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_kf) (void)hipFree(c->d_kf);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1035,6 +1039,76 @@ extern "C" int ll_cellmap_stats(const ll_cellmap *c, int64_t *n_cells, int64_t *
     if (n_points) *n_points = c->dev.n_pts;
     if (frame_idx) *frame_idx = c->dev.frame;
     return 0;
+}
+
+extern "C" int ll_cellmap_features(ll_cellmap *c, int32_t *feature_type, float *feature_vector, float *mean, float *cov, float *eigen_val,
+                                   int64_t capacity_cells)
+{
+    if (!c) return set_err("ll_cellmap_features", "null argument");
+    const int nc = c->dev.n_cells;
+    if (capacity_cells < nc) return set_err("ll_cellmap_features", "buffer too small");
+    if (nc == 0) return 0;
+    HC(hipSetDevice(c->device));
+    if (!c->d_stats) DM(c->d_stats, (size_t)c->dev.cap);  // a cell holds at least one point
+    const char *err = nullptr;
+    if (cellmap_stats(c->dev, c->d_stats, c->stream, &err)) return set_err("ll_cellmap_features", err);
+    std::vector<CellStats> st(nc);
+    HC(hipMemcpyAsync(st.data(), c->d_stats, (size_t)nc * sizeof(CellStats), hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nc; i++) {
+        if (feature_type) feature_type[i] = st[i].type;
+        for (int d = 0; d < 3; d++) {
+            if (feature_vector) feature_vector[3 * (size_t)i + d] = st[i].vec[d];
+            if (mean) mean[3 * (size_t)i + d] = st[i].mean[d];
+            if (eigen_val) eigen_val[3 * (size_t)i + d] = st[i].eval[d];
+        }
+        if (cov)
+            for (int d = 0; d < 6; d++) cov[6 * (size_t)i + d] = st[i].cov[d];
+    }
+    return 0;
+}
+
+extern "C" int ll_cellmap_keyframe_images(ll_cellmap *c, float roi_ratio, float *images, float *ratio_nonzero, float *eigen_R,
+                                          int32_t *n_vectors, float *centre_and_range)
+{
+    if (!c) return set_err("ll_cellmap_keyframe_images", "null argument");
+    if (!(roi_ratio >= 0.f && roi_ratio <= 1.f)) return set_err("ll_cellmap_keyframe_images", "roi_ratio must lie in [0, 1]");
+    HC(hipSetDevice(c->device));
+    if (!c->d_stats) DM(c->d_stats, (size_t)c->dev.cap);
+    if (!c->d_kf) DM(c->d_kf, 1);
+    const char *err = nullptr;
+    if (cellmap_keyframe_images(c->dev, c->d_stats, roi_ratio, c->d_kf, c->stream, &err)) return set_err("ll_cellmap_keyframe_images", err);
+    std::vector<KfOut> h(1);
+    HC(hipMemcpyAsync(h.data(), c->d_kf, sizeof(KfOut), hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    const KfOut &k = h[0];
+    if (images) memcpy(images, k.img, sizeof(k.img));
+    if (ratio_nonzero) memcpy(ratio_nonzero, k.ratio, sizeof(k.ratio));
+    if (eigen_R) memcpy(eigen_R, k.R, sizeof(k.R));
+    if (n_vectors)
+        for (int i = 0; i < 4; i++) n_vectors[i] = k.n_vec[i];
+    if (centre_and_range) {
+        for (int d = 0; d < 3; d++) centre_and_range[d] = k.centre[d];
+        centre_and_range[3] = k.roi_range;
+    }
+    return 0;
+}
+
+extern "C" int ll_keyframe_similarity(int32_t device, const float *img_a, const float *img_b, float *similarity)
+{
+    if (!img_a || !img_b || !similarity) return set_err("ll_keyframe_similarity", "null argument");
+    if (check_device(device)) return -1;
+    const size_t n = (size_t)LL_KF_RES * LL_KF_RES;
+    float *d = nullptr;
+    DM(d, 2 * n + 1);
+    int rc = 0;
+    const char *err = nullptr;
+    if (hipMemcpy(d, img_a, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, img_b, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess || keyframe_similarity(d, d + n, d + 2 * n, nullptr, &err) ||
+        hipMemcpy(similarity, d + 2 * n, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = set_err("ll_keyframe_similarity", err ? err : "device copy failed");
+    (void)hipFree(d);
+    return rc;
 }
 
 extern "C" int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_points, int32_t *cell_ijk, int32_t *cell_start,

@@ -41,4 +41,23 @@ int cellmap_append(CellMapDev &m, const float4 *d_src, int n, hipStream_t s, con
 int cellmap_query_filter(CellMapDev &m, const double *d_pose, float radius, float max_fov_deg, float leaf, int replace, hipStream_t s,
                          const char **err);
 
+// result block of cellmap_keyframe_images (device memory)
+struct KfOut {
+    float img[4][LL_KF_RES * LL_KF_RES];  // m_feature_img_line, _plane, _line_roi, _plane_roi ([phi][theta], blurred)
+    float ratio[4];                       // ratio_of_nonzero_in_img of the same before the blur
+    float R[2][9];                        // m_eigen_R, m_eigen_R_roi (row-major)
+    int n_vec[4];                         // feature vectors that entered each image
+    float centre[3];                      // key-frame centre (get_center)
+    float roi_range;                      // m_roi_range
+    int n_distinct;
+};
+
+// Maps_keyframe::analyze over all cells of the map (CMK:1429-1493): cell features, ROI range, the four direction images
+int cellmap_keyframe_images(CellMapDev &m, CellStats *d_stats, float roi_ratio, KfOut *d_out, hipStream_t s, const char **err);
+// max_similiarity_of_two_image (CMK:1155-1224): d_a, d_b 60 x 60 device images
+int keyframe_similarity(const float *d_a, const float *d_b, float *d_result, hipStream_t s, const char **err);
+
+// determine_feature (CMK:436-473) for every cell, in cell-table order; d_out: device array of n_cells entries
+int cellmap_stats(CellMapDev &m, CellStats *d_out, hipStream_t s, const char **err);
+
 }  // namespace ll

@@ -35,6 +35,8 @@ typedef unsigned int u32;
         }                                     \
     } while (0)
 
+static inline int blocks(int n) { return (n + 255) / 256 > 0 ? (n + 255) / 256 : 1; }
+
 // position of `k` in the ascending table ckey[0 .. n), or -1
 __device__ __forceinline__ int cell_find(const u64 *ckey, int n, u64 k)
 {
@@ -247,6 +249,266 @@ __global__ __launch_bounds__(256) void cm_replace_kernel(int n_pts, const u64 *c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------- statistics
+// determine_feature for every cell (CMK:436-473): one thread per cell walks the cell's points (contiguous in the store)
+// twice -- sum, then the six second moments -- in insertion order, as the reference's float accumulators do.
+__global__ __launch_bounds__(128) void cm_stats_kernel(const float4 *pts, const u64 *ckey, const int *cstart, int n_cells, CellGeom g,
+                                                       CellStats *out)
+{
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (c >= n_cells) return;
+    int k[3];
+    cell_unpack(ckey[c], k);
+    float ctr[3];
+    cell_centre(k, g, ctr);
+    const int first = cstart[c];
+    CellStats s;
+    cell_stats((const float *)(pts + first), 4, cstart[c + 1] - first, ctr, g.box, s);
+    out[c] = s;
+}
+
+int cellmap_stats(CellMapDev &m, CellStats *d_out, hipStream_t s, const char **err)
+{
+    if (m.n_cells > 0) hipLaunchKernelGGL(cm_stats_kernel, dim3((m.n_cells + 127) / 128), dim3(128), 0, s, m.pts, m.ckey, m.cstart, m.n_cells, m.geom, d_out);
+    CMCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------- key-frame images
+// get_center (CMK:1291-1301): float sum of the cell centres in cell order, times (float)(1 / n)
+__global__ void cm_kf_centre_kernel(const u64 *ckey, int n_cells, CellGeom g, KfOut *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < n_cells; c++) {
+        int k[3];
+        cell_unpack(ckey[c], k);
+        float ctr[3];
+        cell_centre(k, g, ctr);
+        for (int d = 0; d < 3; d++) s[d] = s[d] + ctr[d];
+    }
+    const float inv = (float)(1.0 / (double)(float)n_cells);
+    for (int d = 0; d < 3; d++) out->centre[d] = s[d] * inv;
+}
+
+// |centre of the cell - key-frame centre| in float (CMK:1309-1315, 1462)
+__global__ __launch_bounds__(256) void cm_kf_dist_kernel(const u64 *ckey, int n_cells, CellGeom g, const KfOut *out, float *dist)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    int k[3];
+    cell_unpack(ckey[c], k);
+    float ctr[3];
+    cell_centre(k, g, ctr);
+    const float dx = ctr[0] - out->centre[0], dy = ctr[1] - out->centre[1], dz = ctr[2] - out->centre[2];
+    dist[c] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+__global__ __launch_bounds__(256) void cm_kf_distinct_kernel(const float *sorted, int n, u32 *flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+}
+
+// get_ratio_range_of_cell (CMK:1303-1319): element ceil((size - 1) * ratio) of the std::set<float> of distances
+__global__ __launch_bounds__(256) void cm_kf_pick_kernel(const float *sorted, const u32 *flag, const u32 *rank, int n, float ratio, KfOut *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int n_distinct = (int)(rank[n - 1] + flag[n - 1]);
+    const int target = (int)ceilf((float)(n_distinct - 1) * ratio);
+    if (flag[i] && (int)rank[i] == target) out->roi_range = sorted[i];
+    if (i == 0) out->n_distinct = n_distinct;
+}
+
+#define KF_THREADS 1024
+#define KF_BINS (LL_KF_RES * LL_KF_RES)
+
+// generate_feature_img (CMK:1385-1427) for the whole key frame (block 0) and for the cells within roi_range of its centre
+// (block 1).  One workgroup each: the work is a few passes over the cell statistics and a 60 x 60 image.
+__global__ __launch_bounds__(KF_THREADS) void cm_kf_image_kernel(const CellStats *st, const float *dist, int n_cells, int use_roi, KfOut *out)
+{
+    __shared__ double s_red[KF_THREADS / 64][6];
+    __shared__ float s_R[9];
+    __shared__ int s_hist[2][KF_BINS];
+    __shared__ float s_img[KF_BINS], s_tmp[KF_BINS];
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int roi = blockIdx.x;
+    if (roi && !use_roi) return;
+    const float range = out->roi_range;
+    for (int e = tid; e < KF_BINS; e += KF_THREADS) s_hist[0][e] = s_hist[1][e] = 0;
+    if (tid < 4) s_cnt[tid] = 0;
+    // eigen_decompose_of_featurevector (CMK:1554-1567): I + sum of (v v^T) (float products) in double, over the plane cells
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = tid; c < n_cells; c += KF_THREADS) {
+        if (st[c].type != CELL_FEATURE_PLANE || (roi && !(dist[c] < range))) continue;
+        const float *v = st[c].vec;
+        acc[0] += (double)(v[0] * v[0]);
+        acc[1] += (double)(v[0] * v[1]);
+        acc[2] += (double)(v[0] * v[2]);
+        acc[3] += (double)(v[1] * v[1]);
+        acc[4] += (double)(v[1] * v[2]);
+        acc[5] += (double)(v[2] * v[2]);
+    }
+    for (int e = 0; e < 6; e++) {  // fixed-order reduction: lanes, then waves
+        double x = acc[e];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) s_red[wave][e] = x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double m[6];
+        for (int e = 0; e < 6; e++) {
+            double x = 0.0;
+            for (int w = 0; w < KF_THREADS / 64; w++) x += s_red[w][e];
+            m[e] = x;
+        }
+        m[0] += 1.0;  // mat_cov.setIdentity()
+        m[3] += 1.0;
+        m[5] += 1.0;
+        double val[3], V[9];
+        sym3_eigen(m, val, V);
+        // rowwise().reverse(): largest eigenvalue first; the third axis is the cross product of the first two (CMK:1394-1396)
+        float R[9];
+        for (int k = 0; k < 3; k++) {
+            R[k * 3 + 0] = (float)V[k * 3 + 2];
+            R[k * 3 + 1] = (float)V[k * 3 + 1];
+        }
+        R[0 * 3 + 2] = R[1 * 3 + 0] * R[2 * 3 + 1] - R[2 * 3 + 0] * R[1 * 3 + 1];
+        R[1 * 3 + 2] = R[2 * 3 + 0] * R[0 * 3 + 1] - R[0 * 3 + 0] * R[2 * 3 + 1];
+        R[2 * 3 + 2] = R[0 * 3 + 0] * R[1 * 3 + 1] - R[1 * 3 + 0] * R[0 * 3 + 1];
+        for (int e = 0; e < 9; e++) s_R[e] = out->R[roi][e] = R[e];
+    }
+    __syncthreads();
+    // direction histograms (CMK:1409-1421): image 0 = line cells, 1 = plane cells
+    for (int c = tid; c < n_cells; c += KF_THREADS) {
+        const int type = st[c].type;
+        if (type == CELL_FEATURE_SPHERE || (roi && !(dist[c] < range))) continue;
+        const float *v = st[c].vec;
+        float a[3];
+        for (int j = 0; j < 3; j++) a[j] = (s_R[0 * 3 + j] * v[0] + s_R[1 * 3 + j] * v[1]) + s_R[2 * 3 + j] * v[2];  // R^T v
+        int pi, ti;
+        feature_direction(a, &pi, &ti);
+        const int which = type == CELL_FEATURE_PLANE ? 1 : 0;
+        atomicAdd(&s_hist[which][pi * LL_KF_RES + ti], 1);  // integer counts: order-independent
+        atomicAdd(&s_cnt[which], 1);
+    }
+    __syncthreads();
+    float gk[2 * LL_KF_BLUR + 1];
+    kf_gauss_kernel(gk);
+    for (int which = 0; which < 2; which++) {
+        // ratio_of_nonzero_in_img (CMK:1142-1152), then the 9 x 9 Gaussian on the wrap-padded image (CMK:1360-1372)
+        int nz = 0;
+        for (int e = tid; e < KF_BINS; e += KF_THREADS) {
+            s_img[e] = (float)s_hist[which][e];
+            nz += s_hist[which][e] >= 1 ? 1 : 0;
+        }
+        for (int off = 32; off > 0; off >>= 1) nz += __shfl_down(nz, off);
+        if (lane == 0 && nz) atomicAdd(&s_cnt[2 + which], nz);
+        __syncthreads();
+        for (int e = tid; e < KF_BINS; e += KF_THREADS) {  // along a row
+            const int r = e / LL_KF_RES, col = e % LL_KF_RES;
+            float x = 0.f;
+            for (int k = 0; k < 2 * LL_KF_BLUR + 1; k++) x = x + gk[k] * s_img[r * LL_KF_RES + (col + k - LL_KF_BLUR + LL_KF_RES) % LL_KF_RES];
+            s_tmp[e] = x;
+        }
+        __syncthreads();
+        float *dst = out->img[2 * roi + which];
+        for (int e = tid; e < KF_BINS; e += KF_THREADS) {  // along a column
+            const int r = e / LL_KF_RES, col = e % LL_KF_RES;
+            float x = 0.f;
+            for (int k = 0; k < 2 * LL_KF_BLUR + 1; k++) x = x + gk[k] * s_tmp[((r + k - LL_KF_BLUR + LL_KF_RES) % LL_KF_RES) * LL_KF_RES + col];
+            dst[e] = x;
+        }
+        __syncthreads();
+    }
+    if (tid < 2) {
+        out->n_vec[2 * roi + tid] = s_cnt[tid];
+        out->ratio[2 * roi + tid] = (float)s_cnt[2 + tid] / (float)KF_BINS;
+    }
+}
+
+// max_similiarity_of_two_image (CMK:1155-1224): cv::matchTemplate( wrap-padded b, a, CV_TM_CCORR_NORMED ) and its maximum,
+// i.e. the largest normalised correlation of a with b over the circular shifts -30 .. +30 of both axes.
+__global__ __launch_bounds__(KF_THREADS) void cm_kf_similarity_kernel(const float *a, const float *b, float *result)
+{
+    __shared__ float s_a[KF_BINS], s_b[KF_BINS];
+    __shared__ double s_w[KF_THREADS / 64][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double na = 0.0, nb = 0.0;
+    for (int e = tid; e < KF_BINS; e += KF_THREADS) {
+        s_a[e] = a[e];
+        s_b[e] = b[e];
+        na += (double)a[e] * (double)a[e];
+        nb += (double)b[e] * (double)b[e];
+    }
+    __syncthreads();
+    const int half = LL_KF_RES / 2, span = LL_KF_RES + 1;  // result is 61 x 61
+    double best = -1.0e300;
+    for (int sft = tid; sft < span * span; sft += KF_THREADS) {
+        const int Y = sft / span, X = sft % span;
+        double num = 0.0;
+        for (int i = 0; i < LL_KF_RES; i++) {
+            const int bi = (Y + i - half + LL_KF_RES) % LL_KF_RES;
+            for (int j = 0; j < LL_KF_RES; j++) num += (double)s_a[i * LL_KF_RES + j] * (double)s_b[bi * LL_KF_RES + (X + j - half + LL_KF_RES) % LL_KF_RES];
+        }
+        best = num > best ? num : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        na += __shfl_down(na, off);
+        nb += __shfl_down(nb, off);
+        const double o = __shfl_down(best, off);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) {
+        s_w[wave][0] = na;
+        s_w[wave][1] = nb;
+        s_w[wave][2] = best;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double A = 0.0, B = 0.0, M = -1.0e300;
+        for (int w = 0; w < KF_THREADS / 64; w++) {
+            A += s_w[w][0];
+            B += s_w[w][1];
+            M = s_w[w][2] > M ? s_w[w][2] : M;
+        }
+        const double t = sqrt(A * B);
+        *result = t > 0.0 ? (float)(M / t) : 0.0f;
+    }
+}
+
+int cellmap_keyframe_images(CellMapDev &m, CellStats *d_stats, float roi_ratio, KfOut *d_out, hipStream_t s, const char **err)
+{
+    CMCHK(hipMemsetAsync(d_out, 0, sizeof(KfOut), s));
+    if (m.n_cells == 0) return 0;
+    if (cellmap_stats(m, d_stats, s, err)) return -1;
+    const int nc = m.n_cells;
+    float *dist = (float *)m.val, *sorted = (float *)m.val2;  // scratch of the sorts, free between operations
+    const int use_roi = roi_ratio > 0.f ? 1 : 0;
+    if (use_roi) {
+        hipLaunchKernelGGL(cm_kf_centre_kernel, dim3(1), dim3(64), 0, s, m.ckey, nc, m.geom, d_out);
+        hipLaunchKernelGGL(cm_kf_dist_kernel, dim3(blocks(nc)), dim3(256), 0, s, m.ckey, nc, m.geom, d_out, dist);
+        size_t tb = m.tmp_bytes;
+        CMCHK(hipcub::DeviceRadixSort::SortKeys(m.tmp, tb, dist, sorted, nc, 0, 32, s));
+        hipLaunchKernelGGL(cm_kf_distinct_kernel, dim3(blocks(nc)), dim3(256), 0, s, sorted, nc, m.flag);
+        tb = m.tmp_bytes;
+        CMCHK(hipcub::DeviceScan::ExclusiveSum(m.tmp, tb, m.flag, m.rank, nc, s));
+        hipLaunchKernelGGL(cm_kf_pick_kernel, dim3(blocks(nc)), dim3(256), 0, s, sorted, m.flag, m.rank, nc, roi_ratio, d_out);
+    }
+    hipLaunchKernelGGL(cm_kf_image_kernel, dim3(2), dim3(KF_THREADS), 0, s, d_stats, dist, nc, use_roi, d_out);
+    CMCHK(hipGetLastError());
+    return 0;
+}
+
+int keyframe_similarity(const float *d_a, const float *d_b, float *d_result, hipStream_t s, const char **err)
+{
+    hipLaunchKernelGGL(cm_kf_similarity_kernel, dim3(1), dim3(KF_THREADS), 0, s, d_a, d_b, d_result);
+    CMCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 int cellmap_alloc(CellMapDev &m, int cap, float resolution, int revisit_threshold, const char **err)
 {
@@ -303,8 +565,6 @@ void cellmap_free(CellMapDev &m)
         if (p) (void)hipFree(p);
     memset(&m, 0, sizeof(m));
 }
-
-static inline int blocks(int n) { return (n + 255) / 256 > 0 ? (n + 255) / 256 : 1; }
 
 // pts / pkey [0 .. total) (dropped entries carry the NONE key) -> ordered store + rebuilt cell table.  n_appended: the
 // last n_appended entries are new points whose cells are stamped with the current frame.

@@ -111,6 +111,114 @@ class CellMap:
             cat.append(f)
         return (np.concatenate(cat, 0) if cat else np.zeros((0, 4), F)), keys
 
+    # Points_cloud_cell::determine_feature( if_recompute = 1 ), CMK:436-473 (get_mean :225-237, get_covmat :280-315 with
+    # COMP_TYPE float :41 and the non-incremental update :30, covmat_eig_decompose :239-249).  The eigen decomposition is
+    # LAPACK's (numpy.linalg.eigh) on the float covariance in double -- independent of the device's Jacobi iteration.
+    def features(self):
+        keys = sorted(self.cells)
+        n = len(keys)
+        out = dict(type=np.zeros(n, np.int32), vector=np.zeros((n, 3), F), mean=np.zeros((n, 3), F), cov=np.zeros((n, 6), F),
+                   eigen_val=np.zeros((n, 3), F), margin=np.full(n, np.inf))
+        ia, ib = [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]
+        for i, key in enumerate(keys):
+            p = self.cell_points(key)
+            cnt = len(p)
+            if cnt == 0:
+                continue
+            mean = np.add.accumulate(p, axis=0, dtype=F)[-1] / F(cnt)              # m_xyz_sum / size, sequential float sums
+            out["mean"][i] = mean
+            if cnt < 5:                                                             # CMK:446-451
+                continue
+            c = np.add.accumulate(p[:, ia] * p[:, ib], axis=0, dtype=F)[-1]          # CMK:304-307
+            cov = ((c - F(cnt) * (mean[ia] * mean[ib])) / F(cnt - 1)).astype(F)      # CMK:309-310
+            out["cov"][i] = cov
+            m = np.array([[cov[0], cov[1], cov[2]], [cov[1], cov[3], cov[4]], [cov[2], cov[4], cov[5]]], np.float64)
+            w, v = np.linalg.eigh(m)
+            ev = w.astype(F)
+            out["eigen_val"][i] = ev
+            d = self.centre(key) - mean
+            dist = np.sqrt(F(F(d[0] * d[0]) + F(d[1] * d[1])) + F(d[2] * d[2]), dtype=F)
+            lim = float(self.box) * 0.75
+            third = 1.0 / 3.0
+            # how far the cell is from each decision boundary (tests skip cells that sit on one)
+            out["margin"][i] = min(abs(float(dist) - lim) / lim,
+                                   abs(float(ev[1]) * third - float(ev[0])) / max(abs(float(ev[1])), 1e-30),
+                                   abs(float(ev[2]) * third - float(ev[1])) / max(abs(float(ev[2])), 1e-30))
+            if float(dist) > lim:                                                   # CMK:455-460
+                continue
+            if float(ev[1]) * third > float(ev[0]):                                  # CMK:462-467
+                out["type"][i], out["vector"][i] = 2, v[:, 0].astype(F)
+            elif float(ev[2]) * third > float(ev[1]):                                # CMK:468-472
+                out["type"][i], out["vector"][i] = 1, v[:, 2].astype(F)
+        return out
+
+    # Maps_keyframe::analyze over the cells of this map: get_center / get_ratio_range_of_cell (CMK:1291-1319),
+    # extract_feature_mapping_new (:1429-1484), generate_feature_img (:1385-1427), eigen_decompose_of_featurevector
+    # (:1554-1567), feature_direction (:1071-1089), apply_guassian_blur (:1360-1372, as a circular convolution in double).
+    # `features` may carry the labels / vectors of another implementation, to compare the image stage alone.
+    def keyframe_images(self, roi_ratio=0.9, features=None):
+        f = self.features() if features is None else features
+        keys = sorted(self.cells)
+        n = len(keys)
+        out = dict(images=np.zeros((4, 60, 60), F), ratio_nonzero=np.zeros(4, F), eigen_R=np.zeros((2, 3, 3), F), n_vectors=np.zeros(4, np.int32),
+                   centre=np.zeros(3, F), roi_range=0.0, near_bin_edge=0)
+        if n == 0:
+            return out
+        ctrs = np.array([self.centre(k) for k in keys], F)
+        member = [np.ones(n, bool)]
+        if roi_ratio > 0:
+            centre = np.add.accumulate(ctrs, axis=0, dtype=F)[-1] * F(1.0 / float(F(n)))
+            d = ctrs - centre
+            dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=F)
+            dv = np.unique(dist)                                                   # std::set<float>
+            rng_ = dv[int(np.ceil(F(len(dv) - 1) * F(roi_ratio)))]
+            out["centre"], out["roi_range"] = centre, float(rng_)
+            member.append(dist < rng_)
+        x = np.arange(9) - 4.0
+        gk = np.exp(-0.5 / 16.0 * x * x).astype(F)                                 # cv::getGaussianKernel( 9, 4, CV_32F )
+        gk = (gk.astype(np.float64) * (1.0 / gk.astype(np.float64).sum())).astype(F).astype(np.float64)
+        for roi, mem in enumerate(member):
+            pl = mem & (f["type"] == 2)
+            v = f["vector"][pl]
+            prod = (v[:, :, None] * v[:, None, :]).astype(F).astype(np.float64)    # ( v v^T ) in float, cast to double
+            w, V = np.linalg.eigh(np.eye(3) + prod.sum(0))
+            V = V[:, ::-1].astype(F)                                               # rowwise().reverse(): largest first
+            for j in range(2):                                                     # the device's sign convention
+                lead = V[:, j][np.nonzero(V[:, j])[0][0]]
+                if lead < 0:
+                    V[:, j] = -V[:, j]
+            V[:, 2] = np.array([V[1, 0] * V[2, 1] - V[2, 0] * V[1, 1], V[2, 0] * V[0, 1] - V[0, 0] * V[2, 1], V[0, 0] * V[1, 1] - V[1, 0] * V[0, 1]], F)
+            out["eigen_R"][roi] = V
+            for which, typ in ((0, 1), (1, 2)):
+                vv = f["vector"][mem & (f["type"] == typ)]
+                a = ((V[0][None, :] * vv[:, 0:1] + V[1][None, :] * vv[:, 1:2]) + V[2][None, :] * vv[:, 2:3]).astype(F)
+                a = np.where(a[:, 0:1] < 0, (a * F(-1.0)).astype(F), a).astype(np.float64)
+                phi = np.arctan2(a[:, 1], a[:, 0]) + np.pi / 2
+                with np.errstate(invalid="ignore"):
+                    theta = np.arcsin(a[:, 2]) + np.pi / 2
+                pf, tf = phi / (np.pi / 60), theta / (np.pi / 60)
+                out["near_bin_edge"] += int(np.sum(np.abs(pf - np.round(pf)) < 1e-9) + np.sum(np.abs(tf - np.round(tf)) < 1e-9))
+                pi_ = np.clip(np.floor(pf), 0, 59).astype(int)
+                ti_ = np.where(np.isnan(tf), np.where(a[:, 2] > 0, 59, 0), np.clip(np.floor(np.nan_to_num(tf)), 0, 59)).astype(int)
+                h = np.zeros((60, 60))
+                np.add.at(h, (pi_, ti_), 1.0)
+                out["n_vectors"][2 * roi + which] = len(vv)
+                out["ratio_nonzero"][2 * roi + which] = F(np.sum(h >= 1.0)) / F(3600)
+                blur = sum(gk[k] * np.roll(h, 4 - k, axis=1) for k in range(9))
+                blur = sum(gk[k] * np.roll(blur, 4 - k, axis=0) for k in range(9))
+                out["images"][2 * roi + which] = blur.astype(F)
+        return out
+
+    @staticmethod
+    def max_similarity(img_a, img_b):
+        """max_similiarity_of_two_image (CMK:1155-1224): max over circular shifts of the normalised correlation."""
+        a, b = np.asarray(img_a, np.float64), np.asarray(img_b, np.float64)
+        t = np.sqrt((a * a).sum() * (b * b).sum())
+        if not t > 0:
+            return 0.0
+        corr = np.real(np.fft.ifft2(np.conj(np.fft.fft2(a)) * np.fft.fft2(b)))   # corr[s] = sum a(i) b(i + s), all 60 x 60 shifts
+        return float(corr.max() / t)
+
     def dump(self):
         """points in (cell, insertion) order, cell indices, starts, last-update frames"""
         keys = sorted(self.cells)

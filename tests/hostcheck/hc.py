@@ -203,6 +203,22 @@ class CellMap:
             raise ValueError("leaf too small")
         return out[:n].copy(), nsel.value
 
+    def features(self):
+        nc = self.sizes()[0]
+        o = np.zeros((max(nc, 1), 16), np.float32)
+        self.L.hc_cellmap_features.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.hc_cellmap_features(self.h, o.ctypes.data)
+        o = o[:nc]
+        return dict(type=o[:, 0].astype(np.int32), vector=o[:, 1:4].copy(), mean=o[:, 4:7].copy(), cov=o[:, 7:13].copy(),
+                    eigen_val=o[:, 13:16].copy())
+
+    def keyframe_images(self, roi_ratio=0.9):
+        img = np.zeros((4, 60, 60), np.float32)
+        ratio, R, nv, cr = np.zeros(4, np.float32), np.zeros((2, 3, 3), np.float32), np.zeros(4, np.int32), np.zeros(4, np.float32)
+        self.L.hc_cellmap_keyframe.argtypes = [C.c_void_p, C.c_float] + [C.c_void_p] * 5
+        self.L.hc_cellmap_keyframe(self.h, roi_ratio, img.ctypes.data, ratio.ctypes.data, R.ctypes.data, nv.ctypes.data, cr.ctypes.data)
+        return dict(images=img, ratio_nonzero=ratio, eigen_R=R, n_vectors=nv, centre=cr[:3].copy(), roi_range=float(cr[3]))
+
     def dump(self):
         nc, npts, _ = self.sizes()
         xyzi = np.zeros((max(npts, 1), 4), np.float32)

@@ -742,6 +742,124 @@ int hc_cellmap_sizes(const hc_cellmap *m, int *n_cells, int *n_pts, int *frame)
     return 0;
 }
 
+// stands in for cm_stats_kernel: out per cell = type, vec[3], mean[3], cov[6], eval[3] (16 floats, type as float)
+int hc_cellmap_features(const hc_cellmap *m, float *out16)
+{
+    for (size_t c = 0; c < m->ckey.size(); c++) {
+        int k[3];
+        cell_unpack(m->ckey[c], k);
+        float ctr[3];
+        cell_centre(k, m->g, ctr);
+        CellStats s;
+        cell_stats(&m->pts[4 * (size_t)m->cstart[c]], 4, m->cstart[c + 1] - m->cstart[c], ctr, m->g.box, s);
+        float *o = out16 + 16 * c;
+        o[0] = (float)s.type;
+        for (int d = 0; d < 3; d++) {
+            o[1 + d] = s.vec[d];
+            o[4 + d] = s.mean[d];
+            o[13 + d] = s.eval[d];
+        }
+        for (int d = 0; d < 6; d++) o[7 + d] = s.cov[d];
+    }
+    return 0;
+}
+
+// stands in for cm_kf_centre / dist / pick / image kernels (serial; the PCA sums run in cell order)
+int hc_cellmap_keyframe(const hc_cellmap *m, float roi_ratio, float *img, float *ratio4, float *R18, int32_t *nvec4, float *centre_range4)
+{
+    const int nc = (int)m->ckey.size();
+    memset(img, 0, sizeof(float) * 4 * LL_KF_RES * LL_KF_RES);
+    for (int i = 0; i < 4; i++) ratio4[i] = 0.f, nvec4[i] = 0, centre_range4[i] = 0.f;
+    for (int i = 0; i < 18; i++) R18[i] = 0.f;
+    if (nc == 0) return 0;
+    std::vector<CellStats> st(nc);
+    std::vector<float> ctrs(3 * (size_t)nc), dist(nc, 0.f);
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < nc; c++) {
+        int k[3];
+        cell_unpack(m->ckey[c], k);
+        cell_centre(k, m->g, &ctrs[3 * (size_t)c]);
+        cell_stats(&m->pts[4 * (size_t)m->cstart[c]], 4, m->cstart[c + 1] - m->cstart[c], &ctrs[3 * (size_t)c], m->g.box, st[c]);
+        for (int d = 0; d < 3; d++) sum[d] = sum[d] + ctrs[3 * (size_t)c + d];
+    }
+    const int use_roi = roi_ratio > 0.f;
+    float range = 0.f;
+    if (use_roi) {
+        const float inv = (float)(1.0 / (double)(float)nc);
+        float ctr[3];
+        for (int d = 0; d < 3; d++) ctr[d] = centre_range4[d] = sum[d] * inv;
+        for (int c = 0; c < nc; c++) {
+            const float dx = ctrs[3 * (size_t)c] - ctr[0], dy = ctrs[3 * (size_t)c + 1] - ctr[1], dz = ctrs[3 * (size_t)c + 2] - ctr[2];
+            dist[c] = sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+        std::vector<float> srt = dist;
+        std::sort(srt.begin(), srt.end());
+        srt.erase(std::unique(srt.begin(), srt.end()), srt.end());
+        range = srt[(size_t)ceilf((float)(srt.size() - 1) * roi_ratio)];
+        centre_range4[3] = range;
+    }
+    float gk[2 * LL_KF_BLUR + 1];
+    kf_gauss_kernel(gk);
+    for (int roi = 0; roi < (use_roi ? 2 : 1); roi++) {
+        double mm[6] = {1, 0, 0, 1, 0, 1};
+        for (int c = 0; c < nc; c++) {
+            if (st[c].type != CELL_FEATURE_PLANE || (roi && !(dist[c] < range))) continue;
+            const float *v = st[c].vec;
+            mm[0] += (double)(v[0] * v[0]);
+            mm[1] += (double)(v[0] * v[1]);
+            mm[2] += (double)(v[0] * v[2]);
+            mm[3] += (double)(v[1] * v[1]);
+            mm[4] += (double)(v[1] * v[2]);
+            mm[5] += (double)(v[2] * v[2]);
+        }
+        double val[3], V[9];
+        sym3_eigen(mm, val, V);
+        float R[9];
+        for (int k = 0; k < 3; k++) {
+            R[k * 3 + 0] = (float)V[k * 3 + 2];
+            R[k * 3 + 1] = (float)V[k * 3 + 1];
+        }
+        R[0 * 3 + 2] = R[1 * 3 + 0] * R[2 * 3 + 1] - R[2 * 3 + 0] * R[1 * 3 + 1];
+        R[1 * 3 + 2] = R[2 * 3 + 0] * R[0 * 3 + 1] - R[0 * 3 + 0] * R[2 * 3 + 1];
+        R[2 * 3 + 2] = R[0 * 3 + 0] * R[1 * 3 + 1] - R[1 * 3 + 0] * R[0 * 3 + 1];
+        for (int e = 0; e < 9; e++) R18[9 * roi + e] = R[e];
+        std::vector<int> hist(2 * LL_KF_RES * LL_KF_RES, 0);
+        for (int c = 0; c < nc; c++) {
+            const int type = st[c].type;
+            if (type == CELL_FEATURE_SPHERE || (roi && !(dist[c] < range))) continue;
+            const float *v = st[c].vec;
+            float a[3];
+            for (int j = 0; j < 3; j++) a[j] = (R[0 * 3 + j] * v[0] + R[1 * 3 + j] * v[1]) + R[2 * 3 + j] * v[2];
+            int pi, ti;
+            feature_direction(a, &pi, &ti);
+            const int which = type == CELL_FEATURE_PLANE ? 1 : 0;
+            hist[which * LL_KF_RES * LL_KF_RES + pi * LL_KF_RES + ti]++;
+            nvec4[2 * roi + which]++;
+        }
+        for (int which = 0; which < 2; which++) {
+            const int *h = &hist[which * LL_KF_RES * LL_KF_RES];
+            int nz = 0;
+            std::vector<float> src(LL_KF_RES * LL_KF_RES), tmp(LL_KF_RES * LL_KF_RES);
+            for (int e = 0; e < LL_KF_RES * LL_KF_RES; e++) src[e] = (float)h[e], nz += h[e] >= 1;
+            ratio4[2 * roi + which] = (float)nz / (float)(LL_KF_RES * LL_KF_RES);
+            for (int e = 0; e < LL_KF_RES * LL_KF_RES; e++) {
+                const int r = e / LL_KF_RES, col = e % LL_KF_RES;
+                float x = 0.f;
+                for (int k = 0; k < 2 * LL_KF_BLUR + 1; k++) x = x + gk[k] * src[r * LL_KF_RES + (col + k - LL_KF_BLUR + LL_KF_RES) % LL_KF_RES];
+                tmp[e] = x;
+            }
+            float *dst = img + (size_t)(2 * roi + which) * LL_KF_RES * LL_KF_RES;
+            for (int e = 0; e < LL_KF_RES * LL_KF_RES; e++) {
+                const int r = e / LL_KF_RES, col = e % LL_KF_RES;
+                float x = 0.f;
+                for (int k = 0; k < 2 * LL_KF_BLUR + 1; k++) x = x + gk[k] * tmp[((r + k - LL_KF_BLUR + LL_KF_RES) % LL_KF_RES) * LL_KF_RES + col];
+                dst[e] = x;
+            }
+        }
+    }
+    return 0;
+}
+
 int hc_cellmap_dump(const hc_cellmap *m, float *xyzi, int32_t *ijk, int32_t *start, int32_t *last)
 {
     memcpy(xyzi, m->pts.data(), m->pts.size() * sizeof(float));

@@ -144,7 +144,156 @@ def test_history_feeds_cell_maps_every_frame():
     assert 0 < len(mc) <= 800 and 0 < len(ms) <= 3200
 
 
+def structured_cloud(seed=5, offset=(30.0, -20.0, 5.0)):
+    """planes, lines and blobs some tens of metres from the origin (the float second moments cancel there)"""
+    rng = np.random.default_rng(seed)
+    pts = []
+    for i in range(40):
+        o = rng.uniform(-8, 8, 3) + np.array(offset)
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        u = np.cross(n, [0, 0, 1.0]); u /= np.linalg.norm(u); v = np.cross(n, u)
+        if i % 3 == 0:
+            p = o + rng.uniform(-1.5, 1.5, (3000, 1)) * u + rng.uniform(-1.5, 1.5, (3000, 1)) * v + rng.normal(0, 0.01, (3000, 3))
+        elif i % 3 == 1:
+            p = o + rng.uniform(-2, 2, (800, 1)) * u + rng.normal(0, 0.01, (800, 3))
+        else:
+            p = o + rng.normal(0, 0.3, (500, 3))
+        pts.append(p)
+    c = np.concatenate(pts).astype(np.float32)
+    return np.c_[c, np.zeros(len(c), np.float32)]
+
+
+def same_features(fo, fd):
+    """oracle (LAPACK eigh) vs device arithmetic (double Jacobi): moments bit-identical, eigenvalues to float rounding,
+    labels identical away from the decision boundaries, feature vectors equal up to sign"""
+    assert np.array_equal(bits(fo["mean"]), bits(fd["mean"])) and np.array_equal(bits(fo["cov"]), bits(fd["cov"]))
+    scale = np.abs(fo["eigen_val"]).max(1) + 1e-30
+    assert (np.abs(fo["eigen_val"] - fd["eigen_val"]).max(1) / scale).max() < 3e-7
+    solid = fo["margin"] > 1e-3
+    assert solid.mean() > 0.95 and np.array_equal(fo["type"][solid], fd["type"][solid])
+    m = solid & (fo["type"] > 0)
+    assert np.abs(np.sum(fo["vector"][m] * fd["vector"][m], 1)).min() > 1 - 1e-5
+    assert np.all(fd["vector"][fd["type"] == 0] == 0)
+    v = fd["vector"][fd["type"] > 0]
+    lead = np.where(v[:, 0] != 0, v[:, 0], np.where(v[:, 1] != 0, v[:, 1], v[:, 2]))
+    assert np.all(lead > 0) and np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=1e-6)
+
+
+def test_cell_features_known_answers():
+    m = CellMap(2.0)                                        # cells of 1 m
+    g = np.linspace(0.05, 0.95, 10, dtype=np.float32)
+    plane = np.array([[x, y, 0.5] for x in g for y in g], np.float32)                   # z = 0.5 inside cell (0,0,0)
+    line = np.array([[x + 3.0, 0.5, 0.5] for x in np.linspace(0.05, 0.95, 30)], np.float32)   # along x in cell (3,0,0)
+    blob = np.random.default_rng(1).uniform(0.1, 0.9, (200, 3)).astype(np.float32) + np.float32([0, 3, 0])
+    few = np.array([[6.2, 0.2, 0.2], [6.4, 0.4, 0.4]], np.float32)                       # fewer than 5 points
+    corner = np.array([[9.02 + 0.01 * i, 0.02, 0.02 + 0.001 * i] for i in range(20)], np.float32)   # mean far from the centre
+    m.append(np.concatenate([plane, line, blob, few, corner]))
+    f = m.features()
+    keys = sorted(m.cells)
+    got = {k: (int(f["type"][i]), f["vector"][i]) for i, k in enumerate(keys)}
+    assert got[(0, 0, 0)][0] == 2 and abs(abs(got[(0, 0, 0)][1][2]) - 1) < 1e-5        # plane, normal = z
+    assert got[(3, 0, 0)][0] == 1 and abs(abs(got[(3, 0, 0)][1][0]) - 1) < 1e-5        # line, direction = x
+    assert got[(0, 3, 0)][0] == 0 and got[(6, 0, 0)][0] == 0 and got[(9, 0, 0)][0] == 0
+    i = keys.index((0, 0, 0))
+    assert np.allclose(f["mean"][i], [0.5, 0.5, 0.5], atol=1e-6) and np.allclose(f["eigen_val"][i][0], 0, atol=1e-7)
+
+
+def test_host_build_of_cell_statistics_matches_oracle():
+    from tests.hostcheck import hc
+    c = structured_cloud()
+    o, h = CellMap(1.0), hc.CellMap(1.0)
+    o.append(c); h.append(c)
+    fo = o.features()
+    assert np.bincount(fo["type"], minlength=3).min() > 50     # all three labels occur
+    same_features(fo, h.features())
+    o.query_filter(np.r_[0, 0, 0, 1, 20.0, -20.0, 5.0], 40.0, 60.0, 0.1, 1)     # statistics follow the points the cells hold
+    h.query_filter(np.r_[0, 0, 0, 1, 20.0, -20.0, 5.0], 40.0, 60.0, 0.1, 1)
+    same_features(o.features(), h.features())
+
+
+def same_keyframe(ko, kd):
+    assert ko["near_bin_edge"] == 0                                      # no vector sits on a histogram bin edge
+    assert np.array_equal(ko["n_vectors"], kd["n_vectors"]) and ko["n_vectors"].min() > 20
+    assert np.array_equal(bits(ko["ratio_nonzero"]), bits(kd["ratio_nonzero"]))
+    assert np.array_equal(bits(ko["centre"]), bits(kd["centre"])) and np.float32(ko["roi_range"]) == np.float32(kd["roi_range"])
+    assert np.abs(ko["eigen_R"] - kd["eigen_R"]).max() < 1e-6
+    for i in range(4):                                                   # blur: float sums here, double in the oracle
+        assert np.abs(ko["images"][i] - kd["images"][i]).max() < 2e-6 * max(1.0, float(ko["images"][i].max()))
+        assert abs(float(kd["images"][i].sum()) - ko["n_vectors"][i]) < 1e-2        # the Gaussian is normalised, the padding wraps
+
+
+def test_keyframe_images_host_build_matches_oracle():
+    from tests.hostcheck import hc
+    c = structured_cloud()
+    o, h = CellMap(1.0), hc.CellMap(1.0)
+    o.append(c); h.append(c)
+    ko = o.keyframe_images(0.9)
+    same_keyframe(ko, h.keyframe_images(0.9))
+    assert ko["n_vectors"][2] < ko["n_vectors"][0] and ko["n_vectors"][3] < ko["n_vectors"][1]     # the ROI drops the outer cells
+    k0 = h.keyframe_images(0.0)                                          # no ROI requested
+    assert np.all(k0["images"][2:] == 0) and np.array_equal(bits(k0["images"][:2]), bits(h.keyframe_images(0.9)["images"][:2]))
+    # R: orthonormal, right-handed, first axis = dominant plane-normal direction
+    R = ko["eigen_R"][0].astype(np.float64)
+    assert np.allclose(R.T @ R, np.eye(3), atol=1e-6) and abs(np.linalg.det(R) - 1) < 1e-6
+
+
+def test_keyframe_similarity_oracle_properties():
+    rng = np.random.default_rng(2)
+    a = rng.uniform(0, 1, (60, 60)).astype(np.float32) ** 8            # peaky, like a direction histogram
+    assert abs(CellMap.max_similarity(a, a) - 1.0) < 1e-12
+    assert abs(CellMap.max_similarity(a, np.roll(a, (7, -20), (0, 1))) - 1.0) < 1e-12      # found again under a circular shift
+    b = rng.uniform(0, 1, (60, 60)).astype(np.float32) ** 8
+    s_ab = CellMap.max_similarity(a, b)
+    assert 0 < s_ab < 0.6 and abs(s_ab - CellMap.max_similarity(b, a)) < 1e-12
+    assert CellMap.max_similarity(a, np.zeros((60, 60), np.float32)) == 0.0
+    # brute force over the 61 x 61 window positions of cv::matchTemplate on the wrap-padded image
+    pb = np.pad(b.astype(np.float64), 30, mode="wrap")
+    best = max(float((a * pb[y:y + 60, x:x + 60]).sum()) for y in range(61) for x in range(61))
+    assert abs(best / np.sqrt((a.astype(np.float64) ** 2).sum() * (b.astype(np.float64) ** 2).sum()) - s_ab) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+def test_device_keyframe_images_and_similarity(gpu_lib):
+    from loam_livox_amd.api import Cell_map, keyframe_similarity
+    ca, cb = structured_cloud(5), structured_cloud(6)
+    maps = []
+    for c in (ca, cb):
+        o, d = CellMap(1.0), Cell_map(max_points=1 << 17, resolution=1.0)
+        o.append(c); d.append_cloud(c)
+        ko, kd = o.keyframe_images(0.9), d.keyframe_images(0.9)
+        same_keyframe(ko, kd)
+        k0 = d.keyframe_images(0.0)
+        assert np.all(k0["images"][2:] == 0) and np.array_equal(bits(k0["images"][:2]), bits(kd["images"][:2]))
+        maps.append((ko, kd))
+        d.close()
+    (oa, da), (ob, db) = maps
+    for i in range(4):
+        for x, y in ((da["images"][i], da["images"][i]), (da["images"][i], db["images"][i]), (db["images"][i], np.roll(db["images"][i], (11, 5), (0, 1)))):
+            want = CellMap.max_similarity(x, y)
+            assert abs(keyframe_similarity(x, y) - want) < 1e-5
+    assert abs(keyframe_similarity(da["images"][1], da["images"][1]) - 1.0) < 1e-6
+    assert keyframe_similarity(da["images"][1], np.zeros((60, 60), np.float32)) == 0.0
+    e = Cell_map(max_points=1000, resolution=1.0)
+    assert np.all(e.keyframe_images(0.9)["images"] == 0)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_device_cell_statistics_match_oracle(gpu_lib):
+    from loam_livox_amd.api import Cell_map
+    c = structured_cloud()
+    o, d = CellMap(1.0), Cell_map(max_points=1 << 17, resolution=1.0)
+    o.append(c); d.append_cloud(c)
+    same_features(o.features(), d.features())
+    pose = np.r_[0, 0, 0, 1, 20.0, -20.0, 5.0]
+    o.query_filter(pose, 40.0, 60.0, 0.1, 1); d.query_filter(pose, 40.0, 60.0, 0.1, 1)
+    same_features(o.features(), d.features())
+    e = Cell_map(max_points=1000, resolution=1.0)
+    assert len(e.features()["type"]) == 0
+    d.close(); e.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("replace", [1, 0])
 def test_device_cell_map_bit_exact(gpu_lib, replace):
