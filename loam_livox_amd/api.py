@@ -237,12 +237,13 @@ class History_buffer:
     def enable_cell_map(self, max_points: int = 1 << 20, cell_resolution: float = 1.0, threshold_cell_revisit: int = 5000) -> None:
         """m_pt_cell_map_corners / m_pt_cell_map_planes (laser_mapping.hpp:274-275, 617-624): fed by every add*()."""
         check(self.L.ll_history_enable_cell_map(self.h, max_points, cell_resolution, threshold_cell_revisit), "ll_history_enable_cell_map")
+        self._cell_resolution = cell_resolution
 
     def cell_map(self, kind: int) -> "Cell_map":
         h = self.L.ll_history_cell_map(self.h, kind)
         if not h:
             raise RuntimeError("cell maps are not enabled")
-        return Cell_map(_borrowed=h)
+        return Cell_map(resolution=self._cell_resolution, _borrowed=h)
 
     def refresh_cells(self, map_buffer: "Map_buffer", pose, maximum_search_range_corner: float = 100.0,
                       maximum_search_range_surface: float = 100.0, maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1):
@@ -271,6 +272,7 @@ class Cell_map:
                  _borrowed=None):
         self.L = capi.load()
         self.owned = _borrowed is None
+        self.resolution = resolution
         if self.owned:
             self.h = C.c_void_p()
             check(self.L.ll_cellmap_create(device, max_points, resolution, minimum_revisit_threshold, C.byref(self.h)), "ll_cellmap_create")

@@ -75,6 +75,14 @@ class RegParams(C.Structure):
                          2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 20.0, 0.3, 100.0, 0.0, 1.0, 0, 0, 99999, 0)
 
 
+    @staticmethod
+    def code_defaults():
+        """The member initialisers of Point_cloud_registration alone (PCR:45-103): what a default-constructed registrar
+        (Scene_alignment::m_pc_reg, scene_alignment.hpp:32) runs with."""
+        return RegParams(0, 20, 100, 2, 5, 5, 1, 1, 101, 100, 0, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 200.0 / 50.0, 100.0 / 50.0, 100.0,
+                         0.0, 1.0, 0, 0, 100000, 0)
+
+
 class RegReport(C.Structure):
     _fields_ = [("final_cost", C.c_double), ("initial_cost", C.c_double), ("inlier_threshold", C.c_double),
                 ("angular_diff_deg", C.c_double), ("t_diff", C.c_double), ("icp_iterations", C.c_int),

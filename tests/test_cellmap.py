@@ -252,7 +252,60 @@ def test_keyframe_similarity_oracle_properties():
     assert abs(best / np.sqrt((a.astype(np.float64) ** 2).sum() * (b.astype(np.float64) ** 2).sum()) - s_ab) < 1e-9
 
 
+def keyframe_pair(seed=3):
+    """the structured scene as key frame a; the same scene under a small rigid motion, with noise and 80 % overlap, as b"""
+    c = structured_cloud(5)
+    rng = np.random.default_rng(seed)
+    T = np.r_[synth.quat_from_axis_angle(np.array([0.1, 0.2, 1.0]), np.deg2rad(1.5)), [0.35, -0.2, 0.1]]      # frame b -> frame a
+    R = synth.quat_to_mat(T[:4])
+    xyz = c[:, :3].astype(np.float64)
+    keep = rng.uniform(size=len(xyz)) < 0.8
+    b = ((xyz[keep] - T[4:]) @ R) + rng.normal(0, 0.005, (int(keep.sum()), 3))
+    a = xyz[rng.uniform(size=len(xyz)) < 0.8]
+    z = lambda p: np.c_[p, np.zeros(len(p))].astype(np.float32)
+    return z(a), z(b), T
+
+
+def test_oracle_scene_alignment_recovers_the_motion():
+    from oracle.orc_scene_alignment import SceneAlignment, keyframe_clouds
+    a, b, T = keyframe_pair()
+    ka, kb = CellMap(1.0), CellMap(1.0)
+    ka.append(a); kb.append(b)
+    line_a, plane_a, centre_a = keyframe_clouds(ka)
+    assert len(line_a) > 1000 and len(plane_a) > 10000 and np.all(line_a[:, 3] == 0)
+    sa = SceneAlignment()
+    thr = sa.find_tranfrom_of_two_mappings(ka, kb)
+    dt, dr = synth.pose_error(sa.pose, T)
+    assert dt < 0.03 and dr < 0.002 and 0 < thr < 0.2                 # from a 1.2 m centre offset to centimetres
+    assert len(sa.reports) == 3 and all(r.accepted for r in sa.reports)               # 8x, 4x and 1x resolution (SA:313-352)
+    assert sa.reports[0].n_blocks_last < sa.reports[2].n_blocks_last
+
+
 # ------------------------------------------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+def test_device_scene_alignment_matches_oracle(gpu_lib):
+    from loam_livox_amd.api import Cell_map
+    from loam_livox_amd.scene_alignment import Scene_alignment, keyframe_clouds as dev_clouds
+    from oracle.orc_scene_alignment import SceneAlignment, keyframe_clouds
+    a, b, T = keyframe_pair()
+    ka, kb = CellMap(1.0), CellMap(1.0)
+    da, db = Cell_map(max_points=1 << 17, resolution=1.0), Cell_map(max_points=1 << 17, resolution=1.0)
+    ka.append(a); kb.append(b); da.append_cloud(a); db.append_cloud(b)
+    for o, d in ((ka, da), (kb, db)):                                  # the same cells carry the same labels ...
+        assert np.array_equal(o.features()["type"], d.features()["type"])
+        for x, y in zip(keyframe_clouds(o), dev_clouds(d)):            # ... so the same clouds and centres go in
+            assert np.array_equal(bits(x), bits(y))
+    so, sd = SceneAlignment(), Scene_alignment()
+    thr_o, thr_d = so.find_tranfrom_of_two_mappings(ka, kb), sd.find_tranfrom_of_two_mappings(da, db)
+    dt, dr = synth.pose_error(sd.pose, so.pose)
+    assert dt < 1e-7 and dr < 1e-7 and abs(thr_o - thr_d) < 1e-9
+    assert [r.n_blocks_last for r in sd.reports] == [r.n_blocks_last for r in so.reports]
+    assert [r.icp_iterations for r in sd.reports] == [r.icp_iterations for r in so.reports]
+    dt, dr = synth.pose_error(sd.pose, T)
+    assert dt < 0.03 and dr < 0.002
+    da.close(); db.close()
+
+
 @pytest.mark.gpu
 def test_device_keyframe_images_and_similarity(gpu_lib):
     from loam_livox_amd.api import Cell_map, keyframe_similarity
