@@ -44,6 +44,7 @@ def parse():
                     "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
     ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--cpu-scans", type=int, default=3)
     return ap.parse_args()
 
@@ -190,7 +191,7 @@ def main():
 
     # secondary figure: the same workload in the other query mode (SURVEY 8d reports both), a short untimed-warm-up run
     q_pipe_extra = None
-    if not vox:
+    if not vox and not args.no_q_pipe:
         vq = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev))
 
         def step_q():
