@@ -1386,13 +1386,25 @@ extern "C" int ll_history_enable_cell_map(ll_history *h, int64_t max_points, flo
     if (h->cells[0]) return set_err("ll_history_enable_cell_map", "already enabled");
     if (max_points < h->max_pts) return set_err("ll_history_enable_cell_map", "max_points below max_points_per_frame");
     HC(hipSetDevice(h->device));
-    for (int k = 0; k < 2; k++) {
-        // laser_mapping.hpp:620-624: set_resolution( m_pt_cell_resolution ), m_minimum_revisit_threshold
-        if (ll_cellmap_create(h->device, max_points, cell_resolution, threshold_cell_revisit, &h->cells[k])) return -1;
-        DM(h->d_cmap[k], (size_t)max_points);
-    }
     const char *err = nullptr;
-    if (voxel_alloc(h->vox_cells, 1, (int)max_points, &err)) return set_err("ll_history_enable_cell_map", err);
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++) {
+        // laser_mapping.hpp:620-624: set_resolution( m_pt_cell_resolution ), m_minimum_revisit_threshold
+        ok = ll_cellmap_create(h->device, max_points, cell_resolution, threshold_cell_revisit, &h->cells[k]) == 0 &&
+             hipMalloc((void **)&h->d_cmap[k], (size_t)max_points * sizeof(float4)) == hipSuccess;
+    }
+    if (ok && voxel_alloc(h->vox_cells, 1, (int)max_points, &err)) ok = false;
+    if (!ok) {  // all or nothing: a half-enabled history would fail later in ll_history_refresh_cells
+        const std::string why = err ? std::string(err) : g_err;
+        voxel_free(h->vox_cells);
+        for (int k = 0; k < 2; k++) {
+            cellmap_release(h->cells[k]);
+            h->cells[k] = nullptr;
+            if (h->d_cmap[k]) (void)hipFree(h->d_cmap[k]);
+            h->d_cmap[k] = nullptr;
+        }
+        return set_err("ll_history_enable_cell_map", why.empty() ? "allocation failed" : why.c_str());
+    }
     return 0;
 }
 
