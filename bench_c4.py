@@ -61,9 +61,10 @@ def main():
     step = np.r_[synth.quat_from_axis_angle(np.array([0.1, 0.2, 1.0]), np.deg2rad(0.2 * sgn)), np.array([-0.02, 0.01 * sgn, 0.0])]  # backing away: the view widens
     ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
     scans, truth, cur = [], [], start
+    step_back = pose_inv(step, synth)
     for k in range(F):
-        if k >= 3:
-            cur = synth.pose_compose(cur, step)
+        if k >= 3:  # 25 frames out, 25 frames back: a long sequence stays inside the synthetic room
+            cur = synth.pose_compose(cur, step if ((k - 3) // 25) % 2 == 0 else step_back)
         scans.append(synth.make_moving_scan(world_model, 7000 + 1000 * rank + k, N, inc_true=ident, pose_start=cur, t_phase=0.13 * k).xyzi)
         truth.append(synth.pose_compose(pose_inv(start, synth), cur))
 
