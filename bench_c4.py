@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--plane-res", type=float, default=0.15)
     ap.add_argument("--line-res", type=float, default=0.1)
     ap.add_argument("--matching-mode", type=int, default=0, help="0 = history match buffer (shipped configs), 1 = cell maps (laser_mapping.hpp:689)")
+    ap.add_argument("--max-blocks", type=int, default=0, help="optimization/maximum_residual_blocks (200 in the shipped configs): random "
+                    "sub-sampling of the features on the library's reproducible stream; 0 = every feature is a residual block")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of rank 0's sequence also run through the CPU oracle (0 = skip)")
     args = ap.parse_args()
     import torch
@@ -71,7 +73,7 @@ def main():
     args_map = dict(maximum_history_size=args.history, init_accumulate_frames=2, line_res=args.line_res, plane_res=args.plane_res,
                     icp_max_iterations=10, ceres_max_iterations=20, max_allow_incre_R=20.0, max_allow_incre_T=0.3,
                     minimum_icp_R_diff=1e-3, minimum_icp_T_diff=1e-4, matching_mode=args.matching_mode,
-                    maximum_in_fov_angle=45.0)  # the ICP-diff defaults (0.01 deg / 1 cm, PCR:94-95) stop the ICP a
+                    maximum_in_fov_angle=45.0, maximum_residual_blocks=args.max_blocks)  # the ICP-diff defaults (0.01 deg / 1 cm, PCR:94-95) stop the ICP a
     # centimetre short of convergence every frame, and the lag accumulates in a map grown from those poses
     lm = Laser_mapping(scan_points=N, device=local_rank, **args_map)
     lm.process_new_scan(scans[0])  # warm-up of every kernel; the sequence restarts below

@@ -850,6 +850,7 @@ extern "C" int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_
 struct ll_voxel {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;  // the stream the current contents of dev.out were produced on
     hipEvent_t ev = nullptr;
     VoxelDev dev{};
 };
@@ -899,6 +900,7 @@ extern "C" int ll_voxel_filter(ll_voxel *v, int32_t n_clouds, const float *xyzi,
     HC(hipMemcpyAsync(v->dev.n, n_points, (size_t)n_clouds * sizeof(int), hipMemcpyHostToDevice, v->stream));
     const char *err = nullptr;
     if (voxel_filter(v->dev, v->dev.in, v->dev.n, stride_points, n_clouds, leaf, v->stream, &err)) return set_err("ll_voxel_filter", err);
+    v->last_stream = v->stream;
     HC(hipMemcpyAsync(out_xyzi, v->dev.out, total * sizeof(float4), hipMemcpyDeviceToHost, v->stream));
     HC(hipMemcpyAsync(n_out, v->dev.n_out, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost, v->stream));
     std::vector<int> st(n_clouds);
@@ -914,6 +916,7 @@ extern "C" int ll_voxel_counts(ll_voxel *v, int32_t n_clouds, int32_t *n_out, in
     if (!v || n_clouds < 1 || n_clouds > v->dev.max_clouds) return set_err("ll_voxel_counts", "bad argument");
     HC(hipSetDevice(v->device));
     HC(hipStreamSynchronize(v->stream));
+    if (v->last_stream && v->last_stream != v->stream) HC(hipStreamSynchronize(v->last_stream));
     if (n_out) HC(hipMemcpy(n_out, v->dev.n_out, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost));
     if (status) HC(hipMemcpy(status, v->dev.status, (size_t)n_clouds * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
@@ -939,6 +942,7 @@ extern "C" int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe
         return set_err("ll_reg_enqueue_fe_downsampled", err);
     if (voxel_filter(vs->dev, fe->dev.surf_feat, fe->dev.n_surf, fe->dev.stride, n_scans, ls, r->stream, &err))
         return set_err("ll_reg_enqueue_fe_downsampled", err);
+    vc->last_stream = vs->last_stream = r->stream;
     r->dev.corner_feat = vc->dev.out;
     r->dev.surf_feat = vs->dev.out;
     r->dev.n_corner = vc->dev.n_out;
@@ -1309,7 +1313,9 @@ extern "C" int ll_history_add_voxel(ll_history *h, ll_voxel *vc, ll_voxel *vs, i
     if (vc->device != h->device || vs->device != h->device) return set_err("ll_history_add_voxel", "handles live on different devices");
     if (cloud < 0 || cloud >= vc->dev.max_clouds || cloud >= vs->dev.max_clouds) return set_err("ll_history_add_voxel", "cloud index out of range");
     HC(hipSetDevice(h->device));
-    HC(hipDeviceSynchronize());
+    // wait for the filters' producers only (a device-wide barrier would serialise independent sequences sharing the GPU)
+    if (vc->last_stream) HC(hipStreamSynchronize(vc->last_stream));
+    if (vs->last_stream && vs->last_stream != vc->last_stream) HC(hipStreamSynchronize(vs->last_stream));
     int nc = 0, ns = 0;
     HC(hipMemcpy(&nc, vc->dev.n_out + cloud, sizeof(int), hipMemcpyDeviceToHost));
     HC(hipMemcpy(&ns, vs->dev.n_out + cloud, sizeof(int), hipMemcpyDeviceToHost));

@@ -70,7 +70,8 @@ class LaserMapping:
     def __init__(self, maximum_history_size=100, line_res=0.1, plane_res=0.4, init_accumulate_frames=50, input_downsample_mode=1,
                  icp_max_iterations=20, ceres_max_iterations=100, max_allow_incre_R=4.0, max_allow_incre_T=2.0, max_allow_final_cost=100.0,
                  minimum_icp_R_diff=0.01, minimum_icp_T_diff=0.01, matching_mode=0, cell_resolution=1.0, threshold_cell_revisit=5000,
-                 maximum_search_range_corner=100.0, maximum_search_range_surface=100.0, maximum_in_fov_angle=30.0, down_sample_replace=1):
+                 maximum_search_range_corner=100.0, maximum_search_range_surface=100.0, maximum_in_fov_angle=30.0, down_sample_replace=1,
+                 maximum_residual_blocks=0, subsample_seed=1):
         self.hist = History(maximum_history_size, line_res, plane_res)
         self.mode = matching_mode
         self.cell_args = ((maximum_search_range_corner, maximum_search_range_surface), maximum_in_fov_angle, down_sample_replace)
@@ -82,6 +83,8 @@ class LaserMapping:
         self.prm.para_max_angular_rate, self.prm.para_max_speed, self.prm.max_final_cost = max_allow_incre_R, max_allow_incre_T, max_allow_final_cost
         self.prm.mapping_init_accumulate_frames = init_accumulate_frames
         self.prm.minimum_icp_R_diff, self.prm.minimum_icp_T_diff = minimum_icp_R_diff, minimum_icp_T_diff
+        if maximum_residual_blocks > 0:    # optimization/maximum_residual_blocks: sub-sampling on the reproducible stream (PCR:232-238)
+            self.prm.maximum_allow_residual_block, self.prm.subsample_seed = maximum_residual_blocks, subsample_seed
         self.frame = 0
         self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
         self.maps = [np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)]
