@@ -62,6 +62,14 @@ struct MapKind {
     int64_t n_valid = 0;        // finite points stored in the grid
     Grid grid{};                // device pointers + geometry
     size_t ncell = 0;
+    // Buffers are kept between builds and only grow: the mapping loop rebuilds its match buffer every frame
+    // (laser_mapping.hpp:539-546), and a hipMalloc / hipFree pair per temporary costs more than the build itself.
+    size_t cap_pts = 0, cap_cells = 0;       // capacity of pts / cell_start (elements)
+    size_t cap_n = 0, cap_tmp = 0;           // capacity of the per-point scratch (elements) and of b_tmp (bytes)
+    unsigned int *b_keys = nullptr, *b_keys2 = nullptr;
+    int *b_vals = nullptr, *b_vals2 = nullptr, *b_counts = nullptr;   // b_counts shares cap_cells
+    void *b_tmp = nullptr;
+    float *b_mm = nullptr;
 };
 
 // builds the grid for `n` device-resident raw points (stride floats apart); fills mk. Returns 0 or a HIP error.

@@ -93,19 +93,36 @@ __global__ void gather_kernel(const float *raw, int stride, int64_t n_valid, con
     pts[j] = p;
 }
 
+// grow-only device buffer: reallocated (with 25 % headroom) when `need` elements do not fit
+template <typename T>
+static int grow(T **p, size_t *cap, size_t need, const char **err)
+{
+    if (need <= *cap && *p) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4 + 16;
+    HIPCHK(hipMalloc((void **)p, want * sizeof(T)));
+    *cap = want;
+    return 0;
+}
+
 int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err)
 {
-    map_free(mk);
+    if (mk.pts16) (void)hipFree(mk.pts16);  // a previous fp16 conversion does not survive a rebuild
+    if (mk.perm) (void)hipFree(mk.perm);
+    mk.pts16 = nullptr;
+    mk.perm = nullptr;
     mk.n = n;
-    float *d_mm = nullptr;
-    HIPCHK(hipMalloc(&d_mm, 6 * sizeof(float)));
+    mk.n_valid = 0;
+    if (!mk.b_mm) HIPCHK(hipMalloc((void **)&mk.b_mm, 6 * sizeof(float)));
+    float *d_mm = mk.b_mm;
     const float init[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, s));
     if (n > 0) hipLaunchKernelGGL(aabb_kernel, dim3(1024), dim3(256), 0, s, d_raw, stride, n, d_mm, d_mm + 3);
     float mm[6];
     HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(d_mm));
     Grid g{};
     if (!(mm[0] <= mm[3])) {  // no finite point
         mm[0] = mm[1] = mm[2] = 0.f;
@@ -135,16 +152,18 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
     const size_t ncell = (size_t)g.nx * g.ny * g.nz;
     mk.ncell = ncell;
 
-    unsigned int *d_keys = nullptr, *d_keys2 = nullptr;
-    int *d_vals = nullptr, *d_vals2 = nullptr, *d_counts = nullptr;
-    void *d_tmp = nullptr;
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    HIPCHK(hipMalloc(&d_keys, nn * sizeof(unsigned int)));
-    HIPCHK(hipMalloc(&d_keys2, nn * sizeof(unsigned int)));
-    HIPCHK(hipMalloc(&d_vals, nn * sizeof(int)));
-    HIPCHK(hipMalloc(&d_vals2, nn * sizeof(int)));
-    HIPCHK(hipMalloc(&d_counts, (ncell + 1) * sizeof(int)));
-    HIPCHK(hipMalloc(&mk.cell_start, (ncell + 1) * sizeof(int)));
+    {   // per-point scratch and the cell tables; buffers of one group share a capacity (same need, same growth)
+        size_t c[4] = {mk.cap_n, mk.cap_n, mk.cap_n, mk.cap_n}, k[2] = {mk.cap_cells, mk.cap_cells};
+        mk.cap_n = mk.cap_cells = 0;  // stays 0 if an allocation fails half way: the next build starts over
+        if (grow(&mk.b_keys, &c[0], nn, err) || grow(&mk.b_keys2, &c[1], nn, err) || grow(&mk.b_vals, &c[2], nn, err) ||
+            grow(&mk.b_vals2, &c[3], nn, err) || grow(&mk.b_counts, &k[0], ncell + 1, err) || grow(&mk.cell_start, &k[1], ncell + 1, err))
+            return -1;
+        mk.cap_n = c[0];
+        mk.cap_cells = k[0];
+    }
+    unsigned int *d_keys = mk.b_keys, *d_keys2 = mk.b_keys2;
+    int *d_vals = mk.b_vals, *d_vals2 = mk.b_vals2, *d_counts = mk.b_counts;
     HIPCHK(hipMemsetAsync(d_counts, 0, (ncell + 1) * sizeof(int), s));
     if (n > 0)
         hipLaunchKernelGGL(cellkey_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_raw, stride, n, g,
@@ -157,7 +176,18 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
     if (n > 0)
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, d_keys, d_keys2, d_vals, d_vals2, (int)n, 0, end_bit, s));
     if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
-    HIPCHK(hipMalloc(&d_tmp, tmp_bytes > 0 ? tmp_bytes : 16));
+    {
+        char *t = (char *)mk.b_tmp;
+        size_t c = mk.cap_tmp;
+        if (grow(&t, &c, tmp_bytes > 0 ? tmp_bytes : 16, err)) {
+            mk.b_tmp = nullptr;
+            mk.cap_tmp = 0;
+            return -1;
+        }
+        mk.b_tmp = t;
+        mk.cap_tmp = c;
+    }
+    void *d_tmp = mk.b_tmp;
     size_t tb = tmp_bytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_counts, mk.cell_start, (int)(ncell + 1), s));
     tb = tmp_bytes;
@@ -167,17 +197,11 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
     HIPCHK(hipMemcpyAsync(&n_valid, mk.cell_start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     mk.n_valid = n_valid;
-    HIPCHK(hipMalloc(&mk.pts, (size_t)(n_valid > 0 ? n_valid : 1) * sizeof(f4)));
+    if (grow(&mk.pts, &mk.cap_pts, (size_t)(n_valid > 0 ? n_valid : 1), err)) return -1;
     if (n_valid > 0)
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, s, d_raw, stride,
                            (int64_t)n_valid, d_vals2, mk.pts);
     HIPCHK(hipStreamSynchronize(s));
-    (void)hipFree(d_keys);
-    (void)hipFree(d_keys2);
-    (void)hipFree(d_vals);
-    (void)hipFree(d_vals2);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_tmp);
     g.pts = mk.pts;
     g.cell_start = mk.cell_start;
     mk.grid = g;
@@ -186,16 +210,10 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
 
 void map_free(MapKind &mk)
 {
-    if (mk.pts) (void)hipFree(mk.pts);
-    if (mk.cell_start) (void)hipFree(mk.cell_start);
-    if (mk.pts16) (void)hipFree(mk.pts16);
-    if (mk.perm) (void)hipFree(mk.perm);
-    mk.pts = nullptr;
-    mk.cell_start = nullptr;
-    mk.pts16 = nullptr;
-    mk.perm = nullptr;
-    mk.n = mk.n_valid = 0;
-    mk.ncell = 0;
+    void *ptrs[] = {mk.pts, mk.cell_start, mk.pts16, mk.perm, mk.b_keys, mk.b_keys2, mk.b_vals, mk.b_vals2, mk.b_counts, mk.b_tmp, mk.b_mm};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    mk = MapKind{};
 }
 
 // ---- fp16-point records (BASELINE config C5) ---------------------------------------------------------------------
@@ -297,6 +315,7 @@ int map_to_f16(MapKind &mk, hipStream_t s, const char **err)
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(mk.pts));
     mk.pts = nullptr;
+    mk.cap_pts = 0;
     mk.grid.pts = nullptr;
     mk.grid.pts16 = mk.pts16;
     mk.grid.perm = mk.perm;
