@@ -260,7 +260,7 @@ def main():
         "ambiguous_labels": int(n_amb), "setup_s": {"synthetic_data": round(t_data, 1), "map_upload_grid_build": round(t_map, 2)},
     }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg belongs to the N = 1 line only
         # CPU baseline: the oracle (C restatement of the reference algorithm; the reference binary cannot be built
         # here) on one host core, bounded sample of the same workload.  It is the checker, never the product.
         from oracle import orc
