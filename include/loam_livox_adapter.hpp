@@ -292,6 +292,64 @@ class History_buffer {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+// Points_cloud_map<float> (cell_map_keyframe.hpp:477-790) with the cell statistics and key-frame descriptors the loop
+// detection reads (determine_feature :436-473, Maps_keyframe::analyze :1385-1493), resident on the device.
+class Points_cloud_map {
+   public:
+    enum Feature_type { e_feature_sphere = 0, e_feature_line = 1, e_feature_plane = 2 };  // cell_map_keyframe.hpp:46-51
+
+    explicit Points_cloud_map(int64_t max_points, float resolution = 1.0f, int m_minimum_revisit_threshold = 2147483647, int device = 0)
+    {
+        check(ll_cellmap_create(device, max_points, resolution, m_minimum_revisit_threshold, &h_), "ll_cellmap_create");
+    }
+    ~Points_cloud_map()
+    {
+        if (h_) ll_cellmap_destroy(h_);
+    }
+    Points_cloud_map(const Points_cloud_map &) = delete;
+    Points_cloud_map &operator=(const Points_cloud_map &) = delete;
+
+    template <class Cloud>
+    void append_cloud(const Cloud &cloud)  // :619-672 (intensity is not kept, :82)
+    {
+        const std::vector<float> v = cloud_to_xyzi(cloud);
+        check(ll_cellmap_append(h_, v.data(), (int32_t)(v.size() / 4)), "ll_cellmap_append");
+    }
+    int64_t get_cells_size() const  // :551-554
+    {
+        int64_t n = 0;
+        check(ll_cellmap_stats(h_, &n, nullptr, nullptr), "ll_cellmap_stats");
+        return n;
+    }
+    // m_feature_type / m_feature_vector of every cell, in ascending cell-index order
+    void determine_features(std::vector<int32_t> &feature_type, std::vector<float> &feature_vector)
+    {
+        const int64_t n = get_cells_size();
+        feature_type.assign((size_t)n, 0);
+        feature_vector.assign((size_t)n * 3, 0.f);
+        check(ll_cellmap_features(h_, feature_type.data(), feature_vector.data(), nullptr, nullptr, nullptr, n), "ll_cellmap_features");
+    }
+    // m_feature_img_line, m_feature_img_plane, m_feature_img_line_roi, m_feature_img_plane_roi (60 x 60 each, row = phi bin)
+    // and m_ratio_nonzero_line / _plane of the four histograms; the map stands for the key frame's cell set
+    void analyze(std::vector<float> &images, float ratio_nonzero[4], float roi_ratio = 0.9f)
+    {
+        images.assign((size_t)4 * 60 * 60, 0.f);
+        check(ll_cellmap_keyframe_images(h_, roi_ratio, images.data(), ratio_nonzero, nullptr, nullptr, nullptr), "ll_cellmap_keyframe_images");
+    }
+    // Maps_keyframe::max_similiarity_of_two_image (:1155-1196) of two 60 x 60 images
+    static float max_similiarity_of_two_image(const float *img_a, const float *img_b, int device = 0)
+    {
+        float s = 0.f;
+        check(ll_keyframe_similarity(device, img_a, img_b, &s), "ll_keyframe_similarity");
+        return s;
+    }
+    ll_cellmap *handle() { return h_; }
+
+   private:
+    ll_cellmap *h_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------------------
 class Point_cloud_registration {
    public:
     // configuration fields with the reference names and defaults (point_cloud_registration.hpp:45-103)

@@ -113,12 +113,33 @@ int main(int argc, char **argv)
             n_hist_surf = buf_s.size();
         }
 
+        // the scan's full cloud through a cell map: labels, key-frame images, self-similarity (cell_map_keyframe.hpp)
+        int64_t n_map_cells = 0;
+        int n_line_cells = 0, n_plane_cells = 0;
+        float self_sim = 0.f, ratio_nz[4] = {0, 0, 0, 0};
+        {
+            loam_livox_hip::Points_cloud_map cell_map(1 << 16, 1.0f);
+            cell_map.append_cloud(full);
+            n_map_cells = cell_map.get_cells_size();
+            std::vector<int32_t> ftype;
+            std::vector<float> fvec;
+            cell_map.determine_features(ftype, fvec);
+            for (int32_t t : ftype) {
+                n_line_cells += t == loam_livox_hip::Points_cloud_map::e_feature_line;
+                n_plane_cells += t == loam_livox_hip::Points_cloud_map::e_feature_plane;
+            }
+            std::vector<float> images;
+            cell_map.analyze(images, ratio_nz);
+            self_sim = loam_livox_hip::Points_cloud_map::max_similiarity_of_two_image(images.data() + 3600, images.data() + 3600);
+        }
+
         FILE *o = fopen(argv[5], "w");
         fprintf(o, "%d %zu %zu %zu %d %zu %zu\n", m_laser_scan_number, n_corner_raw, n_surf_raw, full.size(), reg_res, corners->size(), surface->size());
         for (int i = 0; i < 7; i++) fprintf(o, "%.17g ", pc_reg.m_para_buffer_RT[i]);
         fprintf(o, "\n%.9g %.9g\n", piece_start, piece_end);
         fprintf(o, "%zu %zu\n", n_hist_corner, n_hist_surf);
         fprintf(o, "%lld %lld %lld %lld\n", (long long)n_cell_corner, (long long)n_cell_surf, (long long)n_cells, (long long)n_cell_pts);
+        fprintf(o, "%lld %d %d %.9g %.9g %.9g\n", (long long)n_map_cells, n_line_cells, n_plane_cells, self_sim, ratio_nz[0], ratio_nz[1]);
         fclose(o);
     } catch (const std::exception &e) {
         fprintf(stderr, "adapter_demo: %s\n", e.what());

@@ -71,3 +71,16 @@ def test_adapter_demo_matches_oracle(tmp_path, small_world, scans, downsample):
     cc, cs = h.refresh_cells(pose, (100.0, 100.0), 45.0, 1)
     assert [int(v) for v in lines[4].split()] == [len(cc), len(cs), len(h.cells[1].cells), h.cells[1].n_points()]
     assert len(cs) > 0.5 * len(ms)
+    # ... and Points_cloud_map: cells, labels, key-frame image of the scan's full cloud
+    from oracle.orc_cellmap import CellMap
+    km = CellMap(1.0)
+    km.append(orc.feature_cloud(o, fi))
+    f = km.features()
+    n_cells, n_line, n_plane, self_sim, rz_line, rz_plane = [float(v) for v in lines[5].split()]
+    loose = int(np.sum(f["margin"] <= 1e-3))                  # cells on a decision boundary may fall either way
+    assert n_cells == len(km.cells) > 100
+    assert abs(n_line - np.sum(f["type"] == 1)) <= loose and abs(n_plane - np.sum(f["type"] == 2)) <= loose and n_plane > 20
+    ko = km.keyframe_images(0.9)
+    if loose == 0:
+        assert abs(rz_line - ko["ratio_nonzero"][0]) < 1e-6 and abs(rz_plane - ko["ratio_nonzero"][1]) < 1e-6
+    assert abs(self_sim - 1.0) < 1e-5
