@@ -121,7 +121,7 @@ struct RegDev {
     // residual blocks, slot layout per scan: [0, cap_c) corner queries, [cap_c, cap_c + cap_s) surface queries
     int cap_c, cap_s, cap;        // cap = cap_c + cap_s
     float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
-    double *blk_av;               // [B][6][cap] a'(3) then v'(3) in the frame of pose_last
+    double *blk_av;               // [B][6 * cap] per scan {a0, v0}[cap], {v1, v2}[cap], {a1, a2}[cap] (16-byte pairs; ll_reg_kernels.hip av_load), frame of pose_last
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)

@@ -287,6 +287,32 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
     if (tid < 2) rd.work_n[(((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2 + tid] = s_n[tid];
 }
 
+// Block constants of one scan (blk_av, 6 * cap doubles) as three arrays of 16-byte pairs: {a0, v0}[cap], {v1, v2}[cap] and
+// {a1, a2}[cap] (line slots only; a plane block folds a' into a0 = n'.a').  A plane block is then one float4 and two
+// 16-byte loads per lane instead of one float4 and four 8-byte loads.  cap is even and the base 256-byte aligned.
+__device__ __forceinline__ void av_store(double *av, int cap, int slot, bool line, const double a[3], const double v[3])
+{
+    reinterpret_cast<double2 *>(av)[slot] = make_double2(a[0], v[0]);
+    reinterpret_cast<double2 *>(av + (size_t)2 * cap)[slot] = make_double2(v[1], v[2]);
+    if (line) reinterpret_cast<double2 *>(av + (size_t)4 * cap)[slot] = make_double2(a[1], a[2]);
+}
+__device__ __forceinline__ void av_load(const double *av, int cap, int slot, bool line, double &a0, double &a1, double &a2, double &v0,
+                                        double &v1, double &v2)
+{
+    const double2 x = reinterpret_cast<const double2 *>(av)[slot];
+    const double2 y = reinterpret_cast<const double2 *>(av + (size_t)2 * cap)[slot];
+    a0 = x.x;
+    v0 = x.y;
+    v1 = y.x;
+    v2 = y.y;
+    a1 = a2 = 0.0;
+    if (line) {
+        const double2 z = reinterpret_cast<const double2 *>(av + (size_t)4 * cap)[slot];
+        a1 = z.x;
+        a2 = z.y;
+    }
+}
+
 // K6b: residual-block constants (fp64) from the neighbours found by K6a.
 __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot)
 {
@@ -332,13 +358,7 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
             const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
             rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
             double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-            av[slot] = a_out[0];
-            if (kind == 0) {  // line blocks keep the full a'; plane blocks only the scalar n'.a'
-                av[(size_t)rd.cap + slot] = a_out[1];
-                av[(size_t)2 * rd.cap + slot] = a_out[2];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++) av[(size_t)(3 + c) * rd.cap + slot] = v_out[c];
+            av_store(av, rd.cap, slot, kind == 0, a_out, v_out);  // line blocks keep the full a'; plane blocks only the scalar n'.a'
         }
     }
     rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)
@@ -449,12 +469,7 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
         const int slot = slot_of(j, nC, rd.cap_c);
         nfl = rd.blk_flag[sb + slot];
         nf = rd.blk_f[sb + slot];
-        na0 = av[slot];
-        na1 = slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0;
-        na2 = slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0;
-        nv0 = av[(size_t)3 * rd.cap + slot];
-        nv1 = av[(size_t)4 * rd.cap + slot];
-        nv2 = av[(size_t)5 * rd.cap + slot];
+        av_load(av, rd.cap, slot, slot < rd.cap_c, na0, na1, na2, nv0, nv1, nv2);
     }
     while (j < total) {
         const unsigned char fl = nfl;
@@ -465,12 +480,7 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
             const int slot = slot_of(jn, nC, rd.cap_c);
             nfl = rd.blk_flag[sb + slot];
             nf = rd.blk_f[sb + slot];
-            na0 = av[slot];
-            na1 = slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0;
-            na2 = slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0;
-            nv0 = av[(size_t)3 * rd.cap + slot];
-            nv1 = av[(size_t)4 * rd.cap + slot];
-            nv2 = av[(size_t)5 * rd.cap + slot];
+            av_load(av, rd.cap, slot, slot < rd.cap_c, na0, na1, na2, nv0, nv1, nv2);
         }
         if (fl & BLK_ACTIVE) LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
         j = jn;
@@ -688,8 +698,8 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
             const unsigned char fl = rd.blk_flag[sb + slot];
             if (!(fl & BLK_ACTIVE)) continue;
             const float4 ff = rd.blk_f[sb + slot];
-            const double a[3] = {av[slot], slot < rd.cap_c ? av[(size_t)rd.cap + slot] : 0.0, slot < rd.cap_c ? av[(size_t)2 * rd.cap + slot] : 0.0};
-            const double v[3] = {av[(size_t)3 * rd.cap + slot], av[(size_t)4 * rd.cap + slot], av[(size_t)5 * rd.cap + slot]};
+            double a[3], v[3];
+            av_load(av, rd.cap, slot, slot < rd.cap_c, a[0], a[1], a[2], v[0], v[1], v[2]);
             double l1v;
             LL_CTX_L1(l1v, fl & 3, ff, a, v, rc.huber_a, st->pose_last);
             rd.blk_l1[sb + slot] = l1v;
@@ -1013,14 +1023,8 @@ struct BlkRegs {
 __device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const double *av, int slot, BlkRegs &r)
 {
     r.f = rd.blk_f[sb + slot];
-    r.a0 = av[slot];
     // surface slots hold plane blocks: a' is folded into the scalar a0 = n'.a' (ll_reg_core.h block_plane)
-    const bool line = slot < rd.cap_c;
-    r.a1 = line ? av[(size_t)rd.cap + slot] : 0.0;
-    r.a2 = line ? av[(size_t)2 * rd.cap + slot] : 0.0;
-    r.v0 = av[(size_t)3 * rd.cap + slot];
-    r.v1 = av[(size_t)4 * rd.cap + slot];
-    r.v2 = av[(size_t)5 * rd.cap + slot];
+    av_load(av, rd.cap, slot, slot < rd.cap_c, r.a0, r.a1, r.a2, r.v0, r.v1, r.v2);
 }
 
 template <int DEBLUR>
