@@ -43,5 +43,42 @@ def main():
         print("scene", k, "features", len(ci), len(si), "blocks", rep.n_blocks_last, "ret", ret)
 
 
+def cells():
+    """cell-map path: appends with the revisit rule, radius + field-of-view query with replace, labels, key-frame images"""
+    from oracle.orc_cellmap import CellMap
+    rng = np.random.default_rng(4711)
+    frames = []
+    for f in range(5):
+        o = rng.uniform(-4, 4, 3) * np.array([1, 1, 0.3])
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        u = np.cross(n, [0, 0, 1.0]); u /= np.linalg.norm(u); v = np.cross(n, u)
+        plane = o + rng.uniform(-2, 2, (1500, 1)) * u + rng.uniform(-2, 2, (1500, 1)) * v + rng.normal(0, 0.01, (1500, 3))
+        line = o + n * 0.5 + rng.uniform(-2, 2, (300, 1)) * u + rng.normal(0, 0.01, (300, 3))
+        blob = rng.uniform(-5, 5, (300, 3))
+        c = np.concatenate([plane, line, blob]).astype(np.float32)
+        if f == 3:
+            c[:, 0] += 12.0
+        frames.append(np.c_[c, np.full(len(c), 7.0, np.float32)].astype(np.float32))
+    pose = np.r_[synth.quat_from_axis_angle(np.array([0.1, -0.2, 1.0]), np.deg2rad(20.0)), [-6.0, 0.5, 0.2]]
+    m = CellMap(1.0, 2)
+    for c in frames:
+        m.append(c)
+    cat, keys = m.query_filter(pose, 9.0, 50.0, 0.2, 1)
+    xyz, ijk, start, last = m.dump()
+    f = m.features()
+    kf = m.keyframe_images(0.9)
+    other = CellMap(1.0)
+    other.append(frames[0])
+    sim = CellMap.max_similarity(kf["images"][1], other.keyframe_images(0.0)["images"][1])
+    np.savez_compressed(
+        os.path.join(HERE, "cells0.npz"), frames=np.stack(frames), pose=pose, radius=9.0, fov=50.0, leaf=0.2, revisit=2, resolution=1.0,
+        query_cloud=cat, n_selected=len(keys), store_xyz=xyz, cell_ijk=ijk, cell_start=start, cell_last=last, feat_type=f["type"],
+        feat_vector=f["vector"], feat_mean=f["mean"], feat_cov=f["cov"], feat_eval=f["eigen_val"], feat_margin=f["margin"],
+        kf_images=kf["images"], kf_ratio=kf["ratio_nonzero"], kf_R=kf["eigen_R"], kf_nvec=kf["n_vectors"], kf_centre=kf["centre"],
+        kf_range=kf["roi_range"], kf_near_edge=kf["near_bin_edge"], similarity=sim)
+    print("cells0:", len(m.cells), "cells,", m.n_points(), "points,", len(keys), "selected,", np.bincount(f["type"], minlength=3), "labels, sim", sim)
+
+
 if __name__ == "__main__":
     main()
+    cells()
