@@ -399,10 +399,25 @@ class Point_cloud_registration {
     template <class CloudPtr>
     int find_out_incremental_transfrom(CloudPtr map_corner, CloudPtr map_surf, CloudPtr scan_corner, CloudPtr scan_surf)
     {
-        if (!reg_) check(ll_reg_create(device, 1, max_features, &reg_), "ll_reg_create");
-        if (!map_) check(ll_map_create(device, &map_), "ll_map_create");
         upload_if_changed(LL_MAP_CORNER, *map_corner, key_[0]);
         upload_if_changed(LL_MAP_SURF, *map_surf, key_[1]);
+        return find_out_incremental_transfrom(scan_corner, scan_surf);
+    }
+
+    // The search structure the registrar matches against.  History_buffer::refresh( pc_reg.map() ) /
+    // refresh_cells( pc_reg.map(), ... ) rebuild it on the device (update_buff_for_matching, laser_mapping.hpp:460-566);
+    // the 2-argument form below then registers against it without a map cloud ever crossing the bus.
+    ll_map *map()
+    {
+        if (!map_) check(ll_map_create(device, &map_), "ll_map_create");
+        return map_;
+    }
+
+    template <class CloudPtr>
+    int find_out_incremental_transfrom(CloudPtr scan_corner, CloudPtr scan_surf)
+    {
+        if (!reg_) check(ll_reg_create(device, 1, max_features, &reg_), "ll_reg_create");
+        map();
         const std::vector<float> c = cloud_to_xyzi(*scan_corner), s = cloud_to_xyzi(*scan_surf);
         ll_reg_params p;
         ll_reg_default_params(&p);
@@ -461,6 +476,7 @@ class Point_cloud_registration {
     void upload_if_changed(int kind, const Cloud &c, Key &k)
     {
         if (k.p == (const void *)c.points.data() && k.n == c.points.size()) return;
+        map();
         const std::vector<float> v = cloud_to_xyzi(c);
         check(ll_map_upload(map_, kind, v.data(), 4, (int64_t)c.points.size(), 0.0f), "ll_map_upload");
         k.p = (const void *)c.points.data();
