@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
-    ap.add_argument("--cpu-scans", type=int, default=3)
+    ap.add_argument("--cpu-scans", type=int, default=16, help="scans of the step also run through the CPU oracle (about 10 s on one core)")
     return ap.parse_args()
 
 
