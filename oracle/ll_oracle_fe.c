@@ -1,7 +1,8 @@
 /*
  * ll_oracle_fe.c -- CPU ORACLE (test infrastructure only, see ll_oracle.h) for the Livox
  * feature extractor: a plain-C restatement of hku-mars/loam_livox
- * source/livox_feature_extractor.hpp (LFE).  PARITY UNPINNED (no reference fixtures exist).
+ * source/livox_feature_extractor.hpp (LFE).  Pinned BIT-EXACT against the reference's own header compiled here
+ * (oracle/_ref, tests/test_ref_pin.py, tests/golden/ref_scene*.npz).
  *
  * All arithmetic is fp32 unless the reference promotes to double (noted inline).
  * Compile with -ffp-contract=off: the reference is built without FMA contraction

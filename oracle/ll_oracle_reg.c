@@ -3,7 +3,9 @@
  * registration inner loop: a plain-C restatement of hku-mars/loam_livox
  *   source/point_cloud_registration.hpp (PCR:163-583, 607-685)
  *   source/ceres_icp.hpp                (ICP:81-380, residual functors)
- * PARITY UNPINNED (no reference fixtures exist; PCL/Ceres/Eigen are absent, see ll_oracle.h).
+ * Pinned against the reference's own text compiled here (oracle/_ref, tests/test_ref_pin.py): functor residuals and
+ * Jacobians to 1e-12, the driver's pose / costs / thresholds to 1e-9; FLANN, Ceres' LM and Eigen stay restated
+ * (see ll_oracle.h).
  *
  * Third-party behaviour restated from the libraries' published algorithms:
  *
