@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--q-pipe", action="store_true", help="Q-pipe query mode (SURVEY 8d): device VoxelGrid (leaf 0.1 corner / 0.4 surface, "
                     "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
     ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
+    ap.add_argument("--legacy-solver", action="store_true", help="A/B: round-1 solver fast path (49-byte fp64 plane blocks, no LDS block cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--cpu-scans", type=int, default=16, help="scans of the step also run through the CPU oracle (about 10 s on one core)")
@@ -121,8 +122,8 @@ def main():
     p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
     p.maximum_allow_residual_block = N
     reg.set_profiling(True)
-    if args.force_general:
-        reg.set_debug(False, force_general_solver=True)
+    if args.force_general or args.legacy_solver:
+        reg.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver)
 
     vox = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
 

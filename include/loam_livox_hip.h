@@ -231,7 +231,9 @@ int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corne
 /* enable: bit 0 = record the k-NN taps; bit 1 = force the general (HBM-resident) solver path that scans with
  * more than 24576 residual blocks use, for testing it on small inputs; bit 2 = disable the exact neighbour reuse
  * across ICP iterations (every iteration runs the full 5-NN search); bit 3 = try the reuse from ICP iteration 1
- * already (default: from iteration 2, the first pose update usually moves the queries too far). */
+ * already (default: from iteration 2, the first pose update usually moves the queries too far); bit 4 = run the
+ * round-1 solver fast path (49-byte fp64 plane blocks re-read on every evaluation) instead of the compact 32-byte
+ * blocks with the LDS block cache -- an A/B switch, results agree to rounding. */
 int ll_reg_set_debug(ll_reg *r, int32_t enable);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -13,7 +13,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libloamlivox_hip.so")
+# LL_LIB_OUT: build an instrumented / A-B variant next to the product library (e.g. with LL_EXTRA_HIPCC_FLAGS=-DLL_SOLVE_TIMING)
+# and load it with LL_LIB_PATH (capi.py); the default is the product library.
+LIB = os.environ.get("LL_LIB_OUT") or os.path.join(HERE, "libloamlivox_hip.so")
 SOURCES = ["ll_api.hip", "ll_fe_kernels.hip", "ll_map_kernels.hip", "ll_reg_kernels.hip", "ll_voxel_kernels.hip", "ll_cellmap_kernels.hip"]
 HEADERS = ["ll_device.h", "ll_fe_core.h", "ll_knn_core.h", "ll_reg_core.h", "ll_voxel.h", "ll_voxel_core.h", "ll_cellmap.h", "ll_cellmap_core.h", "../../include/loam_livox_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
@@ -39,7 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     cc = hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if not os.environ.get("LL_LIB_OUT") else "build_" + os.path.basename(LIB).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []

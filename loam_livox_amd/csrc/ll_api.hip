@@ -562,6 +562,8 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     DM(d.state, B);
     DM(d.blk_f, B * d.cap);
     DM(d.blk_av, B * 6 * d.cap);
+    DM(d.blk_pa, B * d.cap_s);
+    DM(d.blk_pb, B * d.cap_s);
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
     DM(d.qw, B * d.cap);
@@ -593,7 +595,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -642,6 +644,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->force_general = (debug & 2) ? 1 : 0;
     c->knn_reuse = (debug & 4) ? 0 : 1;
     c->knn_reuse_from = (debug & 8) ? 1 : 2;  // bit 3: also try reuse at ICP iteration 1 (test coverage)
+    c->solver_legacy = (debug & 16) ? 1 : 0;  // bit 4: round-1 solver fast path (A/B)
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)

@@ -102,7 +102,7 @@ struct RegConst {
     int knn_reuse;       // exact neighbour reuse across ICP iterations (ll_knn_core.h)
     int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
-    int pad1;
+    int solver_legacy;   // A/B switch: round-1 fast path (49-byte fp64 plane blocks, no LDS block cache)
     unsigned int subsample_seed;  // a13 (0 = off)
     int max_blocks;               // maximum_allow_residual_block
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
@@ -122,6 +122,8 @@ struct RegDev {
     int cap_c, cap_s, cap;        // cap = cap_c + cap_s
     float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
     double *blk_av;               // [B][6 * cap] per scan {a0, v0}[cap], {v1, v2}[cap], {a1, a2}[cap] (16-byte pairs; ll_reg_kernels.hip av_load), frame of pose_last
+    int4 *blk_pa, *blk_pb;        // [B][cap_s] compact plane blocks (32 B): pa = {bits f.x, f.y, f.z, nq.x}, pb = {nq.y, nq.z, c lo, c hi};
+                                  // nq = Q1.31 normal in the frame of pose_last, c = n'.a' (fp64) -- ll_reg_core.h q31_encode
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)

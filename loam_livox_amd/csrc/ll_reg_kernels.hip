@@ -313,6 +313,16 @@ __device__ __forceinline__ void av_load(const double *av, int cap, int slot, boo
     }
 }
 
+// Scans whose blocks go to the compact fast path of the solver (solve_fast2): no motion deblur (the blur ratio would be
+// a 33rd..36th byte), planes padded to whole 512-thread rounds + lines within the register budget of the L1 phase.
+#define FAST_MAX_BLOCKS 24576
+__device__ __forceinline__ bool scan_is_compact(const RegDev &rd, const RegConst &rc, int b)
+{
+    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
+    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+    return !rc.if_motion_deblur && !rc.force_general && !rc.solver_legacy && nSp + nC <= FAST_MAX_BLOCKS;
+}
+
 // K6b: residual-block constants (fp64) from the neighbours found by K6a.
 __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot)
 {
@@ -340,6 +350,7 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
     if (nn.w && feature_ok) {
         const Grid &g = kind ? gs : gc;
         double a_out[3], v_out[3];
+        int nq[3] = {0, 0, 0};
         const f4 p0 = g.pts[nn.x], p1 = g.pts[nn.y];
         const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
         const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
@@ -350,15 +361,23 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
             if (rc.icp_plane) {
                 const f4 p2 = g.pts[nn.z];
                 const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
-                flag = block_plane(st->pose_last, pa, pb, pc, a_out, v_out) ? (BLK_PLANE | BLK_ACTIVE | 8) : BLK_NONE;
+                flag = block_plane(st->pose_last, pa, pb, pc, a_out, v_out, nq) ? (BLK_PLANE | BLK_ACTIVE | 8) : BLK_NONE;
             }
         }
         if (flag & BLK_ACTIVE) {
             const float4 f = load_feature(rd, b, kind, q);
-            const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
-            rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
-            double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-            av_store(av, rd.cap, slot, kind == 0, a_out, v_out);  // line blocks keep the full a'; plane blocks only the scalar n'.a'
+            if (kind == 1 && scan_is_compact(rd, rc, b)) {
+                // compact plane block: 32 bytes, two coalesced 16-byte planes (ll_device.h blk_pa / blk_pb)
+                const size_t ps = (size_t)b * rd.cap_s + q;
+                const long long cb = __double_as_longlong(a_out[0]);
+                rd.blk_pa[ps] = make_int4(__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), nq[0]);
+                rd.blk_pb[ps] = make_int4(nq[1], nq[2], (int)(cb & 0xffffffffll), (int)(cb >> 32));
+            } else {
+                const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
+                rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
+                double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+                av_store(av, rd.cap, slot, kind == 0, a_out, v_out);  // line blocks keep the full a'; plane blocks only the scalar n'.a'
+            }
         }
     }
     rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)
@@ -617,8 +636,7 @@ __device__ void solve_epilogue(const RegConst &rc, RegState *st, SolveShared &sh
 }
 
 
-// capacities shared by the two solver paths (the fast path is described further down)
-#define FAST_MAX_BLOCKS 24576
+// capacities shared by the solver paths (the fast paths are described further down)
 #define FAST_MAXK (FAST_MAX_BLOCKS / RS_THREADS)
 #define HT_SIZE 16384
 #define HT_PART 6144  // keys per de-duplication round (load factor <= 0.375)
@@ -1010,202 +1028,15 @@ __device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegSt
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// Fast path (<= FAST_MAX_BLOCKS residual blocks per scan, i.e. every BASELINE Mid-40 configuration): block
-// flags live in LDS, the per-block L1 values of the inlier test live in registers, the std::set
-// de-duplication runs in an LDS hash table and the rank select reads registers -- the only HBM traffic left is
-// one coalesced sweep over the block constants per cost evaluation, software-pipelined one block ahead.
-struct BlkRegs {
-    float4 f;
-    double a0, a1, a2, v0, v1, v2;
-};
-
-__device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const double *av, int slot, BlkRegs &r)
+// std::set de-duplication + rank select of the loss-corrected L1 values held in registers (l1r[k] = value of the
+// thread's k-th block, < 0 for "no active block"): sets sh.thr = max(inliner_dis, element at int(ratio * n_distinct))
+// (PCR:153-161, 484-485).  `total` only sizes the rounds of the heavily-duplicated fallback.
+template <int NK>
+__device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], int total, unsigned long long *s_table, SolveShared &sh,
+                                                      const RegConst &rc)
 {
-    r.f = rd.blk_f[sb + slot];
-    // surface slots hold plane blocks: a' is folded into the scalar a0 = n'.a' (ll_reg_core.h block_plane)
-    av_load(av, rd.cap, slot, slot < rd.cap_c, r.a0, r.a1, r.a2, r.v0, r.v1, r.v2);
-}
-
-template <int DEBLUR>
-__device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a, int deblur,
-                                 const unsigned char *s_flag, SolveShared &sh)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t sb = (size_t)b * rd.cap;
-    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    LL_CTX_DECL(x)
-    double acc[LL_NACC];
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
-#if RS_PREFETCH >= 2
-    // Two blocks ahead: with one workgroup per CU (LDS) the sweep is bound by latency x bytes in flight.  Measured at C2
-    // (A/B in one run): 4.46 ms of solver per step against 4.66 ms one block ahead; three ahead 4.64 ms; a ring with
-    // refill-after-use 4.85 ms and worse with depth.  The register sets rotate by name, the accumulation order is unchanged.
-    int j = tid;
-    BlkRegs cur, nxt, nx2;
-    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
-    if (j + RS_THREADS < total) load_blk(rd, sb, av, slot_of(j + RS_THREADS, nC, rd.cap_c), nxt);
-    while (j < total) {
-        const int jf = j + 2 * RS_THREADS;
-        if (jf < total) load_blk(rd, sb, av, slot_of(jf, nC, rd.cap_c), nx2);
-        const unsigned char fl = s_flag[j];
-        if (fl & BLK_ACTIVE) {
-            const double a[3] = {cur.a0, cur.a1, cur.a2};
-            const double v[3] = {cur.v0, cur.v1, cur.v2};
-            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
-        }
-        cur = nxt;
-        nxt = nx2;
-        j += RS_THREADS;
-    }
-#elif RS_PREFETCH
-    int j = tid;
-    BlkRegs cur, nxt;
-    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
-    while (j < total) {
-        const int jn = j + RS_THREADS;
-        if (jn < total) load_blk(rd, sb, av, slot_of(jn, nC, rd.cap_c), nxt);  // in flight while we compute
-        const unsigned char fl = s_flag[j];
-        if (fl & BLK_ACTIVE) {
-            const double a[3] = {cur.a0, cur.a1, cur.a2};
-            const double v[3] = {cur.v0, cur.v1, cur.v2};
-            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
-        }
-        cur = nxt;
-        j = jn;
-    }
-#else
-    for (int j = tid; j < total; j += RS_THREADS) {
-        BlkRegs cur;
-        load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);  // unconditional: no dependence on the flag
-        const unsigned char fl = s_flag[j];
-        if (fl & BLK_ACTIVE) {
-            const double a[3] = {cur.a0, cur.a1, cur.a2};
-            const double v[3] = {cur.v0, cur.v1, cur.v2};
-            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
-        }
-    }
-#endif
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) {
-        const double s = wave_sum(acc[i]);
-        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
-    }
-    __syncthreads();
-    if (tid < LL_NACC) {
-        double s = 0.0;
-        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
-        sh.sum[tid] = s;
-    }
-    __syncthreads();
-}
-
-template <int DEBLUR>
-__device__ void solver_lm_fast(const RegDev &rd, const RegConst &rc, int b, int nC, int total, const double *x0, int max_iter,
-                               int n_active, const unsigned char *s_flag, SolveShared &sh)
-{
+    static_assert(NK == FAST_MAXK, "register tile of the fast paths");
     const int tid = threadIdx.x;
-    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
-    __syncthreads();
-    {
-        LL_T0(t0);
-        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.x, rc.huber_a, DEBLUR, s_flag, sh);
-        LL_TACC(0, t0);
-    }
-    {
-        LL_T0(t1);
-        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
-        __syncthreads();
-        LL_TACC(1, t1);
-    }
-    while (sh.need) {
-        LL_T0(t0);
-        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.cand, rc.huber_a, DEBLUR, s_flag, sh);
-        LL_TACC(0, t0);
-        LL_T0(t1);
-        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
-        __syncthreads();
-        LL_TACC(1, t1);
-    }
-}
-
-template <int DEBLUR>
-__device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
-                           unsigned long long *s_table, unsigned char *s_flag)
-{
-    const int tid = threadIdx.x;
-    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
-    const int total = nC + nS;
-    const size_t sb = (size_t)b * rd.cap;
-    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    if (tid < 6) sh.tcyc[tid] = 0;
-    __syncthreads();
-    LL_T0(t_total);
-
-    // ---- flags -> LDS, census (PCR:325,425) -------------------------------------------------------------------
-    {
-        int na = 0, nca = 0, nsa = 0;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const unsigned char fl = rd.blk_flag0[sb + slot_of(j, nC, rd.cap_c)];
-            s_flag[j] = fl;
-            na += (fl & BLK_ACTIVE) ? 1 : 0;
-            if (fl & 8) {
-                if (j < nC) nca++; else nsa++;
-            }
-        }
-        na = block_sum_int(na, sh);
-        nca = block_sum_int(nca, sh);
-        nsa = block_sum_int(nsa, sh);
-        if (rc.subsample_seed && na > rc.max_blocks) {  // a13: "Number of residual blocks too Large, drop them" (PCR:438-458)
-            int kept = 0;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const unsigned char fl = s_flag[j];
-                if (!(fl & BLK_ACTIVE)) continue;
-                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, j, na, rc.max_blocks))
-                    s_flag[j] = fl & ~BLK_ACTIVE;
-                else
-                    kept++;
-            }
-            na = block_sum_int(kept, sh);
-        }
-        if (tid == 0) {
-            sh.n_active = na;
-            sh.n_corner_avail = nca;
-            sh.n_surf_avail = nsa;
-        }
-        __syncthreads();
-    }
-
-    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, sh);
-    int lm_iters = sh.ctl.iteration;
-
-    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers ------------------
-    double l1r[FAST_MAXK];
-    LL_T0(t_l1);
-    {
-        LL_CTX_DECL(sh.ctl.x)
-#pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++) {
-            const int j = tid + k * RS_THREADS;
-            double l1 = -1.0;  // marker: not an active block
-            if (j < total) {
-                const unsigned char fl = s_flag[j];
-                if (fl & BLK_ACTIVE) {
-                    BlkRegs br;
-                    load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), br);
-                    const double a[3] = {br.a0, br.a1, br.a2};
-                    const double v[3] = {br.v0, br.v1, br.v2};
-                    LL_CTX_L1(l1, fl & 3, br.f, a, v, rc.huber_a, st->pose_last);
-                }
-            }
-            l1r[k] = l1;
-        }
-    }
-
-    __syncthreads();
-    LL_TACC(2, t_l1);
     LL_T0(t_dd);
     // ---- std::set semantics (PCR:155-160): which values are distinct, and how many ---------------------------------
     // Exact duplicates among the residuals are rare, so the common case is made cheap: every key sets one bit of a
@@ -1451,6 +1282,206 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         if (tid == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
     }
     __syncthreads();
+    LL_TACC(4, t_sel);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path (<= FAST_MAX_BLOCKS residual blocks per scan, i.e. every BASELINE Mid-40 configuration): block
+// flags live in LDS, the per-block L1 values of the inlier test live in registers, the std::set
+// de-duplication runs in an LDS hash table and the rank select reads registers -- the only HBM traffic left is
+// one coalesced sweep over the block constants per cost evaluation, software-pipelined one block ahead.
+struct BlkRegs {
+    float4 f;
+    double a0, a1, a2, v0, v1, v2;
+};
+
+__device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const double *av, int slot, BlkRegs &r)
+{
+    r.f = rd.blk_f[sb + slot];
+    // surface slots hold plane blocks: a' is folded into the scalar a0 = n'.a' (ll_reg_core.h block_plane)
+    av_load(av, rd.cap, slot, slot < rd.cap_c, r.a0, r.a1, r.a2, r.v0, r.v1, r.v2);
+}
+
+template <int DEBLUR>
+__device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a, int deblur,
+                                 const unsigned char *s_flag, SolveShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t sb = (size_t)b * rd.cap;
+    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+    LL_CTX_DECL(x)
+    double acc[LL_NACC];
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
+#if RS_PREFETCH >= 2
+    // Two blocks ahead: with one workgroup per CU (LDS) the sweep is bound by latency x bytes in flight.  Measured at C2
+    // (A/B in one run): 4.46 ms of solver per step against 4.66 ms one block ahead; three ahead 4.64 ms; a ring with
+    // refill-after-use 4.85 ms and worse with depth.  The register sets rotate by name, the accumulation order is unchanged.
+    int j = tid;
+    BlkRegs cur, nxt, nx2;
+    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
+    if (j + RS_THREADS < total) load_blk(rd, sb, av, slot_of(j + RS_THREADS, nC, rd.cap_c), nxt);
+    while (j < total) {
+        const int jf = j + 2 * RS_THREADS;
+        if (jf < total) load_blk(rd, sb, av, slot_of(jf, nC, rd.cap_c), nx2);
+        const unsigned char fl = s_flag[j];
+        if (fl & BLK_ACTIVE) {
+            const double a[3] = {cur.a0, cur.a1, cur.a2};
+            const double v[3] = {cur.v0, cur.v1, cur.v2};
+            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
+        }
+        cur = nxt;
+        nxt = nx2;
+        j += RS_THREADS;
+    }
+#elif RS_PREFETCH
+    int j = tid;
+    BlkRegs cur, nxt;
+    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
+    while (j < total) {
+        const int jn = j + RS_THREADS;
+        if (jn < total) load_blk(rd, sb, av, slot_of(jn, nC, rd.cap_c), nxt);  // in flight while we compute
+        const unsigned char fl = s_flag[j];
+        if (fl & BLK_ACTIVE) {
+            const double a[3] = {cur.a0, cur.a1, cur.a2};
+            const double v[3] = {cur.v0, cur.v1, cur.v2};
+            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
+        }
+        cur = nxt;
+        j = jn;
+    }
+#else
+    for (int j = tid; j < total; j += RS_THREADS) {
+        BlkRegs cur;
+        load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);  // unconditional: no dependence on the flag
+        const unsigned char fl = s_flag[j];
+        if (fl & BLK_ACTIVE) {
+            const double a[3] = {cur.a0, cur.a1, cur.a2};
+            const double v[3] = {cur.v0, cur.v1, cur.v2};
+            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
+        }
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) {
+        const double s = wave_sum(acc[i]);
+        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
+    }
+    __syncthreads();
+    if (tid < LL_NACC) {
+        double s = 0.0;
+        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
+        sh.sum[tid] = s;
+    }
+    __syncthreads();
+}
+
+template <int DEBLUR>
+__device__ void solver_lm_fast(const RegDev &rd, const RegConst &rc, int b, int nC, int total, const double *x0, int max_iter,
+                               int n_active, const unsigned char *s_flag, SolveShared &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
+    __syncthreads();
+    {
+        LL_T0(t0);
+        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.x, rc.huber_a, DEBLUR, s_flag, sh);
+        LL_TACC(0, t0);
+    }
+    {
+        LL_T0(t1);
+        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
+    while (sh.need) {
+        LL_T0(t0);
+        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.cand, rc.huber_a, DEBLUR, s_flag, sh);
+        LL_TACC(0, t0);
+        LL_T0(t1);
+        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
+}
+
+template <int DEBLUR>
+__device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
+                           unsigned long long *s_table, unsigned char *s_flag)
+{
+    const int tid = threadIdx.x;
+    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
+    const int total = nC + nS;
+    const size_t sb = (size_t)b * rd.cap;
+    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+    if (tid < 6) sh.tcyc[tid] = 0;
+    __syncthreads();
+    LL_T0(t_total);
+
+    // ---- flags -> LDS, census (PCR:325,425) -------------------------------------------------------------------
+    {
+        int na = 0, nca = 0, nsa = 0;
+        for (int j = tid; j < total; j += RS_THREADS) {
+            const unsigned char fl = rd.blk_flag0[sb + slot_of(j, nC, rd.cap_c)];
+            s_flag[j] = fl;
+            na += (fl & BLK_ACTIVE) ? 1 : 0;
+            if (fl & 8) {
+                if (j < nC) nca++; else nsa++;
+            }
+        }
+        na = block_sum_int(na, sh);
+        nca = block_sum_int(nca, sh);
+        nsa = block_sum_int(nsa, sh);
+        if (rc.subsample_seed && na > rc.max_blocks) {  // a13: "Number of residual blocks too Large, drop them" (PCR:438-458)
+            int kept = 0;
+            for (int j = tid; j < total; j += RS_THREADS) {
+                const unsigned char fl = s_flag[j];
+                if (!(fl & BLK_ACTIVE)) continue;
+                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, j, na, rc.max_blocks))
+                    s_flag[j] = fl & ~BLK_ACTIVE;
+                else
+                    kept++;
+            }
+            na = block_sum_int(kept, sh);
+        }
+        if (tid == 0) {
+            sh.n_active = na;
+            sh.n_corner_avail = nca;
+            sh.n_surf_avail = nsa;
+        }
+        __syncthreads();
+    }
+
+    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
+    solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, sh);
+    int lm_iters = sh.ctl.iteration;
+
+    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers ------------------
+    double l1r[FAST_MAXK];
+    LL_T0(t_l1);
+    {
+        LL_CTX_DECL(sh.ctl.x)
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++) {
+            const int j = tid + k * RS_THREADS;
+            double l1 = -1.0;  // marker: not an active block
+            if (j < total) {
+                const unsigned char fl = s_flag[j];
+                if (fl & BLK_ACTIVE) {
+                    BlkRegs br;
+                    load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), br);
+                    const double a[3] = {br.a0, br.a1, br.a2};
+                    const double v[3] = {br.v0, br.v1, br.v2};
+                    LL_CTX_L1(l1, fl & 3, br.f, a, v, rc.huber_a, st->pose_last);
+                }
+            }
+            l1r[k] = l1;
+        }
+    }
+
+    __syncthreads();
+    LL_TACC(2, t_l1);
+    inlier_threshold_regs(l1r, total, s_table, sh, rc);
     // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
     {
         const double thr = sh.thr;
@@ -1471,13 +1502,298 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         __syncthreads();
     }
 
-    LL_TACC(4, t_sel);
     // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
     {
         __shared__ double x_start_f[7];
         if (tid < 7) x_start_f[tid] = sh.ctl.x[tid];
         __syncthreads();
         solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, x_start_f, rc.ceres_max_iterations, sh.n_active, s_flag, sh);
+    }
+    lm_iters += sh.ctl.iteration;
+    solve_epilogue(rc, st, sh, lm_iters);
+#ifdef LL_SOLVE_TIMING
+    LL_TACC(5, t_total);
+    if (tid == 0)
+        for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Compact fast path (round 2; scan_is_compact()).  What changed against solve_fast, and why (round-1 profile: the
+// solver launch moved 9.4x its algorithmic bytes, re-reading 49 B per plane block on each of ~9 cost evaluations at the
+// ~13 B/clk a single CU pulls from beyond its L2):
+//   * plane blocks are 32 bytes (f fp32, normal Q1.31, offset fp64 -- ll_reg_core.h q31_encode) in two coalesced
+//     16-byte planes: one third fewer bytes per evaluation and two loads per block instead of three;
+//   * the first PC_RECS plane blocks of the scan are kept in LDS across the evaluations of a solve: the 128 KB of
+//     s_table are idle while the LM iterations run (the set de-duplication needs them only between the two solves), so
+//     the first evaluation of each solve copies the records it streams into LDS and the later evaluations -- and the L1
+//     pass after the prerun -- read those blocks from LDS instead of HBM / Infinity Cache;
+//   * the thread <-> block map puts the planes first (thread t owns planes t, t + 512, ...; lines follow from the next
+//     whole round), so cached and streamed blocks are separate loops with no divergence;
+//   * the LM controller is inlined (ll_reg_core.h LL_LM_FN): no calling-convention spills on the lane everyone waits for.
+// The arithmetic per block, the reduction order inside a thread (planes, then lines), the wave / workgroup reduction and
+// everything after the L1 pass are those of solve_fast.
+#define PC_RECS 4096  // plane records cached in LDS (2 x 16 B each) = sizeof(s_table); a multiple of RS_THREADS
+
+struct PRec {
+    int4 a, b;
+};
+__device__ __forceinline__ void prec_load(const int4 *pa, const int4 *pb, int p, PRec &r)
+{
+    r.a = pa[p];
+    r.b = pb[p];
+}
+__device__ __forceinline__ void prec_decode(const PRec &r, double f[3], double a[3], double v[3])
+{
+    f[0] = (double)__int_as_float(r.a.x);
+    f[1] = (double)__int_as_float(r.a.y);
+    f[2] = (double)__int_as_float(r.a.z);
+    v[0] = q31_decode(r.a.w);
+    v[1] = q31_decode(r.b.x);
+    v[2] = q31_decode(r.b.y);
+    a[0] = __hiloint2double(r.b.w, r.b.z);  // n'.a'
+    a[1] = 0.0;
+    a[2] = 0.0;
+}
+
+// workgroup evaluation of cost / g / H at x over the active blocks -> sh.sum.  FILL: first evaluation of a solve, every
+// plane record is streamed and the first PC_RECS are copied to the LDS cache; otherwise those come from the cache.
+template <bool FILL>
+__device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a,
+                                          const unsigned char *s_flag, int4 *cA, int4 *cB, SolveShared &sh)
+{
+    constexpr int DEBLUR = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LL_CTX_DECL(x)
+    double acc[LL_NACC];
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
+    const int4 *pa = rd.blk_pa + (size_t)b * rd.cap_s;
+    const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
+    int p = tid;
+    if (!FILL) {
+        const int ncached = nS < PC_RECS ? nS : PC_RECS;
+        for (; p < ncached; p += RS_THREADS) {
+            PRec r;
+            r.a = cA[p];
+            r.b = cB[p];
+            if (s_flag[p] & BLK_ACTIVE) {
+                double f[3], a[3], v[3];
+                prec_decode(r, f, a, v);
+                block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
+            }
+        }
+    }
+    {
+        // streamed planes, three records (96 B per lane) in flight
+        PRec r0, r1, r2, r3;
+        r0.a = r0.b = r1.a = r1.b = r2.a = r2.b = r3.a = r3.b = make_int4(0, 0, 0, 0);
+        if (p < nS) prec_load(pa, pb, p, r0);
+        if (p + RS_THREADS < nS) prec_load(pa, pb, p + RS_THREADS, r1);
+        if (p + 2 * RS_THREADS < nS) prec_load(pa, pb, p + 2 * RS_THREADS, r2);
+        while (p < nS) {
+            const int pf = p + 3 * RS_THREADS;
+            if (pf < nS) prec_load(pa, pb, pf, r3);
+            if (FILL && p < PC_RECS) {
+                cA[p] = r0.a;
+                cB[p] = r0.b;
+            }
+            if (s_flag[p] & BLK_ACTIVE) {
+                double f[3], a[3], v[3];
+                prec_decode(r0, f, a, v);
+                block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
+            }
+            r0 = r1;
+            r1 = r2;
+            r2 = r3;
+            p += RS_THREADS;
+        }
+    }
+    {
+        // line blocks (a few hundred per Mid-40 scan): the 65-byte fp64 form
+        const size_t sb = (size_t)b * rd.cap;
+        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+        const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+        for (int l = tid; l < nC; l += RS_THREADS) {
+            if (!(s_flag[nSp + l] & BLK_ACTIVE)) continue;
+            BlkRegs br;
+            load_blk(rd, sb, av, l, br);
+            const double a[3] = {br.a0, br.a1, br.a2};
+            const double v[3] = {br.v0, br.v1, br.v2};
+            LL_CTX_ACCUM(BLK_LINE, br.f, a, v, huber_a, acc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) {
+        const double s = wave_sum(acc[i]);
+        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
+    }
+    __syncthreads();
+    if (tid < LL_NACC) {
+        double s = 0.0;
+        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
+        sh.sum[tid] = s;
+    }
+    __syncthreads();
+}
+
+// one ceres::Solve on the compact layout: starts at x0, leaves the result in sh.ctl
+__device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
+                                           int n_active, const unsigned char *s_flag, int4 *cA, int4 *cB, SolveShared &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
+    __syncthreads();
+    {
+        LL_T0(t0);
+        solver_eval2<true>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, s_flag, cA, cB, sh);
+        LL_TACC(0, t0);
+    }
+    {
+        LL_T0(t1);
+        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
+    while (sh.need) {
+        LL_T0(t0);
+        solver_eval2<false>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, sh);
+        LL_TACC(0, t0);
+        LL_T0(t1);
+        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
+}
+
+__device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, unsigned long long *s_table,
+                            unsigned char *s_flag)
+{
+    constexpr int DEBLUR = 0;
+    const int tid = threadIdx.x;
+    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
+    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;  // lines start at a whole round
+    const int totp = nSp + nC;                                        // <= FAST_MAX_BLOCKS (scan_is_compact)
+    const size_t sb = (size_t)b * rd.cap;
+    int4 *cA = (int4 *)s_table, *cB = cA + PC_RECS;
+    if (tid < 6) sh.tcyc[tid] = 0;
+    __syncthreads();
+    LL_T0(t_total);
+
+    // ---- flags -> LDS in the solver's order (planes, padding, lines), census (PCR:325,425) -------------------------
+    {
+        int na = 0, nca = 0, nsa = 0;
+        for (int j = tid; j < totp; j += RS_THREADS) {
+            unsigned char fl = 0;
+            if (j < nS)
+                fl = rd.blk_flag0[sb + rd.cap_c + j];
+            else if (j >= nSp)
+                fl = rd.blk_flag0[sb + (j - nSp)];
+            s_flag[j] = fl;
+            na += (fl & BLK_ACTIVE) ? 1 : 0;
+            if (fl & 8) {
+                if (j >= nSp) nca++; else nsa++;
+            }
+        }
+        na = block_sum_int(na, sh);
+        nca = block_sum_int(nca, sh);
+        nsa = block_sum_int(nsa, sh);
+        if (rc.subsample_seed && na > rc.max_blocks) {  // a13 (PCR:438-458); the random stream is indexed by the block's
+            int kept = 0;                               // position in the reference's order: corners, then surfaces
+            for (int j = tid; j < totp; j += RS_THREADS) {
+                const unsigned char fl = s_flag[j];
+                if (!(fl & BLK_ACTIVE)) continue;
+                const int jref = j >= nSp ? j - nSp : nC + j;
+                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, jref, na, rc.max_blocks))
+                    s_flag[j] = fl & ~BLK_ACTIVE;
+                else
+                    kept++;
+            }
+            na = block_sum_int(kept, sh);
+        }
+        if (tid == 0) {
+            sh.n_active = na;
+            sh.n_corner_avail = nca;
+            sh.n_surf_avail = nsa;
+        }
+        __syncthreads();
+    }
+
+    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
+    solver_lm2(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, cA, cB, sh);
+    int lm_iters = sh.ctl.iteration;
+
+    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers; the cached planes come
+    //      from LDS (filled by the prerun's first evaluation) ------------------------------------------------------
+    double l1r[FAST_MAXK];
+    LL_T0(t_l1);
+    {
+        LL_CTX_DECL(sh.ctl.x)
+        const int4 *pa = rd.blk_pa + (size_t)b * rd.cap_s;
+        const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
+        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++) {
+            const int j = tid + k * RS_THREADS;
+            double l1 = -1.0;  // marker: not an active block
+            if (j < totp) {
+                const unsigned char fl = s_flag[j];
+                if (fl & BLK_ACTIVE) {
+                    if (j < nS) {
+                        PRec r;
+                        if (k < PC_RECS / RS_THREADS) {
+                            r.a = cA[j];
+                            r.b = cB[j];
+                        } else {
+                            prec_load(pa, pb, j, r);
+                        }
+                        double f[3], a[3], v[3];
+                        prec_decode(r, f, a, v);
+                        l1 = block_l1(BLK_PLANE, R_, t_, f, a, v, rc.huber_a, st->pose_last);
+                    } else {
+                        BlkRegs br;
+                        load_blk(rd, sb, av, j - nSp, br);
+                        const double a[3] = {br.a0, br.a1, br.a2};
+                        const double v[3] = {br.v0, br.v1, br.v2};
+                        LL_CTX_L1(l1, BLK_LINE, br.f, a, v, rc.huber_a, st->pose_last);
+                    }
+                }
+            }
+            l1r[k] = l1;
+        }
+    }
+    __syncthreads();
+    LL_TACC(2, t_l1);
+
+    inlier_threshold_regs(l1r, totp, s_table, sh, rc);  // overwrites the LDS block cache; the final solve refills it
+
+    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
+    {
+        const double thr = sh.thr;
+        int na = 0;
+#pragma unroll
+        for (int k = 0; k < FAST_MAXK; k++) {
+            const int j = tid + k * RS_THREADS;
+            if (j >= totp) continue;
+            const unsigned char fl = s_flag[j];
+            if (!(fl & BLK_ACTIVE)) continue;
+            if (l1r[k] > thr)
+                s_flag[j] = fl & ~BLK_ACTIVE;
+            else
+                na++;
+        }
+        na = block_sum_int(na, sh);
+        if (tid == 0) sh.n_active = na;
+        __syncthreads();
+    }
+
+    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
+    {
+        __shared__ double x_start_2[7];
+        if (tid < 7) x_start_2[tid] = sh.ctl.x[tid];
+        __syncthreads();
+        solver_lm2(rd, rc, b, nC, nS, x_start_2, rc.ceres_max_iterations, sh.n_active, s_flag, cA, cB, sh);
     }
     lm_iters += sh.ctl.iteration;
     solve_epilogue(rc, st, sh, lm_iters);
@@ -1498,7 +1814,9 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     __shared__ unsigned long long s_table[HT_SIZE];
     __shared__ unsigned char s_flag[FAST_MAX_BLOCKS];
     const int total = rd.n_corner[b] + rd.n_surf[b];
-    if (total <= FAST_MAX_BLOCKS && !rc.force_general)
+    if (!DEBLUR && scan_is_compact(rd, rc, b))
+        solve_fast2(rd, rc, b, st, sh, s_table, s_flag);
+    else if (total <= FAST_MAX_BLOCKS && !rc.force_general)
         solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
     else
         solve_general<DEBLUR>(rd, rc, b, st, sh, s_table);
