@@ -6,21 +6,125 @@
 //
 // The adapter is templated on the cloud type so that it compiles with or without PCL: any type with a
 // `points` std::vector whose elements have float members x, y, z, intensity works (pcl::PointCloud<pcl::PointXYZI>
-// does).  Poses are exposed as plain arrays in the reference's storage order {qx,qy,qz,qw,tx,ty,tz}
-// (m_para_buffer_RT, point_cloud_registration.hpp:51-56); wrap them in Eigen::Map<> in the node if desired.
+// does).  Poses are the reference's own members (m_q_w_curr, m_t_w_curr, m_q_w_last, m_t_w_last, m_q_w_incre, m_t_w_incre;
+// Eigen objects when Eigen is on the include path) next to the raw buffers in the reference's storage order
+// {qx,qy,qz,qw,tx,ty,tz} (m_para_buffer_RT, point_cloud_registration.hpp:51-56).
 //
 // See INTEGRATION.md for the two-line change in laser_feature_extractor.hpp / laser_mapping.hpp.
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "loam_livox_hip.h"
 
+// The registrar's pose members (m_q_w_curr, m_t_w_curr, m_q_w_last, m_t_w_last, m_q_w_incre, m_t_w_incre,
+// point_cloud_registration.hpp:53-56,75-76) are Eigen objects in the reference and the node assigns Eigen objects to them
+// (laser_mapping.hpp:1290-1294, 1498-1499).  With Eigen on the include path they ARE Eigen objects here; without it
+// (no-dependency builds, the C++ smoke test) they are the small look-alikes below.
+#if defined(__has_include)
+#if __has_include(<Eigen/Geometry>) && !defined(LOAM_LIVOX_ADAPTER_NO_EIGEN)
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#define LOAM_LIVOX_ADAPTER_EIGEN 1
+#endif
+#endif
+
 namespace loam_livox_hip {
+
+#if defined(LOAM_LIVOX_ADAPTER_EIGEN)
+typedef Eigen::Quaterniond Quaterniond;
+typedef Eigen::Vector3d Vector3d;
+typedef Eigen::Map<Eigen::Quaterniond> Quaterniond_map;
+typedef Eigen::Map<Eigen::Vector3d> Vector3d_map;
+#else
+struct Quaterniond {  // storage x, y, z, w like Eigen
+    double c[4] = {0, 0, 0, 1};
+    double &x() { return c[0]; }
+    double &y() { return c[1]; }
+    double &z() { return c[2]; }
+    double &w() { return c[3]; }
+    double x() const { return c[0]; }
+    double y() const { return c[1]; }
+    double z() const { return c[2]; }
+    double w() const { return c[3]; }
+    void setIdentity() { c[0] = c[1] = c[2] = 0, c[3] = 1; }
+};
+struct Vector3d {
+    double c[3] = {0, 0, 0};
+    double &operator()(int i) { return c[i]; }
+    double operator()(int i) const { return c[i]; }
+    double &x() { return c[0]; }
+    double &y() { return c[1]; }
+    double &z() { return c[2]; }
+    double x() const { return c[0]; }
+    double y() const { return c[1]; }
+    double z() const { return c[2]; }
+    void setZero() { c[0] = c[1] = c[2] = 0; }
+};
+struct Quaterniond_map {
+    double *p;
+    explicit Quaterniond_map(double *q) : p(q) {}
+    double &x() { return p[0]; }
+    double &y() { return p[1]; }
+    double &z() { return p[2]; }
+    double &w() { return p[3]; }
+    Quaterniond_map &operator=(const Quaterniond &q)
+    {
+        for (int i = 0; i < 4; i++) p[i] = q.c[i];
+        return *this;
+    }
+    operator Quaterniond() const
+    {
+        Quaterniond q;
+        for (int i = 0; i < 4; i++) q.c[i] = p[i];
+        return q;
+    }
+};
+struct Vector3d_map {
+    double *p;
+    explicit Vector3d_map(double *q) : p(q) {}
+    double &operator()(int i) { return p[i]; }
+    Vector3d_map &operator=(const Vector3d &v)
+    {
+        for (int i = 0; i < 3; i++) p[i] = v.c[i];
+        return *this;
+    }
+    operator Vector3d() const
+    {
+        Vector3d v;
+        for (int i = 0; i < 3; i++) v.c[i] = p[i];
+        return v;
+    }
+};
+#endif
+
+// Pointer members the node sets but the device path has no use for (m_logger_common, m_logger_pcd, m_logger_timer,
+// m_timer: point_cloud_registration.hpp:78-82, set at laser_mapping.hpp:1271-1274, scene_alignment.hpp:234-236): any
+// pointer can be assigned, it is kept as-is.
+struct Any_ptr {
+    const void *p = nullptr;
+    template <class T>
+    Any_ptr &operator=(T *q)
+    {
+        p = (const void *)q;
+        return *this;
+    }
+};
+// m_kdtree_corner_from_map / m_kdtree_surf_from_map (point_cloud_registration.hpp:72-73): the device grid replaces the
+// k-d trees, assignments are accepted and dropped.
+struct Any_sink {
+    template <class T>
+    Any_sink &operator=(const T &)
+    {
+        return *this;
+    }
+};
 
 inline void check(int rc, const char *what)
 {
@@ -80,9 +184,10 @@ class Livox_laser {
         if (h_) ll_fe_destroy(h_);
     }
 
-    // std::vector<pcl::PointCloud<PointXYZI>> extract_laser_features(cloud, time_stamp), LFE:722.
-    // The caller only uses the number of petal clouds and the first point of / last point of a few of them
-    // (laser_feature_extractor.hpp:287-322), so every returned cloud holds exactly those two points.
+    // std::vector<pcl::PointCloud<PointXYZI>> extract_laser_features(cloud, time_stamp), LFE:722: the petal clouds of
+    // split_laser_scan (LFE:657-719) -- a new cloud whenever the petal angle changes, the last petal dropped (:681), points
+    // masked 000 / too-near / nan removed, intensity = idx / N (set_intensity(e_I_motion_blur), :283-286), empty petals
+    // removed -- rebuilt on the host from the device's per-point planes.
     template <class Cloud>
     std::vector<Cloud> extract_laser_features(Cloud &laserCloudIn, double time_stamp = -1)
     {
@@ -90,31 +195,64 @@ class Livox_laser {
         raw_ = cloud_to_xyzi(laserCloudIn);
         const int n = (int)laserCloudIn.points.size();
         m_input_points_size = n;
+        first_of_.clear();
         int32_t n_clouds = 0;
         check(ll_fe_extract(h_, raw_.data(), n, time_stamp, &n_clouds), "ll_fe_extract");
-        std::vector<int32_t> type(n), label(n), first(max_points / 50 + 8), last(max_points / 50 + 8);
-        std::vector<float> depth(n), curv(n), view(n), ts(n);
-        check(ll_fe_labels(h_, 0, type.data(), label.data(), depth.data(), nullptr, curv.data(), view.data(), ts.data(), nullptr),
+        std::vector<int32_t> type(n), label(n);
+        std::vector<float> depth(n), curv(n), view(n), ts(n), pang(n);
+        check(ll_fe_labels(h_, 0, type.data(), label.data(), depth.data(), nullptr, curv.data(), view.data(), ts.data(), pang.data()),
               "ll_fe_labels");
         m_pts_info_vec.resize(n);
         for (int i = 0; i < n; i++) m_pts_info_vec[i] = Pt_infos{type[i], label[i], i, ts[i], depth[i], curv[i], view[i]};
         int32_t ns = 0, cl = 0, npc = 0;
-        check(ll_fe_splits(h_, 0, nullptr, &ns, &cl, &npc, first.data(), last.data(), nullptr, nullptr), "ll_fe_splits");
-        std::vector<Cloud> out((size_t)npc);
-        for (int s = 0; s < npc; s++) {
-            out[s].points.resize(first[s] == last[s] ? 1 : 2);
-            out[s].points.front() = laserCloudIn.points[first[s]];
-            out[s].points.back() = laserCloudIn.points[last[s]];
+        check(ll_fe_splits(h_, 0, nullptr, &ns, &cl, &npc, nullptr, nullptr, nullptr, nullptr), "ll_fe_splits");
+        std::vector<Cloud> out;
+        if (cl == 0) return out;  // fewer than 6 split entries (LFE:572, 759-762)
+        int scan_idx = 0;
+        std::vector<Cloud> petals((size_t)cl);
+        for (int i = 0; i < n; i++) {
+            if (i > 0 && pang[i] != pang[i - 1]) scan_idx++;
+            if (scan_idx >= cl) break;  // cannot happen: clutter_size counts the angle changes + 1
+            if (type[i] & (1 | 2 | 32)) continue;  // e_pt_000 | e_pt_too_near | e_pt_nan, LFE:684-688
+            auto pt = laserCloudIn.points[i];
+            pt.intensity = (float)i / (float)n;
+            petals[scan_idx].points.push_back(pt);
         }
+        for (int s = 0; s < scan_idx && s < cl; s++)  // resize(scan_idx): the last petal is dropped, LFE:681
+            if (!petals[s].points.empty()) out.push_back(petals[s]);
+        if ((int)out.size() != npc) throw std::runtime_error("extract_laser_features: petal count differs from the device's");
         return out;
     }
 
-    // Pt_infos *find_pt_info(const T &pt), LFE:206-217: first inserted point with the same xyz
+    // Pt_infos *find_pt_info(const T &pt), LFE:206-217: the first inserted point with the same xyz (the unordered_map keeps
+    // the first of equal keys, LFE:478).  A hash index over the scan is built at the first look-up after an extraction.
     template <class P>
     Pt_infos *find_pt_info(const P &pt)
     {
-        for (size_t i = 0; i < m_pts_info_vec.size(); i++)
-            if (raw_[4 * i] == pt.x && raw_[4 * i + 1] == pt.y && raw_[4 * i + 2] == pt.z) return &m_pts_info_vec[i];
+        if (first_of_.empty() && !m_pts_info_vec.empty()) {
+            size_t cap = 16;
+            while (cap < 2 * m_pts_info_vec.size()) cap <<= 1;
+            first_of_.assign(cap, -1);
+            for (size_t i = 0; i < m_pts_info_vec.size(); i++) {
+                size_t h = hash_xyz(raw_[4 * i], raw_[4 * i + 1], raw_[4 * i + 2]) & (cap - 1);
+                for (;; h = (h + 1) & (cap - 1)) {
+                    const int j = first_of_[h];
+                    if (j < 0) {
+                        first_of_[h] = (int)i;
+                        break;
+                    }
+                    if (raw_[4 * j] == raw_[4 * i] && raw_[4 * j + 1] == raw_[4 * i + 1] && raw_[4 * j + 2] == raw_[4 * i + 2]) break;
+                }
+            }
+        }
+        if (!first_of_.empty()) {
+            const size_t cap = first_of_.size();
+            for (size_t h = hash_xyz(pt.x, pt.y, pt.z) & (cap - 1);; h = (h + 1) & (cap - 1)) {
+                const int j = first_of_[h];
+                if (j < 0) break;
+                if (raw_[4 * j] == pt.x && raw_[4 * j + 1] == pt.y && raw_[4 * j + 2] == pt.z) return &m_pts_info_vec[j];
+            }
+        }
         throw std::runtime_error("find_pt_info: point not in the current scan (assert at livox_feature_extractor.hpp:214)");
     }
 
@@ -159,8 +297,21 @@ class Livox_laser {
         p.piecewise_number = piecewise_number;
         check(ll_fe_create(&p, &h_), "ll_fe_create");
     }
+    static size_t hash_xyz(float x, float y, float z)
+    {
+        uint32_t a, b, c;
+        x = x + 0.0f;  // -0.0f == 0.0f must hash alike (the reference compares with ==, pcl_tools.hpp:32-36)
+        y = y + 0.0f;
+        z = z + 0.0f;
+        std::memcpy(&a, &x, 4);
+        std::memcpy(&b, &y, 4);
+        std::memcpy(&c, &z, 4);
+        uint64_t h = (uint64_t)a * 0x9E3779B97F4A7C15ull ^ ((uint64_t)b << 21) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)c * 0x165667B19E3779F9ull;
+        return (size_t)(h ^ (h >> 29));
+    }
     ll_fe *h_ = nullptr;
     std::vector<float> raw_;
+    std::vector<int> first_of_;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -350,14 +501,90 @@ class Points_cloud_map {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+// Device handles are expensive to create (hipMalloc of the per-scan scratch) and the node constructs a fresh
+// Point_cloud_registration for every scan (laser_mapping.hpp:1348), up to maximum_parallel_thread of them at once
+// (:1737-1742).  Objects therefore borrow their ll_reg from a process-wide pool and give it back in the destructor; the
+// match-buffer ll_map is shared by all of them (an immutable snapshot is pinned by each solve, see ll_map_upload).
+class Handle_pool {
+   public:
+    static Handle_pool &instance()
+    {
+        static Handle_pool p;
+        return p;
+    }
+    ll_reg *acquire(int device, int max_features)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].device == device && free_[i].max_features >= max_features) {
+                    ll_reg *r = free_[i].reg;
+                    free_.erase(free_.begin() + (long)i);
+                    return r;
+                }
+        }
+        ll_reg *r = nullptr;
+        check(ll_reg_create(device, 1, max_features, &r), "ll_reg_create");
+        std::lock_guard<std::mutex> lk(mu_);
+        feat_.push_back(std::make_pair(r, Entry{r, device, max_features}));
+        return r;
+    }
+    void release(ll_reg *r)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto &kv : feat_)
+            if (kv.first == r) {
+                free_.push_back(kv.second);
+                return;
+            }
+    }
+    ll_map *shared_map(int device)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto &m : maps_)
+            if (m.first == device) return m.second;
+        ll_map *m = nullptr;
+        check(ll_map_create(device, &m), "ll_map_create");
+        maps_.push_back(std::make_pair(device, m));
+        return m;
+    }
+    std::mutex &upload_mutex() { return upload_mu_; }
+    struct Key {  // identity of an uploaded cloud: address, size and a sample of its contents
+        const void *p = nullptr;
+        size_t n = 0;
+        uint64_t sample = 0;
+        bool operator==(const Key &o) const { return p == o.p && n == o.n && sample == o.sample; }
+    };
+    Key key[2];
+
+   private:
+    struct Entry {
+        ll_reg *reg;
+        int device, max_features;
+    };
+    Handle_pool() {}
+    ~Handle_pool()
+    {
+        for (auto &kv : feat_) ll_reg_destroy(kv.first);
+        for (auto &m : maps_) ll_map_destroy(m.second);
+    }
+    std::mutex mu_, upload_mu_;
+    std::vector<Entry> free_;
+    std::vector<std::pair<ll_reg *, Entry>> feat_;
+    std::vector<std::pair<int, ll_map *>> maps_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
 class Point_cloud_registration {
    public:
     // configuration fields with the reference names and defaults (point_cloud_registration.hpp:45-103)
     int ICP_PLANE = 1, ICP_LINE = 1;
     int IF_LINE_FEATURE_CHECK = 0, IF_PLANE_FEATURE_CHECK = 0;  // PCR:46,48
+    int line_search_num = 5, plane_search_num = 5;              // PCR:45,47 (the device search is fixed at k = 5)
     int m_if_motion_deblur = 0;
     int m_current_frame_index = 0;
     int m_mapping_init_accumulate_frames = 100;
+    float m_last_time_stamp = 0;
     float m_para_max_angular_rate = 200.0f / 50.0f;
     float m_para_max_speed = 100.0f / 50.0f;
     float m_max_final_cost = 100.0f;
@@ -370,54 +597,122 @@ class Point_cloud_registration {
     double m_maximum_dis_plane_for_match = 50.0, m_maximum_dis_line_for_match = 2.0;
     int m_maximum_allow_residual_block = 100000;
     int m_subsample_seed = 1;  // seed of the reproducible stand-in for m_rand_float (PCR:104); 0 = refuse to sub-sample
-    // state: {qx,qy,qz,qw,tx,ty,tz}
-    double m_para_buffer_RT[7] = {0, 0, 0, 1, 0, 0, 0};        // m_q_w_curr / m_t_w_curr
-    double m_para_buffer_RT_last[7] = {0, 0, 0, 1, 0, 0, 0};   // m_q_w_last / m_t_w_last
+    int m_if_verbose_screen_printf = 1;  // ADD_SCREEN_PRINTF_OUT_METHOD (PCR:119); nothing is printed here
+    // what the node points at its loggers / timer (PCR:78-82, LM:1271-1274, SA:234-236) and the k-d tree members (PCR:72-73)
+    Any_ptr m_logger_common, m_logger_pcd, m_logger_timer, m_timer;
+    Any_sink m_kdtree_corner_from_map, m_kdtree_surf_from_map;
+    // state, with the reference's member names and types (PCR:51-56, 75-76)
+    double m_para_buffer_RT[7] = {0, 0, 0, 1, 0, 0, 0};
+    double m_para_buffer_RT_last[7] = {0, 0, 0, 1, 0, 0, 0};
     double m_para_buffer_incremental[7] = {0, 0, 0, 1, 0, 0, 0};
+    Quaterniond_map m_q_w_incre = Quaterniond_map(m_para_buffer_incremental);
+    Vector3d_map m_t_w_incre = Vector3d_map(m_para_buffer_incremental + 4);
+    Quaterniond m_q_w_curr, m_q_w_last;
+    Vector3d m_t_w_curr, m_t_w_last;
     double m_inlier_threshold = 0, m_angular_diff = 0, m_t_diff = 0;
-    ll_reg_report m_final_opt_summary{};
+    // ceres::Solver::Summary look-alike: the fields and reports the node reads (LM:1041, 1511-1512; PCR:555-559)
+    struct Opt_summary : ll_reg_report {
+        int num_residual_blocks = 0;
+        Opt_summary() : ll_reg_report() {}
+        std::string BriefReport() const
+        {
+            char b[256];
+            std::snprintf(b, sizeof(b), "loam_livox_hip: ICP iterations %d, LM iterations %d, initial_cost %.6e, final_cost %.6e, blocks %d",
+                          icp_iterations, lm_iterations_total, initial_cost, final_cost, n_blocks_last);
+            return b;
+        }
+        std::string FullReport() const { return BriefReport(); }
+    };
+    Opt_summary summary, m_final_opt_summary;
     int device = 0;
     int max_features = 100000;
 
+    Point_cloud_registration()
+    {
+        m_q_w_last.setIdentity();
+        m_t_w_last.setZero();
+        m_q_w_curr.setIdentity();
+        m_t_w_curr.setZero();
+    }
+    // the maps refer to this object's own buffer: copies re-seat them
+    Point_cloud_registration(const Point_cloud_registration &o) { *this = o; }
+    Point_cloud_registration &operator=(const Point_cloud_registration &o)
+    {
+        if (this == &o) return *this;
+        ICP_PLANE = o.ICP_PLANE, ICP_LINE = o.ICP_LINE;
+        IF_LINE_FEATURE_CHECK = o.IF_LINE_FEATURE_CHECK, IF_PLANE_FEATURE_CHECK = o.IF_PLANE_FEATURE_CHECK;
+        m_if_motion_deblur = o.m_if_motion_deblur, m_current_frame_index = o.m_current_frame_index;
+        m_mapping_init_accumulate_frames = o.m_mapping_init_accumulate_frames, m_last_time_stamp = o.m_last_time_stamp;
+        m_para_max_angular_rate = o.m_para_max_angular_rate, m_para_max_speed = o.m_para_max_speed, m_max_final_cost = o.m_max_final_cost;
+        m_para_icp_max_iterations = o.m_para_icp_max_iterations, m_para_cere_max_iterations = o.m_para_cere_max_iterations;
+        m_para_cere_prerun_times = o.m_para_cere_prerun_times;
+        m_minimum_pt_time_stamp = o.m_minimum_pt_time_stamp, m_maximum_pt_time_stamp = o.m_maximum_pt_time_stamp;
+        m_minimum_icp_R_diff = o.m_minimum_icp_R_diff, m_minimum_icp_T_diff = o.m_minimum_icp_T_diff;
+        m_inliner_dis = o.m_inliner_dis, m_inlier_ratio = o.m_inlier_ratio;
+        m_maximum_dis_plane_for_match = o.m_maximum_dis_plane_for_match, m_maximum_dis_line_for_match = o.m_maximum_dis_line_for_match;
+        m_maximum_allow_residual_block = o.m_maximum_allow_residual_block, m_subsample_seed = o.m_subsample_seed;
+        m_if_verbose_screen_printf = o.m_if_verbose_screen_printf;
+        m_logger_common = o.m_logger_common, m_logger_pcd = o.m_logger_pcd, m_logger_timer = o.m_logger_timer, m_timer = o.m_timer;
+        for (int i = 0; i < 7; i++) {
+            m_para_buffer_RT[i] = o.m_para_buffer_RT[i];
+            m_para_buffer_RT_last[i] = o.m_para_buffer_RT_last[i];
+            m_para_buffer_incremental[i] = o.m_para_buffer_incremental[i];
+        }
+        m_q_w_curr = o.m_q_w_curr, m_q_w_last = o.m_q_w_last, m_t_w_curr = o.m_t_w_curr, m_t_w_last = o.m_t_w_last;
+        m_inlier_threshold = o.m_inlier_threshold, m_angular_diff = o.m_angular_diff, m_t_diff = o.m_t_diff;
+        summary = o.summary, m_final_opt_summary = o.m_final_opt_summary;
+        device = o.device, max_features = o.max_features;
+        return *this;
+    }
+
     ~Point_cloud_registration()
     {
-        if (reg_) ll_reg_destroy(reg_);
-        if (map_) ll_map_destroy(map_);
+        if (reg_) Handle_pool::instance().release(reg_);
+    }
+
+    // float refine_blur(in_blur, min_blur, max_blur), PCR:128-141
+    float refine_blur(float in_blur, const float &min_blur, const float &max_blur) const
+    {
+        float res = 1.0f;
+        if (m_if_motion_deblur) {
+            res = (in_blur - min_blur) / (max_blur - min_blur);
+            if (!std::isfinite(res) || res > 1.0f) return 1.0f;
+        }
+        return res;
     }
 
     // int find_out_incremental_transfrom(map_corner, map_surf, kd_corner, kd_surf, scan_corner, scan_surf), PCR:163.
-    // The KdTreeFLANN arguments are accepted and ignored: the device grid replaces them.  The map is re-uploaded
-    // only when the cloud objects (address + size) change, mirroring the match-buffer refresh of
-    // laser_mapping.hpp:460-566.
+    // The KdTreeFLANN arguments are accepted and ignored: the device grid replaces them.  The map is re-uploaded only
+    // when a cloud changes (address, size or a sample of its contents), mirroring the match-buffer refresh of
+    // laser_mapping.hpp:460-566; a solve that is already running keeps the snapshot it started with.
     template <class CloudPtr, class KdTree>
     int find_out_incremental_transfrom(CloudPtr map_corner, CloudPtr map_surf, KdTree &, KdTree &, CloudPtr scan_corner, CloudPtr scan_surf)
     {
         return find_out_incremental_transfrom(map_corner, map_surf, scan_corner, scan_surf);
     }
 
-    // 4-argument overload, PCR:585-605
+    // 4-argument overload, PCR:585-605 (returns 1 without registering when a map cloud is empty, :592-601)
     template <class CloudPtr>
     int find_out_incremental_transfrom(CloudPtr map_corner, CloudPtr map_surf, CloudPtr scan_corner, CloudPtr scan_surf)
     {
-        upload_if_changed(LL_MAP_CORNER, *map_corner, key_[0]);
-        upload_if_changed(LL_MAP_SURF, *map_surf, key_[1]);
+        {
+            std::lock_guard<std::mutex> lk(Handle_pool::instance().upload_mutex());
+            upload_if_changed(LL_MAP_CORNER, *map_corner, Handle_pool::instance().key[0]);
+            upload_if_changed(LL_MAP_SURF, *map_surf, Handle_pool::instance().key[1]);
+        }
         return find_out_incremental_transfrom(scan_corner, scan_surf);
     }
 
     // The search structure the registrar matches against.  History_buffer::refresh( pc_reg.map() ) /
     // refresh_cells( pc_reg.map(), ... ) rebuild it on the device (update_buff_for_matching, laser_mapping.hpp:460-566);
     // the 2-argument form below then registers against it without a map cloud ever crossing the bus.
-    ll_map *map()
-    {
-        if (!map_) check(ll_map_create(device, &map_), "ll_map_create");
-        return map_;
-    }
+    ll_map *map() { return Handle_pool::instance().shared_map(device); }
 
     template <class CloudPtr>
     int find_out_incremental_transfrom(CloudPtr scan_corner, CloudPtr scan_surf)
     {
-        if (!reg_) check(ll_reg_create(device, 1, max_features, &reg_), "ll_reg_create");
-        map();
+        if (!reg_) reg_ = Handle_pool::instance().acquire(device, max_features);
+        ll_map *m = map();
         const std::vector<float> c = cloud_to_xyzi(*scan_corner), s = cloud_to_xyzi(*scan_surf);
         ll_reg_params p;
         ll_reg_default_params(&p);
@@ -444,22 +739,50 @@ class Point_cloud_registration {
         p.max_final_cost = m_max_final_cost;
         p.minimum_pt_time_stamp = m_minimum_pt_time_stamp;
         p.maximum_pt_time_stamp = m_maximum_pt_time_stamp;
+        pose_from_members();
         ll_reg_report rep;
-        const int ret = ll_reg_solve(reg_, map_, c.data(), (int)(c.size() / 4), s.data(), (int)(s.size() / 4), &p, m_para_buffer_RT_last,
+        const int ret = ll_reg_solve(reg_, m, c.data(), (int)(c.size() / 4), s.data(), (int)(s.size() / 4), &p, m_para_buffer_RT_last,
                                      m_para_buffer_RT, m_para_buffer_incremental, &rep);
         check(ret, "ll_reg_solve");
+        members_from_pose();
         m_inlier_threshold = rep.inlier_threshold;
         m_angular_diff = rep.angular_diff_deg;
         m_t_diff = rep.t_diff;
-        if (ret == 1) m_final_opt_summary = rep;  // PCR:574
+        static_cast<ll_reg_report &>(summary) = rep;
+        summary.num_residual_blocks = rep.n_blocks_last;
+        if (ret == 1 && !rep.gated) m_final_opt_summary = summary;  // PCR:574
+        if (ret == 0) m_last_time_stamp = m_minimum_pt_time_stamp;   // PCR:569
         return ret;
+    }
+
+    // void pointAssociateToMap(pi, po, interpolate_s = 1.0, if_undistore = 0), PCR:622-661.  The node calls it per point
+    // with g_if_undistore == 0 (laser_mapping.hpp:80, 1424, 1430): p_w = q_w_curr * p + t_w_curr in double, stored to
+    // float, with Eigen's rotation formula  v + w (2 q x v) + q x (2 q x v).  The Rodrigues-interpolated form needs the
+    // increment of the registration in progress and lives on the device only (if_undistore != 0 throws).
+    template <class P>
+    void pointAssociateToMap(P const *const pi, P *const po, double interpolate_s = 1.0, int if_undistore = 0)
+    {
+        if (!(m_if_motion_deblur == 0 || if_undistore == 0 || interpolate_s == 1.0))
+            throw std::runtime_error("pointAssociateToMap: the motion-deblur interpolation (PCR:633-654) is only available inside the registrar");
+        const double qx = m_q_w_curr.x(), qy = m_q_w_curr.y(), qz = m_q_w_curr.z(), qw = m_q_w_curr.w();
+        const double v[3] = {(double)pi->x, (double)pi->y, (double)pi->z};
+        double uv[3] = {qy * v[2] - qz * v[1], qz * v[0] - qx * v[2], qx * v[1] - qy * v[0]};
+        uv[0] += uv[0];
+        uv[1] += uv[1];
+        uv[2] += uv[2];
+        const double c[3] = {qy * uv[2] - qz * uv[1], qz * uv[0] - qx * uv[2], qx * uv[1] - qy * uv[0]};
+        po->x = (float)((v[0] + qw * uv[0] + c[0]) + m_t_w_curr(0));
+        po->y = (float)((v[1] + qw * uv[1] + c[1]) + m_t_w_curr(1));
+        po->z = (float)((v[2] + qw * uv[2] + c[2]) + m_t_w_curr(2));
+        po->intensity = pi->intensity;
     }
 
     // unsigned int pointcloudAssociateToMap(pc_in, pt_out, if_undistore = 0), PCR:673-685
     template <class Cloud>
     unsigned int pointcloudAssociateToMap(const Cloud &pc_in, Cloud &pt_out, int /*if_undistore*/ = 0)
     {
-        if (!reg_) check(ll_reg_create(device, 1, max_features, &reg_), "ll_reg_create");
+        if (!reg_) reg_ = Handle_pool::instance().acquire(device, max_features);
+        pose_from_members();
         const std::vector<float> in = cloud_to_xyzi(pc_in);
         std::vector<float> out(in.size());
         check(ll_cloud_transform(reg_, in.data(), out.data(), (int)(in.size() / 4), m_para_buffer_RT), "ll_cloud_transform");
@@ -468,23 +791,42 @@ class Point_cloud_registration {
     }
 
    private:
-    struct Key {
-        const void *p = nullptr;
-        size_t n = 0;
-    };
-    template <class Cloud>
-    void upload_if_changed(int kind, const Cloud &c, Key &k)
+    void pose_from_members()
     {
-        if (k.p == (const void *)c.points.data() && k.n == c.points.size()) return;
-        map();
+        m_para_buffer_RT[0] = m_q_w_curr.x(), m_para_buffer_RT[1] = m_q_w_curr.y(), m_para_buffer_RT[2] = m_q_w_curr.z(), m_para_buffer_RT[3] = m_q_w_curr.w();
+        m_para_buffer_RT_last[0] = m_q_w_last.x(), m_para_buffer_RT_last[1] = m_q_w_last.y(), m_para_buffer_RT_last[2] = m_q_w_last.z(),
+        m_para_buffer_RT_last[3] = m_q_w_last.w();
+        for (int i = 0; i < 3; i++) {
+            m_para_buffer_RT[4 + i] = m_t_w_curr(i);
+            m_para_buffer_RT_last[4 + i] = m_t_w_last(i);
+        }
+    }
+    void members_from_pose()
+    {
+        m_q_w_curr.x() = m_para_buffer_RT[0], m_q_w_curr.y() = m_para_buffer_RT[1], m_q_w_curr.z() = m_para_buffer_RT[2], m_q_w_curr.w() = m_para_buffer_RT[3];
+        for (int i = 0; i < 3; i++) m_t_w_curr(i) = m_para_buffer_RT[4 + i];
+    }
+    template <class Cloud>
+    void upload_if_changed(int kind, const Cloud &c, Handle_pool::Key &k)
+    {
+        Handle_pool::Key now;
+        now.p = (const void *)c.points.data();
+        now.n = c.points.size();
+        const size_t step = now.n / 61 + 1;
+        for (size_t i = 0; i < now.n; i += step) {
+            uint32_t b[3];
+            const float v[3] = {c.points[i].x, c.points[i].y, c.points[i].z};
+            std::memcpy(b, v, 12);
+            now.sample = (now.sample ^ b[0]) * 0x100000001B3ull;
+            now.sample = (now.sample ^ b[1]) * 0x100000001B3ull;
+            now.sample = (now.sample ^ b[2]) * 0x100000001B3ull;
+        }
+        if (k == now) return;
         const std::vector<float> v = cloud_to_xyzi(c);
-        check(ll_map_upload(map_, kind, v.data(), 4, (int64_t)c.points.size(), 0.0f), "ll_map_upload");
-        k.p = (const void *)c.points.data();
-        k.n = c.points.size();
+        check(ll_map_upload(map(), kind, v.data(), 4, (int64_t)c.points.size(), 0.0f), "ll_map_upload");
+        k = now;
     }
     ll_reg *reg_ = nullptr;
-    ll_map *map_ = nullptr;
-    Key key_[2];
 };
 
 }  // namespace loam_livox_hip

@@ -533,7 +533,7 @@ class Point_cloud_registration:
         return (int(out[0]), int(out[1])), (int(out[2]), int(out[3]))
 
     def debug_cycles(self, scan: int = 0):
-        out = np.zeros(6, np.int64)
+        out = np.zeros(10, np.int64)
         check(self.L.ll_reg_debug_cycles(self.h, scan, ptr(out)), "ll_reg_debug_cycles")
         return out
 

@@ -798,10 +798,10 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
     return 0;
 }
 
-extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[6])
+extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[10])
 {
     if (!r || scan < 0 || scan >= r->max_scans) return set_err("ll_reg_debug_cycles", "bad argument");
-    for (int i = 0; i < 6; i++) out[i] = r->h_state[scan].dbg_cycles[i];
+    for (int i = 0; i < 10; i++) out[i] = r->h_state[scan].dbg_cycles[i];
     return 0;
 }
 

@@ -92,7 +92,7 @@ struct RegState {
     int icp_iters, n_blocks_last, corner_avail, surf_avail, lm_total;
     int done, accepted, gated, result;
     int pad;
-    long long dbg_cycles[6];  // LL_SOLVE_TIMING builds: eval, LM controller, L1, dedupe, select+prune, total (shader clocks)
+    long long dbg_cycles[10];  // LL_SOLVE_TIMING builds (shader clocks): eval, LM controller, L1, dedupe, select, total, census, prune, epilogue; [9] = L1 shortcuts taken
 };
 
 struct RegConst {

@@ -647,7 +647,9 @@ LL_HD void state_plus(const double x[7], const double d[6], double bound, double
 // factorisation is unchanged.
 LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
 {
-    double L[36];
+    // One reciprocal per pivot instead of a division per element: an fp64 division is a ~30-instruction dependent chain
+    // on the one lane that runs the controller, and the factorisation had 21 of them (+ 6 square roots).
+    double L[36], inv[6];
     int ok = 1;
     LL_UNROLL
     for (int i = 0; i < 6; i++) {
@@ -661,8 +663,9 @@ LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
             if (i == j) {
                 if (!(s > 0.0)) ok = 0;
                 L[i * 6 + i] = sqrt(s);
+                inv[i] = 1.0 / L[i * 6 + i];
             } else {
-                L[i * 6 + j] = s / L[j * 6 + j];
+                L[i * 6 + j] = s * inv[j];
             }
         }
     }
@@ -673,7 +676,7 @@ LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
         LL_UNROLL
         for (int k = 0; k < 6; k++)
             if (k < i) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
+        y[i] = s * inv[i];
     }
     LL_UNROLL
     for (int i = 5; i >= 0; i--) {
@@ -681,7 +684,7 @@ LL_HD int chol_solve6(const double A[36], const double b[6], double x[6])
         LL_UNROLL
         for (int k = 0; k < 6; k++)
             if (k > i) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        x[i] = s * inv[i];
     }
     LL_UNROLL
     for (int i = 0; i < 6; i++)
@@ -710,6 +713,8 @@ struct LmCtl {
     double ls_step;
     int ls_iter, ls_active;
     int done;
+    int last_accept;  // set by lm_update: 0 = the step was not accepted, 1 = accepted and x is the point just evaluated,
+                      // 2 = accepted but x is the first point of a failed line search (not the one just evaluated)
 };
 
 LL_HD double lm_gradient_max_norm(const double x[7], const double g[6], double bound)
@@ -881,6 +886,8 @@ LL_LM_FN int lm_update(LmCtl &c, const double e_in[LL_NACC])
 {
     double e[LL_NACC];
     for (int i = 0; i < LL_NACC; i++) e[i] = e_in[i];
+    c.last_accept = 0;
+    int from_first_eval = 0;
     if (c.bound >= 0) {
         // projected ARMIJO line search (TrustRegionMinimizer::DoLineSearch)
         if (!c.ls_active) {
@@ -913,6 +920,7 @@ LL_LM_FN int lm_update(LmCtl &c, const double e_in[LL_NACC])
                 return 1;
             }
             // failed search: Ceres keeps the full step
+            from_first_eval = c.ls_iter > 1 ? 1 : 0;  // the point just evaluated is the first one only when no retry ran
             for (int i = 0; i < LL_NACC; i++) e[i] = c.first_eval[i];
             for (int i = 0; i < 7; i++) c.cand[i] = c.first_cand[i];
         } else if (c.ls_step != 1.0) {
@@ -936,6 +944,7 @@ LL_LM_FN int lm_update(LmCtl &c, const double e_in[LL_NACC])
     }
     const double relative_decrease = cost_change / c.model_cost_change;
     if (relative_decrease > 1e-3) {
+        c.last_accept = from_first_eval ? 2 : 1;
         double n = 0;
         for (int i = 0; i < 7; i++) {
             c.x[i] = c.cand[i];

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_list_kernel(RegDev rd, R
 #endif
 
 struct SolveShared {
-    long long tcyc[6];
+    long long tcyc[10];
     LmCtl ctl;
     double red[RS_WAVES][LL_NACC];
     double sum[LL_NACC];
@@ -462,6 +462,7 @@ struct SolveShared {
     unsigned long long sel_prefix;
     int sel_rank;
     int n_active, n_corner_avail, n_surf_avail, n_unique;
+    int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
     double thr;
 };
 
@@ -646,6 +647,12 @@ __device__ void solve_epilogue(const RegConst &rc, RegState *st, SolveShared &sh
 #define DD_CB_SIZE (1 << DD_CB_LOG2)
 #define DD_EX_SIZE 4096
 #define DD_MAX_COLL 900    // contested keys beyond this (heavily duplicated input): hash every key instead
+// register-tile de-duplication (inlier_threshold_regs): 2-bit slot states, 64 KB + 32 KB, and a list of twice-contested keys
+#define DD2_WORDS 16384
+#define DD2_SLOTS (DD2_WORDS * 16)
+#define DD2B_WORDS 8192
+#define DD2B_SLOTS (DD2B_WORDS * 16)
+#define DD2_LIST 2048  // twice-contested keys compared exactly; more (heavily duplicated input): hash every key instead
 #define SEL_BINS 4096  // value-range bins of the rank select (must be a multiple of RS_THREADS)
 #define SEL_CAND 1024  // keys of the selected bin ranked exactly; more -> radix-select fallback
 
@@ -1035,7 +1042,7 @@ template <int NK>
 __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], int total, unsigned long long *s_table, SolveShared &sh,
                                                       const RegConst &rc)
 {
-    static_assert(NK == FAST_MAXK, "register tile of the fast paths");
+    static_assert(NK <= 64 && NK <= FAST_MAXK, "register tile of the fast paths (one bit per entry in the 64-bit masks)");
     const int tid = threadIdx.x;
     LL_T0(t_dd);
     // ---- std::set semantics (PCR:155-160): which values are distinct, and how many ---------------------------------
@@ -1045,84 +1052,117 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
     // duplicated inputs (more than DD_MAX_COLL such keys) fall back to hashing every key, HT_PART keys per round.
     unsigned long long first_mask = 0;  // bit k: block k of this thread is the first occurrence of its L1 value
     {
+        // Common case (round 2 form).  Three short, branch-light passes over the thread's keys instead of a
+        // compare-and-swap probe per key (round 1: ~290 instructions per key once the compiler had unrolled the probe loop):
+        //   A  every key marks a 2-bit slot state {bit 0: a key landed here, bit 1: a second key landed here} in a
+        //      256 K-slot table (atomicOr): a key whose slot never gets bit 1 is distinct from every other key;
+        //   B  the keys of contested slots (hash collisions and true duplicates, ~1100 of ~17 k) repeat that in a second
+        //      table under an independent hash: distinct keys that merely collided in A almost surely separate here;
+        //   C  what is contested twice -- true duplicates plus a stray pair -- is appended to a short list and compared
+        //      exactly, each entry against the entries before it.
+        // Slot hashes are two 32-bit multiplies.  Heavily duplicated inputs (list overflow) take the table path below.
         int my = 0;
-        unsigned int *bm = (unsigned int *)s_table;                      // [DD_BM_WORDS] bitmap
-        unsigned int *cb = bm + DD_BM_WORDS;                             // [DD_CB_SIZE] set of contested bit indices
-        unsigned long long *ex = (unsigned long long *)(cb + DD_CB_SIZE); // [DD_EX_SIZE] exact table of the contested keys
-        for (int e = tid; e < DD_BM_WORDS; e += RS_THREADS) bm[e] = 0u;
-        for (int e = tid; e < DD_CB_SIZE; e += RS_THREADS) cb[e] = 0xffffffffu;
-        for (int e = tid; e < DD_EX_SIZE; e += RS_THREADS) ex[e] = HASH_EMPTY;
+        unsigned int *bmA = (unsigned int *)s_table;                       // [DD2_WORDS]  16 slots x 2 bits per word, 64 KB
+        unsigned int *bmB = bmA + DD2_WORDS;                               // [DD2B_WORDS] second table, 32 KB
+        unsigned long long *dl = (unsigned long long *)(bmB + DD2B_WORDS); // [DD2_LIST] twice-contested keys
+        {
+            uint4 *z = (uint4 *)s_table;
+            for (int e = tid; e < (DD2_WORDS + DD2B_WORDS) / 4; e += RS_THREADS) z[e] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid == 0) sh.n_cand = 0;
+        }
         __syncthreads();
-        unsigned long long coll = 0;
-        int ncoll = 0;
+        const int kt = (total + RS_THREADS - 1) / RS_THREADS;  // rounds that can hold a block (uniform)
+        // slot hashes are recomputed in each pass (two 32-bit multiplies) rather than kept: with l1r[48] live, another 48
+        // registers per thread made the compiler spill half of l1r to scratch, and every later pass paid for it
+        auto slot_a = [](unsigned long long key) -> unsigned int {
+            unsigned int h = (unsigned int)key * 0x9E3779B1u;
+            h ^= h >> 15;
+            h += (unsigned int)(key >> 32) * 0x85EBCA77u;
+            h ^= h >> 13;
+            return h & (DD2_SLOTS - 1);
+        };
+        auto slot_b = [](unsigned long long key) -> unsigned int {
+            unsigned int h2 = ((unsigned int)(key >> 32) * 0xC2B2AE3Du) ^ ((unsigned int)key * 0x27D4EB2Fu);
+            return (h2 ^ (h2 >> 16)) & (DD2B_SLOTS - 1);
+        };
+        unsigned long long valid_mask = 0, cont_mask = 0;
 #pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++) {
+        for (int k = 0; k < NK; k++) {
+            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
             const double l1 = l1r[k];
-            if (!(l1 >= 0.0)) continue;  // inactive slot or NaN (NaN never enters the set)
-            const unsigned int hb = (unsigned int)hash64((unsigned long long)__double_as_longlong(l1)) & (DD_BM_WORDS * 32 - 1);
-            const unsigned int bit = 1u << (hb & 31);
-            if (atomicOr(&bm[hb >> 5], bit) & bit) {
-                coll |= 1ull << k;
-                ncoll++;
+            const bool valid = l1 >= 0.0;  // inactive slot or NaN (NaN never enters the set)
+            const unsigned int slot = slot_a((unsigned long long)__double_as_longlong(l1));
+            const unsigned int bit0 = valid ? (1u << ((slot & 15u) * 2u)) : 0u;  // 0: a harmless no-op for padding lanes
+            const unsigned int old = atomicOr(&bmA[slot >> 4], bit0);
+            atomicOr(&bmA[slot >> 4], (old & bit0) << 1);
+            if (valid) valid_mask |= 1ull << k;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
+            const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
+            const unsigned int slot = slot_a(key);
+            const bool contested = ((valid_mask >> k) & 1ull) && ((bmA[slot >> 4] >> ((slot & 15u) * 2u)) & 2u);
+            const unsigned int h2 = slot_b(key);
+            const unsigned int bit0 = contested ? (1u << ((h2 & 15u) * 2u)) : 0u;
+            const unsigned int old = atomicOr(&bmB[h2 >> 4], bit0);
+            atomicOr(&bmB[h2 >> 4], (old & bit0) << 1);
+            if (contested) cont_mask |= 1ull << k;
+        }
+        __syncthreads();
+        unsigned long long twice_mask = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
+            const unsigned int h2 = slot_b((unsigned long long)__double_as_longlong(l1r[k]));
+            if (((cont_mask >> k) & 1ull) && ((bmB[h2 >> 4] >> ((h2 & 15u) * 2u)) & 2u)) twice_mask |= 1ull << k;
+        }
+        // every valid key that is not contested twice is distinct; the rest go through the exact list
+        my = __popcll(valid_mask & ~twice_mask);
+        first_mask = valid_mask & ~twice_mask;
+        int my_pos[2] = {-1, -1};  // list positions of this thread's twice-contested keys (more than two: overflow)
+        int n_twice = __popcll(twice_mask);
+        if (twice_mask) {
+            int got = 0;
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                if (!((twice_mask >> k) & 1ull)) continue;
+                const int pos = atomicAdd(&sh.n_cand, 1);
+                if (pos < DD2_LIST) dl[pos] = (unsigned long long)__double_as_longlong(l1r[k]);
+                if (got < 2) my_pos[got] = pos;
+                got++;
             }
         }
-        const int total_coll = block_sum_int(ncoll, sh);
-        if (total_coll <= DD_MAX_COLL) {
+        const int over = block_sum_int(n_twice > 2 ? 1 : 0, sh);  // its barriers also publish the list
+        const int n_list = sh.n_cand;
+        if (n_list <= DD2_LIST && over == 0) {
+            if (twice_mask) {
+                int got = 0;
 #pragma unroll
-            for (int k = 0; k < FAST_MAXK; k++) {
-                if (!(coll & (1ull << k))) continue;
-                const unsigned int hb = (unsigned int)hash64((unsigned long long)__double_as_longlong(l1r[k])) & (DD_BM_WORDS * 32 - 1);
-                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
-                for (;;) {
-                    const unsigned int old = atomicCAS(&cb[h], 0xffffffffu, hb);
-                    if (old == 0xffffffffu || old == hb) break;
-                    h = (h + 1u) & (DD_CB_SIZE - 1);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < FAST_MAXK; k++) {
-                const double l1 = l1r[k];
-                if (!(l1 >= 0.0)) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
-                const unsigned long long hk = hash64(key);
-                const unsigned int hb = (unsigned int)hk & (DD_BM_WORDS * 32 - 1);
-                bool contested = false;
-                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
-                for (;;) {
-                    const unsigned int c = cb[h];
-                    if (c == 0xffffffffu) break;
-                    if (c == hb) {
-                        contested = true;
-                        break;
-                    }
-                    h = (h + 1u) & (DD_CB_SIZE - 1);
-                }
-                if (!contested) {  // the only key on its bit: distinct from every other key
-                    first_mask |= (1ull << k);
-                    my++;
-                    continue;
-                }
-                unsigned int h2 = (unsigned int)(hk >> 24) & (DD_EX_SIZE - 1);
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&ex[h2], HASH_EMPTY, key);
-                    if (old == HASH_EMPTY) {
-                        first_mask |= (1ull << k);
+                for (int k = 0; k < NK; k++) {
+                    if (!((twice_mask >> k) & 1ull)) continue;
+                    const int pos = my_pos[got < 2 ? got : 1];
+                    got++;
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
+                    bool dup = false;
+                    for (int j = 0; j < pos; j++) dup |= (dl[j] == key);
+                    if (!dup) {
+                        first_mask |= 1ull << k;
                         my++;
-                        break;
                     }
-                    if (old == key) break;
-                    h2 = (h2 + 1u) & (DD_EX_SIZE - 1);
                 }
             }
         } else {
+            first_mask = 0;
+            my = 0;
             const int rounds = (total + HT_PART - 1) / HT_PART;
             for (int rnd = 0; rnd < rounds; rnd++) {
                 __syncthreads();
                 for (int e = tid; e < HT_SIZE; e += RS_THREADS) s_table[e] = HASH_EMPTY;
                 __syncthreads();
 #pragma unroll
-                for (int k = 0; k < FAST_MAXK; k++) {
+                for (int k = 0; k < NK; k++) {
                     const double l1 = l1r[k];
                     if (!(l1 >= 0.0)) continue;
                     const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
@@ -1163,7 +1203,7 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
         unsigned long long *cand = s_table + SEL_BINS / 2;               // [SEL_CAND] keys of the selected bin
         double kmin = INFINITY, kmax = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++)
+        for (int k = 0; k < NK; k++)
             if (first_mask & (1ull << k)) {
                 kmin = fmin(kmin, l1r[k]);
                 kmax = fmax(kmax, l1r[k]);
@@ -1185,7 +1225,7 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
         }
         const double scale = (hi > lo) ? (double)(SEL_BINS - 1) / (hi - lo) : 0.0;
 #pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++)
+        for (int k = 0; k < NK; k++)
             if (first_mask & (1ull << k)) {
                 int bi = (int)((l1r[k] - lo) * scale);
                 bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
@@ -1229,7 +1269,7 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
         if (sh.sel_cnt <= SEL_CAND) {
             const int sel_bin = sh.sel_bin;
 #pragma unroll
-            for (int k = 0; k < FAST_MAXK; k++)
+            for (int k = 0; k < NK; k++)
                 if (first_mask & (1ull << k)) {
                     int bi = (int)((l1r[k] - lo) * scale);
                     bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
@@ -1255,7 +1295,7 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
                 __syncthreads();
                 const unsigned long long prefix = sh.sel_prefix;
 #pragma unroll
-                for (int k = 0; k < FAST_MAXK; k++) {
+                for (int k = 0; k < NK; k++) {
                     if (!(first_mask & (1ull << k))) continue;
                     int bi = (int)((l1r[k] - lo) * scale);
                     bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
@@ -1559,12 +1599,24 @@ __device__ __forceinline__ void prec_decode(const PRec &r, double f[3], double a
 
 // workgroup evaluation of cost / g / H at x over the active blocks -> sh.sum.  FILL: first evaluation of a solve, every
 // plane record is streamed and the first PC_RECS are copied to the LDS cache; otherwise those come from the cache.
-template <bool FILL>
+// L1OUT: this may be the last evaluation of the prerun solve -- also store every active block's loss-corrected L1 norm
+// (the quantity of PCR:476-483) into rd.blk_l1, so that the inlier pass does not have to sweep the blocks again when
+// the candidate is accepted (solve_fast2).
+template <bool FILL, bool L1OUT>
 __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a,
-                                          const unsigned char *s_flag, int4 *cA, int4 *cB, SolveShared &sh)
+                                          const unsigned char *s_flag, int4 *cA, int4 *cB, const double *q_last_g, SolveShared &sh)
 {
     constexpr int DEBLUR = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double q_last[4] = {0.0, 0.0, 0.0, 1.0};
+    if (L1OUT) {
+        q_last[0] = q_last_g[0];
+        q_last[1] = q_last_g[1];
+        q_last[2] = q_last_g[2];
+        q_last[3] = q_last_g[3];
+    }
+    double *l1_planes = rd.blk_l1 + (size_t)b * rd.cap + rd.cap_c;  // slot order: [0, cap_c) corner queries, then surface
+    double *l1_lines = rd.blk_l1 + (size_t)b * rd.cap;
     LL_CTX_DECL(x)
     double acc[LL_NACC];
 #pragma unroll
@@ -1582,6 +1634,7 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
                 double f[3], a[3], v[3];
                 prec_decode(r, f, a, v);
                 block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
+                if (L1OUT) l1_planes[p] = block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last);
             }
         }
     }
@@ -1603,6 +1656,7 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
                 double f[3], a[3], v[3];
                 prec_decode(r0, f, a, v);
                 block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
+                if (L1OUT) l1_planes[p] = block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last);
             }
             r0 = r1;
             r1 = r2;
@@ -1622,6 +1676,11 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
             const double a[3] = {br.a0, br.a1, br.a2};
             const double v[3] = {br.v0, br.v1, br.v2};
             LL_CTX_ACCUM(BLK_LINE, br.f, a, v, huber_a, acc);
+            if (L1OUT) {
+                double l1;
+                LL_CTX_L1(l1, BLK_LINE, br.f, a, v, huber_a, q_last);
+                l1_lines[l] = l1;
+            }
         }
     }
 #pragma unroll
@@ -1639,15 +1698,20 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
 }
 
 // one ceres::Solve on the compact layout: starts at x0, leaves the result in sh.ctl
+template <bool WANT_L1>
 __device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
-                                           int n_active, const unsigned char *s_flag, int4 *cA, int4 *cB, SolveShared &sh)
+                                           int n_active, const unsigned char *s_flag, int4 *cA, int4 *cB, const double *q_last,
+                                           SolveShared &sh)
 {
     const int tid = threadIdx.x;
-    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
+    if (tid == 0) {
+        lm_begin(sh.ctl, x0, max_iter, rc.bound);
+        sh.l1_valid = 0;
+    }
     __syncthreads();
     {
         LL_T0(t0);
-        solver_eval2<true>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, s_flag, cA, cB, sh);
+        solver_eval2<true, false>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, s_flag, cA, cB, q_last, sh);
         LL_TACC(0, t0);
     }
     {
@@ -1657,14 +1721,123 @@ __device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc,
         LL_TACC(1, t1);
     }
     while (sh.need) {
+        // the solve cannot go beyond iteration max_iter: if this candidate is accepted it is the solve's result
+        const bool spec = WANT_L1 && sh.ctl.iteration >= max_iter;
         LL_T0(t0);
-        solver_eval2<false>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, sh);
+        if (spec)
+            solver_eval2<false, true>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
+        else
+            solver_eval2<false, false>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
         LL_TACC(0, t0);
         LL_T0(t1);
-        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
+        if (tid == 0) {
+            sh.need = lm_update(sh.ctl, sh.sum);
+            sh.l1_valid = (spec && !sh.need && sh.ctl.last_accept == 1) ? 1 : 0;
+        }
         __syncthreads();
         LL_TACC(1, t1);
     }
+}
+
+// L1 values of the blocks at the prerun result -> inlier threshold -> prune (PCR:476-499).  A function of its own, not
+// inlined: the 48-entry register tile of L1 values then has the register file to itself instead of competing with the
+// inlined LM controller for it (inlined into solve_fast2 the compiler spilled half of the tile to scratch and every pass
+// over it -- de-duplication, rank select, prune -- ran at memory latency).
+template <int NK>
+__device__ __noinline__ void inlier_phase2(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
+                                           unsigned long long *s_table, unsigned char *s_flag, int nC, int nS)
+{
+    constexpr int DEBLUR = 0;
+    const int tid = threadIdx.x;
+    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+    const int totp = nSp + nC;
+    const size_t sb = (size_t)b * rd.cap;
+    int4 *cA = (int4 *)s_table, *cB = cA + PC_RECS;
+    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483).  Usually the prerun's last evaluation was
+    //      accepted and has left them in blk_l1; otherwise one more pass over the blocks writes them there (a plain
+    //      rolled loop: this is the rare path), the cached planes from LDS ------------------------------------------
+    LL_T0(t_l1);
+    double *l1g = rd.blk_l1 + sb;
+    if (!sh.l1_valid) {
+        LL_CTX_DECL(sh.ctl.x)
+        const int4 *pa = rd.blk_pa + (size_t)b * rd.cap_s;
+        const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
+        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+        for (int j = tid; j < totp; j += RS_THREADS) {
+            if (!(s_flag[j] & BLK_ACTIVE)) continue;
+            if (j < nS) {
+                PRec r;
+                if (j < PC_RECS) {
+                    r.a = cA[j];
+                    r.b = cB[j];
+                } else {
+                    prec_load(pa, pb, j, r);
+                }
+                double f[3], a[3], v[3];
+                prec_decode(r, f, a, v);
+                l1g[rd.cap_c + j] = block_l1(BLK_PLANE, R_, t_, f, a, v, rc.huber_a, st->pose_last);
+            } else {
+                BlkRegs br;
+                load_blk(rd, sb, av, j - nSp, br);
+                const double a[3] = {br.a0, br.a1, br.a2};
+                const double v[3] = {br.v0, br.v1, br.v2};
+                double l1;
+                LL_CTX_L1(l1, BLK_LINE, br.f, a, v, rc.huber_a, st->pose_last);
+                l1g[j - nSp] = l1;
+            }
+        }
+        __syncthreads();  // every thread reads back only what it wrote itself; the barrier orders the LDS cache reads
+                          // above against the table writes below
+    } else if (tid == 0) {
+        sh.tcyc[9] += 1;  // LL_SOLVE_TIMING: how often the shortcut was taken
+    }
+    double l1r[NK];  // the thread's register tile: block j = tid + k * RS_THREADS
+    {
+        const int kt = (totp + RS_THREADS - 1) / RS_THREADS;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {  // unconditional loads from clamped addresses: all in flight together
+            const int j = tid + k * RS_THREADS;
+            double v = -1.0;
+            if (k < kt) {
+                const int jc = j < totp ? j : 0;
+                const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
+                v = l1g[src];
+            }
+            l1r[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int j = tid + k * RS_THREADS;
+            const bool act = j < totp && (s_flag[j < totp ? j : 0] & BLK_ACTIVE);
+            l1r[k] = act ? l1r[k] : -1.0;
+        }
+    }
+    __syncthreads();
+    LL_TACC(2, t_l1);
+
+    inlier_threshold_regs<NK>(l1r, totp, s_table, sh, rc);  // overwrites the LDS block cache; the final solve refills it
+
+    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
+    LL_T0(t_prune);
+    {
+        const double thr = sh.thr;
+        int na = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int j = tid + k * RS_THREADS;
+            if (j >= totp) continue;
+            const unsigned char fl = s_flag[j];
+            if (!(fl & BLK_ACTIVE)) continue;
+            if (l1r[k] > thr)
+                s_flag[j] = fl & ~BLK_ACTIVE;
+            else
+                na++;
+        }
+        na = block_sum_int(na, sh);
+        if (tid == 0) sh.n_active = na;
+        __syncthreads();
+    }
+    LL_TACC(7, t_prune);
 }
 
 __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, unsigned long long *s_table,
@@ -1677,23 +1850,35 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
     const int totp = nSp + nC;                                        // <= FAST_MAX_BLOCKS (scan_is_compact)
     const size_t sb = (size_t)b * rd.cap;
     int4 *cA = (int4 *)s_table, *cB = cA + PC_RECS;
-    if (tid < 6) sh.tcyc[tid] = 0;
+    if (tid < 10) sh.tcyc[tid] = 0;
     __syncthreads();
     LL_T0(t_total);
+    LL_T0(t_census);
 
     // ---- flags -> LDS in the solver's order (planes, padding, lines), census (PCR:325,425) -------------------------
     {
         int na = 0, nca = 0, nsa = 0;
-        for (int j = tid; j < totp; j += RS_THREADS) {
-            unsigned char fl = 0;
-            if (j < nS)
-                fl = rd.blk_flag0[sb + rd.cap_c + j];
-            else if (j >= nSp)
-                fl = rd.blk_flag0[sb + (j - nSp)];
-            s_flag[j] = fl;
-            na += (fl & BLK_ACTIVE) ? 1 : 0;
-            if (fl & 8) {
-                if (j >= nSp) nca++; else nsa++;
+        // eight independent byte loads per thread and trip (clamped addresses, selected afterwards): a conditional load per
+        // trip made this loop a chain of ~34 cold memory round trips (35 us of a 380 us launch)
+        for (int j0 = tid; j0 < totp; j0 += 8 * RS_THREADS) {
+            unsigned char fl8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u * RS_THREADS;
+                const int jc = j < totp ? j : 0;
+                const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
+                fl8[u] = rd.blk_flag0[sb + src];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u * RS_THREADS;
+                if (j >= totp) continue;
+                const unsigned char fl = (j < nS || j >= nSp) ? fl8[u] : (unsigned char)0;
+                s_flag[j] = fl;
+                na += (fl & BLK_ACTIVE) ? 1 : 0;
+                if (fl & 8) {
+                    if (j >= nSp) nca++; else nsa++;
+                }
             }
         }
         na = block_sum_int(na, sh);
@@ -1719,88 +1904,32 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
         }
         __syncthreads();
     }
+    LL_TACC(6, t_census);
 
-    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    solver_lm2(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, cA, cB, sh);
+    // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------
+    solver_lm2<true>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
     int lm_iters = sh.ctl.iteration;
 
-    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers; the cached planes come
-    //      from LDS (filled by the prerun's first evaluation) ------------------------------------------------------
-    double l1r[FAST_MAXK];
-    LL_T0(t_l1);
-    {
-        LL_CTX_DECL(sh.ctl.x)
-        const int4 *pa = rd.blk_pa + (size_t)b * rd.cap_s;
-        const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
-        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-#pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++) {
-            const int j = tid + k * RS_THREADS;
-            double l1 = -1.0;  // marker: not an active block
-            if (j < totp) {
-                const unsigned char fl = s_flag[j];
-                if (fl & BLK_ACTIVE) {
-                    if (j < nS) {
-                        PRec r;
-                        if (k < PC_RECS / RS_THREADS) {
-                            r.a = cA[j];
-                            r.b = cB[j];
-                        } else {
-                            prec_load(pa, pb, j, r);
-                        }
-                        double f[3], a[3], v[3];
-                        prec_decode(r, f, a, v);
-                        l1 = block_l1(BLK_PLANE, R_, t_, f, a, v, rc.huber_a, st->pose_last);
-                    } else {
-                        BlkRegs br;
-                        load_blk(rd, sb, av, j - nSp, br);
-                        const double a[3] = {br.a0, br.a1, br.a2};
-                        const double v[3] = {br.v0, br.v1, br.v2};
-                        LL_CTX_L1(l1, BLK_LINE, br.f, a, v, rc.huber_a, st->pose_last);
-                    }
-                }
-            }
-            l1r[k] = l1;
-        }
-    }
-    __syncthreads();
-    LL_TACC(2, t_l1);
-
-    inlier_threshold_regs(l1r, totp, s_table, sh, rc);  // overwrites the LDS block cache; the final solve refills it
-
-    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
-    {
-        const double thr = sh.thr;
-        int na = 0;
-#pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++) {
-            const int j = tid + k * RS_THREADS;
-            if (j >= totp) continue;
-            const unsigned char fl = s_flag[j];
-            if (!(fl & BLK_ACTIVE)) continue;
-            if (l1r[k] > thr)
-                s_flag[j] = fl & ~BLK_ACTIVE;
-            else
-                na++;
-        }
-        na = block_sum_int(na, sh);
-        if (tid == 0) sh.n_active = na;
-        __syncthreads();
-    }
+    if (totp <= 36 * RS_THREADS)  // the Mid-40 configurations: a 36-entry register tile per thread
+        inlier_phase2<36>(rd, rc, b, st, sh, s_table, s_flag, nC, nS);
+    else
+        inlier_phase2<FAST_MAXK>(rd, rc, b, st, sh, s_table, s_flag, nC, nS);
 
     // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
     {
         __shared__ double x_start_2[7];
         if (tid < 7) x_start_2[tid] = sh.ctl.x[tid];
         __syncthreads();
-        solver_lm2(rd, rc, b, nC, nS, x_start_2, rc.ceres_max_iterations, sh.n_active, s_flag, cA, cB, sh);
+        solver_lm2<false>(rd, rc, b, nC, nS, x_start_2, rc.ceres_max_iterations, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
     }
     lm_iters += sh.ctl.iteration;
+    LL_T0(t_epi);
     solve_epilogue(rc, st, sh, lm_iters);
+    LL_TACC(8, t_epi);
 #ifdef LL_SOLVE_TIMING
     LL_TACC(5, t_total);
     if (tid == 0)
-        for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
+        for (int i = 0; i < 10; i++) st->dbg_cycles[i] += sh.tcyc[i];
 #endif
 }
 

@@ -498,6 +498,8 @@ template <typename T> class Map<Quaternion<T>>
     const T &w() const { return p[ 3 ]; }
     Matrix<T, 4, 1> coeffs() const { return Quaternion<T>( p ).coeffs(); }
     Matrix<T, 3, 3> toRotationMatrix() const { return Quaternion<T>( p ).toRotationMatrix(); }
+    T angularDistance( const Quaternion<T> &o ) const { return Quaternion<T>( p ).angularDistance( o ); }
+    Matrix<T, 3, 1> vec() const { return Quaternion<T>( p ).vec(); }
     void setIdentity() { *this = Quaternion<T>::Identity(); }
 };
 template <typename T, int R, int C> class Map<Matrix<T, R, C>>

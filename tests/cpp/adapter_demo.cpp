@@ -84,11 +84,23 @@ int main(int argc, char **argv)
         pc_reg.m_para_max_angular_rate = 20.0f;
         pc_reg.m_para_max_speed = 0.3f;
         pc_reg.max_features = 30000;
-        for (int i = 0; i < 7; i++) pc_reg.m_para_buffer_RT[i] = pc_reg.m_para_buffer_RT_last[i] = pose[i];
+        // init_pointcloud_registration, laser_mapping.hpp:1290-1294: the node assigns the pose members
+        pc_reg.m_q_w_curr.x() = pose[0], pc_reg.m_q_w_curr.y() = pose[1], pc_reg.m_q_w_curr.z() = pose[2], pc_reg.m_q_w_curr.w() = pose[3];
+        for (int i = 0; i < 3; i++) pc_reg.m_t_w_curr(i) = pose[4 + i];
+        pc_reg.m_q_w_last = pc_reg.m_q_w_curr;
+        pc_reg.m_t_w_last = pc_reg.m_t_w_curr;
         KdTreeStub kd_c, kd_s;
         const int reg_res = pc_reg.find_out_incremental_transfrom(map_corner, map_surf, kd_c, kd_s, corners, surface);
         Cloud world;
         pc_reg.pointcloudAssociateToMap(*corners, world);
+        // the per-point form the node uses in "Add new frame" (laser_mapping.hpp:1424, 1430) must agree with the cloud form
+        for (size_t i = 0; i < corners->size(); i++) {
+            PointXYZI sel;
+            pc_reg.pointAssociateToMap(&corners->points[i], &sel, 1.0, 0);
+            if (sel.x != world.points[i].x || sel.y != world.points[i].y || sel.z != world.points[i].z) return 6;
+        }
+        if (pc_reg.m_q_w_incre.w() != pc_reg.m_para_buffer_incremental[3] || pc_reg.m_t_w_incre(1) != pc_reg.m_para_buffer_incremental[5]) return 7;
+        if (reg_res == 1 && pc_reg.m_final_opt_summary.BriefReport().empty()) return 8;
 
         // "Add new frame" + match-buffer refresh through the adapter (laser_mapping.hpp:1417-1478, 517-546)
         size_t n_hist_corner = 0, n_hist_surf = 0;
