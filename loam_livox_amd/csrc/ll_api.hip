@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -105,13 +107,9 @@ static FeConst make_fe_const(const ll_fe_params &p)
     return c;
 }
 
-extern "C" int ll_fe_create(const ll_fe_params *p, ll_fe **out)
+extern "C" void ll_fe_destroy(ll_fe *h);
+static int fe_create_impl(const ll_fe_params *p, ll_fe *h)
 {
-    if (!p || !out) return set_err("ll_fe_create", "null argument");
-    if (p->max_points < 1 || p->max_scans < 1) return set_err("ll_fe_create", "bad capacity");
-    if (p->piecewise_number < 1 || p->piecewise_number > LL_MAX_PIECES) return set_err("ll_fe_create", "piecewise_number out of range");
-    if (check_device(p->device)) return -1;
-    ll_fe *h = new ll_fe();
     h->prm = *p;
     h->fc = make_fe_const(*p);
     const size_t B = p->max_scans, N = p->max_points, BN = B * N;
@@ -119,7 +117,9 @@ extern "C" int ll_fe_create(const ll_fe_params *p, ll_fe **out)
     memset(&d, 0, sizeof(d));
     d.stride = (int)N;
     d.split_cap = (int)(N / 50 + 8);
-    d.ambig_cap = 4096;
+    // view-angle ambiguity list (ll_fe_resolve): sized for the whole batch -- 1/16 of the points, at least 4096; a batch that
+    // still overflows it makes ll_fe_resolve fail instead of silently keeping device-libm labels
+    d.ambig_cap = (int)((BN / 16 > 4096 ? BN / 16 : 4096) < 0x7fffffffull ? (BN / 16 > 4096 ? BN / 16 : 4096) : 0x7fffffffull);
     HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HC(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     DM(h->d_xyzi, BN);
@@ -161,6 +161,20 @@ extern "C" int ll_fe_create(const ll_fe_params *p, ll_fe **out)
     HC(hipMemset(d.n_full, 0, B * sizeof(int)));
     HC(hipMemset(d.info, 0, B * sizeof(FeScanInfo)));
     h->h_npts.assign(B, 0);
+    return 0;
+}
+
+extern "C" int ll_fe_create(const ll_fe_params *p, ll_fe **out)
+{
+    if (!p || !out) return set_err("ll_fe_create", "null argument");
+    if (p->max_points < 1 || p->max_scans < 1) return set_err("ll_fe_create", "bad capacity");
+    if (p->piecewise_number < 1 || p->piecewise_number > LL_MAX_PIECES) return set_err("ll_fe_create", "piecewise_number out of range");
+    if (check_device(p->device)) return -1;
+    ll_fe *h = new ll_fe();
+    if (fe_create_impl(p, h)) {  // a failed allocation half way: release what was built (fields start out null)
+        ll_fe_destroy(h);
+        return -1;
+    }
     *out = h;
     return 0;
 }
@@ -230,7 +244,9 @@ static int fe_resolve_ambiguous(ll_fe *h)
     HC(hipMemcpyAsync(&n_amb, h->dev.n_ambig, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HC(hipStreamSynchronize(h->stream));
     if (n_amb <= 0) return 0;
-    const int n_list = n_amb < h->dev.ambig_cap ? n_amb : h->dev.ambig_cap;
+    if (n_amb > h->dev.ambig_cap)
+        return set_err("ll_fe_resolve", "more points inside the view-angle ambiguity band than the list holds (degenerate minimum_view_angle?)");
+    const int n_list = n_amb;
     std::vector<int2> list(n_list);
     HC(hipMemcpy(list.data(), h->dev.ambig_list, n_list * sizeof(int2), hipMemcpyDeviceToHost));
     const size_t N = h->prm.max_points;
@@ -381,11 +397,57 @@ extern "C" int ll_fe_select(ll_fe *h, float minimum_blur, float maximum_blur, in
 
 // ============================================================================================== map
 
+// A search structure is an IMMUTABLE snapshot once published (the match buffer is refreshed on one thread,
+// laser_mapping.hpp:568, while process_new_scan threads register against it, :1737-1742): ll_map_upload /
+// ll_history_refresh* build the next grid in buffers nobody else sees and swap the published pointer under the mutex;
+// every solve pins the snapshots it was launched with until it has been collected.  A snapshot that only the pool still
+// references is recycled for the next build (its buffers keep their capacity).
+struct MapSnap {
+    MapKind mk;
+    int device = 0;
+    ~MapSnap()
+    {
+        (void)hipSetDevice(device);
+        map_free(mk);
+    }
+};
 struct ll_map {
     int device = 0;
     hipStream_t stream = nullptr;
-    MapKind kind[2];
+    std::mutex mu;
+    std::shared_ptr<MapSnap> cur[2];
+    std::vector<std::shared_ptr<MapSnap>> pool[2];
 };
+
+static std::shared_ptr<MapSnap> map_pin(const ll_map *cm, int kind)
+{
+    ll_map *m = const_cast<ll_map *>(cm);
+    std::lock_guard<std::mutex> lk(m->mu);
+    return m->cur[kind];
+}
+static std::shared_ptr<MapSnap> map_build_target(ll_map *m, int kind)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (auto &s : m->pool[kind])
+        if (s.use_count() == 1) return s;  // referenced by the pool only: not published, not pinned
+    std::shared_ptr<MapSnap> s = std::make_shared<MapSnap>();
+    s->device = m->device;
+    m->pool[kind].push_back(s);
+    return s;
+}
+static void map_publish(ll_map *m, int kind, const std::shared_ptr<MapSnap> &s)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->cur[kind] = s;
+}
+// builds the grid of `n` device-resident points into a fresh snapshot and publishes it
+static int map_rebuild(ll_map *m, int kind, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err)
+{
+    std::shared_ptr<MapSnap> t = map_build_target(m, kind);
+    if (map_build(t->mk, d_raw, stride, n, cell, s, err)) return -1;  // returns with the stream drained
+    map_publish(m, kind, t);
+    return 0;
+}
 
 extern "C" int ll_map_create(int32_t device, ll_map **out)
 {
@@ -402,8 +464,10 @@ extern "C" void ll_map_destroy(ll_map *m)
 {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    map_free(m->kind[0]);
-    map_free(m->kind[1]);
+    for (int k = 0; k < 2; k++) {
+        m->cur[k].reset();
+        m->pool[k].clear();  // snapshots still pinned by a registrar die with its pin
+    }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -419,9 +483,12 @@ extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t 
     float *d_raw = nullptr;
     const size_t bytes = (size_t)(n > 0 ? n : 1) * stride_floats * sizeof(float);
     HC(hipMalloc(&d_raw, bytes));
-    if (n > 0) HC(hipMemcpyAsync(d_raw, xyz, (size_t)n * stride_floats * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (n > 0 && hipMemcpyAsync(d_raw, xyz, (size_t)n * stride_floats * sizeof(float), hipMemcpyHostToDevice, m->stream) != hipSuccess) {
+        (void)hipFree(d_raw);
+        return set_err("ll_map_upload", "host to device copy failed");
+    }
     const char *err = nullptr;
-    const int rc = map_build(m->kind[kind], d_raw, stride_floats, n, cell_size, m->stream, &err);
+    const int rc = map_rebuild(m, kind, d_raw, stride_floats, n, cell_size, m->stream, &err);
     (void)hipFree(d_raw);
     if (rc != 0) return set_err("map_build", err ? err : "failed");
     return 0;
@@ -431,15 +498,21 @@ extern "C" int ll_map_to_f16(ll_map *m, int32_t kind)
 {
     if (!m || kind < 0 || kind > 1) return set_err("ll_map_to_f16", "bad argument");
     HC(hipSetDevice(m->device));
+    std::shared_ptr<MapSnap> snap = map_pin(m, kind);
+    if (!snap) return set_err("ll_map_to_f16", "map kind not uploaded");
+    // converts the published snapshot in place (C5 experiment path): the caller must not have a registration in flight
+    if (snap.use_count() > 3) return set_err("ll_map_to_f16", "the snapshot is pinned by a registration in flight");
     const char *err = nullptr;
-    if (map_to_f16(m->kind[kind], m->stream, &err)) return set_err("ll_map_to_f16", err ? err : "failed");
+    if (map_to_f16(snap->mk, m->stream, &err)) return set_err("ll_map_to_f16", err ? err : "failed");
     return 0;
 }
 
 extern "C" int ll_map_dequantized(ll_map *m, int32_t kind, float *xyz, int64_t capacity_points)
 {
     if (!m || kind < 0 || kind > 1 || !xyz) return set_err("ll_map_dequantized", "bad argument");
-    const MapKind &mk = m->kind[kind];
+    std::shared_ptr<MapSnap> snap = map_pin(m, kind);
+    if (!snap) return set_err("ll_map_dequantized", "map kind not uploaded");
+    const MapKind &mk = snap->mk;
     if (capacity_points < mk.n) return set_err("ll_map_dequantized", "buffer too small");
     HC(hipSetDevice(m->device));
     float *d_out = nullptr;
@@ -457,14 +530,16 @@ extern "C" int ll_map_dequantized(ll_map *m, int32_t kind, float *xyz, int64_t c
 extern "C" int64_t ll_map_size(const ll_map *m, int32_t kind)
 {
     if (!m || kind < 0 || kind > 1) return -1;
-    return m->kind[kind].n;
+    std::shared_ptr<MapSnap> snap = map_pin(m, kind);
+    return snap ? snap->mk.n : 0;
 }
 
 extern "C" int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, int32_t n_queries, float max_sq_dis, int32_t *idx5,
                            float *sq_dis5)
 {
     if (!m || !queries_xyz || !idx5 || !sq_dis5) return set_err("ll_map_knn5", "null argument");
-    if (kind < 0 || kind > 1 || (!m->kind[kind].pts && !m->kind[kind].pts16)) return set_err("ll_map_knn5", "map kind not uploaded");
+    std::shared_ptr<MapSnap> snap = (kind < 0 || kind > 1) ? nullptr : map_pin(m, kind);
+    if (!snap || (!snap->mk.pts && !snap->mk.pts16)) return set_err("ll_map_knn5", "map kind not uploaded");
     if (n_queries <= 0) return 0;
     HC(hipSetDevice(m->device));
     float *d_q = nullptr, *d_d2 = nullptr;
@@ -473,7 +548,7 @@ extern "C" int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, in
     DM(d_d2, (size_t)n_queries * 5);
     DM(d_idx, (size_t)n_queries * 5);
     HC(hipMemcpyAsync(d_q, queries_xyz, (size_t)n_queries * 3 * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    launch_knn5(m->kind[kind].grid, d_q, n_queries, max_sq_dis, d_idx, d_d2, m->stream);
+    launch_knn5(snap->mk.grid, d_q, n_queries, max_sq_dis, d_idx, d_d2, m->stream);
     HC(hipGetLastError());
     HC(hipMemcpyAsync(idx5, d_idx, (size_t)n_queries * 5 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HC(hipMemcpyAsync(sq_dis5, d_d2, (size_t)n_queries * 5 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
@@ -498,6 +573,7 @@ struct ll_reg {
     int *d_nc = nullptr, *d_ns = nullptr;
     std::vector<RegState> h_state;
     std::vector<int> h_nc, h_ns;
+    std::shared_ptr<MapSnap> pinned[2];  // map snapshots of the solve in flight (released once it has been collected)
     int debug = 0, profiling = 0;
     int last_n_scans = 0, last_gated = 0;
     // profiling
@@ -539,12 +615,9 @@ extern "C" void ll_reg_default_params(ll_reg_params *p)
     p->maximum_pt_time_stamp = 1.0f;      // PCR:93
 }
 
-extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_features_per_scan, ll_reg **out)
+extern "C" void ll_reg_destroy(ll_reg *r);
+static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_features_per_scan, ll_reg *r)
 {
-    if (!out) return set_err("ll_reg_create", "null argument");
-    if (max_scans < 1 || max_features_per_scan < 1) return set_err("ll_reg_create", "bad capacity");
-    if (check_device(device)) return -1;
-    ll_reg *r = new ll_reg();
     r->device = device;
     r->max_scans = max_scans;
     r->max_feat = max_features_per_scan;
@@ -586,6 +659,19 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
     r->h_state.resize(B);
     r->h_nc.assign(B, 0);
     r->h_ns.assign(B, 0);
+    return 0;
+}
+
+extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_features_per_scan, ll_reg **out)
+{
+    if (!out) return set_err("ll_reg_create", "null argument");
+    if (max_scans < 1 || max_features_per_scan < 1) return set_err("ll_reg_create", "bad capacity");
+    if (check_device(device)) return -1;
+    ll_reg *r = new ll_reg();
+    if (reg_create_impl(device, max_scans, max_features_per_scan, r)) {
+        ll_reg_destroy(r);
+        return -1;
+    }
     *out = r;
     return 0;
 }
@@ -694,7 +780,12 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     if (map->device != r->device) return set_err("ll_reg", "map lives on another device");
     make_reg_const(prm, r->debug, &r->rc);
     // PCR:199 gate
-    const bool run = map->kind[0].n > 0 && map->kind[1].n > 50 && prm->current_frame_index > prm->mapping_init_accumulate_frames;
+    // the snapshots this solve runs against, whatever ll_map_upload / ll_history_refresh* publish meanwhile
+    r->pinned[0] = map_pin(map, 0);
+    r->pinned[1] = map_pin(map, 1);
+    const MapKind empty_kind{};
+    const MapKind &mk0 = r->pinned[0] ? r->pinned[0]->mk : empty_kind, &mk1 = r->pinned[1] ? r->pinned[1]->mk : empty_kind;
+    const bool run = mk0.n > 0 && mk1.n > 50 && prm->current_frame_index > prm->mapping_init_accumulate_frames;
     r->last_gated = run ? 0 : 1;
     r->last_n_scans = n_scans;
     for (int b = 0; b < n_scans; b++) {
@@ -733,11 +824,11 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     if (prm->subsample_seed && (max_nc > 2 * prm->maximum_allow_residual_block || max_ns > 2 * prm->maximum_allow_residual_block))
         r->rc.knn_reuse = 0;  // skipped features change from iteration to iteration: every iteration searches
     if (run) {
-        if (!map->kind[0].pts || !map->kind[1].pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
+        if (!mk0.pts || !mk1.pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
         HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));
         for (int it = 0; it < prm->icp_max_iterations; it++) {
             prof_begin(r, 0);
-            launch_reg_knn_build(r->dev, r->rc, map->kind[0].grid, map->kind[1].grid, n_scans, it, max_nc, max_ns, r->stream);
+            launch_reg_knn_build(r->dev, r->rc, mk0.grid, mk1.grid, n_scans, it, max_nc, max_ns, r->stream);
             prof_end(r);
             prof_begin(r, 1);
             launch_reg_solve(r->dev, r->rc, n_scans, r->stream);
@@ -759,6 +850,8 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
     HC(hipSetDevice(r->device));
     HC(hipMemcpyAsync(r->h_state.data(), r->dev.state, (size_t)n_scans * sizeof(RegState), hipMemcpyDeviceToHost, r->stream));
     HC(hipStreamSynchronize(r->stream));
+    r->pinned[0].reset();  // the solve has left the device: its map snapshots may be recycled
+    r->pinned[1].reset();
     for (int b = 0; b < n_scans; b++) {
         const RegState &s = r->h_state[b];
         for (int i = 0; i < 7; i++) {
@@ -1165,6 +1258,9 @@ struct ll_history {
     const float4 *map_src[2] = {nullptr, nullptr};
 };
 
+extern "C" void ll_history_destroy(ll_history *h);
+static int history_create_impl(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res, float plane_res,
+                               ll_history *h);
 extern "C" int ll_history_create(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res,
                                  float plane_res, ll_history **out)
 {
@@ -1174,6 +1270,17 @@ extern "C" int ll_history_create(int32_t device, int32_t maximum_history_size, i
     if ((int64_t)(maximum_history_size + 1) * max_points_per_frame >= 0x7fffffffLL) return set_err("ll_history_create", "history too large");
     if (check_device(device)) return -1;
     ll_history *h = new ll_history();
+    if (history_create_impl(device, maximum_history_size, max_points_per_frame, line_res, plane_res, h)) {
+        ll_history_destroy(h);
+        return -1;
+    }
+    *out = h;
+    return 0;
+}
+
+static int history_create_impl(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res, float plane_res,
+                               ll_history *h)
+{
     h->device = device;
     h->max_hist = maximum_history_size;
     h->max_pts = max_points_per_frame;
@@ -1192,11 +1299,8 @@ extern "C" int ll_history_create(int32_t device, int32_t maximum_history_size, i
     DM(h->d_n, 1);
     DM(h->d_pose, 8);
     const char *err = nullptr;
-    if (voxel_alloc(h->vox_frame, 1, max_points_per_frame, &err) || voxel_alloc(h->vox_map, 1, (int)cap, &err)) {
-        ll_history_destroy(h);
+    if (voxel_alloc(h->vox_frame, 1, max_points_per_frame, &err) || voxel_alloc(h->vox_map, 1, (int)cap, &err))
         return set_err("ll_history_create", err);
-    }
-    *out = h;
     return 0;
 }
 
@@ -1360,7 +1464,7 @@ extern "C" int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_cor
         // the search structure (laser_mapping.hpp:539-546: two KdTreeFLANN::setInputCloud) is the device grid
         const char *err = nullptr;
         const float cell = match_cell_size(kind, h->res[kind]);
-        if (map_build(map->kind[kind], (const float *)h->d_map[kind], 4, n_out, cell, h->stream, &err)) return set_err("map_build", err ? err : "failed");
+        if (map_rebuild(map, kind, (const float *)h->d_map[kind], 4, n_out, cell, h->stream, &err)) return set_err("map_build", err ? err : "failed");
     }
     HC(hipStreamSynchronize(h->stream));
     if (n_map_corner) *n_map_corner = h->n_map[0];
@@ -1455,7 +1559,7 @@ extern "C" int ll_history_refresh_cells(ll_history *h, ll_map *map, const double
         h->n_map[kind] = n_out;
         h->map_src[kind] = h->d_cmap[kind];
         const char *err = nullptr;
-        if (map_build(map->kind[kind], (const float *)h->d_cmap[kind], 4, n_out, match_cell_size(kind, leaf1), h->stream, &err))
+        if (map_rebuild(map, kind, (const float *)h->d_cmap[kind], 4, n_out, match_cell_size(kind, leaf1), h->stream, &err))
             return set_err("map_build", err ? err : "failed");
     }
     HC(hipStreamSynchronize(h->stream));
@@ -1477,11 +1581,18 @@ extern "C" int ll_reg_upload_features(ll_reg *r, int32_t n_scans, const float *c
 {
     if (!r || !n_corner || !n_surf) return set_err("ll_reg_upload_features", "null argument");
     if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_upload_features", "n_scans out of range");
+    if (stride_corner < 0 || stride_surf < 0) return set_err("ll_reg_upload_features", "negative stride");
+    for (int b = 0; b < n_scans; b++) {  // validate everything before the first copy: a caller mistake must not become a host over-read
+        if (n_corner[b] < 0 || n_corner[b] > r->max_feat || n_surf[b] < 0 || n_surf[b] > r->max_feat)
+            return set_err("ll_reg_upload_features", "feature count exceeds capacity");
+        if ((n_corner[b] > 0 && !corner_xyzi) || (n_surf[b] > 0 && !surf_xyzi))
+            return set_err("ll_reg_upload_features", "null feature array with a non-zero count");
+        if (n_scans > 1 && (n_corner[b] > stride_corner || n_surf[b] > stride_surf))
+            return set_err("ll_reg_upload_features", "feature count exceeds the per-scan stride");
+    }
     HC(hipSetDevice(r->device));
     const size_t F = r->max_feat;
     for (int b = 0; b < n_scans; b++) {
-        if (n_corner[b] < 0 || n_corner[b] > r->max_feat || n_surf[b] < 0 || n_surf[b] > r->max_feat)
-            return set_err("ll_reg_upload_features", "feature count exceeds capacity");
         if (n_corner[b] > 0)
             HC(hipMemcpyAsync(r->d_corner + b * F, corner_xyzi + (size_t)b * stride_corner * 4, (size_t)n_corner[b] * sizeof(float4),
                               hipMemcpyHostToDevice, r->stream));

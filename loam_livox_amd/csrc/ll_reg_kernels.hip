@@ -287,6 +287,31 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
     if (tid < 2) rd.work_n[(((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2 + tid] = s_n[tid];
 }
 
+// Loads through an explicit global (address space 1) pointer.  Inside a non-inlined device function the compiler cannot
+// tell that a pointer taken from RegDev is global and emits flat_load, which also counts on lgkmcnt: the wait in front
+// of every LDS flag read then drained the whole software pipeline of record loads (round-2 profile of solver_eval2).
+typedef int ll_v4i __attribute__((ext_vector_type(4)));
+typedef float ll_v4f __attribute__((ext_vector_type(4)));
+typedef double ll_v2d __attribute__((ext_vector_type(2)));
+#define LL_AS_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ int4 gload_i4(const int4 *p)
+{
+    const ll_v4i v = *(const LL_AS_GLOBAL ll_v4i *)p;
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 gload_f4(const float4 *p)
+{
+    const ll_v4f v = *(const LL_AS_GLOBAL ll_v4f *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 gload_d2(const double2 *p)
+{
+    const ll_v2d v = *(const LL_AS_GLOBAL ll_v2d *)p;
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void gstore_f64(double *p, double v) { *(LL_AS_GLOBAL double *)p = v; }
+__device__ __forceinline__ double gload_f64(const double *p) { return *(const LL_AS_GLOBAL double *)p; }
+
 // Block constants of one scan (blk_av, 6 * cap doubles) as three arrays of 16-byte pairs: {a0, v0}[cap], {v1, v2}[cap] and
 // {a1, a2}[cap] (line slots only; a plane block folds a' into a0 = n'.a').  A plane block is then one float4 and two
 // 16-byte loads per lane instead of one float4 and four 8-byte loads.  cap is even and the base 256-byte aligned.
@@ -299,15 +324,15 @@ __device__ __forceinline__ void av_store(double *av, int cap, int slot, bool lin
 __device__ __forceinline__ void av_load(const double *av, int cap, int slot, bool line, double &a0, double &a1, double &a2, double &v0,
                                         double &v1, double &v2)
 {
-    const double2 x = reinterpret_cast<const double2 *>(av)[slot];
-    const double2 y = reinterpret_cast<const double2 *>(av + (size_t)2 * cap)[slot];
+    const double2 x = gload_d2(reinterpret_cast<const double2 *>(av) + slot);
+    const double2 y = gload_d2(reinterpret_cast<const double2 *>(av + (size_t)2 * cap) + slot);
     a0 = x.x;
     v0 = x.y;
     v1 = y.x;
     v2 = y.y;
     a1 = a2 = 0.0;
     if (line) {
-        const double2 z = reinterpret_cast<const double2 *>(av + (size_t)4 * cap)[slot];
+        const double2 z = gload_d2(reinterpret_cast<const double2 *>(av + (size_t)4 * cap) + slot);
         a1 = z.x;
         a2 = z.y;
     }
@@ -1337,7 +1362,7 @@ struct BlkRegs {
 
 __device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const double *av, int slot, BlkRegs &r)
 {
-    r.f = rd.blk_f[sb + slot];
+    r.f = gload_f4(rd.blk_f + sb + slot);
     // surface slots hold plane blocks: a' is folded into the scalar a0 = n'.a' (ll_reg_core.h block_plane)
     av_load(av, rd.cap, slot, slot < rd.cap_c, r.a0, r.a1, r.a2, r.v0, r.v1, r.v2);
 }
@@ -1581,8 +1606,8 @@ struct PRec {
 };
 __device__ __forceinline__ void prec_load(const int4 *pa, const int4 *pb, int p, PRec &r)
 {
-    r.a = pa[p];
-    r.b = pb[p];
+    r.a = gload_i4(pa + p);
+    r.b = gload_i4(pb + p);
 }
 __device__ __forceinline__ void prec_decode(const PRec &r, double f[3], double a[3], double v[3])
 {
@@ -1634,35 +1659,54 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
                 double f[3], a[3], v[3];
                 prec_decode(r, f, a, v);
                 block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
-                if (L1OUT) l1_planes[p] = block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last);
+                if (L1OUT) gstore_f64(l1_planes + p, block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last));
             }
         }
     }
     {
-        // streamed planes, three records (96 B per lane) in flight
+        // streamed planes, three records (96 B per lane) in flight; the loop is unrolled four times by hand so that the
+        // register sets rotate by name (the rolled form spent 15 64-bit moves per block on r0 = r1, r1 = r2, ...), and
+        // each record's flag byte is fetched from LDS together with it.  A/B in one run (B = 256, instrumented build,
+        // cycles in cost evaluations per scan): rolled + flat loads 4.56 M, rolled + global loads 4.43 M, unrolled + flat
+        // 4.22 M, unrolled + global 4.20 M
+#define LL_PLANE_LOAD(R, FL, P)              \
+    if ((P) < nS) {                          \
+        prec_load(pa, pb, (P), R);           \
+        FL = s_flag[(P)];                    \
+    }
+#define LL_PLANE_USE(R, FL, P)                                                                         \
+    if ((P) < nS) {                                                                                    \
+        if (FILL && (P) < PC_RECS) {                                                                   \
+            cA[(P)] = R.a;                                                                             \
+            cB[(P)] = R.b;                                                                             \
+        }                                                                                              \
+        if (FL & BLK_ACTIVE) {                                                                         \
+            double f[3], a[3], v[3];                                                                   \
+            prec_decode(R, f, a, v);                                                                   \
+            block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);                                \
+            if (L1OUT) gstore_f64(l1_planes + (P), block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last)); \
+        }                                                                                              \
+    }
         PRec r0, r1, r2, r3;
         r0.a = r0.b = r1.a = r1.b = r2.a = r2.b = r3.a = r3.b = make_int4(0, 0, 0, 0);
-        if (p < nS) prec_load(pa, pb, p, r0);
-        if (p + RS_THREADS < nS) prec_load(pa, pb, p + RS_THREADS, r1);
-        if (p + 2 * RS_THREADS < nS) prec_load(pa, pb, p + 2 * RS_THREADS, r2);
+        unsigned char f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+        constexpr int S = RS_THREADS;
+        LL_PLANE_LOAD(r0, f0, p)
+        LL_PLANE_LOAD(r1, f1, p + S)
+        LL_PLANE_LOAD(r2, f2, p + 2 * S)
         while (p < nS) {
-            const int pf = p + 3 * RS_THREADS;
-            if (pf < nS) prec_load(pa, pb, pf, r3);
-            if (FILL && p < PC_RECS) {
-                cA[p] = r0.a;
-                cB[p] = r0.b;
-            }
-            if (s_flag[p] & BLK_ACTIVE) {
-                double f[3], a[3], v[3];
-                prec_decode(r0, f, a, v);
-                block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
-                if (L1OUT) l1_planes[p] = block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last);
-            }
-            r0 = r1;
-            r1 = r2;
-            r2 = r3;
-            p += RS_THREADS;
+            LL_PLANE_LOAD(r3, f3, p + 3 * S)
+            LL_PLANE_USE(r0, f0, p)
+            LL_PLANE_LOAD(r0, f0, p + 4 * S)
+            LL_PLANE_USE(r1, f1, p + S)
+            LL_PLANE_LOAD(r1, f1, p + 5 * S)
+            LL_PLANE_USE(r2, f2, p + 2 * S)
+            LL_PLANE_LOAD(r2, f2, p + 6 * S)
+            LL_PLANE_USE(r3, f3, p + 3 * S)
+            p += 4 * S;
         }
+#undef LL_PLANE_LOAD
+#undef LL_PLANE_USE
     }
     {
         // line blocks (a few hundred per Mid-40 scan): the 65-byte fp64 form
@@ -1801,7 +1845,7 @@ __device__ __noinline__ void inlier_phase2(const RegDev &rd, const RegConst &rc,
             if (k < kt) {
                 const int jc = j < totp ? j : 0;
                 const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
-                v = l1g[src];
+                v = gload_f64(l1g + src);
             }
             l1r[k] = v;
         }

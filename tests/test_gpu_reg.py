@@ -391,3 +391,86 @@ def test_pose_against_exact_reference_arithmetic(dev_map, small_world, scans, k)
     assert abs(g.n_blocks_last - rep.n_blocks_last) <= 2                          # an inlier exactly at the threshold may flip
     assert np.isclose(g.final_cost, rep.final_cost, rtol=1e-6)
     reg.close()
+
+
+def test_map_refresh_while_registering_uses_immutable_snapshots(gpu_lib, small_world, scans):
+    """update_buff_for_matching refreshes the match buffer on its own thread (laser_mapping.hpp:568) while
+    process_new_scan threads register against it (:1737-1742).  ll_map_upload publishes a new immutable snapshot and a
+    solve keeps the one it started with: with one thread re-uploading two different maps in turn and two threads
+    registering the same scan over and over, every result must be bit-identical to the serial result against one map
+    or the other -- never a mixture, never a crash."""
+    import threading
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    maps = [(small_world["corner"], small_world["surf"])]
+    shift = np.array([0.004, -0.003, 0.002], np.float32)  # a second, slightly displaced map: a different answer
+    maps.append((small_world["corner"] + shift, small_world["surf"] + shift))
+
+    def solve(reg, m):
+        reg.m_pose_w_last = sc.pose_init.copy()
+        reg.m_pose_w_curr = sc.pose_init.copy()
+        ret = reg.find_out_incremental_transfrom(m, fc, fs)
+        return ret, reg.m_pose_w_curr.copy(), reg.report.n_blocks_last
+
+    serial = []
+    for c, s in maps:
+        m = Map_buffer()
+        m.setInputCloud(Map_buffer.CORNER, c)
+        m.setInputCloud(Map_buffer.SURF, s)
+        reg = Point_cloud_registration(max_scans=1, max_features=24000)
+        set_params(reg, 4, 20, 1)
+        serial.append(solve(reg, m))
+        reg.close(); m.close()
+    assert not np.array_equal(serial[0][1], serial[1][1])
+
+    shared = Map_buffer()
+    shared.setInputCloud(Map_buffer.CORNER, maps[0][0])
+    shared.setInputCloud(Map_buffer.SURF, maps[0][1])
+    stop = threading.Event()
+    errors, results = [], []
+
+    def refresher():
+        k = 0
+        try:
+            while not stop.is_set():
+                k ^= 1
+                # both kinds of one map are swapped one after the other: a solve may see corner of one and surface of
+                # the other map only between the two calls, so the kinds are uploaded under the registrars' pause lock
+                with gate:
+                    shared.setInputCloud(Map_buffer.CORNER, maps[k][0])
+                    shared.setInputCloud(Map_buffer.SURF, maps[k][1])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    gate = threading.Lock()
+
+    def registrar():
+        try:
+            reg = Point_cloud_registration(max_scans=1, max_features=24000)
+            set_params(reg, 4, 20, 1)
+            reg.upload_features([fc], [fs])
+            for _ in range(12):
+                with gate:  # pin a consistent pair of snapshots ...
+                    reg.enqueue_uploaded(shared, 1, sc.pose_init[None], sc.pose_init[None])
+                res, pc, _, reps = reg.collect(1)  # ... the kernels run while the refresher is already uploading again
+                results.append((int(res[0]), pc[0].copy(), reps[0].n_blocks_last))
+            reg.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=refresher)] + [threading.Thread(target=registrar) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads[1:]:
+        t.join()
+    stop.set()
+    threads[0].join()
+    shared.close()
+    assert not errors, errors
+    assert len(results) == 24
+    seen = set()
+    for ret, pose, nb in results:
+        match = [i for i in range(2) if ret == serial[i][0] and np.array_equal(pose, serial[i][1]) and nb == serial[i][2]]
+        assert match, "a registration mixed two map snapshots"
+        seen.add(match[0])
+    assert seen == {0, 1}  # the refresher really did swap maps under the registrars
