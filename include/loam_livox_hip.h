@@ -87,6 +87,12 @@ int ll_fe_select(ll_fe *h, float minimum_blur, float maximum_blur, int32_t *corn
  * is given explicitly per scan (current_time = m_current_time of livox_feature_extractor.hpp:727-731). */
 int ll_fe_upload(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points,
                  const double *current_time);
+/* The same without the final wait: the copies are queued on the handle's stream and the call returns; xyzi and
+ * current_time must stay valid (and should be page-locked host memory for a true asynchronous copy) until ll_fe_sync or
+ * a later synchronous call on this handle.  Lets the next batch cross PCIe while the previous one is being processed
+ * on another handle (bench.py "streamed" figure). */
+int ll_fe_upload_async(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points,
+                       const double *current_time);
 int ll_fe_extract_batch(ll_fe *h, int32_t n_scans); /* asynchronous on the handle's stream */
 /* piece >= 0: use the device-computed piece-wise window `piece`; piece < 0: explicit [minimum,maximum]_blur */
 int ll_fe_select_batch(ll_fe *h, int32_t n_scans, int32_t piece, float minimum_blur, float maximum_blur);

@@ -97,11 +97,16 @@ class Livox_laser:
                     piece_end=pe[:P].copy())
 
     # -- batched, device-resident path ------------------------------------------------------------------------
-    def upload(self, scans: np.ndarray, current_time: np.ndarray, first_scan: int = 0):
+    def upload(self, scans: np.ndarray, current_time: np.ndarray, first_scan: int = 0, wait: bool = True):
+        """wait=False: ll_fe_upload_async -- the arrays are kept referenced on the object until the next upload / sync and
+        should be page-locked (e.g. views of torch pinned tensors) for the copy to overlap other work."""
+        assert scans.dtype == np.float32 and scans.flags["C_CONTIGUOUS"] if not wait else True
         scans = np.ascontiguousarray(scans, np.float32)
         assert scans.ndim == 3 and scans.shape[2] == 4
         ct = np.ascontiguousarray(current_time, np.float64)
-        check(self.L.ll_fe_upload(self.h, first_scan, scans.shape[0], ptr(scans), scans.shape[1], ptr(ct)), "ll_fe_upload")
+        fn = self.L.ll_fe_upload if wait else self.L.ll_fe_upload_async
+        check(fn(self.h, first_scan, scans.shape[0], ptr(scans), scans.shape[1], ptr(ct)), "ll_fe_upload")
+        self._pending_upload = None if wait else (scans, ct)
         for i in range(scans.shape[0]):
             self._n[first_scan + i] = scans.shape[1]
 

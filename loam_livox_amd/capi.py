@@ -56,6 +56,7 @@ SYMBOLS = {
     "ll_fe_splits": (_i32, [_vp, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp, _vp]),
     "ll_fe_select": (_i32, [_vp, _f, _f, _vp, C.POINTER(_i32), _vp, C.POINTER(_i32), _vp, C.POINTER(_i32), _vp, _vp]),
     "ll_fe_upload": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),
+    "ll_fe_upload_async": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),
     "ll_fe_extract_batch": (_i32, [_vp, _i32]),
     "ll_fe_select_batch": (_i32, [_vp, _i32, _i32, _f, _f]),
     "ll_fe_counts": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),

@@ -204,8 +204,20 @@ extern "C" int ll_fe_sync(ll_fe *h)
     return 0;
 }
 
+static int fe_upload_impl(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points, const double *current_time,
+                          bool wait);
 extern "C" int ll_fe_upload(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points,
                             const double *current_time)
+{
+    return fe_upload_impl(h, first_scan, n_scans, xyzi, n_points, current_time, true);
+}
+extern "C" int ll_fe_upload_async(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points,
+                                  const double *current_time)
+{
+    return fe_upload_impl(h, first_scan, n_scans, xyzi, n_points, current_time, false);
+}
+static int fe_upload_impl(ll_fe *h, int32_t first_scan, int32_t n_scans, const float *xyzi, int32_t n_points, const double *current_time,
+                          bool wait)
 {
     if (!h || !xyzi || !current_time) return set_err("ll_fe_upload", "null argument");
     if (first_scan < 0 || n_scans < 0 || first_scan + n_scans > h->prm.max_scans) return set_err("ll_fe_upload", "scan range exceeds max_scans");
@@ -218,7 +230,7 @@ extern "C" int ll_fe_upload(ll_fe *h, int32_t first_scan, int32_t n_scans, const
     for (int i = 0; i < n_scans; i++) h->h_npts[first_scan + i] = n_points;
     HC(hipMemcpyAsync(h->d_npts + first_scan, h->h_npts.data() + first_scan, n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HC(hipMemcpyAsync(h->d_time0 + first_scan, current_time, n_scans * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HC(hipStreamSynchronize(h->stream));  // the caller's buffers may be reused right away
+    if (wait) HC(hipStreamSynchronize(h->stream));  // the caller's buffers may be reused right away
     return 0;
 }
 
