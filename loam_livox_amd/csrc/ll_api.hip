@@ -649,6 +649,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.blk_av, B * 6 * d.cap);
     DM(d.blk_pa, B * d.cap_s);
     DM(d.blk_pb, B * d.cap_s);
+    DM(d.blk_pc, B * d.cap_s);
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
     DM(d.qw, B * d.cap);
@@ -693,7 +694,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -122,8 +122,9 @@ struct RegDev {
     int cap_c, cap_s, cap;        // cap = cap_c + cap_s
     float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
     double *blk_av;               // [B][6 * cap] per scan {a0, v0}[cap], {v1, v2}[cap], {a1, a2}[cap] (16-byte pairs; ll_reg_kernels.hip av_load), frame of pose_last
-    int4 *blk_pa, *blk_pb;        // [B][cap_s] compact plane blocks (32 B): pa = {bits f.x, f.y, f.z, nq.x}, pb = {nq.y, nq.z, c lo, c hi};
-                                  // nq = Q1.31 normal in the frame of pose_last, c = n'.a' (fp64) -- ll_reg_core.h q31_encode
+    int4 *blk_pa, *blk_pb, *blk_pc;  // [B][cap_s] packed plane blocks of the round-2 fast path, 48 B in three coalesced 16-byte planes:
+                                  // pa = {bits f.x, f.y, f.z, 0} (fp32, sensor frame), pb = {n'.x, n'.y} (fp64), pc = {n'.z, c = n'.a'} (fp64);
+                                  // the same numbers as blk_f / blk_av hold, so every solver path computes bit-identical blocks
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)

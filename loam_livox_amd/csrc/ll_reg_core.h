@@ -153,26 +153,11 @@ LL_HD bool block_line(const double pose_last[7], const double pa[3], const doubl
     return true;
 }
 
-// Q1.31 fixed point for the components of a plane normal in the frame of pose_last (|n'| <= 1 by construction):
-// value = q * 2^-31, absolute error <= 2^-32 per component.  The device keeps a plane block as 32 bytes
-// {f.xyz (fp32, exact), n'.xyz (Q1.31), c = n'.a' (fp64, computed from the QUANTISED normal)}, so the stored plane is an
-// exactly consistent plane whose direction differs from the reference's double normal by <= 4e-10 rad: a residual
-// changes by <= 4e-10 x |p - a'| metres (north-star tolerance: 1e-4 m).  oracle/ emulates the same rounding on request
-// (orc_reg_params.plane_normal_q31) so that the tests can still compare iteration for iteration.
-LL_HD int q31_encode(double v)
-{
-    double s = rint(v * 2147483648.0);
-    if (s > 2147483647.0) s = 2147483647.0;
-    if (s < -2147483647.0) s = -2147483647.0;
-    return (int)s;
-}
-LL_HD double q31_decode(int q) { return (double)q * (1.0 / 2147483648.0); }
-
 // plane block from neighbours 0, k/2, k-1 (point_cloud_registration.hpp:416-418, ceres_icp.hpp:328-334); a_out[0] = n'.a';
 // n = (ab/|ab|) x (ac/|ac|) is NOT re-normalised.  Degenerate triples (a==b or a==c) are skipped (the
-// reference would produce NaN residuals).  v_out is the Q1.31-rounded normal (nq_out its integer form).
+// reference would produce NaN residuals).
 LL_HD bool block_plane(const double pose_last[7], const double pa[3], const double pb[3], const double pc[3],
-                       double a_out[3], double v_out[3], int nq_out[3])
+                       double a_out[3], double v_out[3])
 {
     double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
     double ac[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
@@ -188,11 +173,6 @@ LL_HD bool block_plane(const double pose_last[7], const double pa[3], const doub
     double a_loc[3];
     quat_rot_inv(pose_last, rel, a_loc);
     quat_rot_inv(pose_last, n, v_out);
-    for (int i = 0; i < 3; i++) {
-        if (!(v_out[i] == v_out[i])) return false;  // NaN pose / neighbours: no block
-        nq_out[i] = q31_encode(v_out[i]);
-        v_out[i] = q31_decode(nq_out[i]);
-    }
     // a plane block only ever needs n'.a' (r = ((p - a').n') n'), so it is stored as one scalar: 8 B instead of 24 B
     // per block on every cost evaluation
     a_out[0] = dot3(v_out, a_loc);

@@ -166,10 +166,6 @@ typedef struct {
     int subsample_seed;             /* 0: the sub-sampling branches (PCR:232-238,339-345,438-458) are dead; else they run on the
                                        counter-based uniform stream defined in ll_oracle_reg.c (the reference's mt19937 seeded from
                                        random_device cannot be reproduced) */
-    int plane_normal_q31;           /* 0: exact fp64 plane normals (the reference).  1: emulate the device's block format
-                                       (loam_livox_amd/csrc/ll_reg_core.h q31_encode): the normal, expressed in the frame of
-                                       pose_last, is rounded to Q1.31 per component (direction error <= 4e-10 rad) so that the
-                                       tests can follow the HIP solver iteration for iteration */
 } orc_reg_params;
 
 typedef struct {
@@ -211,9 +207,6 @@ typedef struct {
  * (ICP:255-256 line; ICP:328-334 plane). */
 void orc_block_line(orc_block *b, const double f[3], const double pa[3], const double pb[3], double s);
 void orc_block_plane(orc_block *b, const double f[3], const double pa[3], const double pb[3], const double pc[3], double s);
-
-/* Device-format emulation (see orc_reg_params.plane_normal_q31): rounds the plane normal of b, in the frame of pose_last, to Q1.31. */
-void orc_block_quantise_normal(orc_block *b, const double pose_last[7]);
 
 /* Raw (un-robustified) residual of one block at increment x = {qx,qy,qz,qw,tx,ty,tz}. ICP:262-288,338-366 */
 void orc_block_residual(const orc_block *b, const double pose_last[7], const double x[7], int deblur, double r[3]);

@@ -256,23 +256,6 @@ void orc_block_plane(orc_block *b, const double f[3], const double pa[3], const 
     cross3(ab, ac, b->v); /* ICP:334, NOT re-normalised */
 }
 
-/* Emulation of the device's plane-block format (orc_reg_params.plane_normal_q31; NOT reference behaviour): the normal is
- * rotated into the frame of pose_last, each component rounded to a multiple of 2^-31 (saturating), and rotated back. */
-void orc_block_quantise_normal(orc_block *b, const double pose_last[7])
-{
-    quat q = pose_q(pose_last), qc = {-q.x, -q.y, -q.z, q.w};
-    double nl[3], nw[3];
-    quat_rot(&qc, b->v, nl);
-    for (int i = 0; i < 3; i++) {
-        double sc = rint(nl[i] * 2147483648.0);
-        if (sc > 2147483647.0) sc = 2147483647.0;
-        if (sc < -2147483647.0) sc = -2147483647.0;
-        nl[i] = (double)(int)sc * (1.0 / 2147483648.0);
-    }
-    quat_rot(&q, nl, nw);
-    for (int i = 0; i < 3; i++) b->v[i] = nw[i];
-}
-
 /* functor operator() with T = Jet<double,7> (ICP:262-288, 338-366; _mb: ICP:106-134, 187-218).
  * x = {qx,qy,qz,qw,tx,ty,tz}; derivative slot k = ambient parameter k. */
 static void block_residual_jet(const orc_block *b, const double pose_last[7], const double x[7], int deblur, jet r[3])
@@ -950,9 +933,7 @@ int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_
                     if (norm3(ab) == 0.0 || norm3(ac) == 0.0) continue; /* defined deviation: NaN normal */
                     double f[3] = {po[0], po[1], po[2]};
                     blk_query[nb] = n_corner + i;
-                    orc_block_plane(&blocks[nb], f, a, b, c, deblur ? (double)s * 1.0 : 1.0);
-                    if (prm->plane_normal_q31) orc_block_quantise_normal(&blocks[nb], pose_last);
-                    nb++;
+                    orc_block_plane(&blocks[nb++], f, a, b, c, deblur ? (double)s * 1.0 : 1.0);
                 }
                 surf_avail++; /* PCR:425 */
             }

@@ -54,12 +54,6 @@ class FeTimebase:
         self.tb.last_maximum_time_stamp = result.last_time_stamp
 
 
-# Default of RegParams.plane_normal_q31 when a test does not say: the -m gpu tier (tests/conftest.py) switches it on so
-# that the oracle follows the HIP solver's Q1.31 plane-normal format iteration for iteration; everything else -- and
-# every comparison that is about the REFERENCE's answer -- runs with exact fp64 normals (q31=0).
-EMULATE_DEVICE_FORMAT = False
-
-
 class RegParams(C.Structure):
     _fields_ = [("if_motion_deblur", C.c_int), ("icp_max_iterations", C.c_int), ("ceres_max_iterations", C.c_int),
                 ("ceres_prerun_times", C.c_int), ("line_search_num", C.c_int), ("plane_search_num", C.c_int),
@@ -71,17 +65,14 @@ class RegParams(C.Structure):
                 ("para_max_angular_rate", C.c_float), ("para_max_speed", C.c_float), ("max_final_cost", C.c_float),
                 ("minimum_pt_time_stamp", C.c_float), ("maximum_pt_time_stamp", C.c_float),
                 ("if_line_feature_check", C.c_int), ("if_plane_feature_check", C.c_int),
-                ("maximum_allow_residual_block", C.c_int), ("subsample_seed", C.c_int),
-                ("plane_normal_q31", C.c_int)]
+                ("maximum_allow_residual_block", C.c_int), ("subsample_seed", C.c_int)]
 
     @staticmethod
-    def defaults(icp_iters=10, ceres_iters=20, force_all=0, deblur=0, q31=None):
+    def defaults(icp_iters=10, ceres_iters=20, force_all=0, deblur=0):
         """Code defaults (PCR:45-98; max_final_cost = class default 100, PCR:88) with launch/rosbag.launch
-        bounds (max_allow_incre_R 20, max_allow_incre_T 0.3); sub-sampling disabled.  q31=1 emulates the device's
-        Q1.31 plane-normal format (ll_oracle.h orc_reg_params.plane_normal_q31) -- not reference behaviour."""
-        q31 = int(EMULATE_DEVICE_FORMAT if q31 is None else q31)
+        bounds (max_allow_incre_R 20, max_allow_incre_T 0.3); sub-sampling disabled."""
         return RegParams(deblur, icp_iters, ceres_iters, 2, 5, 5, 1, 1, 100, 50, force_all,
-                         2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 20.0, 0.3, 100.0, 0.0, 1.0, 0, 0, 99999, 0, q31)
+                         2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 20.0, 0.3, 100.0, 0.0, 1.0, 0, 0, 99999, 0)
 
 
     @staticmethod
@@ -89,7 +80,7 @@ class RegParams(C.Structure):
         """The member initialisers of Point_cloud_registration alone (PCR:45-103): what a default-constructed registrar
         (Scene_alignment::m_pc_reg, scene_alignment.hpp:32) runs with."""
         return RegParams(0, 20, 100, 2, 5, 5, 1, 1, 101, 100, 0, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 200.0 / 50.0, 100.0 / 50.0, 100.0,
-                         0.0, 1.0, 0, 0, 100000, 0, int(EMULATE_DEVICE_FORMAT))
+                         0.0, 1.0, 0, 0, 100000, 0)
 
 
 class RegReport(C.Structure):
@@ -295,14 +286,6 @@ def make_block_plane(f, a, b, c, s=1.0) -> Block:
     blk = Block()
     lib().orc_block_plane(C.byref(blk), _dp(np.asarray(f, np.float64)), _dp(np.asarray(a, np.float64)),
                           _dp(np.asarray(b, np.float64)), _dp(np.asarray(c, np.float64)), s)
-    return blk
-
-
-def quantise_block_normal(blk: Block, pose_last) -> Block:
-    """device-format emulation: Q1.31 plane normal in the frame of pose_last (ll_oracle.h orc_block_quantise_normal)"""
-    L = lib()
-    L.orc_block_quantise_normal.argtypes = [C.POINTER(Block), C.POINTER(C.c_double)]
-    L.orc_block_quantise_normal(C.byref(blk), _dp(np.ascontiguousarray(pose_last, np.float64)))
     return blk
 
 

@@ -13,18 +13,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
-@pytest.fixture(autouse=True)
-def _oracle_follows_device_block_format(request):
-    """-m gpu tests compare the HIP solver with the oracle iteration for iteration (LM iteration counts, inlier counts,
-    costs to 1e-8).  The device stores a plane normal in Q1.31 (ll_reg_core.h q31_encode, direction error <= 4e-10 rad),
-    so in that tier the oracle emulates the same rounding unless a test asks for the exact reference arithmetic with
-    RegParams.defaults(q31=0) -- tests/test_gpu_reg.py::test_pose_against_exact_reference_arithmetic does."""
-    from oracle import orc
-    orc.EMULATE_DEVICE_FORMAT = request.node.get_closest_marker("gpu") is not None
-    yield
-    orc.EMULATE_DEVICE_FORMAT = False
-
-
 def pytest_collection_modifyitems(config, items):
     """GPU-tier tests are skipped (not failed) on a machine without a HIP device; the HIP library itself never falls back."""
     has_gpu = None

@@ -308,8 +308,7 @@ int hc_eval_blocks(int n, const int32_t *kind, const double *f, const double *a,
 int hc_make_block(int kind, const double *pose_last, const double *pa, const double *pb, const double *pc, double *a_out, double *v_out)
 {
     if (kind == BLK_LINE) return block_line(pose_last, pa, pb, a_out, v_out) ? 1 : 0;
-    int nq[3];
-    return block_plane(pose_last, pa, pb, pc, a_out, v_out, nq) ? 1 : 0;
+    return block_plane(pose_last, pa, pb, pc, a_out, v_out) ? 1 : 0;
 }
 
 int hc_pca_check(int is_plane, const float *pts, double *ev_out)
@@ -445,8 +444,7 @@ int hc_reg_solve(const hc_grid *gc, const hc_grid *gs, const float *corner, int 
                     if (p->icp_plane) {
                         const f4 p0 = G->g.pts[r.pos[0]], p1 = G->g.pts[r.pos[2]], p2 = G->g.pts[r.pos[4]];
                         const double pa[3] = {p0.x, p0.y, p0.z}, pb[3] = {p1.x, p1.y, p1.z}, pc[3] = {p2.x, p2.y, p2.z};
-                        int nq[3];
-                        if (!block_plane(pose_last, pa, pb, pc, b.a, b.v, nq)) continue;
+                        if (!block_plane(pose_last, pa, pb, pc, b.a, b.v)) continue;
                         b.kind = BLK_PLANE;
                         blk.push_back(b);
                         kept[1][q] = b;

@@ -149,7 +149,7 @@ def test_analytic_gauss_newton_matches_jets():
             oblocks.append(orc.make_block_line(f, a, b))
             ok, aa, vv = hc.make_block(1, pose_last, a, b)
         else:
-            oblocks.append(orc.quantise_block_normal(orc.make_block_plane(f, a, b, c), pose_last))
+            oblocks.append(orc.make_block_plane(f, a, b, c))
             ok, aa, vv = hc.make_block(2, pose_last, a, b, c)
         assert ok
         kind.append(1 if i % 2 else 2)
@@ -173,7 +173,7 @@ def test_full_registration_matches_oracle(small_world, scans, k):
     _, _, _, _, fc, fs = oracle_features(sc)
     gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 1.0)
     for force in (0, 1):
-        prm = orc.RegParams.defaults(q31=1, icp_iters=6, ceres_iters=20, force_all=force)
+        prm = orc.RegParams.defaults(icp_iters=6, ceres_iters=20, force_all=force)
         ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
         hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hc_reg_params(6, 20, force), sc.pose_init, sc.pose_init)
         dt, dr = synth.pose_error(pc, hpc)
@@ -187,7 +187,7 @@ def test_rejection_matches_oracle(small_world, scans):
     sc = scans[0]
     _, _, _, _, fc, fs = oracle_features(sc)
     gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 1.0)
-    prm = orc.RegParams.defaults(q31=1, icp_iters=2)
+    prm = orc.RegParams.defaults(icp_iters=2)
     prm.max_final_cost = 1e-6
     ret, pc, _, _ = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     hret, hpc, _, _ = hc.reg_solve(gc, gs, fc, fs, hc_reg_params(2, 20, 0, 0.3, 1e-6), sc.pose_init, sc.pose_init)
@@ -209,7 +209,7 @@ def test_motion_deblur_gauss_newton_matches_jets():
             if i % 2:
                 oblocks.append(orc.make_block_line(f, a, b, s)); ok, aa, vv = hc.make_block(1, pose_last, a, b)
             else:
-                oblocks.append(orc.quantise_block_normal(orc.make_block_plane(f, a, b, c, s), pose_last)); ok, aa, vv = hc.make_block(2, pose_last, a, b, c)
+                oblocks.append(orc.make_block_plane(f, a, b, c, s)); ok, aa, vv = hc.make_block(2, pose_last, a, b, c)
             kind.append(1 if i % 2 else 2); F.append(f); A.append(aa); V.append(vv); S.append(s)
         oc, og, oH = orc.blocks_eval(oblocks, pose_last, x, deblur=1)
         c2, g2, H2 = hc.eval_blocks(kind, np.array(F), np.array(A), np.array(V), x, sblur=S)
@@ -222,7 +222,7 @@ def test_motion_deblur_registration_matches_oracle(small_world, scans):
     fe, ci, si, fi, fc, fs = oracle_features(sc)
     tmin, tmax = float(fe.time_stamp.min()), float(fe.time_stamp.max())
     gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 0.6)
-    prm = orc.RegParams.defaults(q31=1, icp_iters=5, ceres_iters=20, force_all=1, deblur=1)
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1, deblur=1)
     prm.minimum_pt_time_stamp, prm.maximum_pt_time_stamp = tmin, tmax
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     hp = hc.RegParams(1, 5, 20, 2, 1, 1, 1, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 0.3, 20.0, 100.0, tmin, tmax)
@@ -286,7 +286,7 @@ def test_registration_with_pca_checks_matches_oracle(small_world, scans, checks)
     corner = noisy_corner_map(small_world)  # the clean synthetic edges always pass the line test
     tree_c = orc.KdTree(corner)
     gc, gs = hc.Grid(corner, 0.5), hc.Grid(small_world["surf"], 0.6)
-    prm = orc.RegParams.defaults(q31=1, icp_iters=5, ceres_iters=20, force_all=1)
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
     prm.if_line_feature_check, prm.if_plane_feature_check = checks
     ret, pc, pi, rep = orc.reg_solve(tree_c, small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     hp = hc.RegParams(0, 5, 20, 2, 1, 1, 1, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 0.3, 20.0, 100.0, 0.0, 1.0, *checks)
@@ -294,7 +294,7 @@ def test_registration_with_pca_checks_matches_oracle(small_world, scans, checks)
     dt, dr = synth.pose_error(pc, hpc)
     assert ret == hret and dt < 1e-9 and dr < 1e-9
     assert rep.n_blocks_last == hrep[4] and rep.corner_avail == hrep[5] and rep.surf_avail == hrep[6]
-    base = orc.RegParams.defaults(q31=1, icp_iters=5, ceres_iters=20, force_all=1)
+    base = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
     _, _, _, rep0 = orc.reg_solve(tree_c, small_world["tree_s"], fc, fs, base, sc.pose_init, sc.pose_init)
     if checks[0]:  # both checks reject some neighbourhoods
         assert rep.corner_avail < rep0.corner_avail
@@ -310,7 +310,7 @@ def test_registration_with_subsampling_matches_oracle(small_world, scans, max_bl
     sc = scans[1]
     _, _, _, _, fc, fs = oracle_features(sc)
     gc, gs = hc.Grid(small_world["corner"], 1.45), hc.Grid(small_world["surf"], 0.6)
-    prm = orc.RegParams.defaults(q31=1, icp_iters=5, ceres_iters=20, force_all=1)
+    prm = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
     prm.maximum_allow_residual_block, prm.subsample_seed = max_blocks, 7
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     hp = hc.RegParams(0, 5, 20, 2, 1, 1, 1, 2.0, 50.0, 0.1, 0.02, 0.8, 0.01, 0.01, 0.3, 20.0, 100.0, 0.0, 1.0, 0, 0, max_blocks, 7)
@@ -319,7 +319,7 @@ def test_registration_with_subsampling_matches_oracle(small_world, scans, max_bl
     assert ret == hret and dt < 1e-9 and dr < 1e-9
     assert rep.n_blocks_last == hrep[4] and rep.corner_avail == hrep[5] and rep.surf_avail == hrep[6] and rep.lm_iterations_total == hrep[7]
     assert rep.n_blocks_last <= max_blocks * 1.3                      # ~M blocks survive the drop (then 20 % are pruned)
-    base = orc.RegParams.defaults(q31=1, icp_iters=5, ceres_iters=20, force_all=1)
+    base = orc.RegParams.defaults(icp_iters=5, ceres_iters=20, force_all=1)
     _, pc0, _, rep0 = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, base, sc.pose_init, sc.pose_init)
     assert rep0.n_blocks_last > 3 * rep.n_blocks_last
     if max_blocks == 200:

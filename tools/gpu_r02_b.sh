@@ -4,11 +4,11 @@ set -x
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_reg.py tests/test_ref_golden.py tests/test_golden.py tests/test_gpu_full.py tests/test_mapping_sequence.py tests/test_adapter_cpp.py -m gpu -x -q 2>&1 | tail -25 ) > gpurun_out/e_tests.log 2>&1
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-q-pipe > gpurun_out/e_bench_new.json 2> gpurun_out/e_bench_new.err
-LOAM_LIVOX_LIB=$GRAFT_REPO_ROOT/loam_livox_amd/libloamlivox_hip_timing.so timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-q-pipe > gpurun_out/e_timing_new.json 2> gpurun_out/e_timing_new.err
-tail -5 gpurun_out/e_tests.log
-for f in gpurun_out/e_bench_new.json gpurun_out/e_timing_new.json; do echo $f; python - "$f" <<'PY'
+( timeout 900 python -m pytest tests/test_gpu_reg.py tests/test_ref_golden.py tests/test_golden.py tests/test_gpu_full.py tests/test_mapping_sequence.py tests/test_adapter_cpp.py -m gpu -x -q 2>&1 | tail -25 ) > gpurun_out/i_tests.log 2>&1
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-q-pipe > gpurun_out/i_bench_new.json 2> gpurun_out/i_bench_new.err
+LOAM_LIVOX_LIB=$GRAFT_REPO_ROOT/loam_livox_amd/libloamlivox_hip_timing.so timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-q-pipe > gpurun_out/i_timing_new.json 2> gpurun_out/i_timing_new.err
+tail -5 gpurun_out/i_tests.log
+for f in gpurun_out/i_bench_new.json gpurun_out/i_timing_new.json; do echo $f; python - "$f" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
