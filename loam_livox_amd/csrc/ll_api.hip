@@ -661,6 +661,8 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.work_build, B * d.cap);
     d.n_chunks = (int)((F + 255) / 256);  // must match RQ_THREADS in ll_reg_kernels.hip
     DM(d.work_n, B * 4 * (size_t)d.n_chunks);
+    DM(d.work_cnt, B * 4);
+    DM(d.work_off, 2 * 2049);  // 2 lists x (RL_MAX_SEG + 1), ll_reg_kernels.hip
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -679,6 +681,8 @@ extern "C" int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_feat
 {
     if (!out) return set_err("ll_reg_create", "null argument");
     if (max_scans < 1 || max_features_per_scan < 1) return set_err("ll_reg_create", "bad capacity");
+    if ((int64_t)max_scans * 2 * max_features_per_scan >= 0x7fffffffLL)
+        return set_err("ll_reg_create", "max_scans x 2 x max_features_per_scan must stay below 2^31 (work-list entries are 32-bit)");
     if (check_device(device)) return -1;
     ll_reg *r = new ll_reg();
     if (reg_create_impl(device, max_scans, max_features_per_scan, r)) {
@@ -694,7 +698,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.work_cnt, d.work_off, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -70,11 +70,14 @@ __device__ __forceinline__ double wave_sum(double v)
 //                                 re-sort -> the same five neighbours re-evaluated at the new position, slot appended
 //                                            to the chunk's re-sort list;
 //                                 search  -> slot appended to the chunk's search list
-//       reg_knn_list_kernel   : full exact search of the search lists
-//       reg_build_list_kernel : block constants of everything searched or re-sorted
-// Lists are segmented per chunk of RQ_THREADS queries and filled in query order by one workgroup each (no atomics).  In
-// the late iterations a per cent or two of the queries are still searched; the list launch then costs about one
-// search's chain of dependent gathers through caches the solver has just flushed (~100 us), see DESIGN.md.
+//       reg_list_kernel       : full exact search of the search list + block constants of everything searched or re-sorted
+// The two work lists are dense per scan and kind: every re-query workgroup reserves its share of the scan-and-kind's
+// segment with one atomicAdd per list (work_cnt; ~94 workgroups per counter -- a single batch-wide counter cost 280 us
+// of contention per launch), and the list kernel walks all segments as one dense index space (prefix sums of the 2 B
+// counters in LDS, binary search per entry): a small grid of full wavefronts.  Round 1 kept one list segment per
+// 256-query chunk and launched one workgroup per chunk: in the late iterations a chunk holds ~3 searches, the launch was
+// 48 k workgroups with three busy lanes each, and its ~110 us floor (186 us average) was the cost of scheduling them.
+// The order of the entries depends on the order of the atomics; every entry is processed independently, so results do not.
 
 __device__ __forceinline__ void transform_query(const RegState *st, const RegConst &rc, const float4 &f, float pw[3])
 {
@@ -191,46 +194,33 @@ void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
     knn_one(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q, iter);
 }
 
-// the same search over the scan's search list (dense wavefronts)
-__global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
-void reg_knn_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
-{
-    const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
-    if (rd.state[b].done) return;  // the requery kernel did not refresh this scan's lists
-    const int nq = kind ? rd.n_surf[b] : rd.n_corner[b];
-    if (chunk * RQ_THREADS >= nq) return;
-    const int n = rd.work_n[(((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2];
-    const size_t seg = (size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (size_t)chunk * RQ_THREADS;
-    for (int t = threadIdx.x; t < n; t += KB_THREADS) knn_one(rd, rc, gc, gs, b, rd.work_search[seg + t], iter);
-}
-
 // K6r: transform + reuse test (ICP iteration >= 1)
 
-// ordered workgroup compaction: returns this thread's output slot (or -1) and advances *s_base by the number of
-// set predicates.  All threads of the workgroup must call it.
-__device__ __forceinline__ int rq_compact_slot(bool pred, int *s_wave_cnt, int *s_base, int tid)
+// workgroup compaction into a batch-wide dense list: every thread with pred gets a distinct position in
+// list[0 .. *g_total) (the workgroup reserves a contiguous range with one global atomicAdd), -1 otherwise.  Also returns
+// the workgroup's count through *wg_count.  All threads of the workgroup must call it.
+__device__ __forceinline__ int rq_dense_slot(bool pred, int *s_wave_cnt, int *s_base, int *g_total, int tid, int *wg_count)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const unsigned long long m = __ballot(pred);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) s_wave_cnt[wave] = __popcll(m);
     __syncthreads();
-    int off = *s_base;
-    for (int w = 0; w < wave; w++) off += s_wave_cnt[w];
-    const int slot = pred ? off + before : -1;
-    __syncthreads();
-    if (tid == 0) {
-        int tot = 0;
-        for (int w = 0; w < RQ_WAVES; w++) tot += s_wave_cnt[w];
-        *s_base += tot;
+    int off = 0, tot = 0;
+    for (int w = 0; w < RQ_WAVES; w++) {
+        if (w < wave) off += s_wave_cnt[w];
+        tot += s_wave_cnt[w];
     }
+    if (tid == 0) *s_base = tot > 0 ? atomicAdd(g_total, tot) : 0;
     __syncthreads();
+    const int slot = pred ? *s_base + off + before : -1;
+    *wg_count = tot;
+    __syncthreads();  // s_wave_cnt / s_base are reused by the next call
     return slot;
 }
 
-// One workgroup per chunk of RQ_THREADS consecutive queries: no global atomics; each chunk owns the matching
-// RQ_THREADS-entry segment of the work lists (filled in query order) and a pair of counters, so the list kernels
-// run on spatially coherent, densely packed wavefronts.
+// One workgroup per chunk of RQ_THREADS consecutive queries; unstable queries are appended to the batch-wide dense work
+// lists (rq_dense_slot), the per-chunk counts are kept for the debug taps.
 __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 {
     const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
@@ -242,9 +232,7 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
     const int koff = kind ? rd.cap_c : 0;
     const int tid = threadIdx.x;
     __shared__ int s_wave[RQ_WAVES];
-    __shared__ int s_n[2];
-    if (tid < 2) s_n[tid] = 0;
-    __syncthreads();
+    __shared__ int s_base;
     const int q = chunk * RQ_THREADS + tid;
     const int slot = koff + q;
     int state = 0;  // 0 = stable or out of range, 1 = re-sorted, 2 = needs a search
@@ -279,12 +267,18 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
             }
         }
     }
-    const size_t seg = sb + koff + (size_t)chunk * RQ_THREADS;
-    const int a1 = rq_compact_slot(state == 1, s_wave, &s_n[1], tid);
-    if (a1 >= 0) rd.work_build[seg + a1] = slot;
-    const int a2 = rq_compact_slot(state == 2, s_wave, &s_n[0], tid);
-    if (a2 >= 0) rd.work_search[seg + a2] = slot;
-    if (tid < 2) rd.work_n[(((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2 + tid] = s_n[tid];
+    int n1 = 0, n2 = 0;
+    int *cnt = rd.work_cnt + ((size_t)b * 2 + kind) * 2;
+    const size_t seg = sb + koff;  // the scan-and-kind's own segment of the work arrays
+    const int a1 = rq_dense_slot(state == 1, s_wave, &s_base, cnt + 1, tid, &n1);
+    if (a1 >= 0) rd.work_build[seg + a1] = (int)sb + slot;
+    const int a2 = rq_dense_slot(state == 2, s_wave, &s_base, cnt + 0, tid, &n2);
+    if (a2 >= 0) rd.work_search[seg + a2] = (int)sb + slot;
+    if (tid == 0) {
+        const size_t ci = (((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2;
+        rd.work_n[ci] = n2;
+        rd.work_n[ci + 1] = n1;
+    }
 }
 
 // Loads through an explicit global (address space 1) pointer.  Inside a non-inlined device function the compiler cannot
@@ -419,18 +413,62 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
     build_one(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q);
 }
 
-// blocks of everything that was searched or re-sorted this iteration
-__global__ __launch_bounds__(KB_THREADS) void reg_build_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs)
+// ICP iteration >= 2: exact search of the dense search list followed at once by the block constants of the same slot
+// (the lane still holds the neighbours), then the block constants of the re-sorted slots.  Grid-stride over the lists.
+#define RL_THREADS 128
+#define RL_BLOCKS 2048
+#define RL_MAX_SEG 2048  // scan-and-kind segments of one offsets table (max_scans <= 1024); larger batches run in slices
+// exclusive prefix sums of the per-segment list lengths (segment = scan * 2 + kind) -> work_off[list][0 .. n_seg]; one workgroup
+__global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int seg0, int n_seg)
 {
-    const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
-    if (rd.state[b].done) return;
-    const int nq = kind ? rd.n_surf[b] : rd.n_corner[b];
-    if (chunk * RQ_THREADS >= nq) return;
-    const size_t ci = (((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2;
-    const int n0 = rd.work_n[ci], n1 = rd.work_n[ci + 1];
-    const size_t seg = (size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (size_t)chunk * RQ_THREADS;
-    for (int t = threadIdx.x; t < n0 + n1; t += KB_THREADS)
-        build_one(rd, rc, gc, gs, b, t < n0 ? rd.work_search[seg + t] : rd.work_build[seg + t - n0]);
+    __shared__ int s_wave[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sg0 = 2 * tid, sg1 = 2 * tid + 1;  // two segments per thread (n_seg <= 2048)
+    for (int w = 0; w < 2; w++) {
+        const int c0 = sg0 < n_seg ? rd.work_cnt[(size_t)(seg0 + sg0) * 2 + w] : 0;
+        const int c1 = sg1 < n_seg ? rd.work_cnt[(size_t)(seg0 + sg1) * 2 + w] : 0;
+        int incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) s_wave[w][wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; k++) base += s_wave[w][k];
+        const int excl = base + incl - (c0 + c1);
+        int *off_w = rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
+        if (sg0 < n_seg) off_w[sg0] = excl;
+        if (sg1 < n_seg) off_w[sg1] = excl + c0;
+        if (tid == 1023) off_w[n_seg] = base + incl;  // its segments lie beyond n_seg or are the last ones: the grand total
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RL_THREADS) void reg_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int seg0, int n_seg)
+{
+    // The offsets table (<= 16 KB) is searched where it lies: it stays in L1 / L2, and a copy in LDS would cap the
+    // occupancy of this latency-bound kernel (16 KB per 128-thread workgroup: 36 -> 99 us per late iteration at B = 256).
+    const int tid = threadIdx.x;
+    const int stride = gridDim.x * RL_THREADS;
+    for (int w = 0; w < 2; w++) {
+        const int *off = rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
+        const int total = off[n_seg];
+        const int *list = w == 0 ? rd.work_search : rd.work_build;
+        for (int t = blockIdx.x * RL_THREADS + tid; t < total; t += stride) {
+            int lo = 0, hi = n_seg;  // largest segment with off[segment] <= t
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off[mid] <= t) lo = mid; else hi = mid;
+            }
+            const int sgg = seg0 + lo, b = sgg >> 1, kind = sgg & 1;
+            const int e = list[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off[lo])];
+            const int slot = e - b * rd.cap;
+            if (w == 0) knn_one(rd, rc, gc, gs, b, slot, iter);
+            build_one(rd, rc, gc, gs, b, slot);
+        }
+    }
 }
 
 // Evaluation context as plain locals (R_inc / t_inc for the plain blocks, axis-angle for the motion-deblur ones);
@@ -2040,9 +2078,13 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         if (max_nc + max_ns <= 0) return;
         const int mx = max_nc > max_ns ? max_nc : max_ns;
         dim3 cgrid((mx + RQ_THREADS - 1) / RQ_THREADS, n_scans, 2);
+        (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);
         hipLaunchKernelGGL(reg_requery_kernel, cgrid, dim3(RQ_THREADS), 0, s, rd, rc, gc, gs, iter);
-        hipLaunchKernelGGL(reg_knn_list_kernel, cgrid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
-        hipLaunchKernelGGL(reg_build_list_kernel, cgrid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
+        for (int seg0 = 0; seg0 < 2 * n_scans; seg0 += RL_MAX_SEG) {
+            const int n_seg = 2 * n_scans - seg0 < RL_MAX_SEG ? 2 * n_scans - seg0 : RL_MAX_SEG;
+            hipLaunchKernelGGL(reg_list_offsets_kernel, dim3(1), dim3(1024), 0, s, rd, seg0, n_seg);
+            hipLaunchKernelGGL(reg_list_kernel, dim3(n_scans >= 64 ? RL_BLOCKS : 64), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+        }
         return;
     }
     // corner and surface queries share every launch (blockIdx.z = kind): the few hundred corner queries of a scan
