@@ -4,7 +4,8 @@
 Every rank runs loam_livox_amd.mapping.Laser_mapping (extract -> device VoxelGrid -> register -> history add ->
 match-buffer refresh, laser_mapping.hpp:1311-1520 / 460-566, all resident in HBM) over its own synthetic sequence;
 there is no data-path collective.  The one exchange step is the gather of the ranks' sub-maps at the end
-(loam_livox_amd.multigpu.gather_submaps: all_gather of counts + padded all_gather, RCCL when --gpus > 1).
+(loam_livox_amd.multigpu.gather_submaps: the match-buffer clouds are read where they lie on the device --
+ll_history_map_cloud_device -- and exchanged as grouped point-to-point sends, RCCL when --gpus > 1; no host hop).
 
   python bench_c4.py [--frames F]                                  (1 GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench_c4.py --gpus N
@@ -90,14 +91,14 @@ def main():
         errs.append(synth.pose_error(lm.pose, truth[k]))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    sub = np.concatenate([lm.history.map_cloud(0), lm.history.map_cloud(1)], 0)
     t1 = time.perf_counter()
-    counts = [len(sub)]
+    sub = torch.cat([lm.history.map_cloud_device(0), lm.history.map_cloud_device(1)], 0)  # device-resident, no host hop
+    counts = [int(sub.shape[0])]
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        merged, counts = gather_submaps(torch.from_numpy(sub).cuda(), dist)
+        merged, counts = gather_submaps(sub, dist)
         torch.cuda.synchronize()
     t_gather = time.perf_counter() - t1
     result = {

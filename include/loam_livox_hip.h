@@ -299,6 +299,11 @@ int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_corner, int64_
 int32_t ll_history_size(const ll_history *h);
 /* the match buffer clouds of the last refresh (host copy, for inspection / tests): returns the number of points written */
 int64_t ll_history_map_cloud(ll_history *h, int32_t kind, float *xyzi, int64_t capacity_points);
+/* The same clouds where they lie: a BORROWED device pointer (float4 x,y,z,intensity per point, on the history's device)
+ * and the point count.  Valid until the next ll_history_refresh* on this handle; the handle's stream has been drained
+ * when the call returns, so any stream of the caller may read it.  This is what the multi-GPU sub-map gather sends over
+ * RCCL without a host hop. */
+int ll_history_map_cloud_device(ll_history *h, int32_t kind, const float **dev_xyzi, int64_t *n_points);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Match buffer, cell ("cube") mode  (m_matching_mode == 1, the default in code,
@@ -378,6 +383,14 @@ int ll_history_refresh_cells(ll_history *h, ll_map *map, const double pose[7], f
 /* unsigned int Point_cloud_registration::pointcloudAssociateToMap(pc_in, pc_out, if_undistore = 0)
  * (point_cloud_registration.hpp:673-685, no-deblur branch :629): p_w = q*p + t in double, stored float. */
 int ll_cloud_transform(ll_reg *r, const float *in_xyzi, float *out_xyzi, int32_t n, const double pose[7]);
+/* Device-resident form over an extractor's batch (the sub-map of a batched offline run): for every scan
+ * b < n_scans with accept[b] != 0, the selected features of `kind` (0 corner, 1 surface; the last ll_fe_select* of slot b)
+ * are moved to the map frame with poses[b] (pointAssociateToMap, no deblur) and appended, in scan order, to the
+ * caller's DEVICE buffer dev_out_xyzi (float4 per point, capacity_points points) starting at point *n_points, which is
+ * advanced.  Nothing crosses PCIe but the per-scan counts.  Fails, leaving *n_points untouched, if the capacity would
+ * be exceeded. */
+int ll_cloud_transform_fe_device(ll_reg *r, ll_fe *fe, int32_t n_scans, int32_t kind, const int32_t *accept, const double *poses7,
+                                 float *dev_out_xyzi, int64_t capacity_points, int64_t *n_points);
 
 /* HIP-event timing of the kernels launched by the last enqueue/solve on this handle (milliseconds, summed
  * over launches) and launch counts: [0] knn+block-build, [1] solver, [2] finalize. Enabled by

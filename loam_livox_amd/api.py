@@ -194,6 +194,7 @@ class History_buffer:
                  plane_res: float = 0.4, device: int = 0):
         self.L = capi.load()
         self.h = C.c_void_p()
+        self.device = device
         check(self.L.ll_history_create(device, maximum_history_size, max_points_per_frame, line_res, plane_res, C.byref(self.h)),
               "ll_history_create")
 
@@ -266,6 +267,24 @@ class History_buffer:
         if n > 0:
             check(min(0, self.L.ll_history_map_cloud(self.h, kind, ptr(out), n)), "ll_history_map_cloud")
         return out
+
+
+    def map_cloud_device(self, kind: int):
+        """The same cloud as a torch tensor (n, 4) float32 ON THE DEVICE, copied device-to-device out of the handle's
+        buffer (which the next refresh overwrites): the input of the multi-GPU sub-map gather, no host hop."""
+        import torch
+        p, n = C.c_void_p(), C.c_int64(0)
+        check(self.L.ll_history_map_cloud_device(self.h, kind, C.byref(p), C.byref(n)), "ll_history_map_cloud_device")
+        if n.value == 0:
+            return torch.zeros((0, 4), dtype=torch.float32, device=f"cuda:{self.device}")
+        return torch.as_tensor(_DeviceView(p.value, n.value), device=f"cuda:{self.device}").clone()
+
+
+class _DeviceView:
+    """(n, 4) float32 at a raw device address, for torch.as_tensor (zero copy)"""
+
+    def __init__(self, address: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n), 4), "typestr": "<f4", "data": (int(address), False), "version": 2}
 
 
 class Cell_map:
@@ -547,6 +566,18 @@ class Point_cloud_registration:
         n = np.zeros(3, np.int32)
         check(self.L.ll_reg_kernel_times(self.h, ptr(ms), ptr(n)), "ll_reg_kernel_times")
         return ms, n
+
+    def append_to_submap_device(self, fe: "Livox_laser", n_scans: int, kind: int, accept: np.ndarray, poses: np.ndarray, out, n_used: int) -> int:
+        """pointcloudAssociateToMap over an extractor's resident batch, device to device: the selected `kind` features
+        of every accepted scan, moved to the map frame with its pose, are appended to the torch DEVICE tensor `out`
+        ((capacity, 4) float32, contiguous) from row n_used on.  Returns the new row count."""
+        acc = np.ascontiguousarray(accept, np.int32)
+        ps = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        assert out.is_contiguous() and out.shape[1] == 4 and acc.shape[0] >= n_scans and ps.shape[0] >= n_scans
+        n = C.c_int64(int(n_used))
+        check(self.L.ll_cloud_transform_fe_device(self.h, fe.h, int(n_scans), int(kind), ptr(acc), ptr(ps), C.c_void_p(out.data_ptr()),
+                                                  int(out.shape[0]), C.byref(n)), "ll_cloud_transform_fe_device")
+        return int(n.value)
 
     def pointcloudAssociateToMap(self, pc_in: np.ndarray, pose: np.ndarray | None = None) -> np.ndarray:
         pc_in = capi.as_f32(pc_in, 4)

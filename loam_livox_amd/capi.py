@@ -83,6 +83,7 @@ SYMBOLS = {
     "ll_reg_debug_knn": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ll_reg_set_debug": (_i32, [_vp, _i32]),
     "ll_cloud_transform": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "ll_cloud_transform_fe_device": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "ll_reg_set_profiling": (_i32, [_vp, _i32]),
     "ll_reg_kernel_times": (_i32, [_vp, _vp, _vp]),
     "ll_reg_debug_cycles": (_i32, [_vp, _i32, _vp]),
@@ -100,6 +101,7 @@ SYMBOLS = {
     "ll_history_refresh": (_i32, [_vp, _vp, _vp, _vp]),
     "ll_history_size": (_i32, [_vp]),
     "ll_history_map_cloud": (_i64, [_vp, _i32, _vp, _i64]),
+    "ll_history_map_cloud_device": (_i32, [_vp, _i32, _vp, _vp]),
     "ll_cellmap_create": (_i32, [_i32, _i64, C.c_float, _i32, _vp]),
     "ll_cellmap_destroy": (None, [_vp]),
     "ll_cellmap_append": (_i32, [_vp, _vp, _i32]),

@@ -1501,6 +1501,16 @@ extern "C" int64_t ll_history_map_cloud(ll_history *h, int32_t kind, float *xyzi
     return n;
 }
 
+extern "C" int ll_history_map_cloud_device(ll_history *h, int32_t kind, const float **dev_xyzi, int64_t *n_points)
+{
+    if (!h || !dev_xyzi || !n_points || kind < 0 || kind > 1) return set_err("ll_history_map_cloud_device", "bad argument");
+    HC(hipSetDevice(h->device));
+    HC(hipStreamSynchronize(h->stream));
+    *dev_xyzi = (const float *)h->map_src[kind];
+    *n_points = h->n_map[kind];
+    return 0;
+}
+
 static float match_cell_size(int kind, float leaf)
 {
     // Cell size from the voxel leaf the buffer has just been filtered with: the points are about one leaf apart (along
@@ -1678,6 +1688,40 @@ extern "C" int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, f
     D2H_OPT(corner_d25, r->dev.dbg_d2 + base, (size_t)nc * 5, float);
     D2H_OPT(surf_idx5, r->dev.dbg_idx + base + (size_t)r->dev.cap_c * 5, (size_t)ns * 5, int);
     D2H_OPT(surf_d25, r->dev.dbg_d2 + base + (size_t)r->dev.cap_c * 5, (size_t)ns * 5, float);
+    return 0;
+}
+
+extern "C" int ll_cloud_transform_fe_device(ll_reg *r, ll_fe *fe, int32_t n_scans, int32_t kind, const int32_t *accept, const double *poses7,
+                                            float *dev_out_xyzi, int64_t capacity_points, int64_t *n_points)
+{
+    if (!r || !fe || !accept || !poses7 || !dev_out_xyzi || !n_points) return set_err("ll_cloud_transform_fe_device", "null argument");
+    if (fe->prm.device != r->device) return set_err("ll_cloud_transform_fe_device", "extractor lives on another device");
+    if (n_scans < 0 || n_scans > fe->prm.max_scans || kind < 0 || kind > 1 || *n_points < 0)
+        return set_err("ll_cloud_transform_fe_device", "bad argument");
+    if (n_scans == 0) return 0;
+    HC(hipSetDevice(r->device));
+    HC(hipStreamSynchronize(fe->stream));
+    std::vector<int> cnt((size_t)n_scans);
+    HC(hipMemcpy(cnt.data(), kind == 0 ? fe->dev.n_corner : fe->dev.n_surf, (size_t)n_scans * sizeof(int), hipMemcpyDeviceToHost));
+    int64_t total = *n_points;
+    for (int b = 0; b < n_scans; b++)
+        if (accept[b]) total += cnt[(size_t)b];
+    if (total > capacity_points) return set_err("ll_cloud_transform_fe_device", "device buffer too small");
+    double *d_poses = nullptr;
+    DM(d_poses, (size_t)n_scans * 7);
+    hipError_t e = hipMemcpyAsync(d_poses, poses7, (size_t)n_scans * 7 * sizeof(double), hipMemcpyHostToDevice, r->stream);
+    int64_t at = *n_points;
+    const float4 *src = kind == 0 ? fe->dev.corner_feat : fe->dev.surf_feat;
+    for (int b = 0; b < n_scans && e == hipSuccess; b++) {
+        if (!accept[b] || cnt[(size_t)b] == 0) continue;
+        launch_cloud_transform(src + (size_t)b * fe->dev.stride, (float4 *)dev_out_xyzi + at, cnt[(size_t)b], d_poses + (size_t)b * 7, r->stream);
+        at += cnt[(size_t)b];
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    (void)hipFree(d_poses);
+    if (e != hipSuccess) return set_err("ll_cloud_transform_fe_device", hipGetErrorString(e));
+    *n_points = total;
     return 0;
 }
 

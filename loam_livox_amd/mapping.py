@@ -52,6 +52,8 @@ class Laser_mapping:
         self.map_sizes = (0, 0)
         self.last_report = None
         self.stage_s = np.zeros(4)  # cumulative wall time: extract+register, history add, match-buffer refresh, frames
+        self.m_last_time_stamp = 0.0
+        self._host_vox = None
 
     def close(self):
         for h in (self.fe, self.reg, self.map, self.vox[0], self.vox[1], self.history):
@@ -94,4 +96,42 @@ class Laser_mapping:
         t3 = time.perf_counter()
         self.stage_s[1] += t2 - t1
         self.stage_s[2] += t3 - t2
+        return 1
+
+    def process_clouds(self, full: np.ndarray, surface: np.ndarray, corners: np.ndarray) -> int:
+        """process_new_scan as the mapping NODE runs it (laser_mapping.hpp:1316-1520): from the three clouds the
+        feature node published (/pc2_full, /pc2_surface, /pc2_corners; feature_node.Laser_feature.laserCloudHandler),
+        host clouds in, through the same C-ABI entry points tools/ll_node.cpp reaches through the adapter."""
+        reg = self.reg
+        max_t = float(np.max(full[:, 3])) if len(full) else 0.0  # find_min_max_intensity( full ), :1336
+        reg.params.minimum_pt_time_stamp, reg.params.maximum_pt_time_stamp = self.m_last_time_stamp, max_t  # :1345-1346
+        self.m_last_time_stamp = max_t
+        reg.params.current_frame_index = self.m_current_frame_index
+        self.m_current_frame_index += 1
+        if self.m_if_input_downsample_mode:  # :1367-1373
+            if self._host_vox is None:
+                cap = int(self.fe.params.max_points)
+                self._host_vox = (VoxelGrid(cap, 1), VoxelGrid(cap, 1))
+                self._host_vox[0].setLeafSize(*([self.line_res] * 3))
+                self._host_vox[1].setLeafSize(*([self.plane_res] * 3))
+            stacks = []
+            for vg, cloud in zip(self._host_vox, (corners, surface)):
+                if len(cloud):
+                    vg.setInputCloud(cloud)
+                    cloud = vg.filter()
+                stacks.append(cloud)
+            corner_stack, surf_stack = stacks
+        else:
+            corner_stack, surf_stack = corners, surface
+        self.stack_sizes = (len(corner_stack), len(surf_stack))
+        reg.m_pose_w_last = self.pose.copy()
+        reg.m_pose_w_curr = self.pose.copy()
+        reg.m_para_buffer_incremental = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)  # a fresh Point_cloud_registration per scan (:1348)
+        res = reg.find_out_incremental_transfrom(self.map, corner_stack, surf_stack)
+        self.last_report = reg.report
+        if not res:  # :1413-1416
+            return 0
+        self.pose = np.array(reg.m_pose_w_curr, np.float64)
+        self.history.add(corner_stack, surf_stack, self.pose, self.history_add_t_step, self.history_add_angle_step)
+        self.map_sizes = self.history.refresh(self.map)
         return 1

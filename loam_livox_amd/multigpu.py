@@ -3,8 +3,12 @@
 Per-scan odometry does not shard (each scan needs the previous pose and the resident map): "replicas only".
 What shards trivially is a set of independent sub-sequences: one process per GPU, each rank registers its own
 scans against its own resident map with NO data-path collective; the only exchange step is the gather of the
-per-rank sub-maps at the end (variable-length, so: all_gather of counts, then a padded all_gather of the point
-arrays -- RCCL over xGMI when the backend is "nccl", gloo in the CPU tests).
+per-rank sub-maps at the end.  The sub-maps are variable-length and stay where they were produced: each rank's
+contribution is a DEVICE tensor (assembled by ll_cloud_transform_fe_device / ll_history_map_cloud_device, no host
+copy), the counts go round in one small all_gather, and the points travel as one grouped batch of point-to-point
+sends -- every pair of GPUs of an MI355X node has its own xGMI link, so the pairwise pattern uses all 7 links of a
+GPU at once, moves exactly the bytes that exist (no padding to the largest rank), and lands each block at its final
+offset in the receiver's output.  RCCL when the backend is "nccl", gloo in the CPU tests.
 
 The reference has no analogue of the collective (closest: Mapping_refine::refine_mapping concatenating keyframe
 clouds, source/ceres_pose_graph_3d.hpp:503-538).
@@ -22,30 +26,40 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
 
 
 def gather_submaps(local_pts, dist=None):
-    """All-gather variable-length point arrays.  local_pts: torch tensor (n, C) on the rank's device (GPU for nccl,
-    CPU for gloo).  Returns (concatenated tensor in rank order, counts list)."""
+    """All-gather of variable-length point arrays.  local_pts: torch tensor (n, C) on the rank's device (GPU for nccl,
+    CPU for gloo); it is sent from where it lies.  Returns (concatenation in rank order on the same device, counts)."""
     import torch
     import torch.distributed as td
     dist = dist or td
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    local_pts = local_pts.contiguous()
     n = torch.tensor([local_pts.shape[0]], dtype=torch.int64, device=local_pts.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    padded = torch.zeros((cap, local_pts.shape[1]), dtype=local_pts.dtype, device=local_pts.device)
-    padded[: local_pts.shape[0]] = local_pts
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0), counts
+    counts_t = torch.zeros(world, dtype=torch.int64, device=local_pts.device)
+    dist.all_gather_into_tensor(counts_t, n)
+    counts = [int(c) for c in counts_t.tolist()]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    out = torch.empty((int(offs[-1]), local_pts.shape[1]), dtype=local_pts.dtype, device=local_pts.device)
+    out[offs[rank]:offs[rank + 1]] = local_pts
+    ops = []
+    for step in range(1, world):  # pairwise exchange: in step s rank r sends to r+s and receives from r-s
+        dst, src = (rank + step) % world, (rank - step) % world
+        if counts[rank] > 0:
+            ops.append(dist.P2POp(dist.isend, local_pts, dst))
+        if counts[src] > 0:
+            ops.append(dist.P2POp(dist.irecv, out[offs[src]:offs[src + 1]], src))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return out, counts
 
 
-class SequenceRunner:
-    """One rank's share of the batched job: registers its scans (independent units) against the rank's resident map
-    and returns the poses plus the sub-map (accepted scans' features moved to the map frame)."""
+class DeviceHandles:
+    """The three device handles a rank's share runs on (one GPU): resident map, batched extractor, batched registrar."""
 
     def __init__(self, corner_map: np.ndarray, surf_map: np.ndarray, device: int, scan_points: int, batch: int, icp_iters: int = 10):
+        import torch
         from .api import Livox_laser, Map_buffer, Point_cloud_registration
+        self.torch_device = torch.device(f"cuda:{device}")
         self.map = Map_buffer(device=device)
         self.map.setInputCloud(Map_buffer.CORNER, corner_map)
         self.map.setInputCloud(Map_buffer.SURF, surf_map)
@@ -56,28 +70,68 @@ class SequenceRunner:
         p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
         p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
         p.maximum_allow_residual_block = scan_points
-        self.batch = batch
+
+    def register_batch(self, scans: np.ndarray, poses_init: np.ndarray):
+        """extract + register one batch; the selections stay resident in the extractor for append_submap"""
+        n = scans.shape[0]
+        self.fe.upload(scans, np.full(n, 1.0))
+        self.fe.extract_batch(n)
+        self.fe.resolve()
+        self.fe.select_batch(n, 0)
+        res, pc, _, _ = self.reg.solve_batch_fe(self.map, self.fe, n, poses_init, poses_init)
+        return res, pc
+
+    def append_submap(self, n: int, accept: np.ndarray, poses: np.ndarray, out, n_used: int) -> int:
+        """surface features of the accepted scans of the batch just registered -> map frame -> rows of `out` (device)"""
+        from .api import Map_buffer
+        return self.reg.append_to_submap_device(self.fe, n, Map_buffer.SURF, accept, poses, out, n_used)
+
+
+class SequenceRunner:
+    """One rank's share of the batched job: registers its scans (independent units) against the rank's resident map
+    and returns the poses plus the sub-map (accepted scans' surface features moved to the map frame), which is built
+    on the device from the batch's resident selections: one device-to-device transform per accepted scan, no second
+    upload or extraction and no device-to-host copy of the points.
+
+    `handles` is anything with torch_device, register_batch(scans, poses_init) -> (results, poses) and
+    append_submap(n, accept, poses, out, n_used) -> n_used'; DeviceHandles on a GPU, a stub in the gloo test."""
+
+    def __init__(self, handles, scan_points: int, batch: int):
+        self.h, self.scan_points, self.batch = handles, scan_points, batch
+
+    @classmethod
+    def on_device(cls, corner_map, surf_map, device: int, scan_points: int, batch: int, icp_iters: int = 10):
+        return cls(DeviceHandles(corner_map, surf_map, device, scan_points, batch, icp_iters), scan_points, batch)
 
     def run(self, scans: np.ndarray, poses_init: np.ndarray):
-        """scans (S, N, 4) float32, poses_init (S, 7).  Returns (results, poses, submap_xyzi)."""
+        """scans (S, N, 4) float32, poses_init (S, 7).  Returns (results (S,), poses (S, 7), submap torch tensor (n, 4)
+        on handles.torch_device)."""
+        import torch
         S = scans.shape[0]
         poses = np.zeros((S, 7))
         results = np.zeros(S, np.int32)
-        sub = []
+        sub = torch.empty((max(1, S * self.scan_points), 4), dtype=torch.float32, device=self.h.torch_device)
+        used = 0
         for lo in range(0, S, self.batch):
             hi = min(S, lo + self.batch)
-            n = hi - lo
-            self.fe.upload(scans[lo:hi], np.full(n, 1.0))
-            self.fe.extract_batch(n)
-            self.fe.resolve()
-            self.fe.select_batch(n, 0)
-            res, pc, _, _ = self.reg.solve_batch_fe(self.map, self.fe, n, poses_init[lo:hi], poses_init[lo:hi])
+            res, pc = self.h.register_batch(scans[lo:hi], poses_init[lo:hi])
             poses[lo:hi], results[lo:hi] = pc, res
-            for b in range(n):
-                if res[b]:
-                    self.fe.upload(scans[lo + b:lo + b + 1], np.full(1, 1.0))  # slot 0 view for the per-scan accessors
-                    self.fe.extract_batch(1)
-                    g = self.fe.get_features(0.0, 1.0)
-                    sub.append(self.reg.pointcloudAssociateToMap(g["pc_surface"], pc[b]))
-        submap = np.concatenate(sub, axis=0) if sub else np.zeros((0, 4), np.float32)
-        return results, poses, submap
+            used = self.h.append_submap(hi - lo, res, pc, sub, used)
+        return results, poses, sub[:used]
+
+
+def run_sharded(runner: SequenceRunner, scans: np.ndarray, poses_init: np.ndarray, dist=None):
+    """The whole multi-GPU job from one rank's point of view: take this rank's contiguous share of the S independent
+    scans, run it, then exchange -- sub-maps by gather_submaps, the (S, 8) result/pose table by the same gather.
+    Returns (results (S,), poses (S, 7), merged sub-map tensor, per-rank point counts), identical on every rank."""
+    import torch
+    import torch.distributed as td
+    dist = dist or td
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = shard_range(scans.shape[0], rank, world)
+    res, poses, sub = runner.run(scans[mine.start:mine.stop], poses_init[mine.start:mine.stop])
+    table = torch.from_numpy(np.concatenate([res[:, None].astype(np.float64), poses], axis=1)).to(sub.device)
+    table_all, _ = gather_submaps(table, dist)
+    merged, counts = gather_submaps(sub, dist)
+    table_all = table_all.cpu().numpy()
+    return table_all[:, 0].astype(np.int32), table_all[:, 1:], merged, counts

@@ -69,3 +69,73 @@ def test_gather_submaps_world2_gloo(tmp_path):
                           "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+RUNNER_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from loam_livox_amd.multigpu import SequenceRunner, run_sharded, shard_range
+
+
+class StubHandles:
+    '''stands in for DeviceHandles (map + extractor + registrar of one GPU) on the CPU: "registration" returns the
+    initial pose shifted by the scan's mean point and rejects scans whose first intensity is negative; the "features"
+    of a scan are its first 3 + (index %% 4) points.  Deterministic per scan, so any sharding must reproduce it.'''
+    torch_device = torch.device("cpu")
+
+    def register_batch(self, scans, poses_init):
+        self.last = scans
+        res = (scans[:, 0, 3] >= 0).astype(np.int32)
+        poses = poses_init.copy()
+        poses[:, 4:] += scans[:, :, :3].mean(1)
+        return res, poses
+
+    def append_submap(self, n, accept, poses, out, n_used):
+        for b in range(n):
+            if accept[b]:
+                k = 3 + int(self.last[b, 0, 3]) %% 4
+                pts = torch.from_numpy(self.last[b, :k].copy())
+                pts[:, :3] += torch.from_numpy(poses[b, 4:].astype(np.float32))
+                out[n_used:n_used + k] = pts
+                n_used += k
+        return n_used
+
+
+def job(S):
+    rng = np.random.default_rng(77)
+    scans = rng.normal(size=(S, 16, 4)).astype(np.float32)
+    scans[:, 0, 3] = np.arange(S)
+    scans[S // 3, 0, 3] = -1.0            # one rejected scan
+    poses = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], np.float64), (S, 1))
+    poses[:, 4] = np.arange(S)
+    return scans, poses
+
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+for S, batch in ((11, 4), (2, 4), (1, 4)):   # ragged shares, a share smaller than a batch, and a rank with nothing to do
+    scans, poses0 = job(S)
+    res, poses, merged, counts = run_sharded(SequenceRunner(StubHandles(), 16, batch), scans, poses0)
+    # the single-process answer
+    r1, p1, m1 = SequenceRunner(StubHandles(), 16, batch).run(scans, poses0)
+    assert np.array_equal(res, r1) and np.array_equal(poses, p1), (S, rank)
+    assert torch.equal(merged, m1), (S, rank)
+    mine = shard_range(S, rank, world)
+    assert counts[rank] == sum(3 + i %% 4 for i in mine if i != S // 3), (counts, S, rank)
+print("rank", rank, "runner ok")
+dist.destroy_process_group()
+"""
+
+
+def test_sequence_runner_sharding_world2_gloo(tmp_path):
+    """SequenceRunner + run_sharded over two gloo ranks with a stubbed registrar: shares, batching inside a share,
+    rejected scans, the device-side sub-map append and both gathers reproduce the single-process run exactly."""
+    script = tmp_path / "runner_worker.py"
+    script.write_text(RUNNER_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("runner ok") == 2

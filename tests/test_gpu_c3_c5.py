@@ -1,0 +1,147 @@
+"""-m gpu, BASELINE configs C3 and C5 at their full sizes (what tests/test_gpu_full.py is for C2).
+
+C3  Mid-100 = three 24 000-point heads (yaw -38.4 / 0 / +38.4 deg) from a MOVING sensor, features extracted on the
+    device per head and merged (laser_feature_extractor.hpp:348-358), registered with motion-deblur residuals
+    (if_motion_deblur = 1, ceres_icp.hpp:81-233 *_mb functors) against the 20 M-point map.  The merged scan has more
+    than 24 576 residual blocks, so the registrar takes its general (HBM-resident) solver path NATURALLY -- nothing
+    is forced.  Checked against the oracle's extractor + point_cloud_registration.hpp:163-583 restatement.
+C5  exact 5-NN of >= 1 000 queries against the 50 M-point map, fp32 records and fp16-in-cell records, index AND
+    squared-distance arrays compared with brute force on the host.  Brute force is run over an x-slab of the map
+    around each query whose half-width exceeds the largest distance the device reported: a point outside the slab
+    has fl(dx^2 + dy^2 + dz^2) >= fl(dx^2) > that distance (rounding is monotonic), so the slab holds every
+    candidate and the comparison is exact without 40 M distance evaluations per query."""
+import numpy as np
+import pytest
+
+from loam_livox_amd import synth
+from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+N = 24000
+T_MAX = float((N - 1) * np.float32(1e-5))
+
+
+# ----------------------------------------------------------------------------------------------------------- C3
+@pytest.fixture(scope="module")
+def c3(gpu_lib):
+    world, corner, surf = synth.make_maps(20_000_000)
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, corner)
+    m.setInputCloud(Map_buffer.SURF, surf)
+    yield dict(world=world, corner=corner, surf=surf, map=m)
+    m.close()
+
+
+def mid100(world, k):
+    """three heads of one Mid-100 sweep: (scans, pose at sweep start, pose at sweep end)"""
+    rng = np.random.default_rng(7000 + k)
+    pose_start = synth.sensor_pose_in_world(world, rng)
+    inc = np.r_[synth.quat_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0.3, 1.0))), rng.uniform(-0.08, 0.08, 3)]
+    heads = [synth.make_moving_scan(world, 10 * k + h, n=N, inc_true=inc, yaw_offset=float(yaw), pose_start=pose_start)
+             for h, yaw in enumerate(np.deg2rad([-38.4, 0.0, 38.4]))]
+    return heads, pose_start, synth.pose_compose(pose_start, inc)
+
+
+def test_c3_mid100_deblur_20m_map_matches_oracle(c3):
+    sweeps = [mid100(c3["world"], k) for k in range(2)]
+    fe = Livox_laser(max_points=N, piecewise_number=1)
+    corners, surfs = [], []
+    for heads, _, _ in sweeps:
+        cs, ss = [], []
+        for sc in heads:  # every head has its own time base (stamp 0 -> t = i * 1e-5), LFX:322-346
+            fe2 = Livox_laser(max_points=N, piecewise_number=1)
+            fe2.upload(sc.xyzi[None], np.array([0.0]))
+            fe2.extract_batch(1); fe2.resolve()
+            g = fe2.get_features(0.0, 1.0)
+            o = orc.fe_extract(sc.xyzi, 0.0)
+            ci, si, _ = orc.fe_get_features(o, 0.0, 1.0)
+            assert np.array_equal(g["pc_corners"], orc.feature_cloud(o, ci)) and np.array_equal(g["pc_surface"], orc.feature_cloud(o, si))
+            cs.append(g["pc_corners"]); ss.append(g["pc_surface"])
+            fe2.close()
+        corners.append(np.concatenate(cs)); surfs.append(np.concatenate(ss))
+    fe.close()
+    B = len(sweeps)
+    pose_last = np.stack([s[1] for s in sweeps])
+    reg = Point_cloud_registration(max_scans=B, max_features=max(max(len(c) for c in corners), max(len(s) for s in surfs)))
+    p = reg.params
+    p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = 1, 0.0, T_MAX
+    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = 10, 20, 1
+    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
+    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+    p.maximum_allow_residual_block = 3 * N
+    reg.upload_features(corners, surfs)
+    reg.enqueue_uploaded(c3["map"], B, pose_last, pose_last)
+    res, pc, pi, reps = reg.collect(B)
+    reg.close()
+    tc, ts = orc.KdTree(c3["corner"]), orc.KdTree(c3["surf"])
+    prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=1, deblur=1)
+    prm.minimum_pt_time_stamp, prm.maximum_pt_time_stamp, prm.max_final_cost = 0.0, T_MAX, 1000.0
+    prm.maximum_allow_residual_block = 3 * N
+    for b in range(B):
+        ret, opc, opi, orep = orc.reg_solve(tc, ts, corners[b], surfs[b], prm, pose_last[b], pose_last[b])
+        assert orep.n_blocks_last > 24576  # the compact one-workgroup solver cannot hold this scan: general path, not forced
+        dt, dr = synth.pose_error(pc[b], opc)
+        assert res[b] == ret == 1 and dt <= 1e-4 and dr <= 1e-4  # the north-star tolerance ...
+        assert dt < 1e-7 and dr < 1e-7                           # ... and what identical fp64 algorithms give
+        assert reps[b].n_blocks_last == orep.n_blocks_last and reps[b].lm_iterations_total == orep.lm_iterations_total
+        assert reps[b].icp_iterations == orep.icp_iterations
+        # the registration recovers the motion of the sweep (metres / radians against the synthetic truth)
+        et, er = synth.pose_error(pc[b], sweeps[b][2])
+        assert et < 0.05 and er < 0.02
+
+
+# ----------------------------------------------------------------------------------------------------------- C5
+@pytest.fixture(scope="module")
+def c5(gpu_lib):
+    world, _, surf = synth.make_maps(50_000_000)
+    fe = Livox_laser(max_points=N)
+    rng = np.random.default_rng(5)
+    qs = []
+    for k in range(2):
+        sc = synth.make_scan(world, 40 + k, N)
+        fe.extract_laser_features(sc.xyzi, 1.0)
+        f = fe.get_features(0.0, 1.0)["pc_surface"][:, :3]
+        pose = synth.pose_compose(sc.pose_true, np.r_[synth.quat_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0, 1.0))), rng.uniform(-0.1, 0.1, 3)])
+        qs.append(synth.transform_points(pose, f)[::23])
+    fe.close()
+    q = np.ascontiguousarray(np.concatenate(qs), np.float32)
+    # a handful of queries far from every surface (nothing within max_sq_dis), outside the map, and at map points (d = 0)
+    q = np.concatenate([q, surf[[0, 12345678, len(surf) - 1]], surf.max(0)[None] + 100.0, surf.min(0)[None] - 100.0]).astype(np.float32)
+    assert len(q) >= 1000
+    return dict(surf=surf, q=q)
+
+
+def slab_bruteforce(pts, q, idx_dev, d2_dev, max_sq_dis):
+    """exact 5-NN by brute force over the x-slab that must contain every candidate (module docstring)"""
+    order = np.argsort(pts[:, 0], kind="stable")
+    xs = pts[order, 0]
+    bi = np.full((len(q), 5), -1, np.int32)
+    bd = np.full((len(q), 5), np.inf, np.float32)
+    for i in range(len(q)):
+        found = d2_dev[i][np.isfinite(d2_dev[i])]
+        r = np.sqrt(float(found.max()) if len(found) == 5 else max_sq_dis) * 1.001 + 1e-3
+        lo, hi = np.searchsorted(xs, [q[i, 0] - r, q[i, 0] + r])
+        sel = np.sort(order[lo:hi])  # ascending map index: brute force breaks distance ties by the lower index
+        if len(sel) == 0:
+            continue
+        ki, kd = orc.bruteforce_knn(pts[sel], q[i:i + 1], 5)
+        ok = (ki[0] >= 0) & (kd[0] < max_sq_dis)
+        bi[i, ok], bd[i, ok] = sel[ki[0][ok]], kd[0][ok]
+    return bi, bd
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_c5_knn_50m_map_identical_to_bruteforce(c5, f16):
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.SURF, c5["surf"])
+    if f16:
+        m.to_f16(Map_buffer.SURF)
+    max_d2 = 50.0
+    idx, d2 = m.nearestKSearch(Map_buffer.SURF, c5["q"], max_d2)
+    pts = m.dequantized(Map_buffer.SURF) if f16 else c5["surf"]
+    m.close()
+    bi, bd = slab_bruteforce(np.ascontiguousarray(pts, np.float32), c5["q"], idx, d2, max_d2)
+    assert np.array_equal(d2, bd)
+    assert np.array_equal(idx, bi)
+    assert ((idx >= 0).sum(1) == 5).mean() > 0.95 and (idx[-2:] < 0).all()

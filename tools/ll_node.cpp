@@ -1,0 +1,431 @@
+// ll_node -- a ROS-free, compiled host for the two node bodies of hku-mars/loam_livox that sit either side of the hot
+// path, running on include/loam_livox_adapter.hpp (and through it the C ABI / the HIP library):
+//
+//   Laser_feature::laserCloudHandler, Livox branch      source/laser_feature_extractor.hpp:241-392
+//   Laser_mapping::process_new_scan (+ the three cloud  source/laser_mapping.hpp:1316-1520, 836-868
+//   handlers and init_pointcloud_registration)          source/laser_mapping.hpp:1266-1297
+//
+// ROS is absent from the image, so the node/topic surface is kept in shape only: messages are PointCloud2-shaped structs
+// (header, fields, point_step, byte payload), nodes talk through named in-process topics with the reference's names
+// (/laser_points_<i> -> /pc2_full, /pc2_surface, /pc2_corners -> mapping), parameters come from a flat name=value table
+// with the reference's parameter names.  What the reference does on service threads (update_buff_for_matching,
+// laser_mapping.hpp:568-594) is done synchronously after every accepted frame, so a run is reproducible.
+//
+//   ll_node --in seq.bin --out log.txt [--param name=value ...]
+//
+// seq.bin: "LLSEQ001", int32 n_messages, then per message { int32 lidar_index, float64 stamp, int32 n_points,
+// n_points x 4 float32 (x, y, z, intensity) } -- tools/ll_sequence.py writes it.  log.txt gets one line per published
+// piece (PUB: sizes and hashes of the three clouds) and one per processed scan (REG: result, pose, stack and
+// match-buffer sizes); tests/test_ll_node.py compares it with the Python mirrors (feature_node.py / mapping.py).
+#include <cinttypes>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "loam_livox_adapter.hpp"
+
+namespace ll = loam_livox_hip;
+
+// ------------------------------------------------------------------------------------------------ message types
+struct Header {
+    uint32_t seq = 0;
+    double stamp = 0;
+    std::string frame_id;
+};
+struct PointField {
+    std::string name;
+    uint32_t offset = 0;
+    uint8_t datatype = 7;  // FLOAT32
+    uint32_t count = 1;
+};
+struct PointCloud2 {
+    Header header;
+    uint32_t height = 1, width = 0;
+    std::vector<PointField> fields;
+    bool is_bigendian = false;
+    uint32_t point_step = 0, row_step = 0;
+    std::vector<uint8_t> data;
+    bool is_dense = true;
+};
+
+struct PointXYZI {
+    float x = 0, y = 0, z = 0, intensity = 0;
+};
+struct Cloud {
+    typedef std::shared_ptr<Cloud> Ptr;
+    std::vector<PointXYZI> points;
+    size_t size() const { return points.size(); }
+    Cloud &operator+=(const Cloud &o)
+    {
+        points.insert(points.end(), o.points.begin(), o.points.end());
+        return *this;
+    }
+};
+
+static void toROSMsg(const Cloud &c, PointCloud2 &m)
+{
+    static const char *names[4] = {"x", "y", "z", "intensity"};
+    m.fields.resize(4);
+    for (uint32_t i = 0; i < 4; i++) {
+        m.fields[i].name = names[i];
+        m.fields[i].offset = 4 * i;
+    }
+    m.height = 1;
+    m.width = (uint32_t)c.size();
+    m.point_step = 16;
+    m.row_step = 16 * m.width;
+    m.data.resize((size_t)m.row_step);
+    if (m.width) std::memcpy(m.data.data(), c.points.data(), m.data.size());
+}
+
+static void fromROSMsg(const PointCloud2 &m, Cloud &c)
+{
+    int off[4] = {-1, -1, -1, -1};
+    for (const PointField &f : m.fields) {
+        if (f.datatype != 7) continue;
+        if (f.name == "x") off[0] = (int)f.offset;
+        if (f.name == "y") off[1] = (int)f.offset;
+        if (f.name == "z") off[2] = (int)f.offset;
+        if (f.name == "intensity") off[3] = (int)f.offset;
+    }
+    if (off[0] < 0 || off[1] < 0 || off[2] < 0) throw std::runtime_error("fromROSMsg: message has no float32 x / y / z fields");
+    const size_t n = (size_t)m.width * m.height;
+    c.points.assign(n, PointXYZI());
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *p = m.data.data() + i * m.point_step;
+        std::memcpy(&c.points[i].x, p + off[0], 4);
+        std::memcpy(&c.points[i].y, p + off[1], 4);
+        std::memcpy(&c.points[i].z, p + off[2], 4);
+        if (off[3] >= 0) std::memcpy(&c.points[i].intensity, p + off[3], 4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ topics, parameters
+class Topics {
+   public:
+    typedef std::function<void(const PointCloud2 &)> Callback;
+    void subscribe(const std::string &name, Callback cb) { subs_[name].push_back(cb); }
+    void publish(const std::string &name, const PointCloud2 &m)
+    {
+        auto it = subs_.find(name);
+        if (it == subs_.end()) return;
+        for (Callback &cb : it->second) cb(m);
+    }
+
+   private:
+    std::map<std::string, std::vector<Callback>> subs_;
+};
+
+class Params {
+   public:
+    void set(const std::string &kv)
+    {
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) throw std::runtime_error("--param expects name=value, got " + kv);
+        table_[kv.substr(0, eq)] = kv.substr(eq + 1);
+    }
+    template <class T>
+    void param(const std::string &name, T &var, T def) const  // nh.param<T>( name, var, default )
+    {
+        auto it = table_.find(name);
+        var = it == table_.end() ? def : (T)std::atof(it->second.c_str());
+    }
+
+   private:
+    std::map<std::string, std::string> table_;
+};
+
+static uint64_t cloud_hash(const Cloud &c)  // position-weighted sum of the cloud's 32-bit words, mod 2^64 (tools/ll_sequence.py: cloud_hash)
+{
+    uint64_t h = 0;
+    const uint32_t *w = (const uint32_t *)c.points.data();
+    for (size_t i = 0; i < c.size() * 4; i++) h += (uint64_t)w[i] * (uint64_t)(2 * i + 1);
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------ feature node
+class Laser_feature {
+   public:
+    Laser_feature(Topics &topics, const Params &prm, FILE *log) : topics_(topics), log_(log)
+    {
+        // laser_feature_extractor.hpp:135-160 (parameter names as in the launch files)
+        prm.param<int>("common/piecewise_number", m_piecewise_number, 3);
+        prm.param<int>("common/if_motion_deblur", m_if_motion_deblur, 0);
+        prm.param<int>("common/odom_mode", m_odom_mode, 0);
+        prm.param<int>("common/maximum_input_lidar_pointcloud", m_maximum_input_lidar_pointcloud, 3);
+        prm.param<int>("feature_extraction/system_delay", m_para_system_delay, 20);
+        prm.param<float>("feature_extraction/mapping_plane_resolution", m_plane_resolution, 0.8f);
+        prm.param<float>("feature_extraction/mapping_line_resolution", m_line_resolution, 0.8f);
+        prm.param<float>("feature_extraction/livox_min_dis", m_livox.m_livox_min_allow_dis, 1.0f);
+        prm.param<float>("feature_extraction/livox_min_sigma", m_livox.m_livox_min_sigma, 7e-3f);
+        prm.param<float>("feature_extraction/corner_curvature", m_livox.thr_corner_curvature, 0.05f);
+        prm.param<float>("feature_extraction/surface_curvature", m_livox.thr_surface_curvature, 0.01f);
+        prm.param<float>("feature_extraction/minimum_view_angle", m_livox.minimum_view_angle, 10.0f);
+        prm.param<int>("ll/max_points", m_livox.max_points, 24000);
+        m_livox.piecewise_number = m_if_motion_deblur ? 1 : m_piecewise_number;
+        m_voxel_filter_for_surface.setLeafSize(m_plane_resolution / 2, m_plane_resolution / 2, m_plane_resolution / 2);  // :192
+        m_voxel_filter_for_corner.setLeafSize(m_line_resolution, m_line_resolution, m_line_resolution);                  // :193
+        m_voxel_filter_for_surface.max_points = m_voxel_filter_for_corner.max_points = m_livox.max_points * m_maximum_input_lidar_pointcloud;
+        m_map_pointcloud_full_vec_vec.assign((size_t)m_maximum_input_lidar_pointcloud, std::vector<Cloud>((size_t)m_piecewise_number));
+        m_map_pointcloud_surface_vec_vec = m_map_pointcloud_corner_vec_vec = m_map_pointcloud_full_vec_vec;
+        for (int i = 0; i < m_maximum_input_lidar_pointcloud; i++)  // :207-215: one subscription per lidar
+            topics_.subscribe("/laser_points_" + std::to_string(i), [this, i](const PointCloud2 &m) { laserCloudHandler(m, i); });
+    }
+
+    void laserCloudHandler(const PointCloud2 &laserCloudMsg, int current_lidar_index)
+    {
+        if (!m_para_systemInited) {  // :258-267: the first messages of a session are dropped
+            if (++m_para_system_init_count >= m_para_system_delay)
+                m_para_systemInited = true;
+            else
+                return;
+        }
+        Cloud laserCloudIn;
+        fromROSMsg(laserCloudMsg, laserCloudIn);
+        std::vector<Cloud> laserCloudScans = m_livox.extract_laser_features(laserCloudIn, laserCloudMsg.header.stamp);  // :285
+        if (laserCloudScans.size() <= 5) return;                                                                        // :287-290
+        const double n_scans = (double)laserCloudScans.size();
+        const int piece_wise = m_if_motion_deblur ? 1 : m_piecewise_number;  // :305-309
+        std::vector<float> piece_start((size_t)piece_wise), piece_end((size_t)piece_wise);
+        const float n_pts = (float)m_livox.m_pts_info_vec.size();
+        for (int i = 0; i < piece_wise; i++) {  // :312-324: petal range of the piece -> blur-ratio window
+            const int first_petal = (int)(n_scans * i / piece_wise), last_petal = (int)(n_scans * (i + 1) / piece_wise) - 1;
+            piece_start[(size_t)i] = (float)m_livox.find_pt_info(laserCloudScans[(size_t)first_petal].points.front())->idx / n_pts;
+            piece_end[(size_t)i] = (float)m_livox.find_pt_info(laserCloudScans[(size_t)last_petal].points.back())->idx / n_pts;
+        }
+        for (int i = 0; i < piece_wise; i++)  // :326-334
+            m_livox.get_features(m_map_pointcloud_corner_vec_vec[(size_t)current_lidar_index][(size_t)i],
+                                 m_map_pointcloud_surface_vec_vec[(size_t)current_lidar_index][(size_t)i],
+                                 m_map_pointcloud_full_vec_vec[(size_t)current_lidar_index][(size_t)i], piece_start[(size_t)i], piece_end[(size_t)i]);
+        if (current_lidar_index != 0) return;  // :348-351: only lidar 0 publishes
+        for (int i = 0; i < piece_wise; i++) {
+            Cloud::Ptr livox_full(new Cloud()), livox_surface(new Cloud()), livox_corners(new Cloud());
+            for (int ii = 0; ii < m_maximum_input_lidar_pointcloud; ii++) {  // :353-358: the Mid-100's heads are merged here
+                *livox_full += m_map_pointcloud_full_vec_vec[(size_t)ii][(size_t)i];
+                *livox_surface += m_map_pointcloud_surface_vec_vec[(size_t)ii][(size_t)i];
+                *livox_corners += m_map_pointcloud_corner_vec_vec[(size_t)ii][(size_t)i];
+            }
+            m_voxel_filter_for_surface.setInputCloud(livox_surface);  // :372-373
+            m_voxel_filter_for_surface.filter(*livox_surface);
+            m_voxel_filter_for_corner.setInputCloud(livox_corners);   // :379-380
+            m_voxel_filter_for_corner.filter(*livox_corners);
+            std::fprintf(log_, "PUB %zu %zu %zu %016" PRIx64 " %016" PRIx64 " %016" PRIx64 "\n", livox_full->size(), livox_surface->size(),
+                         livox_corners->size(), cloud_hash(*livox_full), cloud_hash(*livox_surface), cloud_hash(*livox_corners));
+            PointCloud2 out;
+            out.header.stamp = laserCloudMsg.header.stamp;  // ros::Time::now() in the node; the message's own stamp keeps runs reproducible
+            out.header.frame_id = "camera_init";
+            toROSMsg(*livox_full, out);
+            topics_.publish("/pc2_full", out);
+            toROSMsg(*livox_surface, out);
+            topics_.publish("/pc2_surface", out);
+            toROSMsg(*livox_corners, out);
+            topics_.publish("/pc2_corners", out);
+            if (m_odom_mode == 0) break;  // :385-388
+        }
+    }
+
+    int m_piecewise_number = 3, m_if_motion_deblur = 0, m_odom_mode = 0, m_maximum_input_lidar_pointcloud = 3;
+    int m_para_system_delay = 20, m_para_system_init_count = 0;
+    bool m_para_systemInited = false;
+    float m_plane_resolution = 0.8f, m_line_resolution = 0.8f;
+    ll::Livox_laser m_livox;  // a single extractor for every lidar: its time base runs across the messages (:92)
+    ll::VoxelGrid<Cloud> m_voxel_filter_for_surface, m_voxel_filter_for_corner;
+    std::vector<std::vector<Cloud>> m_map_pointcloud_full_vec_vec, m_map_pointcloud_surface_vec_vec, m_map_pointcloud_corner_vec_vec;
+
+   private:
+    Topics &topics_;
+    FILE *log_;
+};
+
+// ------------------------------------------------------------------------------------------------ mapping node
+class Laser_mapping {
+   public:
+    Laser_mapping(Topics &topics, const Params &prm, FILE *log) : log_(log)
+    {
+        // laser_mapping.hpp:640-760 (parameter names as in the launch files)
+        prm.param<int>("common/if_motion_deblur", m_if_motion_deblur, 0);
+        prm.param<int>("mapping/init_accumulate_frames", m_mapping_init_accumulate_frames, 50);
+        prm.param<int>("mapping/maximum_histroy_buffer", m_maximum_history_size, 100);
+        prm.param<int>("mapping/if_input_downsample", m_if_input_downsample_mode, 1);
+        prm.param<float>("mapping/mapping_line_resolution", m_line_resolution, 0.1f);
+        prm.param<float>("mapping/mapping_plane_resolution", m_plane_resolution, 0.4f);
+        prm.param<float>("mapping/max_allow_incre_R", m_para_max_angular_rate, 200.0f / 50.0f);
+        prm.param<float>("mapping/max_allow_incre_T", m_para_max_speed, 100.0f / 50.0f);
+        prm.param<float>("mapping/max_allow_final_cost", m_max_final_cost, 100.0f);
+        prm.param<double>("mapping/minimum_icp_R_diff", m_minimum_icp_R_diff, 0.01);
+        prm.param<double>("mapping/minimum_icp_T_diff", m_minimum_icp_T_diff, 0.01);
+        prm.param<double>("mapping/history_add_t_step", m_history_add_t_step, 0.0);
+        prm.param<double>("mapping/history_add_angle_step", m_history_add_angle_step, 0.0);
+        prm.param<int>("optimization/icp_maximum_iteration", m_para_icp_max_iterations, 20);
+        prm.param<int>("optimization/ceres_maximum_iteration", m_para_cere_max_iterations, 100);
+        prm.param<int>("optimization/maximum_residual_blocks", m_para_optimization_maximum_residual_block, 100000);
+        prm.param<int>("ll/subsample_seed", m_subsample_seed, 1);
+        prm.param<int>("ll/max_points", m_max_points, 24000);
+        m_down_sample_filter_corner.setLeafSize(m_line_resolution, m_line_resolution, m_line_resolution);     // :742
+        m_down_sample_filter_surface.setLeafSize(m_plane_resolution, m_plane_resolution, m_plane_resolution);  // :743
+        m_down_sample_filter_corner.max_points = m_down_sample_filter_surface.max_points = 3 * m_max_points;
+        history_.reset(new ll::History_buffer(m_maximum_history_size, 3 * m_max_points, m_line_resolution, m_plane_resolution));
+        // :836-868: the handlers only queue what arrives; a scan is processed once all three clouds of a piece are there
+        topics.subscribe("/pc2_corners", [this](const PointCloud2 &m) { m_queue_corner.push_back(m); try_process(); });
+        topics.subscribe("/pc2_surface", [this](const PointCloud2 &m) { m_queue_surf.push_back(m); try_process(); });
+        topics.subscribe("/pc2_full", [this](const PointCloud2 &m) { m_queue_full.push_back(m); try_process(); });
+    }
+
+    // Laser_mapping::init_pointcloud_registration, laser_mapping.hpp:1266-1297
+    void init_pointcloud_registration(ll::Point_cloud_registration &pc_reg)
+    {
+        pc_reg.m_if_motion_deblur = m_if_motion_deblur;
+        pc_reg.m_current_frame_index = m_current_frame_index;
+        pc_reg.m_mapping_init_accumulate_frames = m_mapping_init_accumulate_frames;
+        pc_reg.m_last_time_stamp = m_last_time_stamp;
+        pc_reg.m_para_max_angular_rate = m_para_max_angular_rate;
+        pc_reg.m_para_max_speed = m_para_max_speed;
+        pc_reg.m_max_final_cost = m_max_final_cost;
+        pc_reg.m_para_icp_max_iterations = m_para_icp_max_iterations;
+        pc_reg.m_para_cere_max_iterations = m_para_cere_max_iterations;
+        pc_reg.m_maximum_allow_residual_block = m_para_optimization_maximum_residual_block;
+        pc_reg.m_subsample_seed = m_para_optimization_maximum_residual_block < 3 * m_max_points ? m_subsample_seed : 0;
+        pc_reg.m_minimum_pt_time_stamp = m_minimum_pt_time_stamp;
+        pc_reg.m_maximum_pt_time_stamp = m_maximum_pt_time_stamp;
+        pc_reg.m_minimum_icp_R_diff = m_minimum_icp_R_diff;
+        pc_reg.m_minimum_icp_T_diff = m_minimum_icp_T_diff;
+        pc_reg.max_features = 3 * m_max_points;
+        for (int i = 0; i < 4; i++) pc_reg.m_para_buffer_RT[i] = pose_[i];
+        pc_reg.m_q_w_curr.x() = pose_[0], pc_reg.m_q_w_curr.y() = pose_[1], pc_reg.m_q_w_curr.z() = pose_[2], pc_reg.m_q_w_curr.w() = pose_[3];
+        pc_reg.m_q_w_last = pc_reg.m_q_w_curr;
+        for (int i = 0; i < 3; i++) pc_reg.m_t_w_curr(i) = pc_reg.m_t_w_last(i) = pose_[4 + i];
+    }
+
+    void try_process()
+    {
+        while (!m_queue_corner.empty() && !m_queue_surf.empty() && !m_queue_full.empty()) {
+            fromROSMsg(m_queue_corner.front(), m_laser_cloud_corner_last);
+            fromROSMsg(m_queue_surf.front(), m_laser_cloud_surf_last);
+            fromROSMsg(m_queue_full.front(), m_laser_cloud_full_res);
+            m_queue_corner.pop_front();
+            m_queue_surf.pop_front();
+            m_queue_full.pop_front();
+            process_new_scan();
+        }
+    }
+
+    // Laser_mapping::process_new_scan, laser_mapping.hpp:1316-1520
+    int process_new_scan()
+    {
+        float min_t = 0, max_t = 0;  // find_min_max_intensity( full ): the full cloud carries the time stamps (:1336)
+        for (size_t i = 0; i < m_laser_cloud_full_res.size(); i++) {
+            const float t = m_laser_cloud_full_res.points[i].intensity;
+            if (i == 0 || t < min_t) min_t = t;
+            if (i == 0 || t > max_t) max_t = t;
+        }
+        m_minimum_pt_time_stamp = m_last_time_stamp;  // :1345-1347
+        m_maximum_pt_time_stamp = max_t;
+        m_last_time_stamp = max_t;
+        ll::Point_cloud_registration pc_reg;  // a fresh registrar per scan, like the node (:1348); its device handle is pooled
+        init_pointcloud_registration(pc_reg);
+        m_current_frame_index++;
+        Cloud::Ptr laserCloudCornerStack(new Cloud()), laserCloudSurfStack(new Cloud());
+        if (m_if_input_downsample_mode) {  // :1367-1373
+            m_down_sample_filter_corner.setInputCloud(&m_laser_cloud_corner_last);
+            m_down_sample_filter_corner.filter(*laserCloudCornerStack);
+            m_down_sample_filter_surface.setInputCloud(&m_laser_cloud_surf_last);
+            m_down_sample_filter_surface.filter(*laserCloudSurfStack);
+        } else {
+            *laserCloudCornerStack = m_laser_cloud_corner_last;
+            *laserCloudSurfStack = m_laser_cloud_surf_last;
+        }
+        // the match buffer is resident behind pc_reg.map(): the 2-argument form registers against it (:1405-1411)
+        const int reg_res = pc_reg.find_out_incremental_transfrom(laserCloudCornerStack, laserCloudSurfStack);
+        int64_t n_map[2] = {map_sizes_[0], map_sizes_[1]};
+        if (reg_res != 0) {  // :1413-1416 return on failure; otherwise "Add new frame" (:1417-1478) and the pose hand-over (:1496-1500)
+            history_->add(*laserCloudCornerStack, *laserCloudSurfStack, pc_reg.m_para_buffer_RT, m_history_add_t_step, m_history_add_angle_step);
+            for (int i = 0; i < 7; i++) pose_[i] = pc_reg.m_para_buffer_RT[i];
+            history_->refresh(pc_reg.map(), &n_map[0], &n_map[1]);  // update_buff_for_matching (:460-566), synchronous here
+            map_sizes_[0] = n_map[0], map_sizes_[1] = n_map[1];
+        }
+        std::fprintf(log_, "REG %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %zu %zu %" PRId64 " %" PRId64 " %d\n", m_current_frame_index - 1, reg_res,
+                     pose_[0], pose_[1], pose_[2], pose_[3], pose_[4], pose_[5], pose_[6], laserCloudCornerStack->size(), laserCloudSurfStack->size(),
+                     n_map[0], n_map[1], pc_reg.summary.icp_iterations);
+        return reg_res;
+    }
+
+    int m_if_motion_deblur = 0, m_current_frame_index = 0, m_mapping_init_accumulate_frames = 50, m_maximum_history_size = 100;
+    int m_if_input_downsample_mode = 1, m_para_icp_max_iterations = 20, m_para_cere_max_iterations = 100;
+    int m_para_optimization_maximum_residual_block = 100000, m_subsample_seed = 1, m_max_points = 24000;
+    float m_line_resolution = 0.1f, m_plane_resolution = 0.4f, m_para_max_angular_rate = 4.0f, m_para_max_speed = 2.0f, m_max_final_cost = 100.0f;
+    float m_last_time_stamp = 0, m_minimum_pt_time_stamp = 0, m_maximum_pt_time_stamp = 1.0f;
+    double m_minimum_icp_R_diff = 0.01, m_minimum_icp_T_diff = 0.01, m_history_add_t_step = 0.0, m_history_add_angle_step = 0.0;
+    Cloud m_laser_cloud_corner_last, m_laser_cloud_surf_last, m_laser_cloud_full_res;
+    std::deque<PointCloud2> m_queue_corner, m_queue_surf, m_queue_full;
+    ll::VoxelGrid<Cloud> m_down_sample_filter_corner, m_down_sample_filter_surface;
+
+   private:
+    FILE *log_;
+    std::unique_ptr<ll::History_buffer> history_;
+    double pose_[7] = {0, 0, 0, 1, 0, 0, 0};  // m_q_w_curr / m_t_w_curr
+    int64_t map_sizes_[2] = {0, 0};
+};
+
+// ------------------------------------------------------------------------------------------------ driver
+static bool read_exact(FILE *f, void *p, size_t n) { return n == 0 || std::fread(p, 1, n, f) == n; }
+
+int main(int argc, char **argv)
+{
+    std::string in, out;
+    Params prm;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--in" && i + 1 < argc) in = argv[++i];
+        else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else if (a == "--param" && i + 1 < argc) prm.set(argv[++i]);
+        else {
+            std::fprintf(stderr, "usage: ll_node --in seq.bin --out log.txt [--param name=value ...]\n");
+            return 2;
+        }
+    }
+    if (in.empty() || out.empty()) {
+        std::fprintf(stderr, "usage: ll_node --in seq.bin --out log.txt [--param name=value ...]\n");
+        return 2;
+    }
+    FILE *fi = std::fopen(in.c_str(), "rb"), *fo = std::fopen(out.c_str(), "w");
+    if (!fi || !fo) {
+        std::fprintf(stderr, "ll_node: cannot open %s\n", !fi ? in.c_str() : out.c_str());
+        return 1;
+    }
+    try {
+        char magic[8];
+        int32_t n_msgs = 0;
+        if (!read_exact(fi, magic, 8) || std::memcmp(magic, "LLSEQ001", 8) != 0 || !read_exact(fi, &n_msgs, 4)) throw std::runtime_error("not an LLSEQ001 file");
+        Topics topics;
+        Laser_feature feature_node(topics, prm, fo);
+        Laser_mapping mapping_node(topics, prm, fo);
+        for (int32_t k = 0; k < n_msgs; k++) {
+            int32_t lidar = 0, n = 0;
+            double stamp = 0;
+            if (!read_exact(fi, &lidar, 4) || !read_exact(fi, &stamp, 8) || !read_exact(fi, &n, 4) || n < 0) throw std::runtime_error("truncated sequence file");
+            Cloud c;
+            c.points.resize((size_t)n);
+            if (!read_exact(fi, c.points.data(), (size_t)n * sizeof(PointXYZI))) throw std::runtime_error("truncated sequence file");
+            PointCloud2 m;
+            toROSMsg(c, m);
+            m.header.seq = (uint32_t)k;
+            m.header.stamp = stamp;
+            m.header.frame_id = "livox";
+            topics.publish("/laser_points_" + std::to_string(lidar), m);
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "ll_node: %s\n", e.what());
+        std::fclose(fo);
+        return 1;
+    }
+    std::fclose(fi);
+    std::fclose(fo);
+    return 0;
+}
