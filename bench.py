@@ -91,6 +91,29 @@ def pmc_traffic_bytes(kernel: str, batch: int):
     return (None, None) if best is None else (int(best[1]), os.path.relpath(path, ROOT))
 
 
+def pmc_valu_fp64(kernel: str, batch: int):
+    """fp64 VALU work per launch of `kernel` from the newest committed instruction-mix summary (profiles/r*_pmc_valu.csv:
+    rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 / SQ_INSTS_VALU passes of this command at batch 256, tools/gpu_pmc.sh).
+    Wave-level instruction counts; flops = 64 lanes x (ADD + MUL + 2 FMA)."""
+    import csv
+    path = newest_profile("r*_pmc_valu.csv")
+    if not path or batch != 256:
+        return None
+    best = None
+    with open(path) as f:
+        for d in csv.DictReader(l for l in f if not l.startswith("#")):
+            if d["kernel"].split("<")[0] == "ll::" + kernel and d.get("SQ_INSTS_VALU_FMA_F64_avg"):
+                g = int(d["grid_threads"])
+                if best is None or g > best[0]:
+                    best = (g, d)
+    if best is None:
+        return None
+    d = best[1]
+    add, mul, fma = (float(d[f"SQ_INSTS_VALU_{k}_F64_avg"]) for k in ("ADD", "MUL", "FMA"))
+    return {"fp64_wave_instructions": int(add + mul + fma), "valu_wave_instructions": int(float(d["SQ_INSTS_VALU_avg"])),
+            "flops": 64.0 * (add + mul + 2.0 * fma), "source": os.path.relpath(path, ROOT)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -301,6 +324,17 @@ def main():
                 "plane_block_bytes": plane_bytes,
                 # what the kernel really moves (rocprofv3 PMC passes, profiles/) against the same peak
                 "traffic_frac": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 8e12, 4)}
+
+    # The solver's arithmetic is fp64 VALU (no MFMA shape on this path): the same launch against the fp64 vector peak
+    # (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s = half the guide's 157.3 TFLOP/s fp32 vector figure).
+    vf = pmc_valu_fp64(names[dom], B) if dom == 1 else None
+    if vf is not None:
+        tf = vf["flops"] / (avg_ms * 1e-3) / 1e12
+        # share of the launch during which a SIMD issues VALU work at all: one wave instruction = 4 cycles, 1024 SIMDs
+        busy = vf["valu_wave_instructions"] * 4.0 / 1024.0 / (avg_ms * 1e-3 * 2.4e9)
+        roofline["valu_fp64"] = {"achieved": round(tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(tf / 78.6, 4),
+                                 "fp64_wave_instructions_per_launch": vf["fp64_wave_instructions"],
+                                 "valu_issue_busy_frac_at_2p4GHz": round(busy, 3), "source": vf["source"]}
 
     # ---- whole-path algorithmic bytes per scan, U and C counted per scan ----
     roofline_path = None

@@ -4,6 +4,8 @@
   summarize_rocprof.py trace   <*_kernel_trace.csv>                          -> kernel,grid_threads,workgroup,vgpr,lds_bytes,scratch_bytes,calls,total_ms,avg_us,min_us,max_us
   summarize_rocprof.py pmc     <fetch *_counter_collection.csv> <write ...>  -> kernel,grid_threads,dispatches,fetch_kib_avg,fetch_mib_corrected_x2,write_kib_avg
 
+  summarize_rocprof.py generic <*_counter_collection.csv> [...]              -> kernel,grid_threads,dispatches,<counter>_avg ... (any counters, per-dispatch averages)
+
 FETCH_SIZE / WRITE_SIZE come from two separate --pmc passes (MI355X_MICROARCH.md: never combined with trace domains);
 the x2 on FETCH_SIZE is that guide's gfx950 correction (128-byte requests tallied at 64 B)."""
 import csv
@@ -53,8 +55,27 @@ def pmc(fetch_path, write_path):
         print(f"{key[0]},{key[1]},{len(v)},{fa:.1f},{2 * fa / 1024:.2f},{sum(wv) / len(wv):.1f}")
 
 
+def generic(paths):
+    agg = defaultdict(lambda: defaultdict(list))
+    names = []
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            n = short(r["Kernel_Name"])
+            if not n.startswith("ll::"):
+                continue
+            if r["Counter_Name"] not in names:
+                names.append(r["Counter_Name"])
+            agg[(n, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print("kernel,grid_threads,dispatches," + ",".join(c + "_avg" for c in names))
+    for key, d in sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
+        nd = max(len(v) for v in d.values())
+        print(f"{key[0]},{key[1]},{nd}," + ",".join(f"{sum(d[c]) / len(d[c]):.1f}" if d.get(c) else "" for c in names))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
+    elif sys.argv[1] == "generic":
+        generic(sys.argv[2:])
     else:
         pmc(sys.argv[2], sys.argv[3])
