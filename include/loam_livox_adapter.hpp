@@ -399,6 +399,9 @@ class History_buffer {
               "ll_history_add");
         return added != 0;
     }
+    // The add-frame rule (laser_mapping.hpp:1439-1451) reads the node's m_q_w_curr / m_t_w_curr, which is still the pose
+    // BEFORE the registration whose result add() receives: hand it over first (applies to the next add only).
+    void set_gate_pose(const double pose_before_registration[7]) { check(ll_history_set_gate_pose(h_, pose_before_registration), "ll_history_set_gate_pose"); }
     // update_buff_for_matching(): concatenation of the history -> VoxelGrid -> search grids of `map`
     void refresh(ll_map *map, int64_t *n_corner = nullptr, int64_t *n_surf = nullptr)
     {

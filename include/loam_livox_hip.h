@@ -295,6 +295,12 @@ int ll_history_add_fe(ll_history *h, ll_fe *fe, int32_t scan, const double pose[
  * laser_mapping.hpp:1367-1373,1421-1431) */
 int ll_history_add_voxel(ll_history *h, ll_voxel *vox_corner, ll_voxel *vox_surf, int32_t cloud, const double pose[7],
                          double history_add_t_step, double history_add_angle_step, int32_t *added);
+/* The add-frame rule of laser_mapping.hpp:1439-1451 compares, and on a push records, the node's m_q_w_curr / m_t_w_curr,
+ * which at that point is still the pose BEFORE the registration just done (the new pose is copied back at :1496-1500),
+ * while the clouds are moved with the registered pose.  Hand that pre-registration pose over here before an
+ * ll_history_add* call (it applies to the next add only); without it the registered pose gates as well, which gives the
+ * same pushes as long as both steps are 0.0 (the reference's fixed values). */
+int ll_history_set_gate_pose(ll_history *h, const double pose[7]);
 int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_corner, int64_t *n_map_surf);
 int32_t ll_history_size(const ll_history *h);
 /* the match buffer clouds of the last refresh (host copy, for inspection / tests): returns the number of points written */

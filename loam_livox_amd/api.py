@@ -261,6 +261,11 @@ class History_buffer:
               "ll_history_refresh_cells")
         return nc.value, ns.value
 
+    def set_gate_pose(self, pose) -> None:
+        """the node's pose before the registration whose result the next add() receives (laser_mapping.hpp:1439-1451)"""
+        p = np.ascontiguousarray(pose, np.float64)
+        check(self.L.ll_history_set_gate_pose(self.h, ptr(p)), "ll_history_set_gate_pose")
+
     def map_cloud(self, kind: int) -> np.ndarray:
         n = self.L.ll_history_map_cloud(self.h, kind, None, 0)
         out = np.zeros((max(n, 0), 4), np.float32)

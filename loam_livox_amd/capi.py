@@ -101,6 +101,7 @@ SYMBOLS = {
     "ll_history_refresh": (_i32, [_vp, _vp, _vp, _vp]),
     "ll_history_size": (_i32, [_vp]),
     "ll_history_map_cloud": (_i64, [_vp, _i32, _vp, _i64]),
+    "ll_history_set_gate_pose": (_i32, [_vp, _vp]),
     "ll_history_map_cloud_device": (_i32, [_vp, _i32, _vp, _vp]),
     "ll_cellmap_create": (_i32, [_i32, _i64, C.c_float, _i32, _vp]),
     "ll_cellmap_destroy": (None, [_vp]),

@@ -1266,6 +1266,8 @@ struct ll_history {
     double *d_pose = nullptr;
     VoxelDev vox_frame{}, vox_map{};
     double last_q[4] = {0, 0, 0, 1}, last_t[3] = {0, 0, 0};  // m_last_his_add_q / m_last_his_add_t
+    double gate[7] = {0, 0, 0, 1, 0, 0, 0};                   // ll_history_set_gate_pose: the node's pose BEFORE the registration
+    bool has_gate = false;
     int64_t n_map[2] = {0, 0};
     float4 *d_map[2] = {nullptr, nullptr};   // filtered match buffer of the last refresh
     // m_pt_cell_map_corners / m_pt_cell_map_planes (laser_mapping.hpp:274-275), ll_history_enable_cell_map
@@ -1379,9 +1381,14 @@ static int history_add_common(ll_history *h, const float4 *d_corner, int n_corne
                               double t_step, double angle_step, int32_t *added)
 {
     if (n_corner > h->max_pts || n_surf > h->max_pts) return set_err("ll_history_add", "frame exceeds max_points_per_frame");
-    // laser_mapping.hpp:1439-1440: distance from the pose of the last pushed frame
-    const double r_diff = quat_angular_distance(pose, h->last_q) * 57.3;
-    const double dt[3] = {pose[4] - h->last_t[0], pose[5] - h->last_t[1], pose[6] - h->last_t[2]};
+    // laser_mapping.hpp:1439-1440: distance of the node's m_q_w_curr / m_t_w_curr -- still the pose BEFORE this
+    // registration there (it is copied back at :1496-1500) -- from the pose recorded at the last push.  The gate pose is
+    // handed over by ll_history_set_gate_pose (one-shot); without it the transform pose gates (identical results while
+    // history_add_t_step = history_add_angle_step = 0, the reference's fixed values: every frame is pushed).
+    const double *gp = h->has_gate ? h->gate : pose;
+    h->has_gate = false;
+    const double r_diff = quat_angular_distance(gp, h->last_q) * 57.3;
+    const double dt[3] = {gp[4] - h->last_t[0], gp[5] - h->last_t[1], gp[6] - h->last_t[2]};
     const double t_diff = sqrt(dot3(dt, dt));
     const bool push = h->size < h->max_hist || t_diff > t_step || r_diff > angle_step * 57.3;  // :1446-1448
     if (added) *added = push ? 1 : 0;
@@ -1392,14 +1399,22 @@ static int history_add_common(ll_history *h, const float4 *d_corner, int n_corne
     if (history_push_kind(h, 0, d_corner, n_corner, slot, push)) return -1;
     if (history_push_kind(h, 1, d_surf, n_surf, slot, push)) return -1;
     if (!push) return 0;
-    for (int i = 0; i < 4; i++) h->last_q[i] = pose[i];
-    for (int i = 0; i < 3; i++) h->last_t[i] = pose[4 + i];
+    for (int i = 0; i < 4; i++) h->last_q[i] = gp[i];  // :1450-1451
+    for (int i = 0; i < 3; i++) h->last_t[i] = gp[4 + i];
     h->size++;
     if (h->size > h->max_hist) {  // :1463-1473 pop_front
         h->head = (h->head + 1) % slots;
         h->size--;
     }
     HC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int ll_history_set_gate_pose(ll_history *h, const double pose[7])
+{
+    if (!h || !pose) return set_err("ll_history_set_gate_pose", "null argument");
+    for (int i = 0; i < 7; i++) h->gate[i] = pose[i];
+    h->has_gate = true;
     return 0;
 }
 

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(FE_TILE) void fe_point_kernel(FeDev fb, FeConst fc)
 #define SP_THREADS 1024
 #define SP_WAVES (SP_THREADS / 64)
 #define SP_MAX_SPLITS 4096  // LDS copy of the split list (n/50 + 8 entries; covers n <= 200k)
+#define SP_ITEMS 4          // consecutive points per thread in the two scan passes of fe_split_kernel
+#define SP_CAND_CHUNK 2048  // split candidates staged in LDS for the sequential hysteresis walk
 
 __device__ __forceinline__ int wave_incl_max(int v, int lane)
 {
@@ -169,70 +171,129 @@ __global__ __launch_bounds__(SP_THREADS) void fe_split_kernel(FeDev fb, int piec
     __shared__ int s_carry, s_base, s_nsplit;
     __shared__ int s_split[SP_MAX_SPLITS];
     __shared__ int s_min[16];
+    // Everything a single lane walks sequentially lives in LDS: one lane chasing ~100 dependent global loads per phase
+    // (the candidate list, then the per-run angle / first / last arrays) was most of this kernel's 294 us.
+    __shared__ int s_cand[SP_CAND_CHUNK];
+    __shared__ float s_angle[SP_MAX_SPLITS];
+    __shared__ int s_first[SP_MAX_SPLITS], s_last[SP_MAX_SPLITS];
+    __shared__ int s_hyst[4];  // ns, n_edge, n_zero, last: the hysteresis state carried across candidate chunks
 
     // ---- phase A: inheritance of pt_2d_img / polar_dis_sq2 by x==0 points (LFE:507-508) -------------------
+    // SP_ITEMS consecutive points per thread: a quarter of the workgroup-wide scan steps (and barriers) per scan
     if (tid == 0) s_carry = -1;
     __syncthreads();
-    for (int base = 0; base < n; base += SP_THREADS) {
-        const int i = base + tid;
-        const bool defines = (i < n) && (flags[i] & 1);
-        int v = defines ? i : -1;
-        v = wave_incl_max(v, lane);
-        if (lane == 63) s_wave[wave] = v;
+    for (int base = 0; base < n; base += SP_THREADS * SP_ITEMS) {
+        const int i0 = base + tid * SP_ITEMS;
+        bool defines[SP_ITEMS];
+        int m[SP_ITEMS];
+        int run = -1;
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) {
+            const int i = i0 + k;
+            defines[k] = (i < n) && (flags[i < n ? i : 0] & 1);
+            run = max(run, defines[k] ? i : -1);
+            m[k] = run;
+        }
+        const int incl = wave_incl_max(run, lane);
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = -1;
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        int pre = s_carry;
+        int pre = max(s_carry, excl);
         for (int w = 0; w < wave; w++) pre = max(pre, s_wave[w]);
-        v = max(v, pre);
-        if (i < n && !defines && v >= 0) {
-            polar2[i] = polar2[v];
-            img[i] = img[v];
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) {
+            const int i = i0 + k, v = max(m[k], pre);
+            if (i < n && !defines[k] && v >= 0) {
+                polar2[i] = polar2[v];
+                img[i] = img[v];
+            }
         }
         __syncthreads();
-        if (tid == SP_THREADS - 1) s_carry = v;
+        if (tid == SP_THREADS - 1) s_carry = max(pre, run);
         __syncthreads();
     }
 
     // ---- phase B: direction changes -> candidate list (ascending) ----------------------------------------
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += SP_THREADS) {
-        const int i = base + tid;
-        int kind = 0;
-        if (i >= 1 && i < n) {
-            const int di = dir_of(polar2, flags, i), dp = dir_of(polar2, flags, i - 1);
-            if (di == -1 && dp == 1) kind = 1;        // edge split candidate, LFE:543
-            else if (di == 1 && dp == -1) kind = 2;   // zero split candidate, LFE:553
+    for (int base = 0; base < n; base += SP_THREADS * SP_ITEMS) {
+        const int i0 = base + tid * SP_ITEMS;
+        int kind[SP_ITEMS];
+        int cnt = 0;
+        int dp = dir_of(polar2, flags, (i0 - 1 < n) ? i0 - 1 : 0);  // dir_of() is 0 for i < 1
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) {
+            const int i = i0 + k;
+            kind[k] = 0;
+            if (i >= 1 && i < n) {
+                const int di = dir_of(polar2, flags, i);
+                if (di == -1 && dp == 1) kind[k] = 1;        // edge split candidate, LFE:543
+                else if (di == 1 && dp == -1) kind[k] = 2;   // zero split candidate, LFE:553
+                dp = di;
+            }
+            cnt += kind[k] != 0;
         }
-        const int slot = block_compact_slot(kind != 0, s_wave, &s_base, tid);
-        if (slot >= 0) cand[slot] = (i << 2) | kind;
+        int incl = cnt;  // wave inclusive sum of the per-thread counts
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int slot = s_base + incl - cnt;
+        for (int w = 0; w < wave; w++) slot += s_wave[w];
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++)
+            if (kind[k]) cand[slot++] = ((i0 + k) << 2) | kind[k];
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < SP_WAVES; w++) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
     }
     const int n_cand = s_base;
     __syncthreads();
 
     // ---- phase C: 50-point hysteresis, sequential over candidates (LFE:545-562) ----------------------------
-    if (tid == 0) {
-        int ns = 0, n_edge = 0, n_zero = 0, last = 0;
-        for (int c = 0; c < n_cand; c++) {
-            const int e = cand[c];
-            const int i = e >> 2, kind = e & 3;
-            bool take;
-            if (kind == 1)
-                take = (n_edge == 0) || (i - last > 50);
-            else
-                take = (n_zero == 0) || (i - last > 50);
-            if (take && ns < fb.split_cap - 1) {
-                splits[ns++] = i;
-                last = i;
-                if (kind == 1) n_edge++; else n_zero++;
+    if (tid < 4) s_hyst[tid] = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_cand; c0 += SP_CAND_CHUNK) {
+        const int m = min(SP_CAND_CHUNK, n_cand - c0);
+        for (int k = tid; k < m; k += SP_THREADS) s_cand[k] = cand[c0 + k];
+        __syncthreads();
+        if (tid == 0) {
+            int ns = s_hyst[0], n_edge = s_hyst[1], n_zero = s_hyst[2], last = s_hyst[3];
+            for (int c = 0; c < m; c++) {
+                const int e = s_cand[c];
+                const int i = e >> 2, kind = e & 3;
+                bool take;
+                if (kind == 1)
+                    take = (n_edge == 0) || (i - last > 50);
+                else
+                    take = (n_zero == 0) || (i - last > 50);
+                if (take && ns < fb.split_cap - 1) {
+                    if (ns < SP_MAX_SPLITS) s_split[ns] = i;
+                    splits[ns++] = i;
+                    last = i;
+                    if (kind == 1) n_edge++; else n_zero++;
+                }
             }
+            s_hyst[0] = ns, s_hyst[1] = n_edge, s_hyst[2] = n_zero, s_hyst[3] = last;
         }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int ns = s_hyst[0];
+        if (ns < SP_MAX_SPLITS) s_split[ns] = n - 1;
         splits[ns++] = n - 1;  // LFE:565
         s_nsplit = ns;
     }
     __syncthreads();
     const int ns = s_nsplit;
-    for (int k = tid; k < ns && k < SP_MAX_SPLITS; k += SP_THREADS) s_split[k] = splits[k];
-    __syncthreads();
 
     const bool enough = (ns >= 6) && (ns <= SP_MAX_SPLITS);  // LFE:572
     const int n_runs = enough ? ns - 1 : 0;
@@ -250,17 +311,24 @@ __global__ __launch_bounds__(SP_THREADS) void fe_split_kernel(FeDev fb, int piec
         float ang = (float)((double)atan2f(im.y, im.x) * 57.3);
         ang = (float)((double)ang + 180.0);
         run_angle[v] = ang;
-        // first / last surviving point of the run: idx in (s0, s1], run 0 starts at 0
+        s_angle[v] = ang;
+        // first / last surviving point of the run: idx in (s0, s1], run 0 starts at 0.  Nearly every point survives, so
+        // the two searches stop after a step or two (a run with no survivor is walked once in full)
         const int lo = (v == 0) ? 0 : s0 + 1;
         int first = -1, lastp = -1;
-        for (int i = lo; i <= s1; i++) {
+        for (int i = lo; i <= s1; i++)
             if ((type[i] & (PT_000 | PT_TOO_NEAR | PT_NAN)) == 0) {
-                if (first < 0) first = i;
-                lastp = i;
+                first = i;
+                break;
             }
-        }
-        pet_first[v] = first;
-        pet_last[v] = lastp;
+        if (first >= 0)
+            for (int i = s1; i >= first; i--)
+                if ((type[i] & (PT_000 | PT_TOO_NEAR | PT_NAN)) == 0) {
+                    lastp = i;
+                    break;
+                }
+        s_first[v] = first;
+        s_last[v] = lastp;
     }
     __syncthreads();
     // per-point petal angle
@@ -273,14 +341,14 @@ __global__ __launch_bounds__(SP_THREADS) void fe_split_kernel(FeDev fb, int piec
                 const int mid = (lo + hi) >> 1;
                 if (i <= s_split[mid + 1]) hi = mid; else lo = mid + 1;
             }
-            a = run_angle[lo];
+            a = s_angle[lo];
         }
         polar_angle[i] = a;
     }
     __syncthreads();
     if (tid == 0) {
         // merge runs whose angle compares equal (a new petal starts only where scan_id_index changes, LFE:672),
-        // drop the last petal (LFE:681), drop empty petals (LFE:713-716); compact in place.
+        // drop the last petal (LFE:681), drop empty petals (LFE:713-716); compact in place (in LDS).
         int out = 0;
         if (enough) {
             // a run with no points at all (only possible when the closing entry n-1 duplicates the last split)
@@ -289,19 +357,19 @@ __global__ __launch_bounds__(SP_THREADS) void fe_split_kernel(FeDev fb, int piec
             while (nr > 1 && s_split[nr - 1] == s_split[nr]) nr--;
             int v = 0;
             while (v < nr) {
-                int first = pet_first[v], lastp = pet_last[v];
+                int first = s_first[v], lastp = s_last[v];
                 int w = v + 1;
-                while (w < nr && run_angle[w] == run_angle[v]) {
-                    if (pet_first[w] >= 0) {
-                        if (first < 0) first = pet_first[w];
-                        lastp = pet_last[w];
+                while (w < nr && s_angle[w] == s_angle[v]) {
+                    if (s_first[w] >= 0) {
+                        if (first < 0) first = s_first[w];
+                        lastp = s_last[w];
                     }
                     w++;
                 }
                 const bool is_last = (w >= nr);
                 if (!is_last && first >= 0) {
-                    pet_first[out] = first;
-                    pet_last[out] = lastp;
+                    s_first[out] = first;  // out <= v: never overwrites an entry still to be read
+                    s_last[out] = lastp;
                     out++;
                 }
                 v = w;
@@ -317,23 +385,35 @@ __global__ __launch_bounds__(SP_THREADS) void fe_split_kernel(FeDev fb, int piec
         s_base = out;
     }
     __syncthreads();
+    for (int v = tid; v < s_base; v += SP_THREADS) {  // the petal table callers read (ll_fe_splits)
+        pet_first[v] = s_first[v];
+        pet_last[v] = s_last[v];
+    }
     // ---- piece-wise windows (laser_feature_extractor.hpp:305-323); the caller only gets here when S > 5 -----
     const int S = s_base;
     if (S > 5 && pieces >= 1 && pieces <= LL_MAX_PIECES && pieces <= S) {
         // find_pt_info(...) returns the FIRST inserted point with the same xyz (unordered_map insert, LFE:478)
         if (tid < 2 * pieces) s_min[tid] = 0x7fffffff;
         __syncthreads();
-        for (int q = 0; q < 2 * pieces; q++) {
-            const int pc = q >> 1;
+        // one pass over the points for all 2 * pieces targets; no early exit, so the loads of a thread's iterations overlap
+        __shared__ float4 s_tp[2 * LL_MAX_PIECES];
+        __shared__ int s_tgt[2 * LL_MAX_PIECES];
+        if (tid < 2 * pieces) {
+            const int pc = tid >> 1;
             const int start_scans = (S * pc) / pieces, end_scans = (S * (pc + 1)) / pieces - 1;
-            const int target = (q & 1) ? pet_last[end_scans] : pet_first[start_scans];
-            const float4 tp = pts[target];
-            int best = 0x7fffffff;
-            for (int j = tid; j <= target; j += SP_THREADS) {
-                const float4 p = pts[j];
-                if (p.x == tp.x && p.y == tp.y && p.z == tp.z) { best = j; break; }
+            const int target = (tid & 1) ? s_last[end_scans] : s_first[start_scans];
+            s_tgt[tid] = target;
+            s_tp[tid] = pts[target];
+        }
+        __syncthreads();
+        int far = 0;
+        for (int q = 0; q < 2 * pieces; q++) far = max(far, s_tgt[q]);
+        for (int j = tid; j <= far; j += SP_THREADS) {
+            const float4 p = pts[j];
+            for (int q = 0; q < 2 * pieces; q++) {
+                const float4 tp = s_tp[q];
+                if (j <= s_tgt[q] && p.x == tp.x && p.y == tp.y && p.z == tp.z) atomicMin(&s_min[q], j);
             }
-            if (best != 0x7fffffff) atomicMin(&s_min[q], best);
         }
         __syncthreads();
         if (tid < pieces) {

@@ -82,6 +82,7 @@ class Laser_mapping:
         self.stage_s[3] += 1
         if not res[0]:  # :1413-1416
             return 0
+        self.history.set_gate_pose(self.pose)  # m_q_w_curr is still the pre-registration pose at LM:1439-1451
         if self.m_if_input_downsample_mode:
             self.history.add_voxel(self.vox[0], self.vox[1], 0, pc[0], self.history_add_t_step, self.history_add_angle_step)
         else:
@@ -131,6 +132,7 @@ class Laser_mapping:
         self.last_report = reg.report
         if not res:  # :1413-1416
             return 0
+        self.history.set_gate_pose(self.pose)  # m_q_w_curr is still the pre-registration pose at LM:1439-1451
         self.pose = np.array(reg.m_pose_w_curr, np.float64)
         self.history.add(corner_stack, surf_stack, self.pose, self.history_add_t_step, self.history_add_angle_step)
         self.map_sizes = self.history.refresh(self.map)

@@ -32,14 +32,17 @@ class History:
     def enable_cell_map(self, cell_resolution=1.0, threshold_cell_revisit=5000):      # LM:620-624
         self.cells = (CellMap(cell_resolution, threshold_cell_revisit), CellMap(cell_resolution, threshold_cell_revisit))
 
-    def add(self, corner, surf, pose, t_step=0.0, angle_step=0.0):
-        r_diff = _angular_distance(pose[:4], self.last_q) * 57.3          # LM:1439
-        t_diff = np.linalg.norm(pose[4:] - self.last_t)                  # LM:1440
+    def add(self, corner, surf, pose, t_step=0.0, angle_step=0.0, gate_pose=None):
+        # LM:1439-1451 read Laser_mapping::m_q_w_curr / m_t_w_curr, which there is still the pose BEFORE this registration
+        # (copied back at :1496-1500); the clouds move with the registered pose.  gate_pose = that earlier pose.
+        gp = np.asarray(pose if gate_pose is None else gate_pose, np.float64)
+        r_diff = _angular_distance(gp[:4], self.last_q) * 57.3            # LM:1439
+        t_diff = np.linalg.norm(gp[4:] - self.last_t)                    # LM:1440
         push = len(self.frames[0]) < self.max_hist or t_diff > t_step or r_diff > angle_step * 57.3   # LM:1446-1448
         if not push and self.cells is None:
             return False
         if push:
-            self.last_q, self.last_t = np.array(pose[:4], np.float64), np.array(pose[4:], np.float64)
+            self.last_q, self.last_t = np.array(gp[:4], np.float64), np.array(gp[4:], np.float64)             # LM:1450-1451
         for kind, cloud in enumerate((corner, surf)):
             w = orc.cloud_transform(pose, cloud) if len(cloud) else np.zeros((0, 4), np.float32)  # LM:1421-1431
             w = orc.voxel_grid(w, self.res[kind])[1] if len(w) else w                               # LM:1434-1437
@@ -71,7 +74,8 @@ class LaserMapping:
                  icp_max_iterations=20, ceres_max_iterations=100, max_allow_incre_R=4.0, max_allow_incre_T=2.0, max_allow_final_cost=100.0,
                  minimum_icp_R_diff=0.01, minimum_icp_T_diff=0.01, matching_mode=0, cell_resolution=1.0, threshold_cell_revisit=5000,
                  maximum_search_range_corner=100.0, maximum_search_range_surface=100.0, maximum_in_fov_angle=30.0, down_sample_replace=1,
-                 maximum_residual_blocks=0, subsample_seed=1):
+                 maximum_residual_blocks=0, subsample_seed=1, history_add_t_step=0.0, history_add_angle_step=0.0):
+        self.steps = (history_add_t_step, history_add_angle_step)
         self.hist = History(maximum_history_size, line_res, plane_res)
         self.mode = matching_mode
         self.cell_args = ((maximum_search_range_corner, maximum_search_range_surface), maximum_in_fov_angle, down_sample_replace)
@@ -104,7 +108,7 @@ class LaserMapping:
         self.report = rep
         if not ret:
             return 0
-        self.hist.add(fc, fs, pc)
+        self.hist.add(fc, fs, pc, self.steps[0], self.steps[1], gate_pose=self.pose)   # m_q_w_curr is updated after the add, LM:1496-1500
         self.pose = pc.copy()
         self.maps = self.hist.refresh_cells(self.pose, *self.cell_args) if self.mode else self.hist.refresh()
         self.trees = [orc.KdTree(m) if len(m) else None for m in self.maps]

@@ -82,6 +82,10 @@ def test_history_fifo_and_add_rule():
     assert h.add(c, s, pose2, t_step=0.5, angle_step=0.1)                  # 7 deg > 0.1 * 57.3 deg
     mc, ms = h.refresh()
     assert 0 < len(mc) <= 600 and 0 < len(ms) <= 2400
+    # LM:1439-1451 gate on (and record) the node's pose BEFORE the registration, not the pose the clouds are moved with
+    far = pose2.copy(); far[4] += 5.0
+    assert not h.add(c, s, far, t_step=0.5, angle_step=0.1, gate_pose=pose2)      # registered pose far away, node pose unchanged
+    assert h.add(c, s, pose2, t_step=0.5, angle_step=0.1, gate_pose=far) and np.array_equal(h.last_t, far[4:])
 
 
 # ------------------------------------------------------------------------------------------------------ GPU tier
@@ -103,7 +107,12 @@ def test_device_history_bit_exact(gpu_lib):
             c = np.zeros((0, 4), np.float32)                   # a frame without corner features
         if k in (4, 5):                                        # motion below / above the add thresholds
             pose = synth.pose_compose(pose, np.r_[synth.quat_from_axis_angle(np.array([0, 0, 1.0]), np.deg2rad(1.0 if k == 4 else 8.0)), [0.1, 0, 0]])
-        assert dev.add(c, s, pose, 0.5, 0.1) == ora.add(c, s, pose, 0.5, 0.1)
+        if k == 6:  # the add-frame rule reads the pose before the registration (ll_history_set_gate_pose, one-shot)
+            gate = synth.pose_compose(pose, np.r_[0, 0, 0, 1, 0.7, 0, 0])
+            dev.set_gate_pose(gate)
+            assert dev.add(c, s, pose, 0.5, 0.1) == ora.add(c, s, pose, 0.5, 0.1, gate_pose=gate) == True
+        else:
+            assert dev.add(c, s, pose, 0.5, 0.1) == ora.add(c, s, pose, 0.5, 0.1)
         assert len(dev) == len(ora.frames[0])
         nc, ns = dev.refresh(m)
         mc, ms = ora.refresh()

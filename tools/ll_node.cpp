@@ -345,6 +345,7 @@ class Laser_mapping {
         const int reg_res = pc_reg.find_out_incremental_transfrom(laserCloudCornerStack, laserCloudSurfStack);
         int64_t n_map[2] = {map_sizes_[0], map_sizes_[1]};
         if (reg_res != 0) {  // :1413-1416 return on failure; otherwise "Add new frame" (:1417-1478) and the pose hand-over (:1496-1500)
+            history_->set_gate_pose(pose_);  // m_q_w_curr / m_t_w_curr still hold the previous pose at :1439-1451
             history_->add(*laserCloudCornerStack, *laserCloudSurfStack, pc_reg.m_para_buffer_RT, m_history_add_t_step, m_history_add_angle_step);
             for (int i = 0; i < 7; i++) pose_[i] = pc_reg.m_para_buffer_RT[i];
             history_->refresh(pc_reg.map(), &n_map[0], &n_map[1]);  // update_buff_for_matching (:460-566), synchronous here
