@@ -919,13 +919,12 @@ extern "C" int ll_reg_debug_worklists(ll_reg *r, int32_t n_scans, int64_t out[4]
 {
     if (!r || !out || n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg_debug_worklists", "bad argument");
     HC(hipSetDevice(r->device));
-    const size_t n = (size_t)n_scans * 4 * r->dev.n_chunks;
+    const size_t n = (size_t)n_scans * 4;  // work_cnt: [scan][kind][searched, re-sorted] of the last re-query launch
     std::vector<int> h(n);
     HC(hipStreamSynchronize(r->stream));
-    HC(hipMemcpy(h.data(), r->dev.work_n, n * sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(h.data(), r->dev.work_cnt, n * sizeof(int), hipMemcpyDeviceToHost));
     out[0] = out[1] = out[2] = out[3] = 0;
-    const size_t per_kind = 2 * (size_t)r->dev.n_chunks;  // layout [scan][kind][chunk][2]
-    for (size_t i = 0; i < n; i++) out[2 * ((i / per_kind) & 1) + (i & 1)] += h[i];
+    for (size_t i = 0; i < n; i++) out[i & 3] += h[i];
     return 0;
 }
 

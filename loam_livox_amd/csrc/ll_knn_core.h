@@ -44,6 +44,10 @@ struct Knn5 {
 };
 
 #define LL_KNN_EMPTY 0x7fffffff
+// test-only instrumentation hook (tests/hostcheck counts row look-ups and candidates per query); nothing on the device
+#ifndef LL_KNN_STAT
+#define LL_KNN_STAT(counter, n)
+#endif
 #define LL_KNN_CUBE_FROM 5  // ring at which the search stops growing shells and sweeps the remaining cube (knn5_search_t)
 
 LL_HD void knn5_init(Knn5 &r)
@@ -138,6 +142,8 @@ LL_HD void scan_run_t(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of
                       float max_d2, Knn5 &r)
 {
     const int b = g.cell_start[c_lo], e = g.cell_start[c_hi + 1];
+    LL_KNN_STAT(0, 1);
+    LL_KNN_STAT(1, e - b);
     const typename PT::Row row = PT::row(g, c_lo);
     // four candidates per trip: the four record loads are independent, so their latencies overlap
     for (int j = b; j < e; j += 4) {
@@ -233,7 +239,9 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
     const float m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));  // already shrunk by slack
     const int kmax = (int)ceilf(sqrtf(max_d2) * g.inv_h) + 1;
     for (int k = 1; k <= kmax; k++) {
+        if (k == 2) LL_KNN_STAT(2, 1);
         if (k == LL_KNN_CUBE_FROM) {
+            LL_KNN_STAT(3, 1);
             // ---- phase 3 (sparse surroundings): four rings have not settled the answer -- the query looks into a part
             // of the map with next to no points (the frontier of a growing local map, a sparse voxel-filtered cloud).
             // Shell by shell, the remaining rings would look up the two end cells of every interior row again and

@@ -160,6 +160,34 @@ __device__ __forceinline__ void ref_store(const RegDev &rd, size_t sb, int slot,
     rd.ref_s[sb + slot] = make_float2(__int_as_float(ref.pos[4]), ref.m_set);
 }
 
+// Set-stable query (re-query state 1): the same five neighbours, re-evaluated and re-sorted at the new position; the
+// reuse record moves there with shrunken budgets (knn5_resort).
+__device__ __forceinline__ void resort_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
+{
+    const int kind = slot >= rd.cap_c ? 1 : 0;
+    const size_t sb = (size_t)b * rd.cap;
+    const float4 pw = rd.qw[sb + slot];
+    const float4 rq = rd.ref_q[sb + slot];
+    const float2 rs = rd.ref_s[sb + slot];
+    const int4 rp = rd.ref_p[sb + slot];
+    KnnRef ref;
+    ref.qx = rq.x;
+    ref.qy = rq.y;
+    ref.qz = rq.z;
+    ref.m_strong = rq.w;
+    ref.m_set = rs.y;
+    ref.pos[0] = rp.x;
+    ref.pos[1] = rp.y;
+    ref.pos[2] = rp.z;
+    ref.pos[3] = rp.w;
+    ref.pos[4] = __float_as_int(rs.x);
+    const float delta = knn5_ref_delta(ref, pw.x, pw.y, pw.z);  // the value the re-query kernel classified with
+    Knn5 r;
+    knn5_resort(kind ? gs : gc, ref, delta, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);
+    ref_store(rd, sb, slot, ref);
+    knn_store(rd, rc, sb, slot, kind, iter, r);
+}
+
 __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
 {
     const int kind = slot >= rd.cap_c ? 1 : 0;
@@ -249,22 +277,10 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
         if (!(delta < ref.m_strong)) {  // else: same neighbours, same order: nn and the block are unchanged
             const float2 rs = rd.ref_s[sb + slot];
             ref.m_set = rs.y;
-            if (delta < ref.m_set) {
-                const int4 rp = rd.ref_p[sb + slot];
-                ref.pos[0] = rp.x;
-                ref.pos[1] = rp.y;
-                ref.pos[2] = rp.z;
-                ref.pos[3] = rp.w;
-                ref.pos[4] = __float_as_int(rs.x);
-                Knn5 r;
-                knn5_resort(kind ? gs : gc, ref, delta, pw[0], pw[1], pw[2], kind ? rc.max_d2_plane : rc.max_d2_line, r);
-                ref_store(rd, sb, slot, ref);
-                knn_store(rd, rc, sb, slot, kind, iter, r);
-                state = 1;
-            } else {
-                rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
-                state = 2;
-            }
+            // Both kinds of work are left to the list kernel: the five gathers and the stores of a re-sort in here kept
+            // nearly every wavefront alive for three more dependent round trips (73 % of them hold at least one such lane)
+            rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
+            state = (delta < ref.m_set) ? 1 : 2;
         }
     }
     int n1 = 0, n2 = 0;
@@ -452,6 +468,8 @@ __global__ __launch_bounds__(RL_THREADS) void reg_list_kernel(RegDev rd, RegCons
     // occupancy of this latency-bound kernel (16 KB per 128-thread workgroup: 36 -> 99 us per late iteration at B = 256).
     const int tid = threadIdx.x;
     const int stride = gridDim.x * RL_THREADS;
+    // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
+    // to 99 us but cost 25 % at the long early lists -- profiles/r02 runs U / V -- and was dropped)
     for (int w = 0; w < 2; w++) {
         const int *off = rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
         const int total = off[n_seg];
@@ -466,6 +484,7 @@ __global__ __launch_bounds__(RL_THREADS) void reg_list_kernel(RegDev rd, RegCons
             const int e = list[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off[lo])];
             const int slot = e - b * rd.cap;
             if (w == 0) knn_one(rd, rc, gc, gs, b, slot, iter);
+            else resort_one(rd, rc, gc, gs, b, slot, iter);
             build_one(rd, rc, gc, gs, b, slot);
         }
     }

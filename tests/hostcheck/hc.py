@@ -99,6 +99,15 @@ class Grid:
         lib().hc_knn5(self.h, _p(q), q.shape[0], max_d2, _p(idx), _p(d2))
         return idx, d2
 
+    def knn5_work(self, q, max_d2):
+        """(rows looked up, candidates examined, deepest phase) per query -- instrumentation of the device search"""
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        out = [np.zeros(q.shape[0], np.int32) for _ in range(3)]
+        L = lib()
+        L.hc_knn5_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 3
+        L.hc_knn5_work(self.h, _p(q), q.shape[0], max_d2, *[_p(o) for o in out])
+        return out
+
     def knn5_bounds(self, q, max_d2):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
         cand = np.zeros((q.shape[0], lib().hc_knn_k()), np.int32)

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <vector>
 
+static long long g_knn_stat[4];  // row look-ups, candidates, queries reaching ring 2, queries reaching the cube sweep
+#define LL_KNN_STAT(counter, n) (g_knn_stat[counter] += (n))
 #include "../../loam_livox_amd/csrc/ll_fe_core.h"
 #include "../../loam_livox_amd/csrc/ll_knn_core.h"
 #include "../../loam_livox_amd/csrc/ll_reg_core.h"
@@ -176,6 +178,21 @@ int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx
             idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
             d2[5 * i + k] = r.d2[k];
         }
+    }
+    return 0;
+}
+
+// per-query work of the search: rows looked up, candidates examined, deepest phase reached (1 = 3x3x3 block, 2 = rings, 3 = cube sweep)
+int hc_knn5_work(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *rows, int32_t *cands, int32_t *phase)
+{
+    for (int i = 0; i < nq; i++) {
+        long long before[4];
+        for (int k = 0; k < 4; k++) before[k] = g_knn_stat[k];
+        Knn5 r;
+        knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
+        rows[i] = (int32_t)(g_knn_stat[0] - before[0]);
+        cands[i] = (int32_t)(g_knn_stat[1] - before[1]);
+        phase[i] = g_knn_stat[3] > before[3] ? 3 : (g_knn_stat[2] > before[2] ? 2 : 1);
     }
     return 0;
 }
