@@ -224,27 +224,37 @@ void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 
 // K6r: transform + reuse test (ICP iteration >= 1)
 
-// workgroup compaction into a batch-wide dense list: every thread with pred gets a distinct position in
-// list[0 .. *g_total) (the workgroup reserves a contiguous range with one global atomicAdd), -1 otherwise.  Also returns
-// the workgroup's count through *wg_count.  All threads of the workgroup must call it.
-__device__ __forceinline__ int rq_dense_slot(bool pred, int *s_wave_cnt, int *s_base, int *g_total, int tid, int *wg_count)
+// workgroup compaction into the two dense work lists of a scan-and-kind: every thread with state 1 (re-sort) or 2 (search)
+// gets a distinct position in its list; the workgroup reserves one contiguous range per list with ONE round of ballots, one
+// barrier pair and two independent atomicAdds issued back to back (two rounds doubled the dependent latency every
+// workgroup pays before it can retire).  Returns the position, or -1 for state 0.  All threads must call it.
+__device__ __forceinline__ int rq_dense_slot2(int state, int *s_wave_cnt /*[2][RQ_WAVES]*/, int *s_base /*[2]*/, int *g_cnt /*[0] search, [1] re-sort*/,
+                                              int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    const unsigned long long m = __ballot(pred);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0, tot = 0;
-    for (int w = 0; w < RQ_WAVES; w++) {
-        if (w < wave) off += s_wave_cnt[w];
-        tot += s_wave_cnt[w];
+    const unsigned long long m1 = __ballot(state == 1), m2 = __ballot(state == 2);
+    if (lane == 0) {
+        s_wave_cnt[wave] = __popcll(m1);
+        s_wave_cnt[RQ_WAVES + wave] = __popcll(m2);
     }
-    if (tid == 0) *s_base = tot > 0 ? atomicAdd(g_total, tot) : 0;
     __syncthreads();
-    const int slot = pred ? *s_base + off + before : -1;
-    *wg_count = tot;
-    __syncthreads();  // s_wave_cnt / s_base are reused by the next call
-    return slot;
+    int off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
+    for (int w = 0; w < RQ_WAVES; w++) {
+        const int c1 = s_wave_cnt[w], c2 = s_wave_cnt[RQ_WAVES + w];
+        if (w < wave) off1 += c1, off2 += c2;
+        tot1 += c1, tot2 += c2;
+    }
+    if (tid == 0) {
+        const int b1 = tot1 > 0 ? atomicAdd(g_cnt + 1, tot1) : 0;
+        const int b2 = tot2 > 0 ? atomicAdd(g_cnt + 0, tot2) : 0;
+        s_base[0] = b1;
+        s_base[1] = b2;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (state == 1) return s_base[0] + off1 + __popcll(m1 & below);
+    if (state == 2) return s_base[1] + off2 + __popcll(m2 & below);
+    return -1;
 }
 
 // One workgroup per chunk of RQ_THREADS consecutive queries; unstable queries are appended to the batch-wide dense work
@@ -259,8 +269,8 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
     const size_t sb = (size_t)b * rd.cap;
     const int koff = kind ? rd.cap_c : 0;
     const int tid = threadIdx.x;
-    __shared__ int s_wave[RQ_WAVES];
-    __shared__ int s_base;
+    __shared__ int s_wave[2 * RQ_WAVES];
+    __shared__ int s_base[2];
     const int q = chunk * RQ_THREADS + tid;
     const int slot = koff + q;
     int state = 0;  // 0 = stable or out of range, 1 = re-sorted, 2 = needs a search
@@ -283,18 +293,11 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
             state = (delta < ref.m_set) ? 1 : 2;
         }
     }
-    int n1 = 0, n2 = 0;
     int *cnt = rd.work_cnt + ((size_t)b * 2 + kind) * 2;
     const size_t seg = sb + koff;  // the scan-and-kind's own segment of the work arrays
-    const int a1 = rq_dense_slot(state == 1, s_wave, &s_base, cnt + 1, tid, &n1);
-    if (a1 >= 0) rd.work_build[seg + a1] = (int)sb + slot;
-    const int a2 = rq_dense_slot(state == 2, s_wave, &s_base, cnt + 0, tid, &n2);
-    if (a2 >= 0) rd.work_search[seg + a2] = (int)sb + slot;
-    if (tid == 0) {
-        const size_t ci = (((size_t)b * 2 + kind) * rd.n_chunks + chunk) * 2;
-        rd.work_n[ci] = n2;
-        rd.work_n[ci + 1] = n1;
-    }
+    const int at = rq_dense_slot2(state, s_wave, s_base, cnt, tid);
+    if (state == 1) rd.work_build[seg + at] = (int)sb + slot;
+    if (state == 2) rd.work_search[seg + at] = (int)sb + slot;
 }
 
 // Loads through an explicit global (address space 1) pointer.  Inside a non-inlined device function the compiler cannot
