@@ -56,6 +56,8 @@ def parse():
                     "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
     ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
     ap.add_argument("--legacy-solver", action="store_true", help="A/B: round-1 solver fast path (49-byte fp64 plane blocks, no LDS block cache)")
+    ap.add_argument("--no-solver-groups", action="store_true", help="A/B for the single-scan latency figure: one solver workgroup per scan "
+                    "even for small batches (default: batches of <= 16 scans spread every scan over 8 workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive figure")
@@ -257,6 +259,8 @@ def main():
     for f_ in ("icp_max_iterations", "ceres_max_iterations", "force_all_iterations", "para_max_angular_rate", "para_max_speed",
                "max_final_cost", "current_frame_index", "mapping_init_accumulate_frames", "maximum_allow_residual_block"):
         setattr(reg1.params, f_, getattr(p, f_))
+    if args.no_solver_groups:
+        reg1.set_debug(False, no_solver_groups=True)
     vox1 = (VoxelGrid(N, 1, device=dev), VoxelGrid(N, 1, device=dev)) if vox else None
     for i in range(5):
         torch.cuda.synchronize()
@@ -377,6 +381,8 @@ def main():
         "per_iter_ms_split_per_batch": {"transform_knn_build": round(float(k_ms[0] / args.steps / max(1, args.icp_iters)), 4),
                                         "solve": round(float(k_ms[1] / args.steps / max(1, args.icp_iters)), 4)},
         "single_scan_latency_ms": round(latency_ms, 3),
+        "single_scan_solver_phase_cycles": [int(v) for v in reg1.debug_cycles(0)],
+        "single_scan_solver": "one workgroup per scan" if args.no_solver_groups else "group of 8 workgroups per scan (batches <= 16)",
         "features_per_scan": {"corner": float(nc.mean()), "surface": float(ns.mean())},
         "knn_reuse_last_iter": dict(zip(("searched", "resorted"), reg.debug_worklists(B)), queries=int(nc.sum() + ns.sum()),
                                     corner_searched_resorted=reg.debug_worklists_by_kind(B)[0], corner_queries=int(nc.sum())),

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--matching-mode", type=int, default=0, help="0 = history match buffer (shipped configs), 1 = cell maps (laser_mapping.hpp:689)")
     ap.add_argument("--max-blocks", type=int, default=0, help="optimization/maximum_residual_blocks (200 in the shipped configs): random "
                     "sub-sampling of the features on the library's reproducible stream; 0 = every feature is a residual block")
+    ap.add_argument("--distinct-frames", type=int, default=0, help="generate only this many distinct scans (a multiple of 50, the period of the "
+                    "out-and-back trajectory) and replay them: frame k uses scan k mod D, whose pose is frame k's; 0 = every frame its own scan")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of rank 0's sequence also run through the CPU oracle (0 = skip)")
     args = ap.parse_args()
     import torch
@@ -65,10 +67,14 @@ def main():
     ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
     scans, truth, cur = [], [], start
     step_back = pose_inv(step, synth)
+    D = args.distinct_frames if args.distinct_frames > 0 else F
+    assert D >= F or (D % 50 == 0 and D >= 100), "--distinct-frames must be a multiple of 50 and at least 100"
     for k in range(F):
         if k >= 3:  # 25 frames out, 25 frames back: a long sequence stays inside the synthetic room
             cur = synth.pose_compose(cur, step if ((k - 3) // 25) % 2 == 0 else step_back)
-        scans.append(synth.make_moving_scan(world_model, 7000 + 1000 * rank + k, N, inc_true=ident, pose_start=cur, t_phase=0.13 * k).xyzi)
+        # the trajectory has period 50 from frame 3 on: frame k >= D + 3 is taken from the same pose as frame k - D
+        scans.append(scans[k - D] if k >= D + 3 else
+                     synth.make_moving_scan(world_model, 7000 + 1000 * rank + k, N, inc_true=ident, pose_start=cur, t_phase=0.13 * k).xyzi)
         truth.append(synth.pose_compose(pose_inv(start, synth), cur))
 
     args_map = dict(maximum_history_size=args.history, init_accumulate_frames=2, line_res=args.line_res, plane_res=args.plane_res,

@@ -238,8 +238,11 @@ int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corne
  * more than 24576 residual blocks use, for testing it on small inputs; bit 2 = disable the exact neighbour reuse
  * across ICP iterations (every iteration runs the full 5-NN search); bit 3 = try the reuse from ICP iteration 1
  * already (default: from iteration 2, the first pose update usually moves the queries too far); bit 4 = run the
- * round-1 solver fast path (49-byte fp64 plane blocks re-read on every evaluation) instead of the compact 32-byte
- * blocks with the LDS block cache -- an A/B switch, results agree to rounding. */
+ * round-1 solver fast path (49-byte fp64 plane blocks re-read on every evaluation) instead of the packed 48-byte
+ * records with the LDS record cache -- an A/B switch, results agree to rounding; bit 5 = one workgroup per scan whatever
+ * the batch size (by default batches of up to 16 scans give every scan a group of 8 workgroups whose cost evaluations
+ * each cover an eighth of the blocks, resident in LDS; the sums are then grouped differently, so results agree with the
+ * one-workgroup form to rounding, not bit for bit). */
 int ll_reg_set_debug(ll_reg *r, int32_t enable);
 
 /* ------------------------------------------------------------------------------------------------------------

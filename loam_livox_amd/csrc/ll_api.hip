@@ -663,6 +663,8 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.work_n, B * 4 * (size_t)d.n_chunks);
     DM(d.work_cnt, B * 4);
     DM(d.work_off, 2 * 2049);  // 2 lists x (RL_MAX_SEG + 1), ll_reg_kernels.hip
+    DM(d.grp_ctl, B + 1);
+    DM(d.grp_part, B * 2 * LL_GRP * 28);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -698,7 +700,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.work_cnt, d.work_off, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -748,6 +750,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->knn_reuse = (debug & 4) ? 0 : 1;
     c->knn_reuse_from = (debug & 8) ? 1 : 2;  // bit 3: also try reuse at ICP iteration 1 (test coverage)
     c->solver_legacy = (debug & 16) ? 1 : 0;  // bit 4: round-1 solver fast path (A/B)
+    c->solve_group = (debug & 32) ? 1 : 0;    // bit 5: never spread a scan over a group of workgroups (A/B); 0 = decide per batch size
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)
@@ -840,6 +843,10 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
                                  "339-345,438-458) with a reproducible random stream");
     if (prm->subsample_seed && (max_nc > 2 * prm->maximum_allow_residual_block || max_ns > 2 * prm->maximum_allow_residual_block))
         r->rc.knn_reuse = 0;  // skipped features change from iteration to iteration: every iteration searches
+    // Small batches leave most of the chip idle with one workgroup per scan: spread each scan's cost evaluations over a
+    // group of LL_GRP workgroups (ll_reg_kernels.hip, group_*).  Compact scans only; the others run on the group's first.
+    r->rc.solve_group = (r->rc.solve_group == 1 || n_scans > LL_GRP_MAX_SCANS || r->rc.if_motion_deblur || r->rc.force_general ||
+                         r->rc.solver_legacy) ? 1 : LL_GRP;
     if (run) {
         if (!mk0.pts || !mk1.pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
         HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));
@@ -848,6 +855,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
             launch_reg_knn_build(r->dev, r->rc, mk0.grid, mk1.grid, n_scans, it, max_nc, max_ns, r->stream);
             prof_end(r);
             prof_begin(r, 1);
+            if (r->rc.solve_group > 1) HC(hipMemsetAsync(r->dev.grp_ctl, 0, (size_t)(n_scans + 1) * sizeof(int), r->stream));
             launch_reg_solve(r->dev, r->rc, n_scans, r->stream);
             prof_end(r);
         }

@@ -11,6 +11,8 @@
 namespace ll {
 
 #define LL_MAX_PIECES 8
+#define LL_GRP 8             // workgroups per scan of the grouped solver
+#define LL_GRP_MAX_SCANS 16  // batches up to this size use it (LL_GRP * LL_GRP_MAX_SCANS workgroups stay below the CU count)
 
 struct FeScanInfo {
     int n_split;         // entries in split_idx (incl. the closing n-1)
@@ -103,6 +105,7 @@ struct RegConst {
     int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
     int solver_legacy;   // A/B switch: round-1 fast path (49-byte fp64 plane blocks, no LDS block cache)
+    int solve_group;     // workgroups per scan of the compact solver (1, or LL_GRP for small batches: ll_reg_kernels.hip, group_*)
     unsigned int subsample_seed;  // a13 (0 = off)
     int max_blocks;               // maximum_allow_residual_block
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
@@ -129,6 +132,8 @@ struct RegDev {
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
     float2 *ref_s;                // [B][cap]  x = bits(neighbour 4, -1 when fewer than 5 inside the radius), y = m_set
+    int *grp_ctl;                 // [1 + B] grouped solver: [0] ticket counter, [1 + b] arrival counter of scan b's group barrier (zeroed per launch)
+    double *grp_part;             // [B][2][LL_GRP][28] grouped solver: the workgroups' partial sums of one cost evaluation, double-buffered
     unsigned char *blk_flag0;     // [B][cap]  block flag as built; the solver prunes a copy (LDS, or blk_flag in the general path)
     int *work_search;             // [B][cap]  slots that need a full search this iteration
     int *work_build;              // [B][cap]  slots that were re-sorted (block must be rebuilt)

@@ -549,9 +549,64 @@ struct SolveShared {
     int n_active, n_corner_avail, n_surf_avail, n_unique;
     int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
     double thr;
+    int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
 };
 
 __device__ __forceinline__ int slot_of(int j, int nC, int cap_c) { return j < nC ? j : cap_c + (j - nC); }
+
+// ---- grouped solver (small batches) ------------------------------------------------------------------------------------
+// With one workgroup per scan a batch of B <= 16 scans keeps B of 256 CUs busy and every cost evaluation re-streams the 85 %
+// of the scan's block records that do not fit one CU's LDS.  For such batches a scan is given to a GROUP of LL_GRP
+// workgroups: every workgroup runs the whole control flow redundantly on the same numbers (census, LM controller, set
+// de-duplication, rank select, prune: all deterministic), but a cost evaluation visits only the workgroup's 1/G share of the
+// blocks -- which then fits its LDS record cache, so nothing is streamed after the first evaluation -- and the 28 partial sums
+// are exchanged through global memory and added in rank order by every member (identical totals, identical decisions).
+// Membership is by ticket (atomic counter, zeroed per launch): the G workgroups of a group are by construction running, so the
+// flag barrier below cannot wait for a workgroup that has no CU; a partial group waits only for workgroups that start as CUs
+// free up.  Spins are bounded: a barrier that does not complete poisons the result (NaN pose) instead of hanging the device.
+#define LL_GRP_SPIN_LIMIT (1 << 22)
+// FULL: every thread's plain global stores before the barrier (the L1 values) are visible to every member after it, and no
+// member keeps stale lines -- an agent-scope release / acquire fence in every wavefront.  Otherwise only data moved with
+// agent-scope atomics by the calling threads themselves is exchanged (the partial sums) and the barrier is just the counter.
+template <bool FULL>
+__device__ __forceinline__ void group_barrier(const RegDev &rd, int b, SolveShared &sh)
+{
+    if (FULL) __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && !sh.grp_abort) {
+        const int target = (++sh.grp_seq) * sh.grp_G;
+        int *bar = rd.grp_ctl + 1 + b;
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > LL_GRP_SPIN_LIMIT) {
+                sh.grp_abort = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();  // (the partial sums are then read with agent-scope atomic loads, which no cache level may satisfy stale)
+    if (FULL) __threadfence();
+}
+
+// sh.sum (this workgroup's share) -> sh.sum (the scan's totals), the same value in every member.  FULL as above.
+template <bool FULL>
+__device__ __forceinline__ void group_reduce(const RegDev &rd, int b, SolveShared &sh)
+{
+    const int tid = threadIdx.x, G = sh.grp_G;
+    double *part = rd.grp_part + ((size_t)b * 2 + (sh.grp_seq & 1)) * LL_GRP * LL_NACC;
+    if (tid < LL_NACC) {
+        __hip_atomic_store(part + sh.grp_g * LL_NACC + tid, sh.sum[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!FULL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the storing wavefront's own stores have left before it reaches the barrier
+    }
+    group_barrier<FULL>(rd, b, sh);
+    if (tid < LL_NACC) {
+        double t = 0.0;
+        for (int k = 0; k < G; k++) t += __hip_atomic_load(part + k * LL_NACC + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.sum[tid] = t;
+    }
+    __syncthreads();
+}
 
 // workgroup evaluation of cost / g / H at x (LDS) over the active blocks -> sh.sum
 template <int DEBLUR>
@@ -1692,7 +1747,7 @@ __device__ __forceinline__ void prec_decode(const PRec &r, double f[3], double a
 // L1OUT: this may be the last evaluation of the prerun solve -- also store every active block's loss-corrected L1 norm
 // (the quantity of PCR:476-483) into rd.blk_l1, so that the inlier pass does not have to sweep the blocks again when
 // the candidate is accepted (solve_fast2).
-template <bool FILL, bool L1OUT>
+template <bool FILL, bool L1OUT, bool GROUPED>
 __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a,
                                           const unsigned char *s_flag, int4 *cA, int4 *cB, const double *q_last_g, SolveShared &sh)
 {
@@ -1715,14 +1770,23 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
     const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
     const int4 *pc = rd.blk_pc + (size_t)b * rd.cap_s;
     int4 *cC = cB + PC_RECS;
-    int p = tid;
+    // The thread's k-th plane block is p0 + k * GS (one workgroup per scan: G = 1, the familiar tid + k * RS_THREADS); its
+    // first PC_RECS / RS_THREADS visits live in the LDS record cache at tid + k * RS_THREADS.
+    // (GROUPED is a template parameter so that the one-workgroup form keeps compile-time strides: as run-time values they cost
+    // the B = 256 launch 3 %)
+    constexpr int G = GROUPED ? LL_GRP : 1, GS = G * RS_THREADS;
+    constexpr int gshift = GROUPED ? 12 : 9;  // log2(GS): RS_THREADS = 512, LL_GRP = 8
+    static_assert(RS_THREADS == 512 && LL_GRP == 8 && PC_RECS % RS_THREADS == 0, "gshift assumes 512 threads and groups of 8");
+    const int p0 = GROUPED ? sh.grp_g * RS_THREADS + tid : tid;
+    int p = p0;
     if (!FILL) {
         const int ncached = nS < PC_RECS ? nS : PC_RECS;
-        for (; p < ncached; p += RS_THREADS) {
+        for (int k = 0; GROUPED ? (k < PC_RECS / RS_THREADS && p < nS) : p < ncached; k++, p += GS) {
+            const int c = GROUPED ? tid + k * RS_THREADS : p;
             PRec r;
-            r.a = cA[p];
-            r.b = cB[p];
-            r.c = cC[p];
+            r.a = cA[c];
+            r.b = cB[c];
+            r.c = cC[c];
             if (s_flag[p] & BLK_ACTIVE) {
                 double f[3], a[3], v[3];
                 prec_decode(r, f, a, v);
@@ -1742,10 +1806,14 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
     }
 #define LL_PLANE_USE(R, FL, P)                                                                         \
     if ((P) < nS) {                                                                                    \
-        if (FILL && (P) < PC_RECS) {                                                                   \
-            cA[(P)] = R.a;                                                                             \
-            cB[(P)] = R.b;                                                                             \
-            cC[(P)] = R.c;                                                                             \
+        if (FILL) {                                                                                    \
+            const int kk_ = ((P) - p0) >> gshift;                                                      \
+            const int c_ = GROUPED ? tid + kk_ * RS_THREADS : (P); /* one workgroup: the slot is the block index */ \
+            if (GROUPED ? kk_ < PC_RECS / RS_THREADS : (P) < PC_RECS) {                                \
+                cA[c_] = R.a;                                                                          \
+                cB[c_] = R.b;                                                                          \
+                cC[c_] = R.c;                                                                          \
+            }                                                                                          \
         }                                                                                              \
         if (FL & BLK_ACTIVE) {                                                                         \
             double f[3], a[3], v[3];                                                                   \
@@ -1757,7 +1825,7 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
         PRec r0, r1, r2;
         r0.a = r0.b = r0.c = r1.a = r1.b = r1.c = r2.a = r2.b = r2.c = make_int4(0, 0, 0, 0);
         unsigned char f0 = 0, f1 = 0, f2 = 0;
-        constexpr int S = RS_THREADS;
+        constexpr int S = GS;
         LL_PLANE_LOAD(r0, f0, p)
         LL_PLANE_LOAD(r1, f1, p + S)
         while (p < nS) {
@@ -1777,7 +1845,7 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
         const size_t sb = (size_t)b * rd.cap;
         const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
         const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
-        for (int l = tid; l < nC; l += RS_THREADS) {
+        for (int l = p0; l < nC; l += GS) {
             if (!(s_flag[nSp + l] & BLK_ACTIVE)) continue;
             BlkRegs br;
             load_blk(rd, sb, av, l, br);
@@ -1803,10 +1871,15 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
         sh.sum[tid] = s;
     }
     __syncthreads();
+    if (GROUPED) {
+        LL_T0(t_grp);  // LL_SOLVE_TIMING: the exchange's share of the evaluation (slot 9 also counts the L1 shortcut, by ones)
+        group_reduce<L1OUT>(rd, b, sh);  // the evaluation that writes the L1 values publishes them with its exchange
+        LL_TACC(9, t_grp);
+    }
 }
 
 // one ceres::Solve on the compact layout: starts at x0, leaves the result in sh.ctl
-template <bool WANT_L1>
+template <bool WANT_L1, bool GROUPED>
 __device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
                                            int n_active, const unsigned char *s_flag, int4 *cA, int4 *cB, const double *q_last,
                                            SolveShared &sh)
@@ -1819,7 +1892,7 @@ __device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc,
     __syncthreads();
     {
         LL_T0(t0);
-        solver_eval2<true, false>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, s_flag, cA, cB, q_last, sh);
+        solver_eval2<true, false, GROUPED>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, s_flag, cA, cB, q_last, sh);
         LL_TACC(0, t0);
     }
     {
@@ -1833,9 +1906,9 @@ __device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc,
         const bool spec = WANT_L1 && sh.ctl.iteration >= max_iter;
         LL_T0(t0);
         if (spec)
-            solver_eval2<false, true>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
+            solver_eval2<false, true, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
         else
-            solver_eval2<false, false>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
+            solver_eval2<false, false, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
         LL_TACC(0, t0);
         LL_T0(t1);
         if (tid == 0) {
@@ -1877,7 +1950,7 @@ __device__ __noinline__ void inlier_phase2(const RegDev &rd, const RegConst &rc,
             if (!(s_flag[j] & BLK_ACTIVE)) continue;
             if (j < nS) {
                 PRec r;
-                if (j < PC_RECS) {
+                if (j < PC_RECS && sh.grp_G == 1) {  // (a group member's cache holds its own share, in its own order)
                     r.a = cA[j];
                     r.b = cB[j];
                     r.c = cC[j];
@@ -1951,6 +2024,7 @@ __device__ __noinline__ void inlier_phase2(const RegDev &rd, const RegConst &rc,
     LL_TACC(7, t_prune);
 }
 
+template <bool GROUPED>
 __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, unsigned long long *s_table,
                             unsigned char *s_flag)
 {
@@ -2018,7 +2092,7 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
     LL_TACC(6, t_census);
 
     // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------
-    solver_lm2<true>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
+    solver_lm2<true, GROUPED>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
     int lm_iters = sh.ctl.iteration;
 
     if (totp <= 36 * RS_THREADS)  // the Mid-40 configurations: a 36-entry register tile per thread
@@ -2031,10 +2105,16 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
         __shared__ double x_start_2[7];
         if (tid < 7) x_start_2[tid] = sh.ctl.x[tid];
         __syncthreads();
-        solver_lm2<false>(rd, rc, b, nC, nS, x_start_2, rc.ceres_max_iterations, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
+        solver_lm2<false, GROUPED>(rd, rc, b, nC, nS, x_start_2, rc.ceres_max_iterations, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
     }
     lm_iters += sh.ctl.iteration;
     LL_T0(t_epi);
+    if (GROUPED) {
+        group_barrier<false>(rd, b, sh);  // nobody reads st->inc / st->pose_last any more
+        if (sh.grp_g != 0) return;
+        if (sh.grp_abort && tid < 7) sh.ctl.x[tid] = __longlong_as_double(0x7ff8000000000000LL);  // a barrier timed out: poison the pose
+        __syncthreads();
+    }
     solve_epilogue(rc, st, sh, lm_iters);
     LL_TACC(8, t_epi);
 #ifdef LL_SOLVE_TIMING
@@ -2047,15 +2127,37 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
 template <int DEBLUR>
 __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc)
 {
-    const int b = blockIdx.x;
-    RegState *st = rd.state + b;
-    if (st->done) return;
     __shared__ SolveShared sh;
     __shared__ unsigned long long s_table[HT_SIZE];
     __shared__ unsigned char s_flag[FAST_MAX_BLOCKS];
+    int b = blockIdx.x, g = 0, G = 1;
+    if (!DEBLUR && rc.solve_group > 1) {  // grouped launch (n_scans * G workgroups): scan and rank by ticket, see group_barrier
+        if (threadIdx.x == 0) sh.grp_seq = atomicAdd(rd.grp_ctl, 1);
+        __syncthreads();
+        G = rc.solve_group;
+        b = sh.grp_seq / G;
+        g = sh.grp_seq - b * G;
+        __syncthreads();
+    }
+    RegState *st = rd.state + b;
+    if (st->done) return;  // the same answer for every member: the epilogue that sets it runs behind the group's barriers
+    const bool compact = !DEBLUR && scan_is_compact(rd, rc, b);
+    if (!compact) {
+        if (g != 0) return;  // only the compact path knows groups
+        G = 1;
+    }
+    if (threadIdx.x == 0) {
+        sh.grp_g = g;
+        sh.grp_G = G;
+        sh.grp_seq = 0;
+        sh.grp_abort = 0;
+    }
+    __syncthreads();
     const int total = rd.n_corner[b] + rd.n_surf[b];
-    if (!DEBLUR && scan_is_compact(rd, rc, b))
-        solve_fast2(rd, rc, b, st, sh, s_table, s_flag);
+    if (compact && G > 1)
+        solve_fast2<true>(rd, rc, b, st, sh, s_table, s_flag);
+    else if (compact)
+        solve_fast2<false>(rd, rc, b, st, sh, s_table, s_flag);
     else if (total <= FAST_MAX_BLOCKS && !rc.force_general)
         solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
     else
@@ -2123,7 +2225,7 @@ void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStre
     if (rc.if_motion_deblur)
         hipLaunchKernelGGL(reg_solve_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
     else
-        hipLaunchKernelGGL(reg_solve_kernel<0>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
+        hipLaunchKernelGGL(reg_solve_kernel<0>, dim3(n_scans * (rc.solve_group > 1 ? rc.solve_group : 1)), dim3(RS_THREADS), 0, s, rd, rc);
 }
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {

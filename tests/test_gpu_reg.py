@@ -70,17 +70,18 @@ def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
 
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 @pytest.mark.parametrize("force", [0, 1])
-@pytest.mark.parametrize("general", [False, True, "legacy"])
+@pytest.mark.parametrize("general", [False, "single", True, "legacy"])
 def test_registration_matches_oracle(dev_map, small_world, scans, k, force, general):
-    """general=False: round-2 fast path (packed 48-byte plane blocks, LDS block cache); True: the HBM-resident path used
-    by scans with more than 24576 residual blocks (forced here on a normal scan); "legacy": the round-1 fast path
-    (blocks re-read on every evaluation), kept as an A/B switch."""
+    """general=False: round-2 fast path (packed 48-byte plane blocks, LDS record cache) in the form a batch of one takes: the
+    scan spread over a group of 8 workgroups; "single": the same path with one workgroup per scan, as batches of more than
+    16 scans run it; True: the HBM-resident path used by scans with more than 24576 residual blocks (forced here on a normal
+    scan); "legacy": the round-1 fast path (blocks re-read on every evaluation), kept as an A/B switch."""
     sc = scans[k]
     _, _, _, _, fc, fs = oracle_features(sc)
     prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     reg = Point_cloud_registration(max_scans=1, max_features=24000)
-    reg.set_debug(True, force_general_solver=(general is True), legacy_solver=(general == "legacy"))
+    reg.set_debug(True, force_general_solver=(general is True), legacy_solver=(general == "legacy"), no_solver_groups=(general == "single"))
     set_params(reg, 10, 20, force)
     reg.m_pose_w_last = sc.pose_init.copy()
     reg.m_pose_w_curr = sc.pose_init.copy()
@@ -171,6 +172,36 @@ def test_batch_pipeline_equals_single_calls(dev_map, small_world, scans):
     res2, pc2, _, _ = reg.solve_batch(dev_map, [f[0] for f in feats], [f[1] for f in feats], init, init)
     assert np.array_equal(res, res2) and np.allclose(pc, pc2, atol=1e-12)
     fe.close(); reg.close()
+
+
+def test_grouped_and_single_workgroup_solver_agree_across_batch_sizes(dev_map, small_world, scans):
+    """Batches of up to 16 scans give every scan a group of 8 solver workgroups (partial sums exchanged through memory),
+    larger ones a single workgroup.  The grouping of the floating-point sums differs, nothing else: same iteration and block
+    counts, poses equal to rounding, and inside one form a scan's answer does not depend on its slot or on the batch size."""
+    feats = [oracle_features(sc)[4:] for sc in scans]
+    def run(n, groups=True):
+        reg = Point_cloud_registration(max_scans=n, max_features=24000)
+        reg.set_debug(False, no_solver_groups=not groups)
+        set_params(reg, 10, 20, 1)
+        pl = np.stack([scans[i % len(scans)].pose_init for i in range(n)])
+        out = reg.solve_batch(dev_map, [feats[i % len(scans)][0] for i in range(n)], [feats[i % len(scans)][1] for i in range(n)], pl, pl)
+        reg.close()
+        return out
+    r16, p16, _, rep16 = run(16)            # grouped: 128 workgroups
+    r17, p17, _, rep17 = run(17)            # one workgroup per scan
+    r1, p1, _, rep1 = run(1)                # grouped, a single group
+    r1s, p1s, _, rep1s = run(1, False)      # one workgroup
+    assert list(r16) == [1] * 16 and list(r17) == [1] * 17
+    assert np.array_equal(p16[0], p1[0]) and np.array_equal(p16[0], p16[len(scans)])       # same form: bit-identical
+    assert np.array_equal(p17[0], p1s[0]) and np.array_equal(p17[0], p17[len(scans)])
+    for a, b_ in ((p16[:16], p17[:16]),):
+        for i in range(16):
+            dt, dr = synth.pose_error(a[i], b_[i])
+            assert dt < 1e-9 and dr < 1e-9
+    for i in range(16):
+        assert (rep16[i].lm_iterations_total, rep16[i].n_blocks_last, rep16[i].icp_iterations) == \
+               (rep17[i].lm_iterations_total, rep17[i].n_blocks_last, rep17[i].icp_iterations)
+    assert np.all(np.isfinite(p16)) and np.all(np.isfinite(p1))
 
 
 @pytest.mark.parametrize("mode", ["no_reuse", "reuse_from_iter1"])
