@@ -845,8 +845,10 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         r->rc.knn_reuse = 0;  // skipped features change from iteration to iteration: every iteration searches
     // Small batches leave most of the chip idle with one workgroup per scan: spread each scan's cost evaluations over a
     // group of LL_GRP workgroups (ll_reg_kernels.hip, group_*).  Compact scans only; the others run on the group's first.
+    // A scan whose records (nearly) fit one CU's LDS cache gains nothing from it and pays ~3.5 us per exchange: voxel-filtered
+    // clouds of a few thousand features (the mapping loop, Q-pipe) stay on one workgroup.
     r->rc.solve_group = (r->rc.solve_group == 1 || n_scans > LL_GRP_MAX_SCANS || r->rc.if_motion_deblur || r->rc.force_general ||
-                         r->rc.solver_legacy) ? 1 : LL_GRP;
+                         r->rc.solver_legacy || max_nc + max_ns < LL_GRP_MIN_BLOCKS) ? 1 : LL_GRP;
     if (run) {
         if (!mk0.pts || !mk1.pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
         HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));

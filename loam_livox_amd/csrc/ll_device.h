@@ -12,6 +12,7 @@ namespace ll {
 
 #define LL_MAX_PIECES 8
 #define LL_GRP 8             // workgroups per scan of the grouped solver
+#define LL_GRP_MIN_BLOCKS 6000  // ... whose largest scan has at least this many features (below, one CU's LDS cache holds most of a scan)
 #define LL_GRP_MAX_SCANS 16  // batches up to this size use it (LL_GRP * LL_GRP_MAX_SCANS workgroups stay below the CU count)
 
 struct FeScanInfo {

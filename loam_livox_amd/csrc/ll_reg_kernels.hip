@@ -435,7 +435,7 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
 // ICP iteration >= 2: exact search of the dense search list followed at once by the block constants of the same slot
 // (the lane still holds the neighbours), then the block constants of the re-sorted slots.  Grid-stride over the lists.
 #define RL_THREADS 128
-#define RL_BLOCKS 2048
+#define RL_BLOCKS 2048  // x 128 threads; 4096 (every wavefront slot at 64 VGPRs) measured the same, the lists are bound by dependent misses
 #define RL_MAX_SEG 2048  // scan-and-kind segments of one offsets table (max_scans <= 1024); larger batches run in slices
 // exclusive prefix sums of the per-segment list lengths (segment = scan * 2 + kind) -> work_off[list][0 .. n_seg]; one workgroup
 __global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int seg0, int n_seg)
