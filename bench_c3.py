@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench_c3.py -- BASELINE config C3 data point (not the driver's bench.py contract): Mid-100 = three Mid-40 heads
 (3 x 24 000 points, yaw -38.4 / 0 / +38.4 deg) taken from a MOVING sensor, registered with motion-distortion
-compensation (if_motion_deblur = 1, the *_mb residuals) against a 20 M-point map.  Features of the three heads are
-extracted on the GPU per head and merged (laser_feature_extractor.hpp:348-358); the merged scan has > 24 576 residual
-blocks, so the registrar takes its general (HBM-resident) solver path.  Prints one JSON line."""
+compensation (if_motion_deblur = 1, the *_mb residuals) against a 20 M-point map.  The timed step is extract + register:
+the 3 B raw head scans are resident in HBM, every step extracts their features (one extractor batch of 3 B slots, every
+head its own time base), merges the three heads of a sweep on the device (ll_reg_enqueue_fe_merged,
+laser_feature_extractor.hpp:348-358) and registers; the merged scan has > 24 576 residual blocks, so the registrar takes
+its general (HBM-resident) solver path.  --features-resident times the registration alone on pre-merged clouds (the
+round-1 figure).  Prints one JSON line."""
 from __future__ import annotations
 
 import argparse
@@ -27,6 +30,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--cpu-scans", type=int, default=1)
+    ap.add_argument("--features-resident", action="store_true", help="time the registration only, merged feature clouds uploaded once (round-1 mode)")
     ap.add_argument("--no-deblur", action="store_true", help="A/B: register the same scans without the motion-deblur residuals")
     args = ap.parse_args()
     from loam_livox_amd import synth
@@ -35,7 +39,7 @@ def main():
     world, corner, surf = synth.make_maps(args.map_points)
     N, B = 24000, args.batch
     fe = Livox_laser(max_points=N, piecewise_number=1)
-    merged = []
+    merged, raw = [], []
     for k in range(args.distinct):
         rng = np.random.default_rng(7000 + k)
         pose_start = synth.sensor_pose_in_world(world, rng)
@@ -48,6 +52,7 @@ def main():
             fe2.extract_batch(1); fe2.resolve()
             g = fe2.get_features(0.0, 1.0)
             cs.append(g["pc_corners"]); ss.append(g["pc_surface"])
+            raw.append(sc.xyzi)
             fe2.close()
         merged.append((np.concatenate(cs), np.concatenate(ss), pose_start, synth.pose_compose(pose_start, inc)))
     corners = [merged[b % args.distinct][0] for b in range(B)]
@@ -68,27 +73,42 @@ def main():
     p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
     p.maximum_allow_residual_block = 3 * N
     reg.set_profiling(True)
-    # the merged feature clouds are uploaded once: the timed region starts with its inputs resident in HBM, like bench.py
     t0 = time.perf_counter()
-    reg.upload_features(corners, surfs)
+    if args.features_resident:
+        # the merged feature clouds are uploaded once: the timed region starts with them resident in HBM
+        reg.upload_features(corners, surfs)
+        def step():
+            reg.enqueue_uploaded(mp, B, pose_last, pose_last)
+    else:
+        # the raw head scans are uploaded once; every step extracts, merges the heads on the device and registers
+        feb = Livox_laser(max_points=N, max_scans=3 * B, piecewise_number=1)
+        feb.upload(np.stack([raw[3 * (b % args.distinct) + h] for b in range(B) for h in range(3)]), np.zeros(3 * B))
+        def step():
+            feb.extract_batch(3 * B)
+            feb.resolve()
+            feb.select_batch(3 * B, -1, 0.0, 1.0)
+            reg.enqueue_fe_merged(mp, feb, B, 3, pose_last, pose_last)
+    if not args.features_resident:
+        feb.sync()
     t_upload = time.perf_counter() - t0
     for _ in range(args.warmup):
-        reg.enqueue_uploaded(mp, B, pose_last, pose_last)
+        step()
         reg.collect(B)
     t0 = time.perf_counter()
     kms = np.zeros(3)
     for _ in range(args.steps):
-        reg.enqueue_uploaded(mp, B, pose_last, pose_last)
+        step()
         res, pc, pi, reps = reg.collect(B)
         kms += reg.kernel_times()[0]
     el = time.perf_counter() - t0
     err = [synth.pose_error(pc[b], pose_true[b]) for b in range(B)]
-    out = {"metric": "scans_per_s", "value": round(B * args.steps / el, 2), "unit": "Mid-100 scans/s (registration with deblur; merged feature clouds resident in HBM, their one-off upload is reported as feature_upload_s)",
+    out = {"metric": "scans_per_s", "value": round(B * args.steps / el, 2), "unit": ("Mid-100 scans/s (registration with deblur; merged feature clouds resident in HBM, their one-off upload is reported as feature_upload_s)"
+                    if args.features_resident else "Mid-100 scans/s (extract 3 heads + merge on the device + register with deblur; raw scans resident in HBM)"),
            "config": {"workload": "C3: 3x24k-pt Mid-100 scan from a moving sensor vs 20M-pt map, if_motion_deblur=1, 10 ICP iters (fixed)",
                       "map_points": int(len(corner) + len(surf)), "batch": B, "features_per_scan": {"corner": float(np.mean([len(c) for c in corners])), "surface": float(np.mean([len(s) for s in surfs]))}},
            "ms_per_step": round(1e3 * el / args.steps, 2), "kernel_ms_per_step": {"knn+build": round(float(kms[0] / args.steps), 2), "solver": round(float(kms[1] / args.steps), 2)},
            "accepted_frac": float(np.mean(res)), "median_err_vs_truth_m": float(np.median([e[0] for e in err])), "median_err_vs_truth_rad": float(np.median([e[1] for e in err])),
-           "blocks_last": float(np.mean([r.n_blocks_last for r in reps])), "map_upload_grid_build_s": round(t_map, 2), "feature_upload_s": round(t_upload, 3)}
+           "blocks_last": float(np.mean([r.n_blocks_last for r in reps])), "map_upload_grid_build_s": round(t_map, 2), "feature_upload_s" if args.features_resident else "scan_upload_s": round(t_upload, 3)}
     if args.cpu_scans > 0:
         from oracle import orc
         tb = time.perf_counter()

@@ -225,6 +225,13 @@ int ll_reg_solve_batch(ll_reg *r, const ll_map *map, int32_t n_scans, const floa
 
 /* Asynchronous halves of ll_reg_solve_batch_fe for benchmarking with inputs resident in HBM:
  * _enqueue uploads only the poses (n_scans*7 doubles) and launches; _collect synchronises and downloads. */
+/* Mid-100 / multi-lidar form (laser_feature_extractor.hpp:348-358: the clouds of all lidars are concatenated before they are
+ * published): registrar scan b is the concatenation, in head order, of the selected features of extractor slots
+ * b * heads ... b * heads + heads - 1 (corner clouds together, surface clouds together), merged device to device.  Every
+ * head keeps its own time base (its slot's stamp); n_scans * heads <= the extractor's max_scans, the merged counts must fit
+ * the registrar's max_features.  Followed by ll_reg_collect like the other _enqueue forms. */
+int ll_reg_enqueue_fe_merged(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, int32_t heads, const ll_reg_params *prm,
+                             const double *poses_last, const double *poses_curr, const double *poses_incre);
 int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
                       const double *poses_last, const double *poses_curr, const double *poses_incre);
 int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, double *poses_incre, ll_reg_report *reports,

@@ -514,6 +514,14 @@ class Point_cloud_registration:
         check(self.L.ll_reg_enqueue_fe(self.h, map_buffer.h, fe.h, n_scans, C.byref(self.params), ptr(pl), ptr(pc), None),
               "ll_reg_enqueue_fe")
 
+    def enqueue_fe_merged(self, map_buffer: Map_buffer, fe: Livox_laser, n_scans: int, heads: int, poses_last, poses_curr):
+        """Mid-100 (laser_feature_extractor.hpp:348-358): registrar scan b = the selected features of extractor slots
+        b * heads ... b * heads + heads - 1, concatenated on the device (corner clouds together, surface clouds together)."""
+        pl = np.ascontiguousarray(poses_last, np.float64).reshape(n_scans, 7)
+        pc = np.ascontiguousarray(poses_curr, np.float64).reshape(n_scans, 7)
+        check(self.L.ll_reg_enqueue_fe_merged(self.h, map_buffer.h, fe.h, n_scans, int(heads), C.byref(self.params), ptr(pl), ptr(pc), None),
+              "ll_reg_enqueue_fe_merged")
+
     def enqueue_fe_downsampled(self, map_buffer: Map_buffer, fe: Livox_laser, vox_corner: "VoxelGrid", vox_surf: "VoxelGrid",
                                line_res: float, plane_res: float, n_scans: int, poses_last, poses_curr):
         """m_if_input_downsample_mode (laser_mapping.hpp:1367-1373): voxel-filter the selected features on the device, then

@@ -79,6 +79,7 @@ SYMBOLS = {
     "ll_reg_upload_features": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32]),
     "ll_reg_enqueue_uploaded": (_i32, [_vp, _vp, _i32, C.POINTER(RegParams), _vp, _vp, _vp]),
     "ll_reg_enqueue_fe": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(RegParams), _vp, _vp, _vp]),
+    "ll_reg_enqueue_fe_merged": (_i32, [_vp, _vp, _vp, _i32, _i32, C.POINTER(RegParams), _vp, _vp, _vp]),
     "ll_reg_collect": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ll_reg_debug_knn": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ll_reg_set_debug": (_i32, [_vp, _i32]),

@@ -1658,6 +1658,31 @@ extern "C" int ll_reg_upload_features(ll_reg *r, int32_t n_scans, const float *c
     return 0;
 }
 
+extern "C" int ll_reg_enqueue_fe_merged(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, int32_t heads, const ll_reg_params *prm,
+                                        const double *poses_last, const double *poses_curr, const double *poses_incre)
+{
+    if (!r || !fe) return set_err("ll_reg_enqueue_fe_merged", "null handle");
+    if (fe->prm.device != r->device) return set_err("ll_reg_enqueue_fe_merged", "extractor lives on another device");
+    if (heads < 1 || n_scans < 1 || n_scans > r->max_scans || (int64_t)n_scans * heads > fe->prm.max_scans)
+        return set_err("ll_reg_enqueue_fe_merged", "n_scans * heads exceeds the extractor capacity (or n_scans the registrar's)");
+    HC(hipSetDevice(r->device));
+    HC(hipEventRecord(r->ev_wait, fe->stream));
+    HC(hipStreamWaitEvent(r->stream, r->ev_wait, 0));
+    const int F = r->max_feat;
+    launch_reg_merge_heads(fe->dev.corner_feat, fe->dev.surf_feat, fe->dev.n_corner, fe->dev.n_surf, fe->dev.stride, heads, r->d_corner, r->d_surf,
+                           r->d_nc, r->d_ns, F, n_scans, r->stream);
+    HC(hipGetLastError());
+    r->uploaded_scans = n_scans;
+    r->dev.corner_feat = r->d_corner;
+    r->dev.surf_feat = r->d_surf;
+    r->dev.n_corner = r->d_nc;
+    r->dev.n_surf = r->d_ns;
+    r->dev.feat_stride_c = F;
+    r->dev.feat_stride_s = F;
+    // a merged cloud larger than the registrar's capacity shows in the counts: reg_enqueue refuses it
+    return reg_enqueue(r, map, n_scans, prm, poses_last, poses_curr, poses_incre);
+}
+
 extern "C" int ll_reg_enqueue_uploaded(ll_reg *r, const ll_map *map, int32_t n_scans, const ll_reg_params *prm, const double *poses_last,
                                        const double *poses_curr, const double *poses_incre)
 {

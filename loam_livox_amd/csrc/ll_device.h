@@ -159,5 +159,7 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);
+void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride, int heads,
+                            float4 *dst_corner, float4 *dst_surf, int *dst_nc, int *dst_ns, int dst_stride, int n_scans, hipStream_t s);
 
 }  // namespace ll

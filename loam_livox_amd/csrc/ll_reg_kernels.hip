@@ -2231,6 +2231,33 @@ void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipS
 {
     hipLaunchKernelGGL(reg_finalize_kernel, dim3((n_scans + 63) / 64), dim3(64), 0, s, rd, rc, n_scans);
 }
+// Mid-100: the selected features of `heads` consecutive extractor slots (the lidars of one sweep) become ONE registrar scan,
+// corner clouds and surface clouds each concatenated in head order (laser_feature_extractor.hpp:348-358), device to device.
+// grid (chunks of the extractor stride, n_scans * heads, 2 kinds).  Points beyond the registrar's capacity are not written;
+// the counts are, so the host sees the overflow.
+__global__ void reg_merge_heads_kernel(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride,
+                                       int heads, float4 *dst_corner, float4 *dst_surf, int *dst_nc, int *dst_ns, int dst_stride)
+{
+    const int slot = blockIdx.y, kind = blockIdx.z;
+    const int b = slot / heads, h = slot - b * heads;
+    const int *cnt = kind ? fe_ns : fe_nc;
+    int off = 0;
+    for (int k = 0; k < h; k++) off += cnt[b * heads + k];
+    const int n = cnt[slot];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && off + i < dst_stride) {
+        const float4 *src = (kind ? fe_surf : fe_corner) + (size_t)slot * fe_stride;
+        float4 *dst = (kind ? dst_surf : dst_corner) + (size_t)b * dst_stride;
+        dst[off + i] = src[i];
+    }
+    if (i == 0 && h == heads - 1) (kind ? dst_ns : dst_nc)[b] = off + n;
+}
+void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride, int heads,
+                            float4 *dst_corner, float4 *dst_surf, int *dst_nc, int *dst_ns, int dst_stride, int n_scans, hipStream_t s)
+{
+    hipLaunchKernelGGL(reg_merge_heads_kernel, dim3((fe_stride + 255) / 256, n_scans * heads, 2), dim3(256), 0, s, fe_corner, fe_surf, fe_nc,
+                       fe_ns, fe_stride, heads, dst_corner, dst_surf, dst_nc, dst_ns, dst_stride);
+}
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s)
 {
     if (n <= 0) return;

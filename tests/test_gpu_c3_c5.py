@@ -91,6 +91,61 @@ def test_c3_mid100_deblur_20m_map_matches_oracle(c3):
         assert et < 0.05 and er < 0.02
 
 
+def test_c3_heads_merged_on_the_device_equal_the_host_merge(c3):
+    """ll_reg_enqueue_fe_merged: the three heads of a sweep extracted as three slots of one batch and concatenated on the
+    device give bit for bit the registration of the host-side concatenation (laser_feature_extractor.hpp:348-358)."""
+    sweeps = [mid100(c3["world"], k) for k in range(2)]
+    B, H = len(sweeps), 3
+    fe = Livox_laser(max_points=N, max_scans=B * H, piecewise_number=1)
+    fe.upload(np.stack([h.xyzi for heads, _, _ in sweeps for h in heads]), np.zeros(B * H))  # every head its own time base
+    fe.extract_batch(B * H); fe.resolve(); fe.select_batch(B * H, -1, 0.0, 1.0)
+    nc, ns, _, _ = fe.counts(B * H)
+    pose_last = np.stack([s[1] for s in sweeps])
+    def registrar():
+        reg = Point_cloud_registration(max_scans=B, max_features=3 * N)
+        p = reg.params
+        p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = 1, 0.0, T_MAX
+        p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = 6, 20, 1
+        p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
+        p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+        p.maximum_allow_residual_block = 3 * N
+        return reg
+    reg = registrar()
+    reg.enqueue_fe_merged(c3["map"], fe, B, H, pose_last, pose_last)
+    res_d, pc_d, _, rep_d = reg.collect(B)
+    reg.close()
+    # host merge of per-head feature clouds taken from single-scan extractions
+    corners, surfs = [], []
+    for heads, _, _ in sweeps:
+        cs, ss = [], []
+        for sc in heads:
+            fe2 = Livox_laser(max_points=N, piecewise_number=1)
+            fe2.upload(sc.xyzi[None], np.array([0.0]))
+            fe2.extract_batch(1); fe2.resolve()
+            g = fe2.get_features(0.0, 1.0)
+            cs.append(g["pc_corners"]); ss.append(g["pc_surface"])
+            fe2.close()
+        corners.append(np.concatenate(cs)); surfs.append(np.concatenate(ss))
+    assert [len(c) for c in corners] == [int(nc[b * H:(b + 1) * H].sum()) for b in range(B)]
+    assert [len(s_) for s_ in surfs] == [int(ns[b * H:(b + 1) * H].sum()) for b in range(B)]
+    reg = registrar()
+    reg.upload_features(corners, surfs)
+    reg.enqueue_uploaded(c3["map"], B, pose_last, pose_last)
+    res_h, pc_h, _, rep_h = reg.collect(B)
+    reg.close(); fe.close()
+    assert list(res_d) == list(res_h) == [1] * B and np.array_equal(pc_d, pc_h)
+    assert [(r.n_blocks_last, r.lm_iterations_total) for r in rep_d] == [(r.n_blocks_last, r.lm_iterations_total) for r in rep_h]
+    # too many merged features for the registrar: refused, not truncated
+    small = Point_cloud_registration(max_scans=B, max_features=N)
+    small.params.maximum_allow_residual_block = 3 * N
+    fe3 = Livox_laser(max_points=N, max_scans=B * H, piecewise_number=1)
+    fe3.upload(np.stack([h.xyzi for heads, _, _ in sweeps for h in heads]), np.zeros(B * H))
+    fe3.extract_batch(B * H); fe3.resolve(); fe3.select_batch(B * H, -1, 0.0, 1.0)
+    with pytest.raises(RuntimeError):
+        small.enqueue_fe_merged(c3["map"], fe3, B, H, pose_last, pose_last)
+    small.close(); fe3.close()
+
+
 # ----------------------------------------------------------------------------------------------------------- C5
 @pytest.fixture(scope="module")
 def c5(gpu_lib):
