@@ -660,7 +660,6 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.work_search, B * d.cap);
     DM(d.work_build, B * d.cap);
     d.n_chunks = (int)((F + 255) / 256);  // must match RQ_THREADS in ll_reg_kernels.hip
-    DM(d.work_n, B * 4 * (size_t)d.n_chunks);
     DM(d.work_cnt, B * 4);
     DM(d.work_off, 2 * 2049);  // 2 lists x (RL_MAX_SEG + 1), ll_reg_kernels.hip
     DM(d.grp_ctl, B + 1);
@@ -700,7 +699,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_n, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -851,7 +850,6 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
                          r->rc.solver_legacy || max_nc + max_ns < LL_GRP_MIN_BLOCKS) ? 1 : LL_GRP;
     if (run) {
         if (!mk0.pts || !mk1.pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
-        HC(hipMemsetAsync(r->dev.work_n, 0, (size_t)n_scans * 4 * r->dev.n_chunks * sizeof(int), r->stream));
         for (int it = 0; it < prm->icp_max_iterations; it++) {
             prof_begin(r, 0);
             launch_reg_knn_build(r->dev, r->rc, mk0.grid, mk1.grid, n_scans, it, max_nc, max_ns, r->stream);

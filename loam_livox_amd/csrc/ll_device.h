@@ -138,12 +138,11 @@ struct RegDev {
     unsigned char *blk_flag0;     // [B][cap]  block flag as built; the solver prunes a copy (LDS, or blk_flag in the general path)
     int *work_search;             // [B][cap]  slots that need a full search this iteration
     int *work_build;              // [B][cap]  slots that were re-sorted (block must be rebuilt)
-    int *work_n;                  // [B][2 kinds][n_chunks][2] per-chunk list lengths (search, re-sorted)
     int *work_off;                // [2][2 B + 1] exclusive prefix sums of work_cnt per list (reg_list_offsets_kernel)
     int *work_cnt;                // [B][2 kinds][2] lengths of this ICP iteration's work lists (search, re-sorted) per scan and kind:
                                   // work_search / work_build hold (scan * cap + slot) entries, dense inside the scan-and-kind's own
                                   // segment [scan * cap + kind * cap_c, ...); one atomic per re-query workgroup and list reserves a range
-    int n_chunks;                 // chunks of 1024 queries per (scan, kind)
+    int n_chunks;                 // chunks of 256 queries (RQ_THREADS) per (scan, kind): the re-query kernel's grid
     int4 *nn;                     // [B][cap]  neighbour positions (cell-sorted order) + found flag (K6a -> K6b)
     unsigned char *blk_flag;      // [B][cap]  BLK_* bits
     double *blk_l1;               // [B][cap]  scratch for the inlier threshold
