@@ -1,19 +1,28 @@
 // ll_reg_kernels.hip -- HIP kernels (gfx950, wave64) of the scan-to-map registrar.
 //
-//   K6  reg_knn_kernel + reg_build_kernel : per query: transform with the current pose (pointAssociateToMap,
-//                              point_cloud_registration.hpp:622-661), exact 5-NN on the cell grid
-//                              (:249,351), match-radius tests (:254,353), line / plane block constants
+//   K6  reg_transform_kernel, reg_knn_kernel, reg_build_kernel (ICP iterations 0 and 1): per query: transform with the
+//                              current pose (pointAssociateToMap, point_cloud_registration.hpp:622-661), exact 5-NN on
+//                              the cell grid (:249,351), match-radius tests (:254,353), line / plane block constants
 //                              (:300-323, :416-423; ceres_icp.hpp:255-256, 328-334)
-//   K8/K9 reg_solve_kernel   : ONE workgroup per scan runs what the reference does between :460 and :531:
+//       reg_requery_kernel, reg_list_offsets_kernel, reg_list_kernel (ICP iteration >= 2): exact neighbour reuse -- every
+//                              query is classified against two displacement budgets (ll_knn_core.h), the few that need a
+//                              new search or a re-sort go to dense per-(scan, kind) work lists, one fused kernel searches /
+//                              re-sorts them and rebuilds their blocks
+//   K8/K9 reg_solve_kernel   : ONE workgroup per scan (a group of LL_GRP workgroups per scan for batches of <= 16 scans,
+//                              group_barrier / group_reduce below) runs what the reference does between :460 and :531:
 //                              the 2-iteration prerun solve, the loss-corrected L1 evaluation, the
 //                              std::set-deduplicated 80-th percentile inlier threshold (:153-161), the prune,
 //                              the final solve and the pose composition -- replacing ceres::Solve /
 //                              Problem::Evaluate by a 28-value (21 H + 6 g + 1 cost) workgroup reduction and a
 //                              Levenberg-Marquardt controller on lane 0.  No host round trip per iteration.
+//                              Three forms: solve_fast2 (packed 48-byte plane records, LDS record cache; every C2 scan),
+//                              solve_fast (round-1 layout, A/B switch), solve_general (> 24 576 blocks or motion deblur:
+//                              flags and L1 values in HBM)
 //        reg_finalize_kernel : accept / reject (:559-573)
+//        reg_merge_heads_kernel : Mid-100, the feature clouds of a sweep's heads concatenated on the device
 //
-// No MFMA: 6x6 systems are reduced, not multiplied.  Blocks live in HBM as SoA planes (64 B + 1 flag per
-// block), read coalesced once per cost evaluation.
+// No MFMA: 6x6 systems are reduced, not multiplied.  Plane blocks live in HBM as three 16-byte planes (48 B + 1 flag per
+// block), line blocks as 65 B; every cost evaluation streams the part of them that does not fit the LDS record cache.
 #include <hip/hip_runtime.h>
 
 #include "ll_device.h"
