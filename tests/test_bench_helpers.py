@@ -1,0 +1,49 @@
+"""CPU tier: the pieces of bench.py and tools/ that turn committed rocprofv3 summaries into the numbers of the bench line --
+a format drift in profiles/ must fail here, not silently null the `roofline` fields on the GPU box."""
+import csv
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_bench_reads_the_committed_counter_summaries():
+    import bench
+    traffic, src = bench.pmc_traffic_bytes("reg_solve_kernel", 256)
+    assert src and src.startswith("profiles/r") and os.path.exists(os.path.join(ROOT, src))
+    assert 0.2e9 < traffic < 5e9  # bytes per B = 256 solver launch: above the 0.21 GB of block records, far below a TB
+    assert bench.pmc_traffic_bytes("reg_solve_kernel", 8) == (None, None)  # measured at batch 256 only
+    vf = bench.pmc_valu_fp64("reg_solve_kernel", 256)
+    assert vf and vf["source"].startswith("profiles/r") and vf["fp64_wave_instructions"] < vf["valu_wave_instructions"]
+    assert 1e9 < vf["flops"] < 1e11
+    assert bench.pmc_valu_fp64("no_such_kernel", 256) is None
+    # the newest summary wins (round tags sort lexicographically)
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.csv")))[-1]
+    assert os.path.relpath(newest, ROOT) == src
+
+
+def test_summarize_rocprof_generic_and_trace(tmp_path):
+    tool = os.path.join(ROOT, "tools", "summarize_rocprof.py")
+    pmc = tmp_path / "counter_collection.csv"
+    with open(pmc, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
+        for v in (10.0, 30.0):
+            w.writerow(["void ll::reg_solve_kernel<0>(ll::RegDev, ll::RegConst)", 131072, "SQ_INSTS_VALU", v])
+        w.writerow(["void ll::reg_solve_kernel<0>(ll::RegDev, ll::RegConst)", 512, "SQ_INSTS_VALU", 7.0])
+        w.writerow(["void other::kernel()", 64, "SQ_INSTS_VALU", 99.0])
+    out = subprocess.run([sys.executable, tool, "generic", str(pmc)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert out[0] == "kernel,grid_threads,dispatches,SQ_INSTS_VALU_avg"
+    assert out[1] == "ll::reg_solve_kernel<0>,131072,2,20.0" and out[2] == "ll::reg_solve_kernel<0>,512,1,7.0" and len(out) == 3
+    trace = tmp_path / "kernel_trace.csv"
+    with open(trace, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z", "Workgroup_Size_X", "VGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                    "Start_Timestamp", "End_Timestamp"])
+        w.writerow(["void ll::reg_knn_kernel(ll::RegDev)", 1024, 2, 1, 128, 56, 0, 0, 1000, 3000])
+        w.writerow(["void ll::reg_knn_kernel(ll::RegDev)", 1024, 2, 1, 128, 56, 0, 0, 5000, 9000])
+    out = subprocess.run([sys.executable, tool, "trace", str(trace)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert out[1] == "ll::reg_knn_kernel,2048,128,56,0,0,2,0.006,3.0,2.0,4.0"
