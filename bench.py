@@ -56,6 +56,7 @@ def parse():
                     "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
     ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
     ap.add_argument("--legacy-solver", action="store_true", help="A/B: round-1 solver fast path (49-byte fp64 plane blocks, no LDS block cache)")
+    ap.add_argument("--packed48-solver", action="store_true", help="A/B: round-2 compact solver path (48-byte packed plane records) instead of the plane table")
     ap.add_argument("--no-solver-groups", action="store_true", help="A/B for the single-scan latency figure: one solver workgroup per scan "
                     "even for small batches (default: batches of <= 16 scans spread every scan over 8 workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,8 +172,8 @@ def main():
     p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
     p.maximum_allow_residual_block = N
     reg.set_profiling(True)
-    if args.force_general or args.legacy_solver:
-        reg.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver)
+    if args.force_general or args.legacy_solver or args.packed48_solver:
+        reg.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver, packed48_solver=args.packed48_solver)
 
     vox = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
 

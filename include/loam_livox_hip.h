@@ -416,9 +416,10 @@ int ll_reg_kernel_times(ll_reg *r, float ms[3], int32_t launches[3]);
 
 /* Builds compiled with -DLL_SOLVE_TIMING accumulate shader-clock counts per solver phase of scan slot `scan`:
  * [0] cost evaluations, [1] LM controller, [2] L1 pass, [3] de-duplication, [4] rank select, [5] total, [6] flag census,
- * [7] prune, [8] epilogue; [9] counts how often the L1 pass took the values its last prerun evaluation had left behind.
- * Zeros in normal builds. */
-int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[10]);
+ * [7] prune, [8] epilogue (plane-table path: table build); [9] counts how often the L1 pass took the values its last prerun
+ * evaluation had left behind; plane-table path: [10] census load waits, [11] triple inserts, [12] block sums, [13] id compaction,
+ * [14] plane constants, [15] id pass + LDS fill.  Zeros in normal builds. */
+int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[16]);
 
 /* Lengths of the neighbour-reuse work lists left by the last ICP iteration of the last solve, summed over the first
  * n_scans slots: out[0] / out[1] = corner queries that needed a full search / whose five neighbours were re-sorted,

@@ -650,6 +650,12 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.blk_pa, B * d.cap_s);
     DM(d.blk_pb, B * d.cap_s);
     DM(d.blk_pc, B * d.cap_s);
+    DM(d.blk_id, B * d.cap_s);
+    {
+        const int lim = d.cap_s < 24576 ? d.cap_s : 24576;  // FAST_MAX_BLOCKS: larger scans never take the plane-table path
+        d.tab_cap = (lim + 4095) / 4096 * 4096;
+    }
+    DM(d.pl_tab, B * (size_t)d.tab_cap * 2);
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
     DM(d.qw, B * d.cap);
@@ -699,7 +705,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -750,6 +756,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->knn_reuse_from = (debug & 8) ? 1 : 2;  // bit 3: also try reuse at ICP iteration 1 (test coverage)
     c->solver_legacy = (debug & 16) ? 1 : 0;  // bit 4: round-1 solver fast path (A/B)
     c->solve_group = (debug & 32) ? 1 : 0;    // bit 5: never spread a scan over a group of workgroups (A/B); 0 = decide per batch size
+    c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)
@@ -856,7 +863,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
             prof_end(r);
             prof_begin(r, 1);
             if (r->rc.solve_group > 1) HC(hipMemsetAsync(r->dev.grp_ctl, 0, (size_t)(n_scans + 1) * sizeof(int), r->stream));
-            launch_reg_solve(r->dev, r->rc, n_scans, r->stream);
+            launch_reg_solve(r->dev, r->rc, mk1.grid, n_scans, r->stream);
             prof_end(r);
         }
     }
@@ -916,10 +923,10 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
     return 0;
 }
 
-extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[10])
+extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[16])
 {
     if (!r || scan < 0 || scan >= r->max_scans) return set_err("ll_reg_debug_cycles", "bad argument");
-    for (int i = 0; i < 10; i++) out[i] = r->h_state[scan].dbg_cycles[i];
+    for (int i = 0; i < 16; i++) out[i] = r->h_state[scan].dbg_cycles[i];
     return 0;
 }
 

@@ -95,7 +95,9 @@ struct RegState {
     int icp_iters, n_blocks_last, corner_avail, surf_avail, lm_total;
     int done, accepted, gated, result;
     int pad;
-    long long dbg_cycles[10];  // LL_SOLVE_TIMING builds (shader clocks): eval, LM controller, L1, dedupe, select, total, census, prune, epilogue; [9] = L1 shortcuts taken
+    long long dbg_cycles[16];  // LL_SOLVE_TIMING builds (shader clocks): eval, LM controller, L1, dedupe, select, total, census (+ triple inserts), prune,
+                               // epilogue (plane-table path: table build), [9] = exchanges / L1 shortcuts taken; plane-table path: [10] census load waits,
+                               // [11] inserts, [12] block sums, [13] id compaction, [14] plane constants, [15] id pass + LDS fill
 };
 
 struct RegConst {
@@ -107,6 +109,7 @@ struct RegConst {
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
     int solver_legacy;   // A/B switch: round-1 fast path (49-byte fp64 plane blocks, no LDS block cache)
     int solve_group;     // workgroups per scan of the compact solver (1, or LL_GRP for small batches: ll_reg_kernels.hip, group_*)
+    int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     unsigned int subsample_seed;  // a13 (0 = off)
     int max_blocks;               // maximum_allow_residual_block
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
@@ -129,6 +132,11 @@ struct RegDev {
     int4 *blk_pa, *blk_pb, *blk_pc;  // [B][cap_s] packed plane blocks of the round-2 fast path, 48 B in three coalesced 16-byte planes:
                                   // pa = {bits f.x, f.y, f.z, 0} (fp32, sensor frame), pb = {n'.x, n'.y} (fp64), pc = {n'.z, c = n'.a'} (fp64);
                                   // the same numbers as blk_f / blk_av hold, so every solver path computes bit-identical blocks
+    // round-3 compact path (solve_fast3): the plane constants {n', c} are stored once per DISTINCT neighbour triple of a scan
+    // (a scan's ~17 k plane blocks share 2.4 - 4.6 k triples), built by the solver itself at the start of every launch
+    unsigned short *blk_id;       // [B][cap_s] plane id of every surface block (relative to its solver workgroup's table region)
+    int4 *pl_tab;                 // [B][tab_cap][2] plane table: {n'.x, n'.y}, {n'.z, c = n'.a'} (fp64), frame of pose_last
+    int tab_cap;                  // entries per scan: min(cap_s, 24576) rounded up to 4096 (LL_GRP regions of whole 512-thread rounds)
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
@@ -155,7 +163,7 @@ struct RegDev {
 
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
                           int max_nc, int max_ns, hipStream_t s);
-void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);
 void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride, int heads,

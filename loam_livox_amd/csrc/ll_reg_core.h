@@ -181,6 +181,16 @@ LL_HD bool block_plane(const double pose_last[7], const double pa[3], const doub
     return true;
 }
 
+// the early-out of block_plane alone (same arithmetic): the plane-table solver path decides a block's flag at build time
+// and computes the plane constants once per distinct neighbour triple inside the solver
+LL_HD bool plane_degenerate(const double pa[3], const double pb[3], const double pc[3])
+{
+    const double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double ac[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+    const double nab = sqrt(dot3(ab, ab)), nac = sqrt(dot3(ac, ac));
+    return nab == 0.0 || nac == 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------- K7: PCA checks
 // Optional neighbourhood checks of point_cloud_registration.hpp:259-292 (line) and :357-389 (plane), switched by
 // IF_LINE_FEATURE_CHECK / IF_PLANE_FEATURE_CHECK (:46,48; 0 in every shipped configuration).  Covariance of the

@@ -326,12 +326,60 @@ __device__ __forceinline__ float4 gload_f4(const float4 *p)
     const ll_v4f v = *(const LL_AS_GLOBAL ll_v4f *)p;
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// x, y, z of a float4 record as a 12-byte load: with the 16-byte form the register allocator parks another in-flight value
+// in the unused w lane, and the write-after-write hazard on that register drains the load pipeline (solver_eval3)
+typedef float ll_v3f __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void gload_f3(const float4 *p, float &x, float &y, float &z)
+{
+    const ll_v3f v = *(const LL_AS_GLOBAL ll_v3f *)p;
+    x = v.x;
+    y = v.y;
+    z = v.z;
+}
 __device__ __forceinline__ double2 gload_d2(const double2 *p)
 {
     const ll_v2d v = *(const LL_AS_GLOBAL ll_v2d *)p;
     return make_double2(v.x, v.y);
 }
+// ... and through an explicit LDS (address space 3) pointer: a generic pointer into a __shared__ array that crossed a
+// function boundary becomes flat_load / flat_store / flat_atomic, which count on both wait counters
+#define LL_AS_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ int4 lds_load_i4(const int4 *p)
+{
+    const ll_v4i v = *(const LL_AS_LDS ll_v4i *)p;
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_store_i4(int4 *p, const int4 &v)
+{
+    ll_v4i w;
+    w.x = v.x;
+    w.y = v.y;
+    w.z = v.z;
+    w.w = v.w;
+    *(LL_AS_LDS ll_v4i *)p = w;
+}
 __device__ __forceinline__ void gstore_f64(double *p, double v) { *(LL_AS_GLOBAL double *)p = v; }
+__device__ __forceinline__ unsigned char gload_u8(const unsigned char *p) { return *(const LL_AS_GLOBAL unsigned char *)p; }
+__device__ __forceinline__ void gstore_u16(unsigned short *p, unsigned short v) { *(LL_AS_GLOBAL unsigned short *)p = v; }
+__device__ __forceinline__ void gstore_i4(int4 *p, const int4 &v)
+{
+    ll_v4i w;
+    w.x = v.x;
+    w.y = v.y;
+    w.z = v.z;
+    w.w = v.w;
+    *(LL_AS_GLOBAL ll_v4i *)p = w;
+}
+__device__ __forceinline__ f4 gload_pt(const f4 *p)
+{
+    const ll_v4f v = *(const LL_AS_GLOBAL ll_v4f *)p;
+    f4 o;
+    o.x = v.x;
+    o.y = v.y;
+    o.z = v.z;
+    o.w = v.w;
+    return o;
+}
 __device__ __forceinline__ double gload_f64(const double *p) { return *(const LL_AS_GLOBAL double *)p; }
 
 // Block constants of one scan (blk_av, 6 * cap doubles) as three arrays of 16-byte pairs: {a0, v0}[cap], {v1, v2}[cap] and
@@ -408,6 +456,12 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
             if (rc.icp_plane) {
                 const f4 p2 = g.pts[nn.z];
                 const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
+                if (!rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
+                    // plane-table path: only the flag is decided here; the solver computes {n', c} once per distinct
+                    // (nn0, nn2, nn4) triple from rd.nn (solve_fast3)
+                    rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
+                    return;
+                }
                 flag = block_plane(st->pose_last, pa, pb, pc, a_out, v_out) ? (BLK_PLANE | BLK_ACTIVE | 8) : BLK_NONE;
             }
         }
@@ -545,7 +599,7 @@ __global__ __launch_bounds__(RL_THREADS) void reg_list_kernel(RegDev rd, RegCons
 #endif
 
 struct SolveShared {
-    long long tcyc[10];
+    long long tcyc[16];
     LmCtl ctl;
     double red[RS_WAVES][LL_NACC];
     double sum[LL_NACC];
@@ -553,10 +607,12 @@ struct SolveShared {
     int hist[256];
     int sel_bin, sel_cnt, n_cand;
     int isum[RS_WAVES];
+    unsigned long long lsum[RS_WAVES];
     unsigned long long sel_prefix;
     int sel_rank;
     int n_active, n_corner_avail, n_surf_avail, n_unique;
     int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
+    int pt_T, pt_Tl, pt_kc, pt_priv;  // plane-table path: distinct triples, table entries in LDS, record rounds cached in LDS, private entries
     double thr;
     int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
 };
@@ -666,6 +722,20 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
         sh.sum[tid] = s;
     }
     __syncthreads();
+}
+
+// three counts (each < 2^20) in one reduction: a | b << 20 | c << 40
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, SolveShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)__shfl_down((long long)v, off);
+    if (lane == 0) sh.lsum[wave] = v;
+    __syncthreads();
+    unsigned long long s = 0;
+    for (int w = 0; w < RS_WAVES; w++) s += sh.lsum[w];
+    __syncthreads();
+    return s;
 }
 
 __device__ int block_sum_int(int v, SolveShared &sh)
@@ -2044,7 +2114,7 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
     const int totp = nSp + nC;                                        // <= FAST_MAX_BLOCKS (scan_is_compact)
     const size_t sb = (size_t)b * rd.cap;
     int4 *cA = (int4 *)s_table, *cB = cA + PC_RECS;
-    if (tid < 10) sh.tcyc[tid] = 0;
+    if (tid < 16) sh.tcyc[tid] = 0;
     __syncthreads();
     LL_T0(t_total);
     LL_T0(t_census);
@@ -2129,16 +2199,758 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
 #ifdef LL_SOLVE_TIMING
     LL_TACC(5, t_total);
     if (tid == 0)
-        for (int i = 0; i < 10; i++) st->dbg_cycles[i] += sh.tcyc[i];
+        for (int i = 0; i < 16; i++) st->dbg_cycles[i] += sh.tcyc[i];
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Round-3 compact path (scan_is_compact(), default): PLANE TABLE.  A scan's ~17 k plane blocks are built from only 2.4 - 4.6 k
+// distinct ordered (nn0, nn2, nn4) neighbour triples (the queries of a wall patch share their nearest map points), and every
+// block with the same triple carries bit-identical {n', c} -- 32 of the 48 bytes solve_fast2 re-streams on each of ~7 cost
+// evaluations.  Here the solver workgroup de-duplicates the triples itself at the start of every launch:
+//   1. census: block flags -> a 64-bit activity mask per thread (bit k <-> block tid + k * 512 in the planes / padding / lines
+//      order of solve_fast2; no flag array in LDS);
+//   2. every active plane block's triple (rd.nn) goes into an LDS hash table of 8192 16-byte slots: the key is claimed with a
+//      64-bit compare-and-swap on {p0, p1} and a 32-bit one on p2 -- whoever loses either moves on to the next slot, nobody
+//      ever waits for another lane -- and the slot index is parked in rd.blk_id;
+//   3. the occupied slots are numbered densely (prefix sum in slot order), one thread per slot gathers the three map points
+//      and computes {n', c} with block_plane() -- the arithmetic reg_build_kernel used per block -- into the scan's table in
+//      HBM (rd.pl_tab); blocks that found no slot within PT_MAX_PROBE probes get a private entry at the top of the table;
+//   4. rd.blk_id[p] <- dense id; the first PT_TCAP (4864) table entries are copied into LDS, where the hash table was;
+//   5. a cost evaluation streams 18 bytes per block (the fp32 feature point straight from the extractor's cloud + the 16-bit
+//      id) instead of 48 and reads the plane from LDS (ids beyond the LDS part: one 32-byte gather from the table in L2);
+//      whatever LDS the table leaves free caches the first records {f, id} of the scan across the evaluations of a solve.
+// Every block still evaluates exactly the numbers the other paths evaluate, in the same order: results are bit-identical to
+// solve_fast2's (one workgroup per scan) and iteration-for-iteration equal to the oracle's.
+#define PT_SLOTS 8192
+#define PT_MAX_PROBE 192
+#define PT_LDS_BYTES 155648           // s_raw of reg_solve_kernel: 152 KB
+#define PT_TCAP (PT_LDS_BYTES / 32)   // table entries that fit LDS
+#define PT_EMPTY_A 0xffffffffffffffffull
+#define PT_EMPTY_B 0xffffffffu
+#define PT_PRIVATE 0xffffu   // rd.blk_id between the two passes: no slot found, the block gets a private table entry
+#define PT_INACTIVE 0xfffeu  // ... not an active plane block
+
+struct PtSlot {
+    unsigned long long a;  // (p0 << 32) | p1
+    unsigned int b;        // p2
+    unsigned int id;       // dense plane id (after the compaction)
+};
+
+__device__ __forceinline__ unsigned short gload_u16(const unsigned short *p) { return *(const LL_AS_GLOBAL unsigned short *)p; }
+
+__device__ __forceinline__ unsigned int pt_hash(unsigned int p0, unsigned int p1, unsigned int p2)
+{
+    unsigned int h = p0 * 0x9E3779B1u;
+    h ^= h >> 15;
+    h += p1 * 0x85EBCA77u;
+    h ^= h >> 13;
+    h += p2 * 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h;
+}
+
+// slot of the triple (inserting it if new), or PT_PRIVATE.  Lock-free and wait-free per probe: a slot belongs to the first
+// {p0, p1} that lands on its `a` word AND the first p2 that lands on its `b` word; a lane that loses either race (or finds
+// another key) probes on, and every lane with the same triple walks the same probe sequence to the same slot.
+__device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned int p0, unsigned int p1, unsigned int p2)
+{
+    const unsigned long long A = ((unsigned long long)p0 << 32) | (unsigned long long)p1;
+    const unsigned int hh = pt_hash(p0, p1, p2);
+    unsigned int h = hh & (PT_SLOTS - 1);
+    // double hashing (odd step, power-of-two table: a full cycle).  A wavefront waits for its slowest lane, and with linear
+    // probing some lane of nearly every wavefront sat in one of the long clusters (2 - 3 k cycles per round of 64 inserts
+    // at 43 % load)
+    const unsigned int step = ((hh >> 13) | 1u) & (PT_SLOTS - 1);
+    for (int probe = 0; probe < PT_MAX_PROBE; probe++) {
+        // two independent relaxed reads decide the common case (four of five blocks find their triple already there); each
+        // word of a slot is written once, by an atomic, so a stale or half-claimed view only sends the lane through the
+        // compare-and-swaps.  (Not `volatile`: the memory legalizer brackets a volatile access with waits for every outstanding
+        // store, one HBM round trip per insert.)
+        unsigned long long a = __hip_atomic_load(&ht[h].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned int bb = __hip_atomic_load(&ht[h].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a == A && bb == p2) return h;
+        if (a == PT_EMPTY_A) {  // (on failure the builtin leaves the value it found in `a`)
+            if (__hip_atomic_compare_exchange_strong(&ht[h].a, &a, A, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) a = A;
+        }
+        if (a == A) {
+            if (bb == PT_EMPTY_B) {
+                if (__hip_atomic_compare_exchange_strong(&ht[h].b, &bb, p2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) bb = p2;
+            }
+            if (bb == p2) return h;
+        }
+        h = (h + step) & (PT_SLOTS - 1);
+    }
+    return PT_PRIVATE;
+}
+
+// {n', c} of one neighbour triple -> two int4 (the arithmetic of reg_build_kernel's plane blocks: block_plane)
+__device__ __forceinline__ void pt_plane(const f4 *map_pts, const double *pose_last, unsigned int i0, unsigned int i1, unsigned int i2, int4 &ob, int4 &oc)
+{
+    const f4 m0 = gload_pt(map_pts + i0), m1 = gload_pt(map_pts + i1), m2 = gload_pt(map_pts + i2);
+    const double pa[3] = {(double)m0.x, (double)m0.y, (double)m0.z};
+    const double pb[3] = {(double)m1.x, (double)m1.y, (double)m1.z};
+    const double pc[3] = {(double)m2.x, (double)m2.y, (double)m2.z};
+    double a_out[3] = {0.0, 0.0, 0.0}, v_out[3] = {0.0, 0.0, 0.0};
+    (void)block_plane(pose_last, pa, pb, pc, a_out, v_out);  // degenerate triples never reach the table (build_one clears their flag)
+    ob = make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1]));
+    oc = make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0]));
+}
+
+__device__ __forceinline__ int4 *pt_table_global(const RegDev &rd, int b, int g, bool grouped)
+{
+    return rd.pl_tab + ((size_t)b * rd.tab_cap + (grouped ? (size_t)g * (rd.tab_cap / LL_GRP) : 0)) * 2;
+}
+
+// steps 1 - 4 above: the census of all blocks and the plane table of this workgroup's share of the plane blocks.  Returns the
+// thread's activity mask.  Every loop that touches HBM keeps eight (four) independent loads in flight from clamped addresses.
+#define PT_MAP_OFF (PT_SLOTS * 16)  // byte offset in s_raw of the id -> slot map (unsigned short[PT_SLOTS]) used during the build
+template <bool GROUPED>
+__device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &rd, const RegConst &rc, const f4 *map_pts, int b, const RegState *st,
+                                                                  int nC, int nS, uint4 *s_raw, SolveShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = GROUPED ? LL_GRP : 1, GS = G * RS_THREADS;
+    const int g = GROUPED ? sh.grp_g : 0;
+    const int p0 = g * RS_THREADS + tid;
+    const int kp = (nS + GS - 1) / GS;
+    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+    const int totp = nSp + nC;
+    const size_t sb = (size_t)b * rd.cap;
+    LL_AS_LDS PtSlot *ht = (LL_AS_LDS PtSlot *)s_raw;
+    LL_AS_LDS unsigned short *slot_of_id = (LL_AS_LDS unsigned short *)((LL_AS_LDS char *)s_raw + PT_MAP_OFF);
+    LL_T0(t_census);
+    for (int e = tid; e < PT_SLOTS; e += RS_THREADS) lds_store_i4((int4 *)s_raw + e, make_int4(-1, -1, -1, -1));
+    if (tid == 0) sh.pt_priv = 0;
+    __syncthreads();
+    const int4 *nn = rd.nn + sb + rd.cap_c;
+    const unsigned char *flag0 = rd.blk_flag0 + sb;
+    unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
+    // ---- census (PCR:325,425) of all blocks + pass 1 of the own plane blocks: triples -> hash slots -----------------------
+    unsigned long long act = 0;
+    int na = 0, nca = 0, nsa = 0;
+    for (int k0 = 0; k0 * RS_THREADS < totp; k0 += 8) {
+        LL_T0(t_trip);
+        unsigned char fl8[8];
+        int4 t8[GROUPED ? 1 : 8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = tid + (k0 + u) * RS_THREADS;
+            const int jc = j < totp ? j : 0;
+            const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
+            fl8[u] = gload_u8(flag0 + src);
+            if (!GROUPED) t8[u] = gload_i4(nn + (j < nS ? j : 0));
+        }
+        if (GROUPED) {  // of eight consecutive rounds exactly one (round = g mod 8) is this member's
+            const int j = tid + (k0 + g) * RS_THREADS;
+            t8[0] = gload_i4(nn + (j < nS ? j : 0));
+        }
+        unsigned int h8[GROUPED ? 1 : 8];
+#ifdef LL_SOLVE_TIMING
+        if (fl8[0] == 255 && t8[0].x == -12345) act |= 1ull << 63;  // (forces the loads to have landed before the timer below)
+        LL_TACC(10, t_trip);
+        LL_T0(t_ins);
+#endif
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = tid + (k0 + u) * RS_THREADS;
+            const unsigned char fl = (j < totp && (j < nS || j >= nSp)) ? fl8[u] : (unsigned char)0;
+            const bool active = (fl & BLK_ACTIVE) != 0;
+            if (active) {
+                act |= 1ull << (k0 + u);
+                na++;
+            }
+            if (fl & 8) {
+                if (j >= nSp) nca++; else nsa++;
+            }
+            if (!GROUPED || u == g) {
+                const int4 t = t8[GROUPED ? 0 : u];
+                const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z) : PT_INACTIVE;
+                if (h == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
+                h8[GROUPED ? 0 : u] = h;
+            }
+        }
+        // the slot indices leave together at the end of the trip: a store between the inserts makes the wait for the next
+        // flag byte a wait for that store (the counters are imprecise behind divergent code), one HBM round trip per block
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = tid + (k0 + u) * RS_THREADS;
+            if ((!GROUPED || u == g) && j < nS) gstore_u16(ids + j, (unsigned short)h8[GROUPED ? 0 : u]);
+        }
+#ifdef LL_SOLVE_TIMING
+        LL_TACC(11, t_ins);
+#endif
+    }
+    LL_T0(t_sums);
+    {
+        const unsigned long long tot = block_sum_u64((unsigned long long)na | ((unsigned long long)nca << 20) | ((unsigned long long)nsa << 40), sh);
+        na = (int)(tot & 0xfffffull);
+        nca = (int)((tot >> 20) & 0xfffffull);
+        nsa = (int)((tot >> 40) & 0xfffffull);
+    }
+    if (rc.subsample_seed && na > rc.max_blocks) {  // a13 (PCR:438-458); the random stream is indexed by the block's
+        int kept = 0;                               // position in the reference's order: corners, then surfaces
+        for (int k = 0; k * RS_THREADS < totp; k++) {  // (a dropped block's triple stays in the table, unused)
+            if (!((act >> k) & 1ull)) continue;
+            const int j = tid + k * RS_THREADS;
+            const int jref = j >= nSp ? j - nSp : nC + j;
+            if (subsample_drop_block(rc.subsample_seed, st->icp_iters, jref, na, rc.max_blocks))
+                act &= ~(1ull << k);
+            else
+                kept++;
+        }
+        na = block_sum_int(kept, sh);
+    }
+    if (tid == 0) {
+        sh.n_active = na;
+        sh.n_corner_avail = nca;
+        sh.n_surf_avail = nsa;
+    }
+    __syncthreads();  // (also: every insert has landed)
+    LL_TACC(12, t_sums);
+    LL_TACC(6, t_census);
+    LL_T0(t_tab);
+    LL_T0(t_cmp);
+    // ---- dense ids in slot order; id -> slot map --------------------------------------------------------------------------
+    constexpr int SPT = PT_SLOTS / RS_THREADS;  // slots per thread: tid, tid + 512, ... (consecutive slots per thread would put
+    unsigned int occ = 0;                       // all 64 lanes of a read on one LDS bank)
+#pragma unroll
+    for (int i = 0; i < SPT; i++)
+        if (ht[tid + i * RS_THREADS].b != PT_EMPTY_B) occ |= 1u << i;
+    const int cnt = __popc(occ);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) sh.isum[wave] = incl;
+    __syncthreads();
+    int base = incl - cnt, T = 0;
+    for (int w = 0; w < RS_WAVES; w++) {
+        if (w < wave) base += sh.isum[w];
+        T += sh.isum[w];
+    }
+    {
+        int rk = base;
+#pragma unroll
+        for (int i = 0; i < SPT; i++)
+            if (occ & (1u << i)) {
+                ht[tid + i * RS_THREADS].id = (unsigned int)rk;
+                slot_of_id[rk] = (unsigned short)(tid + i * RS_THREADS);
+                rk++;
+            }
+    }
+    __syncthreads();
+    LL_TACC(13, t_cmp);
+    LL_T0(t_pl);
+    // ---- plane constants -> the table in HBM: thread t computes ids t, t + 512, ... (four triples' gathers in flight) ------
+    int4 *tabG = pt_table_global(rd, b, g, GROUPED);
+    double pose_last[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
+    for (int i0 = tid; i0 < T; i0 += 4 * RS_THREADS) {
+        f4 m[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int id = i0 + u * RS_THREADS;
+            const unsigned int sl = slot_of_id[id < T ? id : i0];
+            const unsigned long long sa = ht[sl].a;
+            const unsigned int sb2 = ht[sl].b;
+            m[u][0] = gload_pt(map_pts + (unsigned int)(sa >> 32));
+            m[u][1] = gload_pt(map_pts + (unsigned int)sa);
+            m[u][2] = gload_pt(map_pts + sb2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int id = i0 + u * RS_THREADS;
+            const double pa[3] = {(double)m[u][0].x, (double)m[u][0].y, (double)m[u][0].z};
+            const double pb[3] = {(double)m[u][1].x, (double)m[u][1].y, (double)m[u][1].z};
+            const double pc[3] = {(double)m[u][2].x, (double)m[u][2].y, (double)m[u][2].z};
+            double a_out[3] = {0.0, 0.0, 0.0}, v_out[3] = {0.0, 0.0, 0.0};
+            (void)block_plane(pose_last, pa, pb, pc, a_out, v_out);  // degenerate triples never reach the table (build_one clears their flag)
+            if (id < T) {
+                gstore_i4(tabG + 2 * id, make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1])));
+                gstore_i4(tabG + 2 * id + 1, make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0])));
+            }
+        }
+    }
+    LL_TACC(14, t_pl);
+    LL_T0(t_p2);
+    // ---- pass 2: slot -> dense id (nothing but arithmetic and LDS reads between the loads and the stores of a trip) ---------
+    const int region = GROUPED ? rd.tab_cap / LL_GRP : rd.tab_cap;
+    for (int k0 = 0; k0 < kp; k0 += 8) {
+        unsigned short h8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int p = p0 + (k0 + u) * GS;
+            h8[u] = gload_u16(ids + (p < nS ? p : 0));
+        }
+        unsigned int id8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned int h = h8[u];
+            const unsigned int sid = ht[h < PT_SLOTS ? h : 0u].id;
+            id8[u] = h < PT_SLOTS ? sid : (h == PT_PRIVATE ? PT_PRIVATE : 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int p = p0 + (k0 + u) * GS;
+            if (p < nS) gstore_u16(ids + p, (unsigned short)id8[u]);
+        }
+    }
+    if (sh.pt_priv > 0) {  // (uniform; rare: the hash table was too crowded around some triples -- those blocks get entries of
+        int npriv = 0;     //  their own at the top of the table region, numbered per thread and then across the workgroup)
+        for (int k = 0; k < kp; k++) {
+            const int p = p0 + k * GS;
+            if (p < nS && gload_u16(ids + p) == PT_PRIVATE) npriv++;
+        }
+        int incl2 = npriv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl2, off);
+            if (lane >= off) incl2 += y;
+        }
+        __syncthreads();
+        if (lane == 63) sh.isum[wave] = incl2;
+        __syncthreads();
+        int pid = incl2 - npriv;
+        for (int w = 0; w < wave; w++) pid += sh.isum[w];
+        for (int k = 0; k < kp; k++) {
+            const int p = p0 + k * GS;
+            if (p >= nS || gload_u16(ids + p) != PT_PRIVATE) continue;
+            const unsigned int id = (unsigned int)(region - 1 - pid);
+            pid++;
+            const int4 t = gload_i4(nn + p);
+            int4 ob, oc;
+            pt_plane(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
+            gstore_i4(tabG + 2 * id, ob);
+            gstore_i4(tabG + 2 * id + 1, oc);
+            gstore_u16(ids + p, (unsigned short)id);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();  // the hash table is dead, the table in HBM complete
+    // ---- the first PT_TCAP entries -> LDS; the rest of s_raw caches records ----------------------------------------------
+    const int Tl = T < PT_TCAP ? T : PT_TCAP;
+    int4 *s_tab = (int4 *)s_raw;
+    for (int e0 = tid; e0 < 2 * Tl; e0 += 8 * RS_THREADS) {
+        int4 v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * RS_THREADS;
+            v8[u] = gload_i4(tabG + (e < 2 * Tl ? e : e0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * RS_THREADS;
+            if (e < 2 * Tl) lds_store_i4(s_tab + e, v8[u]);
+        }
+    }
+    if (tid == 0) {
+        // (T beyond the LDS part, or private entries: the evaluation takes its slower form, solver_eval3)
+        const int kc = ((PT_TCAP - Tl) * 2) / RS_THREADS;
+        sh.pt_T = sh.pt_priv > 0 ? PT_TCAP + 1 : T;
+        sh.pt_Tl = Tl;
+        sh.pt_kc = kc < kp ? kc : kp;
+    }
+    __syncthreads();
+    LL_TACC(15, t_p2);
+    LL_TACC(8, t_tab);
+    return act;
+}
+
+// after the inlier phase has used s_raw for its tables
+__device__ __forceinline__ void plane_table_reload(const RegDev &rd, int b, bool grouped, uint4 *s_raw, SolveShared &sh)
+{
+    const int4 *tabG = pt_table_global(rd, b, grouped ? sh.grp_g : 0, grouped);
+    int4 *s_tab = (int4 *)s_raw;
+    const int n = 2 * sh.pt_Tl;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 8 * RS_THREADS) {
+        int4 v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * RS_THREADS;
+            v8[u] = gload_i4(tabG + (e < n ? e : e0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * RS_THREADS;
+            if (e < n) lds_store_i4(s_tab + e, v8[u]);
+        }
+    }
+    __syncthreads();
+}
+
+struct Rec3 {
+    int fx, fy, fz;  // bits of the fp32 feature point (sensor frame)
+    unsigned int id;
+};
+struct Pl3 {
+    int4 b, c;  // {n'.x, n'.y}, {n'.z, c}
+};
+
+// The plane loop of a cost evaluation, rounds [KB, KE) of this thread's blocks.  Everything the waitcnt pass has to see
+// through is straight-line: loads are unconditional (clamped addresses), only arithmetic and LDS stores sit behind
+// predicates -- a load behind a branch (a conditional global fallback for the plane, a cached / streamed switch inside the
+// loop) made the compiler drain the whole pipeline with vmcnt(0) at every stage (first build of this path: 66 k cycles per
+// evaluation against 25 k of fp64 issue).  Records are prefetched four rounds ahead (5 register sets rotating by name), the
+// plane of the next record is fetched from the LDS table while the current one is evaluated.
+//   FROM_CACHE: records from the LDS record cache (rounds < kc of an evaluation that does not FILL); else 18 B per lane and
+//   record from HBM.  TAB_LDS: the scan's whole table is in LDS (T <= PT_TCAP) -- the fast form; otherwise a plane with
+//   id >= Tl is gathered from the table in HBM behind a branch (correct, same summation order, not pipelined).
+#define LL3_LOAD(R, K)                                                                             \
+    {                                                                                              \
+        if (FROM_CACHE_) {                                                                         \
+            const int kc_ = (K) < kc ? (K) : kc - 1;                                               \
+            const int4 c_ = lds_load_i4(cache + tid + kc_ * RS_THREADS);                           \
+            R.fx = c_.x;                                                                           \
+            R.fy = c_.y;                                                                           \
+            R.fz = c_.z;                                                                           \
+            R.id = (unsigned int)c_.w;                                                             \
+        } else {                                                                                   \
+            const int pp_ = p0 + (K) * GS;                                                         \
+            const int pc_ = pp_ < nS ? pp_ : 0;                                                    \
+            float fx_, fy_, fz_;                                                                   \
+            gload_f3(feat + pc_, fx_, fy_, fz_);                                                   \
+            R.id = gload_u16(ids + pc_);                                                           \
+            R.fx = __float_as_int(fx_);                                                            \
+            R.fy = __float_as_int(fy_);                                                            \
+            R.fz = __float_as_int(fz_);                                                            \
+        }                                                                                          \
+    }
+#define LL3_PLANE(Q, R)                                                                            \
+    {                                                                                              \
+        if (TAB_LDS || R.id < (unsigned int)Tl) {                                                  \
+            Q.b = lds_load_i4(tabL + 2 * R.id);                                                    \
+            Q.c = lds_load_i4(tabL + 2 * R.id + 1);                                                \
+        } else {                                                                                   \
+            Q.b = gload_i4(tabG + 2 * R.id);                                                       \
+            Q.c = gload_i4(tabG + 2 * R.id + 1);                                                   \
+        }                                                                                          \
+    }
+#define LL3_USE(R, Q, K)                                                                                   \
+    if ((K) < KE_) {                                                                                       \
+        const int pp_ = p0 + (K) * GS;                                                                     \
+        if (FILL && (K) < kc) lds_store_i4(cache + tid + (K) * RS_THREADS, make_int4(R.fx, R.fy, R.fz, (int)R.id)); \
+        if (pp_ < nS && ((act >> (g + G * (K))) & 1ull)) { /* (a group member's last round may reach into the lines' bits) */ \
+            const double f[3] = {(double)__int_as_float(R.fx), (double)__int_as_float(R.fy), (double)__int_as_float(R.fz)}; \
+            const double v[3] = {__hiloint2double(Q.b.y, Q.b.x), __hiloint2double(Q.b.w, Q.b.z), __hiloint2double(Q.c.y, Q.c.x)}; \
+            const double a[3] = {__hiloint2double(Q.c.w, Q.c.z), 0.0, 0.0};                                \
+            block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);                                    \
+            if (L1OUT) gstore_f64(l1_planes + pp_, block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last)); \
+        }                                                                                                  \
+    }
+#define LL3_PIPE(FROM_CACHE, KB, KE)                                   \
+    {                                                                  \
+        constexpr bool FROM_CACHE_ = FROM_CACHE;                       \
+        const int KB_ = (KB), KE_ = (KE);                              \
+        if (KB_ < KE_) {                                               \
+            Rec3 r0, r1, r2, r3, r4;                                   \
+            Pl3 q0, q1, q2, q3, q4;                                    \
+            LL3_LOAD(r0, KB_)                                          \
+            LL3_LOAD(r1, KB_ + 1)                                      \
+            LL3_LOAD(r2, KB_ + 2)                                      \
+            LL3_LOAD(r3, KB_ + 3)                                      \
+            LL3_PLANE(q0, r0)                                          \
+            for (int k = KB_; k < KE_; k += 5) {                       \
+                LL3_LOAD(r4, k + 4)                                    \
+                LL3_PLANE(q1, r1)                                      \
+                LL3_USE(r0, q0, k)                                     \
+                LL3_LOAD(r0, k + 5)                                    \
+                LL3_PLANE(q2, r2)                                      \
+                LL3_USE(r1, q1, k + 1)                                 \
+                LL3_LOAD(r1, k + 6)                                    \
+                LL3_PLANE(q3, r3)                                      \
+                LL3_USE(r2, q2, k + 2)                                 \
+                LL3_LOAD(r2, k + 7)                                    \
+                LL3_PLANE(q4, r4)                                      \
+                LL3_USE(r3, q3, k + 3)                                 \
+                LL3_LOAD(r3, k + 8)                                    \
+                LL3_PLANE(q0, r0)                                      \
+                LL3_USE(r4, q4, k + 4)                                 \
+            }                                                          \
+        }                                                              \
+    }
+
+// workgroup evaluation of cost / g / H at x over the active blocks -> sh.sum (FILL / L1OUT / GROUPED as in solver_eval2)
+template <bool FILL, bool L1OUT, bool GROUPED>
+__device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a, unsigned long long act,
+                                          uint4 *s_raw, const double *q_last_g, SolveShared &sh)
+{
+    constexpr int DEBLUR = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double q_last[4] = {0.0, 0.0, 0.0, 1.0};
+    if (L1OUT) {
+        q_last[0] = q_last_g[0];
+        q_last[1] = q_last_g[1];
+        q_last[2] = q_last_g[2];
+        q_last[3] = q_last_g[3];
+    }
+    double *l1_planes = rd.blk_l1 + (size_t)b * rd.cap + rd.cap_c;
+    double *l1_lines = rd.blk_l1 + (size_t)b * rd.cap;
+    LL_CTX_DECL(x)
+    double acc[LL_NACC];
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
+    constexpr int G = GROUPED ? LL_GRP : 1, GS = G * RS_THREADS;
+    const int g = GROUPED ? sh.grp_g : 0;
+    const int p0 = g * RS_THREADS + tid;
+    const int Tl = sh.pt_Tl, kc = sh.pt_kc;
+    const int kp = (nS + GS - 1) / GS;
+    const int4 *tabL = (const int4 *)s_raw;
+    int4 *cache = (int4 *)s_raw + 2 * Tl;
+    const int4 *tabG = pt_table_global(rd, b, g, GROUPED);
+    const unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
+    const float4 *feat = rd.surf_feat + (size_t)b * rd.feat_stride_s;
+    if (sh.pt_T <= PT_TCAP) {  // uniform: the whole table is in LDS (every C2 scan)
+        constexpr bool TAB_LDS = true;
+        if (!FILL) LL3_PIPE(true, 0, kc)
+        LL3_PIPE(false, FILL ? 0 : kc, kp)
+    } else {
+        constexpr bool TAB_LDS = false;
+        if (!FILL) LL3_PIPE(true, 0, kc)
+        LL3_PIPE(false, FILL ? 0 : kc, kp)
+    }
+    {
+        // line blocks (a few hundred per Mid-40 scan): the 65-byte fp64 form
+        const size_t sb = (size_t)b * rd.cap;
+        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+        const int kpl = (nS + RS_THREADS - 1) / RS_THREADS;  // the lines' first round in the activity mask
+        int k = 0;
+        for (int l = p0; l < nC; l += GS, k++) {
+            if (!((act >> (kpl + g + G * k)) & 1ull)) continue;
+            BlkRegs br;
+            load_blk(rd, sb, av, l, br);
+            const double a[3] = {br.a0, br.a1, br.a2};
+            const double v[3] = {br.v0, br.v1, br.v2};
+            LL_CTX_ACCUM(BLK_LINE, br.f, a, v, huber_a, acc);
+            if (L1OUT) {
+                double l1;
+                LL_CTX_L1(l1, BLK_LINE, br.f, a, v, huber_a, q_last);
+                l1_lines[l] = l1;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LL_NACC; i++) {
+        const double s = wave_sum(acc[i]);
+        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
+    }
+    __syncthreads();
+    if (tid < LL_NACC) {
+        double s = 0.0;
+        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
+        sh.sum[tid] = s;
+    }
+    __syncthreads();
+    if (GROUPED) {
+        LL_T0(t_grp);
+        group_reduce<L1OUT>(rd, b, sh);
+        LL_TACC(9, t_grp);
+    }
+}
+#undef LL3_LOAD
+#undef LL3_PLANE
+#undef LL3_USE
+#undef LL3_PIPE
+
+// one ceres::Solve on the plane-table layout: starts at x0, leaves the result in sh.ctl
+template <bool WANT_L1, bool GROUPED>
+__device__ __forceinline__ void solver_lm3(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
+                                           int n_active, unsigned long long act, uint4 *s_raw, const double *q_last, SolveShared &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        lm_begin(sh.ctl, x0, max_iter, rc.bound);
+        sh.l1_valid = 0;
+    }
+    __syncthreads();
+    {
+        LL_T0(t0);
+        solver_eval3<true, false, GROUPED>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, act, s_raw, q_last, sh);
+        LL_TACC(0, t0);
+    }
+    {
+        LL_T0(t1);
+        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
+    while (sh.need) {
+        const bool spec = WANT_L1 && sh.ctl.iteration >= max_iter;  // if this candidate is accepted it is the solve's result
+        LL_T0(t0);
+        if (spec)
+            solver_eval3<false, true, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, act, s_raw, q_last, sh);
+        else
+            solver_eval3<false, false, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, act, s_raw, q_last, sh);
+        LL_TACC(0, t0);
+        LL_T0(t1);
+        if (tid == 0) {
+            sh.need = lm_update(sh.ctl, sh.sum);
+            sh.l1_valid = (spec && !sh.need && sh.ctl.last_accept == 1) ? 1 : 0;
+        }
+        __syncthreads();
+        LL_TACC(1, t1);
+    }
+}
+
+// L1 values at the prerun result -> inlier threshold -> prune (PCR:476-499), the activity mask in place of LDS flags.
+// Returns the pruned mask.
+template <int NK, bool GROUPED>
+__device__ __noinline__ unsigned long long inlier_phase3(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, uint4 *s_raw,
+                                                         unsigned long long act, int nC, int nS)
+{
+    constexpr int DEBLUR = 0;
+    const int tid = threadIdx.x;
+    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+    const int totp = nSp + nC;
+    const size_t sb = (size_t)b * rd.cap;
+    LL_T0(t_l1);
+    double *l1g = rd.blk_l1 + sb;
+    if (!sh.l1_valid) {
+        // rare: the prerun ended on a rejected step (or converged early).  Every workgroup evaluates its own share, from the
+        // table in HBM (a plain rolled loop)
+        LL_CTX_DECL(sh.ctl.x)
+        constexpr int G = GROUPED ? LL_GRP : 1, GS = G * RS_THREADS;
+        const int g = GROUPED ? sh.grp_g : 0;
+        const int p0 = g * RS_THREADS + tid;
+        const int4 *tabG = pt_table_global(rd, b, g, GROUPED);
+        const unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
+        const float4 *feat = rd.surf_feat + (size_t)b * rd.feat_stride_s;
+        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+        int k = 0;
+        for (int p = p0; p < nS; p += GS, k++) {
+            if (!((act >> (g + G * k)) & 1ull)) continue;
+            const float4 ff = gload_f4(feat + p);
+            const unsigned int id = gload_u16(ids + p);
+            const int4 qb = gload_i4(tabG + 2 * id), qc = gload_i4(tabG + 2 * id + 1);
+            const double f[3] = {(double)ff.x, (double)ff.y, (double)ff.z};
+            const double v[3] = {__hiloint2double(qb.y, qb.x), __hiloint2double(qb.w, qb.z), __hiloint2double(qc.y, qc.x)};
+            const double a[3] = {__hiloint2double(qc.w, qc.z), 0.0, 0.0};
+            l1g[rd.cap_c + p] = block_l1(BLK_PLANE, R_, t_, f, a, v, rc.huber_a, st->pose_last);
+        }
+        const int kpl = nSp / RS_THREADS;
+        k = 0;
+        for (int l = p0; l < nC; l += GS, k++) {
+            if (!((act >> (kpl + g + G * k)) & 1ull)) continue;
+            BlkRegs br;
+            load_blk(rd, sb, av, l, br);
+            const double a[3] = {br.a0, br.a1, br.a2};
+            const double v[3] = {br.v0, br.v1, br.v2};
+            double l1;
+            LL_CTX_L1(l1, BLK_LINE, br.f, a, v, rc.huber_a, st->pose_last);
+            l1g[l] = l1;
+        }
+        if (GROUPED)
+            group_barrier<true>(rd, b, sh);  // the other members' shares
+        else
+            __syncthreads();
+    } else if (tid == 0) {
+        sh.tcyc[9] += 1;  // LL_SOLVE_TIMING: how often the shortcut was taken
+    }
+    double l1r[NK];  // the thread's register tile: block j = tid + k * RS_THREADS
+    {
+        const int kt = (totp + RS_THREADS - 1) / RS_THREADS;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {  // unconditional loads from clamped addresses: all in flight together
+            const int j = tid + k * RS_THREADS;
+            double v = -1.0;
+            if (k < kt) {
+                const int jc = j < totp ? j : 0;
+                const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
+                v = gload_f64(l1g + src);
+            }
+            l1r[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; k++) l1r[k] = ((act >> k) & 1ull) ? l1r[k] : -1.0;
+    }
+    __syncthreads();
+    LL_TACC(2, t_l1);
+
+    inlier_threshold_regs<NK>(l1r, totp, (unsigned long long *)s_raw, sh, rc);  // overwrites the LDS plane table and record cache
+
+    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
+    LL_T0(t_prune);
+    {
+        const double thr = sh.thr;
+        int na = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            if (!((act >> k) & 1ull)) continue;
+            if (l1r[k] > thr)
+                act &= ~(1ull << k);
+            else
+                na++;
+        }
+        na = block_sum_int(na, sh);
+        if (tid == 0) sh.n_active = na;
+        __syncthreads();
+    }
+    LL_TACC(7, t_prune);
+    return act;
+}
+
+template <bool GROUPED>
+__device__ void solve_fast3(const RegDev &rd, const RegConst &rc, const f4 *map_pts, int b, RegState *st, SolveShared &sh, uint4 *s_raw)
+{
+    constexpr int DEBLUR = 0;
+    const int tid = threadIdx.x;
+    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
+    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;  // lines start at a whole round
+    const int totp = nSp + nC;                                        // <= FAST_MAX_BLOCKS (scan_is_compact)
+    const size_t sb = (size_t)b * rd.cap;
+    if (tid < 16) sh.tcyc[tid] = 0;
+    __syncthreads();
+    LL_T0(t_total);
+
+    // ---- flags -> the thread's activity mask (bit k: block tid + k * RS_THREADS in the order planes, padding, lines), census
+    //      (PCR:325,425), and the scan's plane table (this workgroup's share of it) ------------------------------------------
+    unsigned long long act = census_and_plane_table<GROUPED>(rd, rc, map_pts, b, st, nC, nS, s_raw, sh);
+
+    // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------
+    solver_lm3<true, GROUPED>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, act, s_raw, st->pose_last, sh);
+    int lm_iters = sh.ctl.iteration;
+
+    if (totp <= 36 * RS_THREADS)  // the Mid-40 configurations: a 36-entry register tile per thread
+        act = inlier_phase3<36, GROUPED>(rd, rc, b, st, sh, s_raw, act, nC, nS);
+    else
+        act = inlier_phase3<FAST_MAXK, GROUPED>(rd, rc, b, st, sh, s_raw, act, nC, nS);
+
+    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
+    {
+        __shared__ double x_start_3[7];
+        if (tid < 7) x_start_3[tid] = sh.ctl.x[tid];
+        plane_table_reload(rd, b, GROUPED, s_raw, sh);  // (its barrier also publishes x_start_3)
+        solver_lm3<false, GROUPED>(rd, rc, b, nC, nS, x_start_3, rc.ceres_max_iterations, sh.n_active, act, s_raw, st->pose_last, sh);
+    }
+    lm_iters += sh.ctl.iteration;
+    if (GROUPED) {
+        group_barrier<false>(rd, b, sh);  // nobody reads st->inc / st->pose_last any more
+        if (sh.grp_g != 0) return;
+        if (sh.grp_abort && tid < 7) sh.ctl.x[tid] = __longlong_as_double(0x7ff8000000000000LL);  // a barrier timed out: poison the pose
+        __syncthreads();
+    }
+    solve_epilogue(rc, st, sh, lm_iters);
+#ifdef LL_SOLVE_TIMING
+    LL_TACC(5, t_total);
+    if (tid == 0)
+        for (int i = 0; i < 16; i++) st->dbg_cycles[i] += sh.tcyc[i];
 #endif
 }
 
 template <int DEBLUR>
-__global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc)
+__global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc, const f4 *map_surf)
 {
     __shared__ SolveShared sh;
-    __shared__ unsigned long long s_table[HT_SIZE];
-    __shared__ unsigned char s_flag[FAST_MAX_BLOCKS];
+    // 152 KB shared by the paths: the round-1 / round-2 forms use 128 KB of tables + 24 KB of block flags, the plane-table form
+    // all of it (hash table -> plane table + record cache; the inlier phase's tables in between)
+    __shared__ uint4 s_raw[PT_LDS_BYTES / 16];
+    static_assert(PT_LDS_BYTES == HT_SIZE * 8 + FAST_MAX_BLOCKS, "s_raw = s_table + s_flag of the older paths");
+    unsigned long long *s_table = (unsigned long long *)s_raw;
+    unsigned char *s_flag = (unsigned char *)s_raw + HT_SIZE * 8;
     int b = blockIdx.x, g = 0, G = 1;
     if (!DEBLUR && rc.solve_group > 1) {  // grouped launch (n_scans * G workgroups): scan and rank by ticket, see group_barrier
         if (threadIdx.x == 0) sh.grp_seq = atomicAdd(rd.grp_ctl, 1);
@@ -2163,7 +2975,11 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     }
     __syncthreads();
     const int total = rd.n_corner[b] + rd.n_surf[b];
-    if (compact && G > 1)
+    if (compact && !rc.solver_packed48 && G > 1)
+        solve_fast3<true>(rd, rc, map_surf, b, st, sh, s_raw);
+    else if (compact && !rc.solver_packed48)
+        solve_fast3<false>(rd, rc, map_surf, b, st, sh, s_raw);
+    else if (compact && G > 1)
         solve_fast2<true>(rd, rc, b, st, sh, s_table, s_flag);
     else if (compact)
         solve_fast2<false>(rd, rc, b, st, sh, s_table, s_flag);
@@ -2229,12 +3045,12 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
     hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
-void launch_reg_solve(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s)
 {
     if (rc.if_motion_deblur)
-        hipLaunchKernelGGL(reg_solve_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc);
+        hipLaunchKernelGGL(reg_solve_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
     else
-        hipLaunchKernelGGL(reg_solve_kernel<0>, dim3(n_scans * (rc.solve_group > 1 ? rc.solve_group : 1)), dim3(RS_THREADS), 0, s, rd, rc);
+        hipLaunchKernelGGL(reg_solve_kernel<0>, dim3(n_scans * (rc.solve_group > 1 ? rc.solve_group : 1)), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
 }
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {

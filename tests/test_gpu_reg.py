@@ -70,18 +70,20 @@ def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
 
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 @pytest.mark.parametrize("force", [0, 1])
-@pytest.mark.parametrize("general", [False, "single", True, "legacy"])
+@pytest.mark.parametrize("general", [False, "single", True, "legacy", "packed48", "packed48_single"])
 def test_registration_matches_oracle(dev_map, small_world, scans, k, force, general):
-    """general=False: round-2 fast path (packed 48-byte plane blocks, LDS record cache) in the form a batch of one takes: the
-    scan spread over a group of 8 workgroups; "single": the same path with one workgroup per scan, as batches of more than
-    16 scans run it; True: the HBM-resident path used by scans with more than 24576 residual blocks (forced here on a normal
-    scan); "legacy": the round-1 fast path (blocks re-read on every evaluation), kept as an A/B switch."""
+    """general=False: round-3 compact path (plane table: {n', c} once per distinct neighbour triple, 18-byte block records) in
+    the form a batch of one takes: the scan spread over a group of 8 workgroups; "single": the same path with one workgroup
+    per scan, as batches of more than 16 scans run it; True: the HBM-resident path used by scans with more than 24576
+    residual blocks (forced here on a normal scan); "legacy": the round-1 fast path (blocks re-read on every evaluation) and
+    "packed48[_single]": the round-2 compact path (48-byte packed plane records), both kept as A/B switches."""
     sc = scans[k]
     _, _, _, _, fc, fs = oracle_features(sc)
     prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     reg = Point_cloud_registration(max_scans=1, max_features=24000)
-    reg.set_debug(True, force_general_solver=(general is True), legacy_solver=(general == "legacy"), no_solver_groups=(general == "single"))
+    reg.set_debug(True, force_general_solver=(general is True), legacy_solver=(general == "legacy"),
+                  no_solver_groups=(general in ("single", "packed48_single")), packed48_solver=str(general).startswith("packed48"))
     set_params(reg, 10, 20, force)
     reg.m_pose_w_last = sc.pose_init.copy()
     reg.m_pose_w_curr = sc.pose_init.copy()
