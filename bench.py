@@ -117,6 +117,35 @@ def pmc_valu_fp64(kernel: str, batch: int):
             "flops": 64.0 * (add + mul + 2.0 * fma), "source": os.path.relpath(path, ROOT)}
 
 
+def pmc_knn_issue(batch: int):
+    """The k-NN class is instruction-bound, not bandwidth-bound (its candidates are cache resident): VALU issue share and lane
+    utilisation of the full-search kernel from the newest committed instruction counters (profiles/r*_pmc_valu.csv) and its
+    average launch time from the newest committed kernel trace (profiles/r*_kernel_trace_by_grid.csv) -- both of this command at
+    batch 256, both labelled.  None when either is missing."""
+    import csv
+    pv, pt = newest_profile("r*_pmc_valu.csv"), newest_profile("r*_kernel_trace_by_grid.csv")
+    if not pv or not pt or batch != 256:
+        return None
+
+    def biggest(path, kernel):
+        best = None
+        with open(path) as f:
+            for d in csv.DictReader(l for l in f if not l.startswith("#")):
+                if d["kernel"] == kernel and (best is None or int(d["grid_threads"]) > int(best["grid_threads"])):
+                    best = d
+        return best
+    c, t = biggest(pv, "ll::reg_knn_kernel"), biggest(pt, "ll::reg_knn_kernel")
+    if not c or not t or not c.get("SQ_INSTS_VALU_avg") or not c.get("SQ_THREAD_CYCLES_VALU_avg") or not c.get("SQ_ACTIVE_INST_VALU_avg"):
+        return None
+    insts, us = float(c["SQ_INSTS_VALU_avg"]), float(t["avg_us"])
+    return {"bound": "valu-issue", "kernel": "reg_knn_kernel", "valu_wave_instructions_per_launch": int(insts),
+            # one wave instruction occupies a SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
+            "valu_issue_frac_at_2p4GHz": round(insts * 4.0 / 1024.0 / (us * 1e-6 * 2.4e9), 3),
+            "lane_utilisation": round(float(c["SQ_THREAD_CYCLES_VALU_avg"]) / (64.0 * float(c["SQ_ACTIVE_INST_VALU_avg"])), 3),
+            "avg_launch_us": us, "queries_per_launch": int(t["grid_threads"]),
+            "sources": [os.path.relpath(pv, ROOT), os.path.relpath(pt, ROOT)]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -375,6 +404,7 @@ def main():
                    "parallelism": f"replicas x{world} (independent scans, no data-path collective)"},
         "roofline": roofline,
         "roofline_path": roofline_path,
+        "roofline_knn": pmc_knn_issue(B),  # the other half of the step: instruction-bound (committed counters, labelled)
         "streamed": streamed,
         "q_pipe": q_pipe_extra,
         "kernel_ms_per_step": {names[i]: round(float(k_ms[i] / args.steps), 3) for i in range(3)},
@@ -450,10 +480,18 @@ def cpu_legs(args, synth, corner, surf, scans, init, B, vox, pc, res, reps, nc, 
     per_thread = 2 if n_thr >= 16 else 4
     done = [0] * n_thr
 
+    audit = [[] for _ in range(n_thr)]  # the same runs extend the parity audit to every scan they touch
+
     def worker(t):
         for j in range(per_thread):
-            one_scan((t * per_thread + j) % B, prm, bool(vox))
+            b = (t * per_thread + j) % B
+            ret, opc, orep, n_ci, n_si, n_fc, n_fs = one_scan(b, prm, bool(vox))
             done[t] += 1
+            audit[t].append((b, synth.pose_error(pc[b], opc),
+                             n_ci == nc_fe[b] and n_si == ns_fe[b] and n_fc == nc[b] and n_fs == ns[b],
+                             orep.n_blocks_last == reps[b].n_blocks_last and orep.corner_avail == reps[b].corner_avail and orep.surf_avail == reps[b].surf_avail,
+                             orep.lm_iterations_total == reps[b].lm_iterations_total and orep.icp_iterations == reps[b].icp_iterations,
+                             ret == res[b]))
 
     threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
     tb = time.perf_counter()
@@ -484,10 +522,20 @@ def cpu_legs(args, synth, corner, surf, scans, init, B, vox, pc, res, reps, nc, 
                                           "ms_per_scan_median": round(1e3 * med_s, 2),
                                           "sample": f"median of {n_runs} runs: voxel-filtered features (0.1 / 0.4 m) and maximum_residual_blocks = 200 "
                                                     "(the shipped configs), the reference's real operating point"}
+    seen = set(range(min(n_runs, B)))
+    for lst in audit:
+        for b, e, s_sets, s_blocks, s_lm, s_res in lst:
+            seen.add(b)
+            errs.append(e)
+            same_sets &= bool(s_sets)
+            same_blocks &= bool(s_blocks)
+            same_lm &= bool(s_lm)
+            same_res &= bool(s_res)
     out["parity_vs_cpu"] = {"max_pose_err_m": float(max(e[0] for e in errs)), "max_pose_err_rad": float(max(e[1] for e in errs)),
                             "feature_counts_identical": bool(same_sets), "lm_and_icp_iteration_counts_identical": bool(same_lm),
                             "residual_block_counts_identical": bool(same_blocks), "accept_reject_identical": bool(same_res),
-                            "scans_compared": int(min(n_runs, B))}
+                            "scans_compared": len(seen),
+                            "note": "device results of the timed step against the oracle: the single-thread runs plus every scan of the all-core leg"}
     return out
 
 

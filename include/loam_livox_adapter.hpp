@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -215,7 +216,9 @@ class Livox_laser {
             if (scan_idx >= cl) break;  // cannot happen: clutter_size counts the angle changes + 1
             if (type[i] & (1 | 2 | 32)) continue;  // e_pt_000 | e_pt_too_near | e_pt_nan, LFE:684-688
             auto pt = laserCloudIn.points[i];
-            pt.intensity = (float)i / (float)n;
+            // set_intensity(e_I_motion_blur) reads find_pt_info(pt)->idx (LFE:278-286, 706): the index of the FIRST inserted point
+            // with these coordinates (the unordered_map keeps the first of equal keys, LFE:478)
+            pt.intensity = (float)find_pt_info(pt)->idx / (float)n;
             petals[scan_idx].points.push_back(pt);
         }
         for (int s = 0; s < scan_idx && s < cl; s++)  // resize(scan_idx): the last petal is dropped, LFE:681
@@ -541,24 +544,34 @@ class Handle_pool {
                 return;
             }
     }
-    ll_map *shared_map(int device)
+    // What the shared match-buffer map of a device holds, as far as this process uploaded it: size and a hash of EVERY point of
+    // the cloud (the node allocates new clouds for each scan and deep-copies the match buffer into them, laser_mapping.hpp:1391-1392,
+    // 1396-1401: an address says nothing, and an allocator may hand the same address out again for other contents), plus the map's
+    // generation right after that upload -- anything else that publishes a structure (History_buffer::refresh) voids the key.
+    struct Key {
+        size_t n = (size_t)-1;
+        uint64_t hash = 0;
+        int64_t generation = -1;
+    };
+    struct Shared_map {
+        int device = 0;
+        ll_map *map = nullptr;
+        Key key[2];
+        std::mutex upload_mu;  // upload + pin of one registration are atomic against another thread's upload
+    };
+    Shared_map &shared(int device)
     {
         std::lock_guard<std::mutex> lk(mu_);
         for (auto &m : maps_)
-            if (m.first == device) return m.second;
+            if (m->device == device) return *m;
         ll_map *m = nullptr;
         check(ll_map_create(device, &m), "ll_map_create");
-        maps_.push_back(std::make_pair(device, m));
-        return m;
+        maps_.push_back(std::unique_ptr<Shared_map>(new Shared_map()));
+        maps_.back()->device = device;
+        maps_.back()->map = m;
+        return *maps_.back();
     }
-    std::mutex &upload_mutex() { return upload_mu_; }
-    struct Key {  // identity of an uploaded cloud: address, size and a sample of its contents
-        const void *p = nullptr;
-        size_t n = 0;
-        uint64_t sample = 0;
-        bool operator==(const Key &o) const { return p == o.p && n == o.n && sample == o.sample; }
-    };
-    Key key[2];
+    ll_map *shared_map(int device) { return shared(device).map; }
 
    private:
     struct Entry {
@@ -566,15 +579,12 @@ class Handle_pool {
         int device, max_features;
     };
     Handle_pool() {}
-    ~Handle_pool()
-    {
-        for (auto &kv : feat_) ll_reg_destroy(kv.first);
-        for (auto &m : maps_) ll_map_destroy(m.second);
-    }
-    std::mutex mu_, upload_mu_;
+    // No HIP calls at static destruction: the runtime may already be gone by then (the handles die with the process).
+    ~Handle_pool() {}
+    std::mutex mu_;
     std::vector<Entry> free_;
     std::vector<std::pair<ll_reg *, Entry>> feat_;
-    std::vector<std::pair<int, ll_map *>> maps_;
+    std::vector<std::unique_ptr<Shared_map>> maps_;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -698,12 +708,13 @@ class Point_cloud_registration {
     template <class CloudPtr>
     int find_out_incremental_transfrom(CloudPtr map_corner, CloudPtr map_surf, CloudPtr scan_corner, CloudPtr scan_surf)
     {
-        {
-            std::lock_guard<std::mutex> lk(Handle_pool::instance().upload_mutex());
-            upload_if_changed(LL_MAP_CORNER, *map_corner, Handle_pool::instance().key[0]);
-            upload_if_changed(LL_MAP_SURF, *map_surf, Handle_pool::instance().key[1]);
-        }
-        return find_out_incremental_transfrom(scan_corner, scan_surf);
+        // the solve pins the snapshots it is enqueued against: with upload and enqueue under one lock, a thread registers against
+        // the clouds it was given even when another thread (laser_mapping.hpp:1737-1742) uploads other ones meanwhile
+        Handle_pool::Shared_map &sm = Handle_pool::instance().shared(device);
+        std::unique_lock<std::mutex> lk(sm.upload_mu);
+        upload_if_changed(sm, LL_MAP_CORNER, *map_corner);
+        upload_if_changed(sm, LL_MAP_SURF, *map_surf);
+        return register_scan(scan_corner, scan_surf, &lk);
     }
 
     // The search structure the registrar matches against.  History_buffer::refresh( pc_reg.map() ) /
@@ -713,6 +724,14 @@ class Point_cloud_registration {
 
     template <class CloudPtr>
     int find_out_incremental_transfrom(CloudPtr scan_corner, CloudPtr scan_surf)
+    {
+        return register_scan(scan_corner, scan_surf, nullptr);
+    }
+
+    // void pointAssociateToMap ... see below
+   private:
+    template <class CloudPtr>
+    int register_scan(CloudPtr scan_corner, CloudPtr scan_surf, std::unique_lock<std::mutex> *held_until_enqueued)
     {
         if (!reg_) reg_ = Handle_pool::instance().acquire(device, max_features);
         ll_map *m = map();
@@ -744,9 +763,15 @@ class Point_cloud_registration {
         p.maximum_pt_time_stamp = m_maximum_pt_time_stamp;
         pose_from_members();
         ll_reg_report rep;
-        const int ret = ll_reg_solve(reg_, m, c.data(), (int)(c.size() / 4), s.data(), (int)(s.size() / 4), &p, m_para_buffer_RT_last,
-                                     m_para_buffer_RT, m_para_buffer_incremental, &rep);
-        check(ret, "ll_reg_solve");
+        // ll_reg_solve in its three steps (upload the scan's features, enqueue = pin the map snapshots + launch, collect)
+        const int32_t nc = (int32_t)(c.size() / 4), ns = (int32_t)(s.size() / 4);
+        const float dummy[4] = {0, 0, 0, 0};
+        check(ll_reg_upload_features(reg_, 1, nc ? c.data() : dummy, &nc, nc > 0 ? nc : 1, ns ? s.data() : dummy, &ns, ns > 0 ? ns : 1),
+              "ll_reg_upload_features");
+        check(ll_reg_enqueue_uploaded(reg_, m, 1, &p, m_para_buffer_RT_last, m_para_buffer_RT, m_para_buffer_incremental), "ll_reg_enqueue_uploaded");
+        if (held_until_enqueued) held_until_enqueued->unlock();
+        int32_t ret = 0;
+        check(ll_reg_collect(reg_, 1, m_para_buffer_RT, m_para_buffer_incremental, &rep, &ret), "ll_reg_collect");
         members_from_pose();
         m_inlier_threshold = rep.inlier_threshold;
         m_angular_diff = rep.angular_diff_deg;
@@ -757,6 +782,8 @@ class Point_cloud_registration {
         if (ret == 0) m_last_time_stamp = m_minimum_pt_time_stamp;   // PCR:569
         return ret;
     }
+
+   public:
 
     // void pointAssociateToMap(pi, po, interpolate_s = 1.0, if_undistore = 0), PCR:622-661.  The node calls it per point
     // with g_if_undistore == 0 (laser_mapping.hpp:80, 1424, 1430): p_w = q_w_curr * p + t_w_curr in double, stored to
@@ -810,23 +837,38 @@ class Point_cloud_registration {
         for (int i = 0; i < 3; i++) m_t_w_curr(i) = m_para_buffer_RT[4 + i];
     }
     template <class Cloud>
-    void upload_if_changed(int kind, const Cloud &c, Handle_pool::Key &k)
+    void upload_if_changed(Handle_pool::Shared_map &sm, int kind, const Cloud &c)
     {
         Handle_pool::Key now;
-        now.p = (const void *)c.points.data();
         now.n = c.points.size();
-        const size_t step = now.n / 61 + 1;
-        for (size_t i = 0; i < now.n; i += step) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)now.n;
+        for (size_t i = 0; i < now.n; i++) {  // every point: ~1 ns each, against a grid build of milliseconds
             uint32_t b[3];
             const float v[3] = {c.points[i].x, c.points[i].y, c.points[i].z};
             std::memcpy(b, v, 12);
-            now.sample = (now.sample ^ b[0]) * 0x100000001B3ull;
-            now.sample = (now.sample ^ b[1]) * 0x100000001B3ull;
-            now.sample = (now.sample ^ b[2]) * 0x100000001B3ull;
+            h = (h ^ (((uint64_t)b[1] << 32) | b[0])) * 0xD6E8FEB86659FD93ull;
+            h = (h ^ (h >> 32) ^ b[2]) * 0xFF51AFD7ED558CCDull;
         }
-        if (k == now) return;
-        const std::vector<float> v = cloud_to_xyzi(c);
-        check(ll_map_upload(map(), kind, v.data(), 4, (int64_t)c.points.size(), 0.0f), "ll_map_upload");
+        now.hash = h;
+        Handle_pool::Key &k = sm.key[kind];
+        if (k.n == now.n && k.hash == now.hash && k.generation == ll_map_generation(sm.map, kind)) return;  // same contents, still the published structure
+        if (now.n == 0) {
+            const float none[4] = {0, 0, 0, 0};
+            check(ll_map_upload(sm.map, kind, none, 4, 0, 0.0f), "ll_map_upload");
+        } else {
+            // ll_map_upload takes x, y, z at any float stride: a point type whose coordinates are three consecutive floats
+            // (pcl::PointXYZI: 8 floats per point) goes as it lies, without a staging copy
+            const auto &p0 = c.points[0];
+            const bool strided = sizeof(p0) % sizeof(float) == 0 && (const void *)(&p0.x + 1) == (const void *)&p0.y &&
+                                 (const void *)(&p0.x + 2) == (const void *)&p0.z;
+            if (strided) {
+                check(ll_map_upload(sm.map, kind, &p0.x, (int32_t)(sizeof(p0) / sizeof(float)), (int64_t)now.n, 0.0f), "ll_map_upload");
+            } else {
+                const std::vector<float> v = cloud_to_xyzi(c);
+                check(ll_map_upload(sm.map, kind, v.data(), 4, (int64_t)now.n, 0.0f), "ll_map_upload");
+            }
+        }
+        now.generation = ll_map_generation(sm.map, kind);
         k = now;
     }
     ll_reg *reg_ = nullptr;

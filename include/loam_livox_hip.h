@@ -123,6 +123,12 @@ void ll_map_destroy(ll_map *m);
  * Point indices reported by the library refer to this input order. */
 int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size);
 int64_t ll_map_size(const ll_map *m, int32_t kind);
+
+/* Number of search structures published for `kind` so far (by ll_map_upload, ll_map_to_f16, ll_history_refresh*).  A host-side
+ * cache of "what did I upload last" (include/loam_livox_adapter.hpp keys the map clouds of find_out_incremental_transfrom,
+ * point_cloud_registration.hpp:163-168, by their contents) stays valid only while this number is the one it saw after its own
+ * upload; -1 for a bad argument. */
+int64_t ll_map_generation(const ll_map *m, int32_t kind);
 /* BASELINE config C5 ("fp16 points / fp32 accumulate k-NN"): replaces the 16-byte fp32 records of an uploaded map kind by
  * 8-byte records -- the point's position inside its grid cell in binary16 (<= 2^-11 cell sizes off) + the cell index
  * bits -- and ll_map_knn5 then returns the exact 5-NN of that dequantised cloud, distances accumulated in fp32.  The

@@ -66,6 +66,7 @@ SYMBOLS = {
     "ll_map_destroy": (None, [_vp]),
     "ll_map_upload": (_i32, [_vp, _i32, _vp, _i32, _i64, _f]),
     "ll_map_size": (_i64, [_vp, _i32]),
+    "ll_map_generation": (_i64, [_vp, _i32]),
     "ll_map_to_f16": (_i32, [_vp, _i32]),
     "ll_map_dequantized": (_i32, [_vp, _i32, _vp, _i64]),
     "ll_map_knn5": (_i32, [_vp, _i32, _vp, _i32, _f, _vp, _vp]),

@@ -429,6 +429,7 @@ struct ll_map {
     std::mutex mu;
     std::shared_ptr<MapSnap> cur[2];
     std::vector<std::shared_ptr<MapSnap>> pool[2];
+    int64_t generation[2] = {0, 0};  // snapshots published so far per kind (ll_map_generation)
 };
 
 static std::shared_ptr<MapSnap> map_pin(const ll_map *cm, int kind)
@@ -451,6 +452,7 @@ static void map_publish(ll_map *m, int kind, const std::shared_ptr<MapSnap> &s)
 {
     std::lock_guard<std::mutex> lk(m->mu);
     m->cur[kind] = s;
+    m->generation[kind]++;
 }
 // builds the grid of `n` device-resident points into a fresh snapshot and publishes it
 static int map_rebuild(ll_map *m, int kind, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err)
@@ -516,6 +518,10 @@ extern "C" int ll_map_to_f16(ll_map *m, int32_t kind)
     if (snap.use_count() > 3) return set_err("ll_map_to_f16", "the snapshot is pinned by a registration in flight");
     const char *err = nullptr;
     if (map_to_f16(snap->mk, m->stream, &err)) return set_err("ll_map_to_f16", err ? err : "failed");
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->generation[kind]++;  // converted in place: not the structure a host-side cache uploaded any more
+    }
     return 0;
 }
 
@@ -537,6 +543,14 @@ extern "C" int ll_map_dequantized(ll_map *m, int32_t kind, float *xyz, int64_t c
     (void)hipFree(d_out);
     if (rc) return set_err("ll_map_dequantized", err ? err : "failed");
     return 0;
+}
+
+extern "C" int64_t ll_map_generation(const ll_map *cm, int32_t kind)
+{
+    if (!cm || kind < 0 || kind > 1) return -1;
+    ll_map *m = const_cast<ll_map *>(cm);
+    std::lock_guard<std::mutex> lk(m->mu);
+    return m->generation[kind];
 }
 
 extern "C" int64_t ll_map_size(const ll_map *m, int32_t kind)
@@ -668,7 +682,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     d.n_chunks = (int)((F + 255) / 256);  // must match RQ_THREADS in ll_reg_kernels.hip
     DM(d.work_cnt, B * 4);
     DM(d.work_off, 2 * 2049);  // 2 lists x (RL_MAX_SEG + 1), ll_reg_kernels.hip
-    DM(d.grp_ctl, B + 1);
+    DM(d.grp_ctl, 2 * B + 1);
     DM(d.grp_part, B * 2 * LL_GRP * 28);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
@@ -756,6 +770,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->knn_reuse_from = (debug & 8) ? 1 : 2;  // bit 3: also try reuse at ICP iteration 1 (test coverage)
     c->solver_legacy = (debug & 16) ? 1 : 0;  // bit 4: round-1 solver fast path (A/B)
     c->solve_group = (debug & 32) ? 1 : 0;    // bit 5: never spread a scan over a group of workgroups (A/B); 0 = decide per batch size
+    c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
@@ -805,10 +820,24 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         return set_err("ll_reg", "negative iteration count");
     if (map->device != r->device) return set_err("ll_reg", "map lives on another device");
     make_reg_const(prm, r->debug, &r->rc);
+    // A solve enqueued earlier on this handle and never collected still reads its snapshots: let it finish before its pins are
+    // replaced (the snapshots could otherwise be recycled and rebuilt under its kernels by a concurrent ll_map_upload / refresh).
+    if (r->pinned[0] || r->pinned[1]) HC(hipStreamSynchronize(r->stream));
     // PCR:199 gate
     // the snapshots this solve runs against, whatever ll_map_upload / ll_history_refresh* publish meanwhile
     r->pinned[0] = map_pin(map, 0);
     r->pinned[1] = map_pin(map, 1);
+    struct PinGuard {  // an enqueue that fails after this point must not leave its pins behind
+        ll_reg *r;
+        bool keep = false;
+        ~PinGuard()
+        {
+            if (!keep) {
+                r->pinned[0].reset();
+                r->pinned[1].reset();
+            }
+        }
+    } pin_guard{r};
     const MapKind empty_kind{};
     const MapKind &mk0 = r->pinned[0] ? r->pinned[0]->mk : empty_kind, &mk1 = r->pinned[1] ? r->pinned[1]->mk : empty_kind;
     const bool run = mk0.n > 0 && mk1.n > 50 && prm->current_frame_index > prm->mapping_init_accumulate_frames;
@@ -862,7 +891,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
             launch_reg_knn_build(r->dev, r->rc, mk0.grid, mk1.grid, n_scans, it, max_nc, max_ns, r->stream);
             prof_end(r);
             prof_begin(r, 1);
-            if (r->rc.solve_group > 1) HC(hipMemsetAsync(r->dev.grp_ctl, 0, (size_t)(n_scans + 1) * sizeof(int), r->stream));
+            if (r->rc.solve_group > 1) HC(hipMemsetAsync(r->dev.grp_ctl, 0, (size_t)(2 * n_scans + 1) * sizeof(int), r->stream));
             launch_reg_solve(r->dev, r->rc, mk1.grid, n_scans, r->stream);
             prof_end(r);
         }
@@ -871,6 +900,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     launch_reg_finalize(r->dev, r->rc, n_scans, r->stream);
     prof_end(r);
     HC(hipGetLastError());
+    pin_guard.keep = true;  // released by ll_reg_collect
     return 0;
 }
 
@@ -884,8 +914,10 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
     HC(hipStreamSynchronize(r->stream));
     r->pinned[0].reset();  // the solve has left the device: its map snapshots may be recycled
     r->pinned[1].reset();
+    int n_aborted = 0;
     for (int b = 0; b < n_scans; b++) {
         const RegState &s = r->h_state[b];
+        n_aborted += s.aborted ? 1 : 0;
         for (int i = 0; i < 7; i++) {
             if (poses_curr) poses_curr[7 * b + i] = s.pose_curr[i];
             if (poses_incre) poses_incre[7 * b + i] = s.inc[i];
@@ -907,6 +939,8 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
             rp.gated = s.gated;
         }
     }
+    if (n_aborted)  // (outputs are filled in: the aborted scans come back rejected, pose restored)
+        return set_err("ll_reg_collect", "a group barrier of the small-batch solver timed out (device oversubscribed?): the affected scans were rejected");
     if (r->profiling) {
         for (int k = 0; k < 3; k++) {
             r->prof_ms[k] = 0.f;

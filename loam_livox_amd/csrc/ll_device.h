@@ -94,7 +94,7 @@ struct RegState {
     double inlier_thr, final_cost, initial_cost, angular_diff, t_diff;
     int icp_iters, n_blocks_last, corner_avail, surf_avail, lm_total;
     int done, accepted, gated, result;
-    int pad;
+    int aborted;  // the grouped solver gave up on a barrier (bounded spin): the scan is rejected and ll_reg_collect reports it
     long long dbg_cycles[16];  // LL_SOLVE_TIMING builds (shader clocks): eval, LM controller, L1, dedupe, select, total, census (+ triple inserts), prune,
                                // epilogue (plane-table path: table build), [9] = exchanges / L1 shortcuts taken; plane-table path: [10] census load waits,
                                // [11] inserts, [12] block sums, [13] id compaction, [14] plane constants, [15] id pass + LDS fill
@@ -109,6 +109,7 @@ struct RegConst {
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
     int solver_legacy;   // A/B switch: round-1 fast path (49-byte fp64 plane blocks, no LDS block cache)
     int solve_group;     // workgroups per scan of the compact solver (1, or LL_GRP for small batches: ll_reg_kernels.hip, group_*)
+    int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     unsigned int subsample_seed;  // a13 (0 = off)
     int max_blocks;               // maximum_allow_residual_block
@@ -141,7 +142,7 @@ struct RegDev {
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
     float2 *ref_s;                // [B][cap]  x = bits(neighbour 4, -1 when fewer than 5 inside the radius), y = m_set
-    int *grp_ctl;                 // [1 + B] grouped solver: [0] ticket counter, [1 + b] arrival counter of scan b's group barrier (zeroed per launch)
+    int *grp_ctl;                 // [1 + 2 B] grouped solver: [0] ticket counter, [1 + 2 b] arrival counter of scan b's group barrier, [2 + 2 b] its abort word (zeroed per launch)
     double *grp_part;             // [B][2][LL_GRP][28] grouped solver: the workgroups' partial sums of one cost evaluation, double-buffered
     unsigned char *blk_flag0;     // [B][cap]  block flag as built; the solver prunes a copy (LDS, or blk_flag in the general path)
     int *work_search;             // [B][cap]  slots that need a full search this iteration

@@ -628,7 +628,8 @@ __device__ __forceinline__ int slot_of(int j, int nC, int cap_c) { return j < nC
 // are exchanged through global memory and added in rank order by every member (identical totals, identical decisions).
 // Membership is by ticket (atomic counter, zeroed per launch): the G workgroups of a group are by construction running, so the
 // flag barrier below cannot wait for a workgroup that has no CU; a partial group waits only for workgroups that start as CUs
-// free up.  Spins are bounded: a barrier that does not complete poisons the result (NaN pose) instead of hanging the device.
+// free up.  Spins are bounded: a barrier that does not complete aborts the scan's registration (RegState::aborted: the
+// scan comes back rejected with its pose restored and ll_reg_collect reports the failure) instead of hanging the device.
 #define LL_GRP_SPIN_LIMIT (1 << 22)
 // FULL: every thread's plain global stores before the barrier (the L1 values) are visible to every member after it, and no
 // member keeps stale lines -- an agent-scope release / acquire fence in every wavefront.  Otherwise only data moved with
@@ -640,15 +641,19 @@ __device__ __forceinline__ void group_barrier(const RegDev &rd, int b, SolveShar
     __syncthreads();
     if (threadIdx.x == 0 && !sh.grp_abort) {
         const int target = (++sh.grp_seq) * sh.grp_G;
-        int *bar = rd.grp_ctl + 1 + b;
+        int *bar = rd.grp_ctl + 1 + 2 * b, *abt = bar + 1;  // the scan's arrival counter and its abort word
         __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > LL_GRP_SPIN_LIMIT) {
+            // a member that gives up tells the others: they must not go on with its stale partial sums, nor wait out their own
+            // limit for arrivals that will never come
+            if (++spins > LL_GRP_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(abt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 sh.grp_abort = 1;
+                __hip_atomic_store(abt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
+        if (!sh.grp_abort && __hip_atomic_load(abt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh.grp_abort = 1;
     }
     __syncthreads();  // (the partial sums are then read with agent-scope atomic loads, which no cache level may satisfy stale)
     if (FULL) __threadfence();
@@ -2191,8 +2196,14 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
     if (GROUPED) {
         group_barrier<false>(rd, b, sh);  // nobody reads st->inc / st->pose_last any more
         if (sh.grp_g != 0) return;
-        if (sh.grp_abort && tid < 7) sh.ctl.x[tid] = __longlong_as_double(0x7ff8000000000000LL);  // a barrier timed out: poison the pose
-        __syncthreads();
+        if (sh.grp_abort) {  // a barrier timed out: nothing this group computed can be trusted (reg_finalize_kernel rejects the scan)
+            if (tid == 0) {
+                st->aborted = 1;
+                st->done = 1;
+                st->icp_iters += 1;
+            }
+            return;
+        }
     }
     solve_epilogue(rc, st, sh, lm_iters);
     LL_TACC(8, t_epi);
@@ -2221,8 +2232,9 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
 //   5. a cost evaluation streams 18 bytes per block (the fp32 feature point straight from the extractor's cloud + the 16-bit
 //      id) instead of 48 and reads the plane from LDS (ids beyond the LDS part: one 32-byte gather from the table in L2);
 //      whatever LDS the table leaves free caches the first records {f, id} of the scan across the evaluations of a solve.
-// Every block still evaluates exactly the numbers the other paths evaluate, in the same order: results are bit-identical to
-// solve_fast2's (one workgroup per scan) and iteration-for-iteration equal to the oracle's.
+// Every block still evaluates the numbers the other paths evaluate ({n', c} from block_plane, bit for bit), in the same order;
+// the compiler contracts the multiply-adds of the two evaluation loops differently, so results agree with solve_fast2's to
+// rounding (pose 1e-12) and iteration for iteration with the oracle's (tests/test_gpu_reg.py).
 #define PT_SLOTS 8192
 #define PT_MAX_PROBE 192
 #define PT_LDS_BYTES 155648           // s_raw of reg_solve_kernel: 152 KB
@@ -2930,8 +2942,14 @@ __device__ void solve_fast3(const RegDev &rd, const RegConst &rc, const f4 *map_
     if (GROUPED) {
         group_barrier<false>(rd, b, sh);  // nobody reads st->inc / st->pose_last any more
         if (sh.grp_g != 0) return;
-        if (sh.grp_abort && tid < 7) sh.ctl.x[tid] = __longlong_as_double(0x7ff8000000000000LL);  // a barrier timed out: poison the pose
-        __syncthreads();
+        if (sh.grp_abort) {  // a barrier timed out: nothing this group computed can be trusted (reg_finalize_kernel rejects the scan)
+            if (tid == 0) {
+                st->aborted = 1;
+                st->done = 1;
+                st->icp_iters += 1;
+            }
+            return;
+        }
     }
     solve_epilogue(rc, st, sh, lm_iters);
 #ifdef LL_SOLVE_TIMING
@@ -2971,7 +2989,7 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
         sh.grp_g = g;
         sh.grp_G = G;
         sh.grp_seq = 0;
-        sh.grp_abort = 0;
+        sh.grp_abort = (rc.test_group_abort && G > 1) ? 1 : 0;  // test switch: behave as if the first barrier had timed out
     }
     __syncthreads();
     const int total = rd.n_corner[b] + rd.n_surf[b];
@@ -2999,7 +3017,9 @@ __global__ void reg_finalize_kernel(RegDev rd, RegConst rc, int n_scans)
     if (st->gated || st->icp_iters == 0) return;
     st->inlier_thr = st->inlier_thr * st->final_cost / st->initial_cost;  // PCR:559
     const float minimize_cost = (float)st->final_cost;                    // PCR:192,519
-    if (st->angular_diff > (double)rc.para_max_angular_rate || minimize_cost > rc.max_final_cost) {  // PCR:561
+    // (an aborted solve, or anything non-finite that reached the pose, is a rejection too: NaN compares false with both limits)
+    const bool broken = st->aborted || !((st->angular_diff - st->angular_diff) == 0.0) || !((st->final_cost - st->final_cost) == 0.0);
+    if (broken || st->angular_diff > (double)rc.para_max_angular_rate || minimize_cost > rc.max_final_cost) {  // PCR:561
         for (int i = 0; i < 7; i++) st->pose_curr[i] = st->pose_last[i];
         st->result = 0;
         st->accepted = 0;

@@ -20,6 +20,9 @@ def test_bench_reads_the_committed_counter_summaries():
     assert vf and vf["source"].startswith("profiles/r") and vf["fp64_wave_instructions"] < vf["valu_wave_instructions"]
     assert 1e9 < vf["flops"] < 1e11
     assert bench.pmc_valu_fp64("no_such_kernel", 256) is None
+    kn = bench.pmc_knn_issue(256)
+    assert kn and kn["bound"] == "valu-issue" and 0.2 < kn["lane_utilisation"] <= 1.0 and 0.05 < kn["valu_issue_frac_at_2p4GHz"] < 1.5
+    assert all(os.path.exists(os.path.join(ROOT, p)) for p in kn["sources"]) and bench.pmc_knn_issue(8) is None
     # the newest summary wins (round tags sort lexicographically)
     newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.csv")))[-1]
     assert os.path.relpath(newest, ROOT) == src
@@ -47,3 +50,19 @@ def test_summarize_rocprof_generic_and_trace(tmp_path):
         w.writerow(["void ll::reg_knn_kernel(ll::RegDev)", 1024, 2, 1, 128, 56, 0, 0, 5000, 9000])
     out = subprocess.run([sys.executable, tool, "trace", str(trace)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
     assert out[1] == "ll::reg_knn_kernel,2048,128,56,0,0,2,0.006,3.0,2.0,4.0"
+
+
+def test_summarize_rocprof_reads_register_counts_from_the_code_object():
+    """VGPR / spill figures come from the gfx950 code objects embedded in the built library, not from rocprofv3's VGPR_Count
+    column (allocation granules: half the register count)"""
+    lib = os.path.join(ROOT, "loam_livox_amd", "libloamlivox_hip.so")
+    if not os.path.exists(lib):
+        import pytest
+        pytest.skip("library not built")
+    tool = os.path.join(ROOT, "tools", "summarize_rocprof.py")
+    out = subprocess.run([sys.executable, tool, "codeobj", lib], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert out[0] == "kernel,vgpr,agpr,sgpr,vgpr_spill,sgpr_spill,scratch_bytes,lds_bytes,waves_per_simd"
+    rows = {r.split(",")[0]: r.split(",") for r in out[1:]}
+    sol = rows["ll::reg_solve_kernel<0>"]
+    assert int(sol[1]) == 256 and int(sol[7]) > 150000 and int(sol[8]) == 2   # one 512-thread workgroup per CU, two waves per SIMD
+    assert 64 <= int(rows["ll::reg_knn_kernel"][1]) <= 128 and int(rows["ll::reg_knn_kernel"][6]) == 0

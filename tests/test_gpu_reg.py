@@ -111,6 +111,77 @@ def test_registration_matches_oracle(dev_map, small_world, scans, k, force, gene
     reg.close()
 
 
+@pytest.mark.parametrize("packed48", [False, True])
+def test_group_barrier_abort_rejects_the_scan(dev_map, scans, packed48):
+    """A group barrier of the small-batch solver that does not complete (bounded spin; forced here) must not hand back a NaN
+    pose as an accepted result: the scan is rejected with its pose restored and ll_reg_collect reports the failure."""
+    import ctypes as C
+    from loam_livox_amd.api import RegReport
+    from loam_livox_amd.capi import ptr
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    assert len(fc) + len(fs) >= 6000  # large enough for the grouped form
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(False, test_group_abort=True, packed48_solver=packed48)
+    set_params(reg, 4, 20, 1)
+    reg.upload_features([fc], [fs])
+    pl = sc.pose_init.reshape(1, 7).copy()
+    reg.enqueue_uploaded(dev_map, 1, pl, pl)
+    pc, pi = np.zeros((1, 7)), np.zeros((1, 7))
+    reps, res = (RegReport * 1)(), np.ones(1, np.int32)
+    rc = reg.L.ll_reg_collect(reg.h, 1, ptr(pc), ptr(pi), reps, ptr(res))
+    assert rc < 0 and b"timed out" in reg.L.ll_last_error()
+    assert res[0] == 0 and reps[0].accepted == 0 and np.array_equal(pc[0], sc.pose_init) and np.all(np.isfinite(pc))
+    # the handle is usable afterwards
+    reg.set_debug(False, packed48_solver=packed48)
+    reg.enqueue_uploaded(dev_map, 1, pl, pl)
+    res2, pc2, _, _ = reg.collect(1)
+    assert res2[0] == 1 and np.all(np.isfinite(pc2)) and not np.array_equal(pc2[0], sc.pose_init)
+    reg.close()
+
+
+@pytest.mark.parametrize("groups", [False, True])
+@pytest.mark.parametrize("world", ["rooms", "random_cloud"])
+def test_plane_table_agrees_with_packed_records(dev_map, scans, groups, world):
+    """The plane-table solver path evaluates, block for block and in the same order, the numbers of the round-2 path that
+    stores {n', c} with every block (the compiler contracts the two instantiations' multiply-adds differently, so they agree to
+    rounding, not to the bit) -- on the synthetic rooms (a few thousand distinct neighbour triples: the whole table in LDS) and
+    against a uniform random cloud, where nearly every block has a triple of its own: the LDS hash table fills up (private
+    table entries), the table overflows its LDS part (planes gathered from HBM) and nothing is de-duplicated."""
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    if world == "rooms":
+        m = dev_map
+    else:
+        rng = np.random.default_rng(5)
+        lo, hi = synth.transform_points(sc.pose_init, fs[:, :3]).min(0) - 1.0, synth.transform_points(sc.pose_init, fs[:, :3]).max(0) + 1.0
+        m = Map_buffer()
+        m.setInputCloud(Map_buffer.CORNER, rng.uniform(lo, hi, (60000, 3)).astype(np.float32))
+        m.setInputCloud(Map_buffer.SURF, rng.uniform(lo, hi, (400000, 3)).astype(np.float32))
+    out = []
+    for packed in (False, True):
+        reg = Point_cloud_registration(max_scans=1, max_features=24000)
+        reg.set_debug(False, packed48_solver=packed, no_solver_groups=not groups)
+        set_params(reg, 2 if world != "rooms" else 4, 20, 1)
+        reg.m_pose_w_last = sc.pose_init.copy()
+        reg.m_pose_w_curr = sc.pose_init.copy()
+        ret = reg.find_out_incremental_transfrom(m, fc, fs)
+        g = reg.report
+        out.append((ret, reg.m_pose_w_curr.copy(), g.final_cost, g.initial_cost, g.inlier_threshold, g.n_blocks_last, g.surf_avail, g.corner_avail,
+                    g.lm_iterations_total))
+        reg.close()
+    a, b = out
+    dt, dr = synth.pose_error(a[1], b[1])
+    tol = 1e-9 if world == "rooms" else 1e-6  # (registration against noise is ill-conditioned: rounding differences grow)
+    assert a[0] == b[0] and dt < tol and dr < tol and np.all(np.isfinite(a[1]))
+    assert a[6:8] == b[6:8] and a[6] > 1000  # blocks found: decided before the solver
+    assert np.isclose(a[3], b[3], rtol=1e-9)  # cost at the first evaluation: every block's constants agree
+    if world == "rooms":
+        assert a[5] == b[5] and a[8] == b[8] and np.isclose(a[2], b[2], rtol=1e-8) and np.isclose(a[4], b[4], rtol=1e-8)
+    if world != "rooms":
+        m.close()
+
+
 def test_reject_gate_and_bounds(dev_map, small_world, scans):
     sc = scans[0]
     _, _, _, _, fc, fs = oracle_features(sc)

@@ -17,7 +17,8 @@ cd "$GRAFT_REPO_ROOT"
 T=$(find /tmp/prof_$TAG/trace -name '*kernel_trace.csv' | head -1)
 F=$(find /tmp/prof_$TAG/fetch -name '*counter_collection.csv' | head -1)
 W=$(find /tmp/prof_$TAG/write -name '*counter_collection.csv' | head -1)
-python tools/summarize_rocprof.py trace "$T" > gpurun_out/${TAG}_kernel_trace_by_grid.csv
+python tools/summarize_rocprof.py trace "$T" loam_livox_amd/libloamlivox_hip.so > gpurun_out/${TAG}_kernel_trace_by_grid.csv
+python tools/summarize_rocprof.py codeobj loam_livox_amd/libloamlivox_hip.so > gpurun_out/${TAG}_code_objects.csv
 python tools/summarize_rocprof.py pmc "$F" "$W" > gpurun_out/${TAG}_pmc_hbm_bytes.csv
 cp $(find /tmp/prof_$TAG/trace -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats_raw.csv
 tail -6 gpurun_out/${TAG}_tests.log

@@ -10,7 +10,7 @@ timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-q-pipe -
 cd /tmp; rm -rf /tmp/prof_$TAG; mkdir -p /tmp/prof_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-q-pipe --no-streamed > /tmp/prof_$TAG/trace.log 2>&1
 cd "$GRAFT_REPO_ROOT"
-python tools/summarize_rocprof.py trace "$(find /tmp/prof_$TAG/trace -name '*kernel_trace.csv' | head -1)" > gpurun_out/${TAG}_kernel_trace_by_grid.csv
+python tools/summarize_rocprof.py trace "$(find /tmp/prof_$TAG/trace -name '*kernel_trace.csv' | head -1)" loam_livox_amd/libloamlivox_hip.so > gpurun_out/${TAG}_kernel_trace_by_grid.csv
 tail -4 gpurun_out/${TAG}_tests.log
 python - gpurun_out/${TAG}_bench.json <<'PY'
 import json,sys
