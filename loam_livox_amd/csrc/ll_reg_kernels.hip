@@ -233,80 +233,104 @@ void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 
 // K6r: transform + reuse test (ICP iteration >= 1)
 
-// workgroup compaction into the two dense work lists of a scan-and-kind: every thread with state 1 (re-sort) or 2 (search)
-// gets a distinct position in its list; the workgroup reserves one contiguous range per list with ONE round of ballots, one
-// barrier pair and two independent atomicAdds issued back to back (two rounds doubled the dependent latency every
-// workgroup pays before it can retire).  Returns the position, or -1 for state 0.  All threads must call it.
-__device__ __forceinline__ int rq_dense_slot2(int state, int *s_wave_cnt /*[2][RQ_WAVES]*/, int *s_base /*[2]*/, int *g_cnt /*[0] search, [1] re-sort*/,
-                                              int tid)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const unsigned long long m1 = __ballot(state == 1), m2 = __ballot(state == 2);
-    if (lane == 0) {
-        s_wave_cnt[wave] = __popcll(m1);
-        s_wave_cnt[RQ_WAVES + wave] = __popcll(m2);
-    }
-    __syncthreads();
-    int off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
-    for (int w = 0; w < RQ_WAVES; w++) {
-        const int c1 = s_wave_cnt[w], c2 = s_wave_cnt[RQ_WAVES + w];
-        if (w < wave) off1 += c1, off2 += c2;
-        tot1 += c1, tot2 += c2;
-    }
-    if (tid == 0) {
-        const int b1 = tot1 > 0 ? atomicAdd(g_cnt + 1, tot1) : 0;
-        const int b2 = tot2 > 0 ? atomicAdd(g_cnt + 0, tot2) : 0;
-        s_base[0] = b1;
-        s_base[1] = b2;
-    }
-    __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (state == 1) return s_base[0] + off1 + __popcll(m1 & below);
-    if (state == 2) return s_base[1] + off2 + __popcll(m2 & below);
-    return -1;
-}
-
-// One workgroup per chunk of RQ_THREADS consecutive queries; unstable queries are appended to the batch-wide dense work
-// lists (rq_dense_slot), the per-chunk counts are kept for the debug taps.
+// One workgroup per chunk of RQ_PER x RQ_THREADS consecutive queries (round 3: four queries per thread -- their eight record loads
+// are in flight together, and a workgroup pays its two barriers and two list reservations once per 1024 queries instead of once per
+// 256; round 2: 73 us per B = 256 launch for 141 MB of records).  Unstable queries are appended to the dense per-(scan, kind) work
+// lists: every thread with state 1 (re-sort) or 2 (search) gets a distinct position in its list; the workgroup reserves one
+// contiguous range per list with one round of ballots per query slice, one barrier pair and two independent atomicAdds issued back
+// to back.  (Within a list the entries of a workgroup are ordered by slice, then wavefront, then lane; nothing depends on the order.)
+#define RQ_PER 4
 __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 {
     const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
-    if (chunk * RQ_THREADS >= n) return;
+    if (chunk * RQ_PER * RQ_THREADS >= n) return;
     const size_t sb = (size_t)b * rd.cap;
     const int koff = kind ? rd.cap_c : 0;
-    const int tid = threadIdx.x;
-    __shared__ int s_wave[2 * RQ_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_cnt[2][RQ_PER * RQ_WAVES];  // [list][slice * RQ_WAVES + wave]
     __shared__ int s_base[2];
-    const int q = chunk * RQ_THREADS + tid;
-    const int slot = koff + q;
-    int state = 0;  // 0 = stable or out of range, 1 = re-sorted, 2 = needs a search
-    if (q < n) {
-        float pw[3];
-        transform_query(st, rc, load_feature(rd, b, kind, q), pw);
-        const float4 rq = rd.ref_q[sb + slot];
-        KnnRef ref;
-        ref.qx = rq.x;
-        ref.qy = rq.y;
-        ref.qz = rq.z;
-        ref.m_strong = rq.w;
-        const float delta = knn5_ref_delta(ref, pw[0], pw[1], pw[2]);  // NaN for a non-finite query -> search
-        if (!(delta < ref.m_strong)) {  // else: same neighbours, same order: nn and the block are unchanged
-            const float2 rs = rd.ref_s[sb + slot];
-            ref.m_set = rs.y;
-            // Both kinds of work are left to the list kernel: the five gathers and the stores of a re-sort in here kept
-            // nearly every wavefront alive for three more dependent round trips (73 % of them hold at least one such lane)
-            rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
-            state = (delta < ref.m_set) ? 1 : 2;
+    float4 ft[RQ_PER], rq[RQ_PER];
+#pragma unroll
+    for (int u = 0; u < RQ_PER; u++) {
+        const int q = (chunk * RQ_PER + u) * RQ_THREADS + tid;
+        const int qc = q < n ? q : 0;
+        ft[u] = load_feature(rd, b, kind, qc);
+        rq[u] = rd.ref_q[sb + koff + qc];
+    }
+    int state[RQ_PER];  // 0 = stable or out of range, 1 = re-sorted, 2 = needs a search
+    unsigned long long m1[RQ_PER], m2[RQ_PER];
+#pragma unroll
+    for (int u = 0; u < RQ_PER; u++) {
+        const int q = (chunk * RQ_PER + u) * RQ_THREADS + tid;
+        const int slot = koff + q;
+        state[u] = 0;
+        if (q < n) {
+            float pw[3];
+            transform_query(st, rc, ft[u], pw);
+            KnnRef ref;
+            ref.qx = rq[u].x;
+            ref.qy = rq[u].y;
+            ref.qz = rq[u].z;
+            ref.m_strong = rq[u].w;
+            const float delta = knn5_ref_delta(ref, pw[0], pw[1], pw[2]);  // NaN for a non-finite query -> search
+            if (!(delta < ref.m_strong)) {  // else: same neighbours, same order: nn and the block are unchanged
+                const float2 rs = rd.ref_s[sb + slot];
+                ref.m_set = rs.y;
+                // Both kinds of work are left to the list kernel: the five gathers and the stores of a re-sort in here kept
+                // nearly every wavefront alive for three more dependent round trips (73 % of them hold at least one such lane)
+                rd.qw[sb + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
+                state[u] = (delta < ref.m_set) ? 1 : 2;
+            }
+        }
+        m1[u] = __ballot(state[u] == 1);
+        m2[u] = __ballot(state[u] == 2);
+        if (lane == 0) {
+            s_cnt[0][u * RQ_WAVES + wave] = __popcll(m1[u]);
+            s_cnt[1][u * RQ_WAVES + wave] = __popcll(m2[u]);
         }
     }
-    int *cnt = rd.work_cnt + ((size_t)b * 2 + kind) * 2;
+    __syncthreads();
+    int off1[RQ_PER], off2[RQ_PER], tot1 = 0, tot2 = 0;
+#pragma unroll
+    for (int u = 0; u < RQ_PER; u++) {
+        off1[u] = off2[u] = 0;
+        for (int w = 0; w < RQ_WAVES; w++) {
+            const int c1 = s_cnt[0][u * RQ_WAVES + w], c2 = s_cnt[1][u * RQ_WAVES + w];
+            if (w < wave) off1[u] += c1, off2[u] += c2;
+            tot1 += c1, tot2 += c2;
+        }
+    }
+    // (offsets of slice u: everything in the slices before it, then the earlier wavefronts of its own)
+    int pre1 = 0, pre2 = 0;
+#pragma unroll
+    for (int u = 0; u < RQ_PER; u++) {
+        int s1 = 0, s2 = 0;
+        for (int w = 0; w < RQ_WAVES; w++) s1 += s_cnt[0][u * RQ_WAVES + w], s2 += s_cnt[1][u * RQ_WAVES + w];
+        off1[u] += pre1;
+        off2[u] += pre2;
+        pre1 += s1;
+        pre2 += s2;
+    }
+    int *cnt = rd.work_cnt + ((size_t)b * 2 + kind) * 2;  // [0] search, [1] re-sort
+    if (tid == 0) {
+        const int b1 = tot1 > 0 ? atomicAdd(cnt + 1, tot1) : 0;
+        const int b2 = tot2 > 0 ? atomicAdd(cnt + 0, tot2) : 0;
+        s_base[0] = b1;
+        s_base[1] = b2;
+    }
+    __syncthreads();
     const size_t seg = sb + koff;  // the scan-and-kind's own segment of the work arrays
-    const int at = rq_dense_slot2(state, s_wave, s_base, cnt, tid);
-    if (state == 1) rd.work_build[seg + at] = (int)sb + slot;
-    if (state == 2) rd.work_search[seg + at] = (int)sb + slot;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int u = 0; u < RQ_PER; u++) {
+        const int q = (chunk * RQ_PER + u) * RQ_THREADS + tid;
+        const int slot = koff + q;
+        if (state[u] == 1) rd.work_build[seg + s_base[0] + off1[u] + __popcll(m1[u] & below)] = (int)sb + slot;
+        if (state[u] == 2) rd.work_search[seg + s_base[1] + off2[u] + __popcll(m2[u] & below)] = (int)sb + slot;
+    }
 }
 
 // Loads through an explicit global (address space 1) pointer.  Inside a non-inlined device function the compiler cannot
@@ -3046,7 +3070,7 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     if (iter >= rc.knn_reuse_from && rc.knn_reuse) {
         if (max_nc + max_ns <= 0) return;
         const int mx = max_nc > max_ns ? max_nc : max_ns;
-        dim3 cgrid((mx + RQ_THREADS - 1) / RQ_THREADS, n_scans, 2);
+        dim3 cgrid((mx + RQ_PER * RQ_THREADS - 1) / (RQ_PER * RQ_THREADS), n_scans, 2);
         (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);
         hipLaunchKernelGGL(reg_requery_kernel, cgrid, dim3(RQ_THREADS), 0, s, rd, rc, gc, gs, iter);
         for (int seg0 = 0; seg0 < 2 * n_scans; seg0 += RL_MAX_SEG) {
