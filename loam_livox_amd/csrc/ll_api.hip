@@ -886,9 +886,13 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
                          r->rc.solver_legacy || max_nc + max_ns < LL_GRP_MIN_BLOCKS) ? 1 : LL_GRP;
     if (run) {
         if (!mk0.pts || !mk1.pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
+        // the searches of a registration that reuses neighbours prune with a guard band (ll_knn_core.h Grid::guard): ~8 % more
+        // candidates per search, displacement budgets set by the true 6th neighbour, a third fewer searches in the late iterations
+        Grid g0 = mk0.grid, g1 = mk1.grid;
+        g0.guard = g1.guard = r->rc.knn_reuse ? 0.05f : 0.0f;
         for (int it = 0; it < prm->icp_max_iterations; it++) {
             prof_begin(r, 0);
-            launch_reg_knn_build(r->dev, r->rc, mk0.grid, mk1.grid, n_scans, it, max_nc, max_ns, r->stream);
+            launch_reg_knn_build(r->dev, r->rc, g0, g1, n_scans, it, max_nc, max_ns, r->stream);
             prof_end(r);
             prof_begin(r, 1);
             if (r->rc.solve_group > 1) HC(hipMemsetAsync(r->dev.grp_ctl, 0, (size_t)(2 * n_scans + 1) * sizeof(int), r->stream));

@@ -28,6 +28,10 @@ struct Grid {
     float ox, oy, oz;  // origin (min corner)
     float inv_h, h;
     float slack;  // conservative allowance for fp32 rounding of cell assignment (metres)
+    float guard;  // reuse guard band (metres, 0 = off): phase 1 prunes a run / end cell only when it lies farther than the running
+                  // 5th best PLUS this -- a few more candidates per search, but the lower bound a pruned run leaves behind is then at
+                  // least d5 + guard, and the displacement budget of the reuse record (half of lb - d5) is set by the true 6th
+                  // neighbour instead of a box distance that exceeds d5 by a hair (the registrar sets 5 cm: half as many late searches)
     int nx, ny, nz;
 };
 
@@ -212,7 +216,14 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
         const float dy = dyc < 0 ? ym : (dyc > 0 ? yp : 0.0f);
         const float dz = dzc < 0 ? zm : (dzc > 0 ? zp : 0.0f);
         const float row2 = dy * dy + dz * dz;
-        const float lim = (r.count == 5) ? r.d2[4] : max_d2;
+        float lim = max_d2;
+        if (r.count == 5) {
+            lim = r.d2[4];
+            if (g.guard > 0.0f) {
+                const float d5g = sqrtf(lim) + g.guard;
+                lim = fminf(d5g * d5g, max_d2);  // (points at or beyond the match radius never count)
+            }
+        }
         if (row2 > lim) {
             r.lb2 = fminf(r.lb2, row2);  // everything in this run is at least this far
             if (row2 >= max_d2) r.out2 = fminf(r.out2, row2);

@@ -149,6 +149,7 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
     const float ext = fmaxf(fmaxf(fabsf(mm[0]), fabsf(mm[3])), fmaxf(fmaxf(fabsf(mm[1]), fabsf(mm[4])), fmaxf(fabsf(mm[2]), fabsf(mm[5])))) +
                       fmaxf(mm[3] - mm[0], fmaxf(mm[4] - mm[1], mm[5] - mm[2]));
     g.slack = 1e-3f * h + 2e-6f * ext;
+    g.guard = 0.0f;
     const size_t ncell = (size_t)g.nx * g.ny * g.nz;
     mk.ncell = ncell;
 

@@ -92,6 +92,12 @@ class Grid:
         except Exception:
             pass
 
+    def set_guard(self, guard: float):
+        """reuse guard band of the search in metres (Grid::guard; 0 = off)"""
+        L = lib()
+        L.hc_grid_set_guard.argtypes = [C.c_void_p, C.c_float]
+        L.hc_grid_set_guard(self.h, float(guard))
+
     def knn5(self, q, max_d2):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
         idx = np.zeros((q.shape[0], 5), np.int32)

@@ -133,6 +133,7 @@ hc_grid *hc_grid_build(const float *xyz, int stride, int64_t n, float cell)
     const float ext = fmaxf(fmaxf(fabsf(mn[0]), fabsf(mx[0])), fmaxf(fmaxf(fabsf(mn[1]), fabsf(mx[1])), fmaxf(fabsf(mn[2]), fabsf(mx[2])))) +
                       fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
     g.slack = 1e-3f * cell + 2e-6f * ext;
+    g.guard = 0.0f;
     const size_t ncell = (size_t)g.nx * g.ny * g.nz;
     std::vector<std::pair<unsigned, int>> kv;
     kv.reserve(n);
@@ -168,6 +169,12 @@ hc_grid *hc_grid_build(const float *xyz, int stride, int64_t n, float cell)
     return G;
 }
 void hc_grid_free(hc_grid *G) { delete G; }
+// reuse guard band of the search (ll_knn_core.h Grid::guard; the registrar runs with 0.05 m)
+int hc_grid_set_guard(hc_grid *G, float guard)
+{
+    G->g.guard = guard;
+    return 0;
+}
 
 int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx, float *d2)
 {

@@ -86,15 +86,22 @@ def test_grid_knn_sparse_outside_and_ties():
     assert hi[500].tolist()[:4] == [100, 101, 102, 103]
 
 
+@pytest.mark.parametrize("guard", [0.0, 0.05, 0.5])
 @pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500)])
-def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts):
-    """the search keeps LL_KNN_K candidates; lb2 / out2 must bound every point outside that list whatever was pruned"""
+def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts, guard):
+    """the search keeps LL_KNN_K candidates; lb2 / out2 must bound every point outside that list whatever was pruned -- with and
+    without the reuse guard band (runs pruned only beyond the 5th best + guard: same lists, larger displacement budgets)"""
     rng = np.random.default_rng(11)
     pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
     g = hc.Grid(pts, cell)
     q = rng.uniform(-2, 32, (400, 3)).astype(np.float32)
     hi, hd = g.knn5(q, max_d2)
+    m0 = g.knn5_bounds(q, max_d2)[3]
+    g.set_guard(guard)
+    gi, gd = g.knn5(q, max_d2)
+    assert np.array_equal(gi, hi) and np.array_equal(gd, hd)
     cand, lb2, out2, m_set, m_strong = g.knn5_bounds(q, max_d2)
+    assert np.all(m_set >= m0 - 1e-7)  # never a smaller budget (on a sparse cloud like this one mostly the same: rings decide)
     assert np.array_equal(cand[:, :5], hi)
     d2_all = ((q[:, None, :].astype(np.float64) - pts[None, :, :]) ** 2).sum(-1)
     for i in range(len(q)):
@@ -112,12 +119,14 @@ def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts):
 
 @pytest.mark.parametrize("cell,max_d2,npts,step", [(0.7, 50.0, 4000, 0.05), (0.5, 2.0, 30000, 0.02), (1.3, 9.0, 1500, 0.3),
                                                    (0.6, 50.0, 60000, 0.01)])
-def test_knn_reuse_chain_is_exact(cell, max_d2, npts, step):
+@pytest.mark.parametrize("guard", [0.0, 0.05])
+def test_knn_reuse_chain_is_exact(cell, max_d2, npts, step, guard):
     """the registrar's reuse over a chain of moves (keep / re-sort the 8 candidates / search) returns at every hop exactly
     what a fresh search returns"""
     rng = np.random.default_rng(12)
     pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
     g = hc.Grid(pts, cell)
+    g.set_guard(guard)
     nq, n_hops = 600, 6
     path = np.zeros((n_hops, nq, 3), np.float32)
     path[0] = rng.uniform(-1, 31, (nq, 3))
