@@ -701,6 +701,8 @@ struct LmCtl {
     double first_eval[LL_NACC];  // evaluation at the full step (kept for a failed line search)
     double first_cand[7];
     double ls_step;
+    double ls_prev_x, ls_prev_f, ls_prev_g;  // the trial before the current one (`previous` of ArmijoLineSearch::DoSearch)
+    int ls_prev_valid;
     int ls_iter, ls_active;
     int done;
     int last_accept;  // set by lm_update: 0 = the step was not accepted, 1 = accepted and x is the point just evaluated,
@@ -752,6 +754,116 @@ LL_HD double lm_cubic_min_step(double f0, double g0, double x1, double f1, doubl
             }
         }
     }
+    return best_x;
+}
+
+// Second and later contractions of a projected line search: Ceres (line_search.cc, CUBIC interpolation with a valid `previous`
+// sample) minimises the QUINTIC through the start (0, f0, g0), the current trial (x1, f1, g1) and the previous one (x2, f2, g2)
+// over [lo, hi] -- FindInterpolatingPolynomial's 6 x 6 system with full pivoting, then the better end point or a real root of the
+// derivative inside the interval (polynomial.cc MinimizePolynomial).  The roots are bracketed by the sign changes of the quartic
+// on a fixed grid of the interval and bisected, like oracle/ll_oracle_reg.c quintic_min_step.  Out of line: this runs only when a
+// bound on t_inc is active and the first interpolated step still fails the Armijo test.
+LL_HD_NOINLINE double lm_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo,
+                                          double hi)
+{
+    double A[6][7];
+    const double xs[3] = {0.0, x1, x2}, fs[3] = {f0, f1, f2}, gs[3] = {g0, g1, g2};
+    for (int sidx = 0; sidx < 3; sidx++) {
+        double pw[6];
+        pw[0] = 1.0;
+        for (int k = 1; k < 6; k++) pw[k] = pw[k - 1] * xs[sidx];
+        for (int j = 0; j <= 5; j++) A[2 * sidx][j] = pw[5 - j];
+        A[2 * sidx][6] = fs[sidx];
+        for (int j = 0; j < 5; j++) A[2 * sidx + 1][j] = (double)(5 - j) * pw[5 - j - 1];
+        A[2 * sidx + 1][5] = 0.0;
+        A[2 * sidx + 1][6] = gs[sidx];
+    }
+    int perm[6] = {0, 1, 2, 3, 4, 5};
+    for (int k = 0; k < 6; k++) {
+        int pr = k, pc = k;
+        double best = -1.0;
+        for (int i = k; i < 6; i++)
+            for (int j = k; j < 6; j++)
+                if (fabs(A[i][j]) > best) {
+                    best = fabs(A[i][j]);
+                    pr = i;
+                    pc = j;
+                }
+        if (!(best > 0.0)) return fmin(fmax(0.5 * x1, lo), hi);
+        if (pr != k)
+            for (int j = 0; j < 7; j++) {
+                const double t = A[k][j];
+                A[k][j] = A[pr][j];
+                A[pr][j] = t;
+            }
+        if (pc != k) {
+            for (int i = 0; i < 6; i++) {
+                const double t = A[i][k];
+                A[i][k] = A[i][pc];
+                A[i][pc] = t;
+            }
+            const int t = perm[k];
+            perm[k] = perm[pc];
+            perm[pc] = t;
+        }
+        for (int i = k + 1; i < 6; i++) {
+            const double m = A[i][k] / A[k][k];
+            for (int j = k; j < 7; j++) A[i][j] -= m * A[k][j];
+        }
+    }
+    double y[6], c[6], d[5];
+    for (int i = 5; i >= 0; i--) {
+        double v = A[i][6];
+        for (int j = i + 1; j < 6; j++) v -= A[i][j] * y[j];
+        y[i] = v / A[i][i];
+    }
+    for (int i = 0; i < 6; i++) c[perm[i]] = y[i];
+    for (int j = 0; j < 5; j++) d[j] = (double)(5 - j) * c[j];
+#define LL_POLY5(x) (((((c[0] * (x) + c[1]) * (x) + c[2]) * (x) + c[3]) * (x) + c[4]) * (x) + c[5])
+#define LL_POLY4(x) ((((d[0] * (x) + d[1]) * (x) + d[2]) * (x) + d[3]) * (x) + d[4])
+    double best_x = lo, best_v = LL_POLY5(lo);
+    {
+        const double vh = LL_POLY5(hi);
+        if (!(best_v < vh)) {
+            best_v = vh;
+            best_x = hi;
+        }
+    }
+    const int NG = 1024;
+    double xa = lo, da = LL_POLY4(lo);
+    for (int k = 1; k <= NG; k++) {
+        const double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
+        const double db = LL_POLY4(xb);
+        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
+            double l = xa, r = xb, dl = da;
+            if (db != 0.0) {
+                for (int it = 0; it < 80; it++) {
+                    const double m = 0.5 * (l + r), dm = LL_POLY4(m);
+                    if (dm == 0.0) {
+                        l = r = m;
+                        break;
+                    }
+                    if ((dl < 0.0) == (dm < 0.0)) {
+                        l = m;
+                        dl = dm;
+                    } else {
+                        r = m;
+                    }
+                }
+            } else {
+                l = r = xb;
+            }
+            const double root = 0.5 * (l + r), v = LL_POLY5(root);
+            if (v < best_v) {
+                best_v = v;
+                best_x = root;
+            }
+        }
+        xa = xb;
+        da = db;
+    }
+#undef LL_POLY5
+#undef LL_POLY4
     return best_x;
 }
 
@@ -845,6 +957,7 @@ LL_LM_FN int lm_propose(LmCtl &c)
         c.ls_step = 1.0;
         c.ls_iter = 0;
         c.ls_active = 0;
+        c.ls_prev_valid = 0;
         return 1;
     }
 }
@@ -889,20 +1002,27 @@ LL_LM_FN int lm_update(LmCtl &c, const double e_in[LL_NACC])
         const bool finite_cost = (cur_cost - cur_cost) == 0.0;
         if (!finite_cost || cur_cost > c.cost + 1e-4 * c.gd * c.ls_step) {
             int failed = 0;
-            double new_step = 0.0;
+            double new_step = 0.0, cg = 0.0;
             if (++c.ls_iter >= 20) {
                 failed = 1;
             } else {
                 if (!finite_cost) {
                     new_step = fmin(fmax(c.ls_step * 0.5, 1e-3 * c.ls_step), 0.6 * c.ls_step);
                 } else {
-                    double cg = 0.0;
                     for (int j = 0; j < 6; j++) cg += e[21 + j] * c.delta[j];
-                    new_step = lm_cubic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, 1e-3 * c.ls_step, 0.6 * c.ls_step);
+                    if (c.ls_prev_valid)  // three samples: the quintic (second and later contractions)
+                        new_step = lm_quintic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, c.ls_prev_x, c.ls_prev_f, c.ls_prev_g, 1e-3 * c.ls_step,
+                                                       0.6 * c.ls_step);
+                    else
+                        new_step = lm_cubic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, 1e-3 * c.ls_step, 0.6 * c.ls_step);
                 }
                 if (new_step * c.dmax < 1e-9) failed = 1;
             }
             if (!failed) {
+                c.ls_prev_valid = finite_cost ? 1 : 0;
+                c.ls_prev_x = c.ls_step;
+                c.ls_prev_f = cur_cost;
+                c.ls_prev_g = cg;
                 c.ls_step = new_step;
                 double sd[6];
                 for (int j = 0; j < 6; j++) sd[j] = c.delta[j] * c.ls_step;

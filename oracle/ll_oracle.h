@@ -185,6 +185,9 @@ typedef struct {
  * pose_last: m_q_w_last/m_t_w_last; pose_curr in: initial guess, out: result; pose_incre: in/out
  * (identity for a fresh Point_cloud_registration, LM:1348).
  * Returns 1 (accepted / gated) or 0 (rejected, pose_curr := pose_last). */
+/* test instrumentation: most contractions any projected line search has taken since the last reset (>= 2: the three-sample
+ * interpolation ran) */
+int orc_dbg_ls_max_contractions(int reset);
 int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_t n_map_corner,
                   const orc_kdtree *tree_surf, const float *map_surf, int64_t n_map_surf, int map_stride,
                   const float *scan_corner, int n_corner, const float *scan_surf, int n_surf,

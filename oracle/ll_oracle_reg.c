@@ -29,8 +29,8 @@
  *      radius update r/max(1/3, 1-(2q-1)^3) on success, r/nu (nu*=2) on failure, r/2 on invalid step,
  *      max 5 consecutive invalid steps.  The 6x6 system (J'J + D'D) y = J'r is solved by dense Cholesky
  *      (DENSE_SCHUR on a 2-block problem is algebraically the same system).
- *    - Documented simplification: when the ARMIJO search has to contract more than once, Ceres fits a
- *      quintic through three samples; the oracle re-fits the two-sample cubic each time.
+ *    - When the ARMIJO search has to contract more than once, Ceres fits a quintic through three samples:
+ *      quintic_min_step below (round 2 re-fitted the two-sample cubic).
  *    - summary.final_cost = min over iteration costs, initial_cost = iteration-0 cost (SetSummaryFinalCost).
  *
  * Deviations from the reference that the oracle DEFINES (reference behaviour is undefined/UB):
@@ -444,6 +444,128 @@ static double gradient_max_norm(const double x[7], const double g[6], double bou
     return m;
 }
 
+/* Ceres 1.14 LineSearch::InterpolatingPolynomialMinimizingStepSize with interpolation_type = CUBIC from the SECOND contraction
+ * of a line search on: three samples with value and gradient -- the start (0, f0, g0), the current trial (x1, f1, g1) and the
+ * previous one (x2, f2, g2) -- give six constraints, i.e. the interpolating QUINTIC (polynomial.cc FindInterpolatingPolynomial:
+ * rows [x^5 .. 1] for a value, [5 x^4 .. 0] for a gradient, solved with a fully pivoted LU), minimised over [lo, hi]
+ * (MinimizePolynomial: the better end point, then every real root of the derivative inside the interval).  Ceres takes the roots
+ * from the eigenvalues of the companion matrix; here the quartic derivative is bracketed on a fixed grid of the interval and each
+ * sign change refined by bisection (a real root without a sign change is no minimum; real parts of complex roots, which Ceres
+ * also evaluates, can never beat the stationary points and end points).  The first contraction keeps the two-sample cubic below. */
+static int g_ls_max_contractions = 0; /* test instrumentation: deepest line search seen */
+int orc_dbg_ls_max_contractions(int reset)
+{
+    int v = g_ls_max_contractions;
+    if (reset) g_ls_max_contractions = 0;
+    return v;
+}
+static double poly_eval(const double *c, int deg, double x)
+{
+    double v = c[0];
+    for (int i = 1; i <= deg; i++) v = v * x + c[i];
+    return v;
+}
+static double quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi)
+{
+    double A[6][7];
+    const double xs[3] = {0.0, x1, x2}, fs[3] = {f0, f1, f2}, gs[3] = {g0, g1, g2};
+    for (int sidx = 0; sidx < 3; sidx++) {
+        double pw[6];
+        pw[0] = 1.0;
+        for (int k = 1; k < 6; k++) pw[k] = pw[k - 1] * xs[sidx];
+        for (int j = 0; j <= 5; j++) A[2 * sidx][j] = pw[5 - j];
+        A[2 * sidx][6] = fs[sidx];
+        for (int j = 0; j < 5; j++) A[2 * sidx + 1][j] = (double)(5 - j) * pw[5 - j - 1];
+        A[2 * sidx + 1][5] = 0.0;
+        A[2 * sidx + 1][6] = gs[sidx];
+    }
+    /* Gaussian elimination with complete pivoting */
+    int colperm[6] = {0, 1, 2, 3, 4, 5};
+    for (int k = 0; k < 6; k++) {
+        int pr = k, pc = k;
+        double best = -1.0;
+        for (int i = k; i < 6; i++)
+            for (int j = k; j < 6; j++)
+                if (fabs(A[i][j]) > best) {
+                    best = fabs(A[i][j]);
+                    pr = i;
+                    pc = j;
+                }
+        if (!(best > 0.0)) return fmin(fmax(0.5 * x1, lo), hi); /* singular (coincident samples): bisect like an invalid sample */
+        if (pr != k)
+            for (int j = 0; j < 7; j++) {
+                double t = A[k][j];
+                A[k][j] = A[pr][j];
+                A[pr][j] = t;
+            }
+        if (pc != k) {
+            for (int i = 0; i < 6; i++) {
+                double t = A[i][k];
+                A[i][k] = A[i][pc];
+                A[i][pc] = t;
+            }
+            int t = colperm[k];
+            colperm[k] = colperm[pc];
+            colperm[pc] = t;
+        }
+        for (int i = k + 1; i < 6; i++) {
+            double m = A[i][k] / A[k][k];
+            for (int j = k; j < 7; j++) A[i][j] -= m * A[k][j];
+        }
+    }
+    double y[6], c[6];
+    for (int i = 5; i >= 0; i--) {
+        double v = A[i][6];
+        for (int j = i + 1; j < 6; j++) v -= A[i][j] * y[j];
+        y[i] = v / A[i][i];
+    }
+    for (int i = 0; i < 6; i++) c[colperm[i]] = y[i];
+    double d[5];
+    for (int j = 0; j < 5; j++) d[j] = (double)(5 - j) * c[j];
+    double best_x = lo, best_v = poly_eval(c, 5, lo);
+    {
+        double vh = poly_eval(c, 5, hi);
+        if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
+            best_v = vh;
+            best_x = hi;
+        }
+    }
+    const int NG = 1024;
+    double xa = lo, da = poly_eval(d, 4, lo);
+    for (int k = 1; k <= NG; k++) {
+        double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
+        double db = poly_eval(d, 4, xb);
+        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
+            double l = xa, r = xb, dl = da;
+            if (db != 0.0) {
+                for (int it = 0; it < 80; it++) {
+                    double m = 0.5 * (l + r), dm = poly_eval(d, 4, m);
+                    if (dm == 0.0) {
+                        l = r = m;
+                        break;
+                    }
+                    if ((dl < 0.0) == (dm < 0.0)) {
+                        l = m;
+                        dl = dm;
+                    } else {
+                        r = m;
+                    }
+                }
+            } else {
+                l = r = xb;
+            }
+            double root = 0.5 * (l + r), v = poly_eval(c, 5, root);
+            if (v < best_v) {
+                best_v = v;
+                best_x = root;
+            }
+        }
+        xa = xb;
+        da = db;
+    }
+    return best_x;
+}
+
 /* minimiser of the cubic Hermite interpolant through (0,f0,g0) and (x1,f1,g1) on [lo,hi] */
 static double cubic_min_step(double f0, double g0, double x1, double f1, double g1, double lo, double hi)
 {
@@ -575,23 +697,33 @@ static void lm_solve(const orc_block *blocks, const unsigned char *active, int n
             double dmax = 0.0;
             for (int j = 0; j < 6; j++) dmax = fmax(dmax, fabs(delta[j]));
             int ls_iter = 0, success = 1;
+            int prev_valid = 0; /* `previous` of ArmijoLineSearch::DoSearch: the trial before the current one */
+            double prev_x = 0.0, prev_f = 0.0, prev_g = 0.0;
             while (!isfinite(cur_cost) || cur_cost > cost + 1e-4 * gd * step_size) {
                 if (++ls_iter >= 20) {
                     success = 0;
                     break;
                 }
-                double new_step;
-                if (!isfinite(cur_cost)) {
+                if (ls_iter > g_ls_max_contractions) g_ls_max_contractions = ls_iter;
+                double new_step, cg = 0.0;
+                const int cur_valid = isfinite(cur_cost) ? 1 : 0;
+                if (!cur_valid) {
                     new_step = fmin(fmax(step_size * 0.5, 1e-3 * step_size), 0.6 * step_size);
                 } else {
-                    double cg = 0.0;
                     for (int j = 0; j < 6; j++) cg += cur_g[j] * delta[j];
-                    new_step = cubic_min_step(cost, gd, step_size, cur_cost, cg, 1e-3 * step_size, 0.6 * step_size);
+                    if (prev_valid)
+                        new_step = quintic_min_step(cost, gd, step_size, cur_cost, cg, prev_x, prev_f, prev_g, 1e-3 * step_size, 0.6 * step_size);
+                    else
+                        new_step = cubic_min_step(cost, gd, step_size, cur_cost, cg, 1e-3 * step_size, 0.6 * step_size);
                 }
                 if (new_step * dmax < 1e-9) {
                     success = 0;
                     break;
                 }
+                prev_valid = cur_valid;
+                prev_x = step_size;
+                prev_f = cur_cost;
+                prev_g = cg;
                 step_size = new_step;
                 double sd[6], sx[7], sH[36];
                 for (int j = 0; j < 6; j++) sd[j] = delta[j] * step_size;

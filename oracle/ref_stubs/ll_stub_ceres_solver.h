@@ -10,8 +10,8 @@
  *   IterationZero: project x on the bounds, evaluate, Jacobi scaling 1/(1+|col|), projected gradient norm;
  *   loop: LM step on the scaled system, model cost change, invalid-step handling, projected ARMIJO line search
  *   (problem has bounds), candidate evaluation, parameter / function tolerance, step quality, radius update.
- * Simplification shared with the oracle: a second or later contraction of the line search re-fits the two-sample cubic
- * (Ceres fits a higher-order polynomial through three samples).
+ * A second or later contraction of the line search interpolates through three samples (quintic_min below), as Ceres does
+ * (round 2 re-fitted the two-sample cubic there).
  */
 #ifndef LL_STUB_CERES_SOLVER_H
 #define LL_STUB_CERES_SOLVER_H
@@ -195,6 +195,128 @@ inline bool cholesky_solve( int n, std::vector<double> A, const std::vector<doub
         if ( !std::isfinite( x[ i ] ) )
             return false;
     return true;
+}
+
+// LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC, with a valid `previous` sample (line_search.cc): three samples
+// with value and gradient -> FindInterpolatingPolynomial's 6 x 6 system (polynomial.cc: a row [x^5 .. 1] per value, [5 x^4 .. 0]
+// per gradient; fully pivoted LU) -> the quintic, minimised over [lo, hi] by MinimizePolynomial: the better end point, then the
+// real roots of the derivative inside the interval.  (Ceres: companion-matrix eigenvalues; here: sign changes of the quartic on a
+// grid of the interval, bisected -- a root without a sign change is no minimum, and the real parts of complex roots that Ceres
+// also tries cannot beat the stationary points.)
+inline double quintic_min( double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi )
+{
+    double       A[ 6 ][ 7 ];
+    const double xs[ 3 ] = { 0.0, x1, x2 }, fs[ 3 ] = { f0, f1, f2 }, gs[ 3 ] = { g0, g1, g2 };
+    for ( int s = 0; s < 3; s++ )
+    {
+        double pw[ 6 ];
+        pw[ 0 ] = 1.0;
+        for ( int k = 1; k < 6; k++ )
+            pw[ k ] = pw[ k - 1 ] * xs[ s ];
+        for ( int j = 0; j <= 5; j++ )
+            A[ 2 * s ][ j ] = pw[ 5 - j ];
+        A[ 2 * s ][ 6 ] = fs[ s ];
+        for ( int j = 0; j < 5; j++ )
+            A[ 2 * s + 1 ][ j ] = ( double ) ( 5 - j ) * pw[ 5 - j - 1 ];
+        A[ 2 * s + 1 ][ 5 ] = 0.0;
+        A[ 2 * s + 1 ][ 6 ] = gs[ s ];
+    }
+    int perm[ 6 ] = { 0, 1, 2, 3, 4, 5 };
+    for ( int k = 0; k < 6; k++ )
+    {
+        int    pr = k, pc = k;
+        double best = -1.0;
+        for ( int i = k; i < 6; i++ )
+            for ( int j = k; j < 6; j++ )
+                if ( std::fabs( A[ i ][ j ] ) > best )
+                {
+                    best = std::fabs( A[ i ][ j ] );
+                    pr = i;
+                    pc = j;
+                }
+        if ( !( best > 0.0 ) )
+            return std::min( std::max( 0.5 * x1, lo ), hi );
+        if ( pr != k )
+            for ( int j = 0; j < 7; j++ )
+                std::swap( A[ k ][ j ], A[ pr ][ j ] );
+        if ( pc != k )
+        {
+            for ( int i = 0; i < 6; i++ )
+                std::swap( A[ i ][ k ], A[ i ][ pc ] );
+            std::swap( perm[ k ], perm[ pc ] );
+        }
+        for ( int i = k + 1; i < 6; i++ )
+        {
+            const double m = A[ i ][ k ] / A[ k ][ k ];
+            for ( int j = k; j < 7; j++ )
+                A[ i ][ j ] -= m * A[ k ][ j ];
+        }
+    }
+    double y[ 6 ], c[ 6 ], d[ 5 ];
+    for ( int i = 5; i >= 0; i-- )
+    {
+        double v = A[ i ][ 6 ];
+        for ( int j = i + 1; j < 6; j++ )
+            v -= A[ i ][ j ] * y[ j ];
+        y[ i ] = v / A[ i ][ i ];
+    }
+    for ( int i = 0; i < 6; i++ )
+        c[ perm[ i ] ] = y[ i ];
+    for ( int j = 0; j < 5; j++ )
+        d[ j ] = ( double ) ( 5 - j ) * c[ j ];
+    auto P = [&]( const double *q, int deg, double x ) {
+        double v = q[ 0 ];
+        for ( int i = 1; i <= deg; i++ )
+            v = v * x + q[ i ];
+        return v;
+    };
+    double bx = lo, bv = P( c, 5, lo );
+    if ( !( bv < P( c, 5, hi ) ) )
+    {
+        bv = P( c, 5, hi );
+        bx = hi;
+    }
+    const int NG = 1024;
+    double    xa = lo, da = P( d, 4, lo );
+    for ( int k = 1; k <= NG; k++ )
+    {
+        const double xb = ( k == NG ) ? hi : lo + ( hi - lo ) * ( ( double ) k / ( double ) NG );
+        const double db = P( d, 4, xb );
+        if ( ( da < 0.0 && db > 0.0 ) || ( da > 0.0 && db < 0.0 ) || db == 0.0 )
+        {
+            double l = xa, r = xb, dl = da;
+            if ( db != 0.0 )
+            {
+                for ( int it = 0; it < 80; it++ )
+                {
+                    const double m = 0.5 * ( l + r ), dm = P( d, 4, m );
+                    if ( dm == 0.0 )
+                    {
+                        l = r = m;
+                        break;
+                    }
+                    if ( ( dl < 0.0 ) == ( dm < 0.0 ) )
+                    {
+                        l = m;
+                        dl = dm;
+                    }
+                    else
+                        r = m;
+                }
+            }
+            else
+                l = r = xb;
+            const double root = 0.5 * ( l + r ), v = P( c, 5, root );
+            if ( v < bv )
+            {
+                bv = v;
+                bx = root;
+            }
+        }
+        xa = xb;
+        da = db;
+    }
+    return bx;
 }
 
 // minimiser on [lo, hi] of the cubic through (0, f0, g0), (x1, f1, g1)
@@ -401,6 +523,8 @@ inline void Solve( const Solver::Options &opt, Problem *problem, Solver::Summary
             bool   valid = eval_at( alpha, &f_cur, &dg_cur );
             int    it = 0;
             bool   success = true;
+            bool   prev_valid = false;  // `previous` of ArmijoLineSearch::DoSearch
+            double prev_x = 0, prev_f = 0, prev_g = 0;
             while ( !valid || f_cur > cost + 1e-4 * gd * alpha )
             {
                 if ( ++it >= 20 )
@@ -411,6 +535,8 @@ inline void Solve( const Solver::Options &opt, Problem *problem, Solver::Summary
                 double na;
                 if ( !valid )
                     na = std::min( std::max( alpha * 0.5, 1e-3 * alpha ), 0.6 * alpha );
+                else if ( prev_valid )
+                    na = quintic_min( cost, gd, alpha, f_cur, dg_cur, prev_x, prev_f, prev_g, 1e-3 * alpha, 0.6 * alpha );
                 else
                     na = cubic_min( cost, gd, alpha, f_cur, dg_cur, 1e-3 * alpha, 0.6 * alpha );
                 if ( na * dmax < 1e-9 )
@@ -418,6 +544,10 @@ inline void Solve( const Solver::Options &opt, Problem *problem, Solver::Summary
                     success = false;
                     break;
                 }
+                prev_valid = valid;
+                prev_x = alpha;
+                prev_f = f_cur;
+                prev_g = dg_cur;
                 alpha = na;
                 valid = eval_at( alpha, &f_cur, &dg_cur );
             }

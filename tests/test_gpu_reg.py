@@ -208,6 +208,31 @@ def test_reject_gate_and_bounds(dev_map, small_world, scans):
     reg.close()
 
 
+@pytest.mark.parametrize("groups", [True, False])
+def test_bounded_line_search_three_sample_interpolation(dev_map, small_world, scans, groups):
+    """start 0.25 m outside a 0.05 m bound on t_inc: the projected line search contracts repeatedly -- from the second contraction
+    on with Ceres' three-sample quintic (lm_quintic_min_step on the controller lane) -- and lands where the oracle does"""
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    start = sc.pose_init.copy()
+    start[4:7] += [0.25, -0.2, 0.1]
+    prm = orc.RegParams.defaults(icp_iters=4)
+    prm.para_max_speed = 0.05
+    ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, start, start)
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(False, no_solver_groups=not groups)
+    p = set_params(reg, 4, 20, 0)
+    p.para_max_speed = 0.05
+    reg.m_pose_w_last = start.copy()
+    reg.m_pose_w_curr = start.copy()
+    gret = reg.find_out_incremental_transfrom(dev_map, fc, fs)
+    dt, dr = synth.pose_error(reg.m_pose_w_curr, pc)
+    assert gret == ret and dt < 1e-7 and dr < 1e-7
+    assert reg.report.lm_iterations_total == rep.lm_iterations_total and reg.report.icp_iterations == rep.icp_iterations
+    assert np.all(np.abs(reg.m_para_buffer_incremental[4:]) <= float(np.float32(0.05)) + 1e-15)
+    reg.close()
+
+
 def test_empty_and_nonfinite_features(dev_map, scans):
     sc = scans[0]
     reg = Point_cloud_registration(max_features=1000)

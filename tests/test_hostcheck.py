@@ -192,6 +192,32 @@ def test_full_registration_matches_oracle(small_world, scans, k):
         assert np.isclose(rep.final_cost, hrep[0], rtol=1e-9) and np.isclose(rep.inlier_threshold, hrep[2], rtol=1e-9)
 
 
+def test_bounded_line_search_with_three_sample_interpolation_matches_oracle(small_world, scans):
+    """A start 0.25 m outside a 0.05 m bound on t_inc (PCR:143-151): the projected Armijo line search contracts up to ten times,
+    from the second contraction on through the three-sample quintic of Ceres' line_search.cc (lm_quintic_min_step in
+    ll_reg_core.h, quintic_min_step in the oracle, quintic_min in the Ceres stand-in of oracle/_ref -- tests/test_ref_pin.py holds
+    the oracle to that build on the same case)."""
+    import ctypes as C
+    sc = scans[0]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    gc, gs = hc.Grid(small_world["corner"], 0.5), hc.Grid(small_world["surf"], 1.0)
+    L = orc.lib()
+    L.orc_dbg_ls_max_contractions.argtypes, L.orc_dbg_ls_max_contractions.restype = [C.c_int], C.c_int
+    for bound, off in ((0.05, [0.25, -0.2, 0.1]), (0.02, [0.3, 0.3, 0.3])):
+        start = sc.pose_init.copy()
+        start[4:7] += off
+        prm = orc.RegParams.defaults(icp_iters=4)
+        prm.para_max_speed = bound
+        L.orc_dbg_ls_max_contractions(1)
+        ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, start, start)
+        assert L.orc_dbg_ls_max_contractions(0) >= 2  # the quintic ran
+        hret, hpc, hpi, hrep = hc.reg_solve(gc, gs, fc, fs, hc_reg_params(4, 20, 0, float(np.float32(bound))), start, start)
+        dt, dr = synth.pose_error(pc, hpc)
+        assert ret == hret and dt < 1e-9 and dr < 1e-9
+        assert rep.lm_iterations_total == hrep[7] and rep.icp_iterations == hrep[3]
+        assert np.all(np.abs(hpi[4:7]) <= float(np.float32(bound)) + 1e-15)
+
+
 def test_rejection_matches_oracle(small_world, scans):
     sc = scans[0]
     _, _, _, _, fc, fs = oracle_features(sc)
