@@ -328,6 +328,27 @@ class VoxelGrid {
     int max_points = 0;  // 0: sized for the first cloud seen (grown on demand)
     int status = 0;      // of the last filter(): 0 filtered, 1 leaf too small (copy of the input, like PCL), 2 no finite point
 
+    VoxelGrid() {}
+    // The node copies its filters by value into every call (laser_mapping.hpp:465-466, 1325-1326): a copy takes the configuration
+    // and creates its own device handle on first use.
+    VoxelGrid(const VoxelGrid &o) : device(o.device), max_points(o.max_points), status(0)
+    {
+        leaf_[0] = o.leaf_[0];
+        leaf_[1] = o.leaf_[1];
+        leaf_[2] = o.leaf_[2];
+    }
+    VoxelGrid &operator=(const VoxelGrid &o)
+    {
+        if (this != &o) {
+            device = o.device;
+            max_points = o.max_points;
+            leaf_[0] = o.leaf_[0];
+            leaf_[1] = o.leaf_[1];
+            leaf_[2] = o.leaf_[2];
+            in_.clear();
+        }
+        return *this;
+    }
     ~VoxelGrid()
     {
         if (h_) ll_voxel_destroy(h_);

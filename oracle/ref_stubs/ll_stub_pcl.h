@@ -227,8 +227,111 @@ template <typename PointT> class KdTreeFLANN
     }
 };
 
+// pcl::VoxelGrid<PointXYZI>::applyFilter as the reference calls it (laser_feature_extractor.hpp:372-381, laser_mapping.hpp:533-537,
+// 1367-1373, 1434-1437), PCL 1.9 semantics with default settings -- the steps listed in oracle/ll_oracle_voxel.c, written for this
+// stub: getMinMax3D over finite points, leaf index from float arithmetic, one centroid (x, y, z, intensity as float sums / count)
+// per occupied leaf in ascending leaf order.  Defined like the oracle where PCL leaves it open: points of a leaf are added in input
+// order, non-finite points are skipped, "leaf too small" copies the input.
 template <typename PointT> class VoxelGrid
 {
+    float                                         leaf_[ 3 ] = { 0, 0, 0 };
+    std::shared_ptr<const PointCloud<PointT>>     in_;
+
+  public:
+    void setLeafSize( float lx, float ly, float lz )
+    {
+        leaf_[ 0 ] = lx;
+        leaf_[ 1 ] = ly;
+        leaf_[ 2 ] = lz;
+    }
+    void setInputCloud( const std::shared_ptr<PointCloud<PointT>> &c ) { in_ = c; }
+    void setInputCloud( const std::shared_ptr<const PointCloud<PointT>> &c ) { in_ = c; }
+    void filter( PointCloud<PointT> &out )
+    {
+        const std::vector<PointT> src = in_ ? in_->points : std::vector<PointT>(); // (the node filters a cloud into itself)
+        out.points.clear();
+        float mn[ 3 ] = { 3.402823466e38f, 3.402823466e38f, 3.402823466e38f }, mx[ 3 ] = { -3.402823466e38f, -3.402823466e38f, -3.402823466e38f };
+        size_t n_valid = 0;
+        for ( const PointT &p : src )
+        {
+            if ( !std::isfinite( p.x ) || !std::isfinite( p.y ) || !std::isfinite( p.z ) )
+                continue;
+            const float v[ 3 ] = { p.x, p.y, p.z };
+            for ( int c = 0; c < 3; c++ )
+            {
+                mn[ c ] = v[ c ] < mn[ c ] ? v[ c ] : mn[ c ];
+                mx[ c ] = v[ c ] > mx[ c ] ? v[ c ] : mx[ c ];
+            }
+            n_valid++;
+        }
+        if ( n_valid == 0 )
+            return;
+        float   inv[ 3 ];
+        int64_t d[ 3 ];
+        bool    too_small = false;
+        for ( int c = 0; c < 3; c++ )
+        {
+            inv[ c ] = 1.0f / leaf_[ c ];
+            const float e = ( mx[ c ] - mn[ c ] ) * inv[ c ];
+            if ( !( e < 9.0e18f ) )
+            {
+                too_small = true;
+                d[ c ] = 0;
+            }
+            else
+                d[ c ] = ( int64_t ) e + 1;
+        }
+        if ( too_small || d[ 0 ] > INT32_MAX || d[ 1 ] > INT32_MAX || d[ 0 ] * d[ 1 ] > INT32_MAX || d[ 2 ] > INT32_MAX || d[ 0 ] * d[ 1 ] * d[ 2 ] > INT32_MAX )
+        {
+            out.points = src; // "Leaf size is too small for the input dataset"
+            return;
+        }
+        int32_t min_b[ 3 ], div_b[ 3 ], mul[ 3 ];
+        for ( int c = 0; c < 3; c++ )
+        {
+            min_b[ c ] = ( int32_t ) std::floor( mn[ c ] * inv[ c ] );
+            div_b[ c ] = ( int32_t ) std::floor( mx[ c ] * inv[ c ] ) - min_b[ c ] + 1;
+        }
+        mul[ 0 ] = 1;
+        mul[ 1 ] = div_b[ 0 ];
+        mul[ 2 ] = div_b[ 0 ] * div_b[ 1 ];
+        std::vector<std::pair<uint32_t, int32_t>> keys;
+        keys.reserve( n_valid );
+        for ( size_t i = 0; i < src.size(); i++ )
+        {
+            const PointT &p = src[ i ];
+            if ( !std::isfinite( p.x ) || !std::isfinite( p.y ) || !std::isfinite( p.z ) )
+                continue;
+            const int32_t i0 = ( int32_t )( std::floor( p.x * inv[ 0 ] ) - ( float ) min_b[ 0 ] );
+            const int32_t i1 = ( int32_t )( std::floor( p.y * inv[ 1 ] ) - ( float ) min_b[ 1 ] );
+            const int32_t i2 = ( int32_t )( std::floor( p.z * inv[ 2 ] ) - ( float ) min_b[ 2 ] );
+            keys.push_back( std::make_pair( ( uint32_t )( i0 * mul[ 0 ] + i1 * mul[ 1 ] + i2 * mul[ 2 ] ), ( int32_t ) i ) );
+        }
+        std::sort( keys.begin(), keys.end() ); // (leaf, input index): input order inside a leaf
+        size_t k = 0;
+        while ( k < keys.size() )
+        {
+            size_t e = k;
+            float  sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+            while ( e < keys.size() && keys[ e ].first == keys[ k ].first )
+            {
+                const PointT &p = src[ keys[ e ].second ];
+                sx = sx + p.x;
+                sy = sy + p.y;
+                sz = sz + p.z;
+                si = si + p.intensity;
+                e++;
+            }
+            const float cnt = ( float ) ( e - k );
+            PointT      o;
+            o.x = sx / cnt;
+            o.y = sy / cnt;
+            o.z = sz / cnt;
+            o.intensity = si / cnt;
+            out.points.push_back( o );
+            k = e;
+        }
+    }
 };
 template <typename PointT> class StatisticalOutlierRemoval
 {

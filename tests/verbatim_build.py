@@ -43,12 +43,17 @@ typedef loam_livox_hip::Point_cloud_registration::Opt_summary Summary_t;
 typedef loam_livox_hip::VoxelGrid<pcl::PointCloud<PointType>> Voxel_t;
 #else
 #include "point_cloud_registration.hpp"  // the reference's own class
+#include <pcl/filters/voxel_grid.h>
 typedef ceres::Solver::Summary Summary_t;
+#ifdef LL_USE_SEQ_REF
+typedef pcl::VoxelGrid<PointType> Voxel_t;  // the stand-in of oracle/ref_stubs (PCL 1.9 semantics, oracle/ll_oracle_voxel.c's definition)
+#else
 struct Voxel_t {  // the down-sampled clouds of the excerpt feed the history (outside the excerpt); the pose does not depend on them
     void setLeafSize( float, float, float ) {}
     template <class P> void setInputCloud( const P & ) {}
     template <class C> void filter( C & ) {}
 };
+#endif
 #endif
 using namespace std;
 int g_if_undistore = 0;  // laser_mapping.hpp:80
@@ -203,5 +208,429 @@ def build(force=False):
     return EXE_A, EXE_B
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The mapping loop: process_new_scan from its first line to the pose read-back, the history add rule and the history branch of
+# update_buff_for_matching, executed frame after frame -- again ONE translation unit, built with the adapter classes and with the
+# reference's own Point_cloud_registration + a stand-in pcl::VoxelGrid.  Verbatim line ranges of source/laser_mapping.hpp:
+#   1243-1258  find_min_max_intensity, refine_blur            1266-1297  init_pointcloud_registration
+#   1299-1314  if_matchbuff_and_pc_sync                        1330-1350, 1352-1404  process_new_scan up to the registration
+#   1405-1445  registration, "Add new frame"                   1446-1463, 1468-1490  history add rule and trimming
+#   1496-1512  pose read-back                                  467-470, 518-531, 533-565  update_buff_for_matching, history branch
+# Left out (declared by the harness instead): the by-value copies of the two filters and the k-d tree locals (:1325-1328, :465-468 --
+# they name pcl::VoxelGrid, which INTEGRATION.md replaces by loam_livox_hip::VoxelGrid), ros::Time::now() (:1351), the two
+# screen_out lines about the cell maps (:1465-1466) and the cell-map appends / service thread (:1491-1493, :1496ff).
+EXE_SA, EXE_SB = os.path.join(OUT, "sequence_adapter"), os.path.join(OUT, "sequence_reference")
+
+SEQ_HARNESS = r'''
+#include <chrono>
+#include <list>
+#include <thread>
+#define PCD_SAVE_RAW 1  // laser_mapping.hpp:76
+double history_add_t_step = 0.00;      // :83
+double history_add_angle_step = 0.00;  // :84
+struct Pcl_tools_stub { template <class C> void save_to_pcd_files( const char *, C &, int ) {} };
+typedef pcl::KdTreeFLANN<PointType> Kd_t;
+
+class Laser_mapping_harness
+{
+  public:
+    // members of Laser_mapping the excerpts touch, with the reference's types and defaults (laser_mapping.hpp:98-280)
+    Common_tools::File_logger m_logger_common, m_logger_pcd, m_logger_timer, m_logger_matching_buff;
+    Common_tools::Timer       m_timer;
+    int    if_motion_deblur = 0, m_current_frame_index = 0, m_mapping_init_accumulate_frames = 50;
+    double m_last_time_stamp = 0, m_minimum_pt_time_stamp = 0, m_maximum_pt_time_stamp = 1.0, m_time_odom = 0;
+    int    m_if_input_downsample_mode = 1, m_maximum_history_size = 100, m_if_save_to_pcd_files = 0;
+    float  m_para_max_angular_rate = 200.0 / 50.0, m_para_max_speed = 100.0 / 50.0, m_max_final_cost = 100.0;
+    int    m_para_icp_max_iterations = 20, m_para_cere_max_iterations = 100, m_para_optimization_maximum_residual_block = 1e5;
+    double m_minimum_icp_R_diff = 0.01, m_minimum_icp_T_diff = 0.01;
+    float  m_line_resolution = 0.4, m_plane_resolution = 0.8;
+    double m_lastest_pc_reg_time = -3e8, m_lastest_pc_matching_refresh_time = -1, m_lastest_pc_income_time = -3e8;
+    double m_maximum_pointcloud_delay_time = 0.1;
+    std::list<pcl::PointCloud<PointType>> m_laser_cloud_corner_history, m_laser_cloud_surface_history, m_laser_cloud_full_history;
+    std::list<double>  m_his_reg_error;
+    Eigen::Quaterniond m_last_his_add_q;
+    Eigen::Vector3d    m_last_his_add_t;
+    int m_if_mapping_updated_corner = true, m_if_mapping_updated_surface = true;
+    pcl::PointCloud<PointType>::Ptr m_laser_cloud_corner_from_map_last, m_laser_cloud_surf_from_map_last;
+    pcl::PointCloud<PointType>::Ptr m_laser_cloud_full_res, m_laser_cloud_corner_last, m_laser_cloud_surf_last;
+    Kd_t m_kdtree_corner_from_map_last, m_kdtree_surf_from_map_last;
+    double m_para_buffer_RT[ 7 ] = { 0, 0, 0, 1, 0, 0, 0 };
+    double m_para_buffer_RT_last[ 7 ] = { 0, 0, 0, 1, 0, 0, 0 };
+    Eigen::Map<Eigen::Quaterniond> m_q_w_curr = Eigen::Map<Eigen::Quaterniond>( m_para_buffer_RT );
+    Eigen::Map<Eigen::Vector3d>    m_t_w_curr = Eigen::Map<Eigen::Vector3d>( m_para_buffer_RT + 4 );
+    Eigen::Map<Eigen::Quaterniond> m_q_w_last = Eigen::Map<Eigen::Quaterniond>( m_para_buffer_RT_last );
+    Eigen::Map<Eigen::Vector3d>    m_t_w_last = Eigen::Map<Eigen::Vector3d>( m_para_buffer_RT_last + 4 );
+    std::mutex m_mutex_mapping, m_mutex_querypointcloud, m_mutex_buff_for_matching_corner, m_mutex_buff_for_matching_surface,
+        m_mutex_dump_full_history;
+    Summary_t      m_final_opt_summary;
+    Voxel_t        m_down_sample_filter_corner, m_down_sample_filter_surface;
+    Pcl_tools_stub m_pcl_tools_raw;
+    int            m_matching_mode = 0;
+    ADD_SCREEN_PRINTF_OUT_METHOD;
+
+    Laser_mapping_harness()
+    {
+        m_laser_cloud_corner_from_map_last.reset( new pcl::PointCloud<PointType>() );
+        m_laser_cloud_surf_from_map_last.reset( new pcl::PointCloud<PointType>() );
+        m_laser_cloud_full_res.reset( new pcl::PointCloud<PointType>() );
+        m_laser_cloud_corner_last.reset( new pcl::PointCloud<PointType>() );
+        m_laser_cloud_surf_last.reset( new pcl::PointCloud<PointType>() );
+        m_last_his_add_q.setIdentity();
+        m_last_his_add_t.setZero();
+    }
+
+// ---- verbatim: laser_mapping.hpp:1243-1258
+@HELPERS@
+// ---- verbatim: laser_mapping.hpp:1266-1297
+@INIT@
+// ---- verbatim: laser_mapping.hpp:1299-1314
+@SYNC@
+// ---- end of excerpts
+
+    void update_buff_for_matching_history_branch()
+    {
+        Voxel_t down_sample_filter_corner = m_down_sample_filter_corner;    // :465-466
+        Voxel_t down_sample_filter_surface = m_down_sample_filter_surface;
+// ---- verbatim: laser_mapping.hpp:467-470
+@UPD_HEAD@
+// ---- end of excerpt
+// ---- verbatim: laser_mapping.hpp:518-531 (the body of the else branch: m_matching_mode == 0)
+@UPD_HIST@
+// ---- end of excerpt
+// ---- verbatim: laser_mapping.hpp:533-565
+@UPD_TAIL@
+// ---- end of excerpt
+    }
+
+    int process_new_scan()
+    {
+        m_timer.tic( "Frame process" );          // :1318-1323
+        m_timer.tic( "Query points for match" );
+        pcl::PointCloud<PointType> current_laser_cloud_full, current_laser_cloud_corner_last, current_laser_cloud_surf_last;
+        Voxel_t down_sample_filter_corner = m_down_sample_filter_corner;    // :1325-1328
+        Voxel_t down_sample_filter_surface = m_down_sample_filter_surface;
+        Kd_t    kdtree_corner_from_map;
+        Kd_t    kdtree_surf_from_map;
+// ---- verbatim: laser_mapping.hpp:1330-1350
+@PNS_A@
+// ---- verbatim: laser_mapping.hpp:1352-1404
+@PNS_B@
+// ---- verbatim: laser_mapping.hpp:1405-1445
+@REG@
+// ---- verbatim: laser_mapping.hpp:1446-1463
+@HIS_A@
+// ---- verbatim: laser_mapping.hpp:1468-1490
+@HIS_B@
+// ---- end of excerpts
+        m_mutex_mapping.unlock();  // :1495
+        m_final_opt_summary = pc_reg.m_final_opt_summary;
+// ---- verbatim: laser_mapping.hpp:1494-1512 is the registration's pose read-back; here :1496-1512
+@POSE@
+// ---- end of excerpt
+        return 1;
+    }
+};
+
+typedef pcl::PointCloud<PointType> Cloud;
+static std::shared_ptr<Cloud> load_cloud( FILE *f, int n )
+{
+    std::shared_ptr<Cloud> c( new Cloud() );
+    for ( int i = 0; i < n; i++ )
+    {
+        float v[ 4 ];
+        if ( fread( v, sizeof( float ), 4, f ) != 4 ) { fprintf( stderr, "short read\n" ); exit( 3 ); }
+        PointType p;
+        p.x = v[ 0 ]; p.y = v[ 1 ]; p.z = v[ 2 ]; p.intensity = v[ 3 ];
+        c->points.push_back( p );
+    }
+    return c;
+}
+
+// argv: frames.bin out.txt line_res plane_res init_accumulate_frames maximum_history_size icp_max_iterations max_final_cost
+// frames.bin: int32 n_frames, then per frame int32 n_corner, n_surf, n_full and the three xyzi clouds (what /pc2_corners,
+// /pc2_surface, /pc2_full carry into the mapping node).  Per frame: process_new_scan, then the match-buffer refresh, like the
+// node's service thread would (synchronously: its timing is not reproducible).  Output per frame: return value, pose, sizes of
+// the history and of the match buffer, checksum-like sums of the match-buffer clouds.
+int main( int argc, char **argv )
+{
+    if ( argc < 9 ) return 2;
+    FILE *f = fopen( argv[ 1 ], "rb" );
+    if ( !f ) return 3;
+    int n_frames = 0;
+    if ( fread( &n_frames, sizeof( int ), 1, f ) != 1 ) return 3;
+    FILE *out = fopen( argv[ 2 ], "w" );
+    Laser_mapping_harness node;
+    node.m_if_verbose_screen_printf = 1;
+    node.m_line_resolution = ( float ) atof( argv[ 3 ] );
+    node.m_plane_resolution = ( float ) atof( argv[ 4 ] );
+    node.m_mapping_init_accumulate_frames = atoi( argv[ 5 ] );
+    node.m_maximum_history_size = atoi( argv[ 6 ] );
+    node.m_para_icp_max_iterations = atoi( argv[ 7 ] );
+    node.m_max_final_cost = ( float ) atof( argv[ 8 ] );
+    node.m_para_max_angular_rate = 20.0f;   // the launch files' max_allow_incre_R / T
+    node.m_para_max_speed = 0.3f;
+    node.m_para_cere_max_iterations = 20;
+    node.m_down_sample_filter_corner.setLeafSize( node.m_line_resolution, node.m_line_resolution, node.m_line_resolution );       // :742-743
+    node.m_down_sample_filter_surface.setLeafSize( node.m_plane_resolution, node.m_plane_resolution, node.m_plane_resolution );
+    for ( int k = 0; k < n_frames; k++ )
+    {
+        int n[ 3 ];
+        if ( fread( n, sizeof( int ), 3, f ) != 3 ) return 3;
+        node.m_laser_cloud_corner_last = load_cloud( f, n[ 0 ] );
+        node.m_laser_cloud_surf_last = load_cloud( f, n[ 1 ] );
+        node.m_laser_cloud_full_res = load_cloud( f, n[ 2 ] );
+        const int res = node.process_new_scan();
+        node.update_buff_for_matching_history_branch();
+        double sc = 0, ss = 0;
+        for ( auto &p : node.m_laser_cloud_corner_from_map_last->points ) sc += ( double ) p.x + 2.0 * p.y + 3.0 * p.z;
+        for ( auto &p : node.m_laser_cloud_surf_from_map_last->points ) ss += ( double ) p.x + 2.0 * p.y + 3.0 * p.z;
+        fprintf( out, "%d %d %d %d %d", res, ( int ) node.m_laser_cloud_corner_history.size(), ( int ) node.m_laser_cloud_surface_history.size(),
+                 ( int ) node.m_laser_cloud_corner_from_map_last->points.size(), ( int ) node.m_laser_cloud_surf_from_map_last->points.size() );
+        for ( int i = 0; i < 7; i++ ) fprintf( out, " %.17g", node.m_para_buffer_RT[ i ] );
+        fprintf( out, " %.17g %.17g\n", sc, ss );
+    }
+    fclose( out );
+    return 0;
+}
+'''
+
+
+def build_sequence(force=False):
+    """-> (adapter exe, reference exe) of the mapping-loop harness; like build()"""
+    if not have_reference():
+        return (EXE_SA if os.path.exists(EXE_SA) else None, EXE_SB if os.path.exists(EXE_SB) else None)
+    from loam_livox_amd import build as libbuild
+    lib = libbuild.build()
+    deps = [os.path.abspath(__file__), os.path.join(ROOT, "include", "loam_livox_adapter.hpp"), os.path.join(ROOT, "include", "loam_livox_hip.h"), lib]
+    deps += [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(ROOT, "oracle", "ref_stubs")) for f in fs]
+    if not force and all(os.path.exists(e) and all(os.path.getmtime(d) <= os.path.getmtime(e) for d in deps) for e in (EXE_SA, EXE_SB)):
+        return EXE_SA, EXE_SB
+    os.makedirs(OUT, exist_ok=True)
+    L = lambda a, b: _lines("source/laser_mapping.hpp", a, b)
+    tu = HEAD + (SEQ_HARNESS.replace("@HELPERS@", L(1243, 1258)).replace("@INIT@", L(1266, 1297)).replace("@SYNC@", L(1299, 1314))
+                 .replace("@UPD_HEAD@", L(467, 470)).replace("@UPD_HIST@", L(518, 531)).replace("@UPD_TAIL@", L(533, 565))
+                 .replace("@PNS_A@", L(1330, 1350)).replace("@PNS_B@", L(1352, 1404)).replace("@REG@", L(1405, 1445))
+                 .replace("@HIS_A@", L(1446, 1463)).replace("@HIS_B@", L(1468, 1490)).replace("@POSE@", L(1496, 1512)))
+    stubs = os.path.join(ROOT, "oracle", "ref_stubs")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_sequence.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        inc = ["-I", os.path.join(stubs, "override"), "-I-", "-I", stubs, "-I", os.path.join(REF, "source"), "-I", os.path.join(REF, "include"),
+               "-I", os.path.join(REF, "include", "tools"), "-I", os.path.join(ROOT, "include")]
+        common = ["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w"]
+        subprocess.check_call(common + ["-DLL_USE_ADAPTER"] + inc + [src, "-o", EXE_SA, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+        subprocess.check_call(common + ["-DLL_USE_SEQ_REF"] + inc + [src, "-o", EXE_SB, "-lpthread"])
+    return EXE_SA, EXE_SB
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_sequence(force=True))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The feature node: Laser_feature::laserCloudHandler from the start-up delay to the end of its Livox branch
+# (source/laser_feature_extractor.hpp:256-392, one verbatim range), message after message -- built with loam_livox_hip::Livox_laser +
+# loam_livox_hip::VoxelGrid and with the reference's own Livox_laser + the stand-in pcl::VoxelGrid.  The ROS surface the lines touch
+# (PointCloud2 with header.stamp, pcl::fromROSMsg / toROSMsg, Publisher::publish, ros::Time::now) is a few structs in the harness.
+EXE_FA, EXE_FB = os.path.join(OUT, "feature_adapter"), os.path.join(OUT, "feature_reference")
+
+FEAT_HEAD = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <iostream>
+#include <Eigen/Eigen>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include "tools/common.h"
+#include "tools/tools_logger.hpp"
+#include "tools/tools_timer.hpp"
+#ifdef LL_USE_ADAPTER
+#include "loam_livox_adapter.hpp"
+using Livox_laser = loam_livox_hip::Livox_laser;                             // INTEGRATION.md section 2
+typedef loam_livox_hip::VoxelGrid<pcl::PointCloud<PointType>> Voxel_t;
+#else
+#include "livox_feature_extractor.hpp"   // the reference's own class
+#include <pcl/filters/voxel_grid.h>
+typedef pcl::VoxelGrid<PointType> Voxel_t;
+#endif
+using namespace std;
+namespace ros
+{
+struct Time
+{
+    double      t = 0;
+    static Time now() { return Time(); }
+    double      toSec() const { return t; }
+};
+} // namespace ros
+namespace sensor_msgs
+{
+struct PointCloud2
+{
+    struct Header
+    {
+        ros::Time   stamp;
+        std::string frame_id;
+    } header;
+    pcl::PointCloud<PointType> cloud;
+};
+typedef std::shared_ptr<const PointCloud2> PointCloud2ConstPtr;
+} // namespace sensor_msgs
+namespace pcl
+{
+template <class C> void fromROSMsg( const sensor_msgs::PointCloud2 &m, C &c ) { c = m.cloud; }
+template <class C> void toROSMsg( const C &c, sensor_msgs::PointCloud2 &m ) { m.cloud = c; }
+} // namespace pcl
+struct Capture_pub
+{
+    std::vector<pcl::PointCloud<PointType>> *sink = nullptr;
+    void publish( const sensor_msgs::PointCloud2 &m ) { sink->push_back( m.cloud ); }
+};
+'''
+
+FEAT_HARNESS = r'''
+class Laser_feature_harness
+{
+  public:
+    Livox_laser m_livox;                        // laser_feature_extractor.hpp:92
+    int         m_laser_scan_number = 64;       // :90
+    int         m_para_system_init_count = 0, m_para_system_delay = 20;
+    bool        m_para_systemInited = false;
+    int         m_if_pub_debug_feature = 1, m_piecewise_number = 3, m_if_motion_deblur = 0, m_lidar_type = 1, m_odom_mode = 0;
+    int         m_maximum_input_lidar_pointcloud = 3;
+    float       m_plane_resolution = 0.8f, m_line_resolution = 0.8f;
+    double      m_minimum_range = 0.1;
+    std::vector<std::vector<pcl::PointCloud<pcl::PointXYZI>>> m_map_pointcloud_corner_vec_vec, m_map_pointcloud_surface_vec_vec,
+        m_map_pointcloud_full_vec_vec;          // :113-115
+    Voxel_t                   m_voxel_filter_for_surface, m_voxel_filter_for_corner;
+    sensor_msgs::PointCloud2  temp_out_msg;
+    Capture_pub               m_pub_pc_livox_corners, m_pub_pc_livox_surface, m_pub_pc_livox_full;
+    Common_tools::File_logger m_file_logger;
+    std::vector<pcl::PointCloud<PointType>> out_full, out_surface, out_corners;
+
+    void init()
+    {
+        m_map_pointcloud_full_vec_vec.resize( m_maximum_input_lidar_pointcloud );      // :163-172
+        m_map_pointcloud_surface_vec_vec.resize( m_maximum_input_lidar_pointcloud );
+        m_map_pointcloud_corner_vec_vec.resize( m_maximum_input_lidar_pointcloud );
+        for ( int i = 0; i < m_maximum_input_lidar_pointcloud; i++ )
+        {
+            m_map_pointcloud_full_vec_vec[ i ].resize( m_piecewise_number );
+            m_map_pointcloud_surface_vec_vec[ i ].resize( m_piecewise_number );
+            m_map_pointcloud_corner_vec_vec[ i ].resize( m_piecewise_number );
+        }
+        m_voxel_filter_for_surface.setLeafSize( m_plane_resolution / 2, m_plane_resolution / 2, m_plane_resolution / 2 );   // :192-193
+        m_voxel_filter_for_corner.setLeafSize( m_line_resolution, m_line_resolution, m_line_resolution );
+        m_pub_pc_livox_full.sink = &out_full;
+        m_pub_pc_livox_surface.sink = &out_surface;
+        m_pub_pc_livox_corners.sink = &out_corners;
+    }
+
+    void laserCloudHandler_excerpt( const sensor_msgs::PointCloud2ConstPtr &laserCloudMsg, int current_lidar_index )
+    {
+// ---- verbatim: laser_feature_extractor.hpp:256-392
+@HANDLER@
+// ---- end of excerpt
+    }
+};
+
+// argv: msgs.bin out.bin piecewise_number odom_mode maximum_input_lidar_pointcloud para_system_delay plane_res line_res if_motion_deblur
+// msgs.bin: int32 n_msgs, then per message int32 n_points, int32 lidar, float64 stamp, the xyzi cloud.
+// out.bin: per message int32 n_published, then per publication three clouds (full, surface, corners) as int32 n + n x xyzi.
+int main( int argc, char **argv )
+{
+    if ( argc < 10 ) return 2;
+    FILE *f = fopen( argv[ 1 ], "rb" );
+    FILE *out = fopen( argv[ 2 ], "wb" );
+    if ( !f || !out ) return 3;
+    Laser_feature_harness node;
+    node.m_piecewise_number = atoi( argv[ 3 ] );
+    node.m_odom_mode = atoi( argv[ 4 ] );
+    node.m_maximum_input_lidar_pointcloud = atoi( argv[ 5 ] );
+    node.m_para_system_delay = atoi( argv[ 6 ] );
+    node.m_plane_resolution = ( float ) atof( argv[ 7 ] );
+    node.m_line_resolution = ( float ) atof( argv[ 8 ] );
+    node.m_if_motion_deblur = atoi( argv[ 9 ] );
+    node.m_livox.thr_corner_curvature = 0.05;   // :152-154, 854, 859
+    node.m_livox.thr_surface_curvature = 0.01;
+    node.m_livox.minimum_view_angle = 10;
+    node.m_livox.m_livox_min_allow_dis = 0.1f;
+    node.m_livox.m_livox_min_sigma = 7e-4f;
+#ifdef LL_USE_ADAPTER
+    node.m_livox.piecewise_number = node.m_if_motion_deblur ? 1 : node.m_piecewise_number;
+    node.m_livox.max_points = 30000;
+#else
+    node.m_livox.m_if_verbose_screen_printf = 1;
+    node.m_livox.m_last_maximum_time_stamp = 0;  // LFE:152 leaves it uninitialised; defined as 0 (DESIGN, oracle)
+#endif
+    node.init();
+    int n_msgs = 0;
+    if ( fread( &n_msgs, sizeof( int ), 1, f ) != 1 ) return 3;
+    for ( int k = 0; k < n_msgs; k++ )
+    {
+        int    hdr[ 2 ];
+        double stamp;
+        if ( fread( hdr, sizeof( int ), 2, f ) != 2 || fread( &stamp, sizeof( double ), 1, f ) != 1 ) return 3;
+        std::shared_ptr<sensor_msgs::PointCloud2> msg( new sensor_msgs::PointCloud2() );
+        msg->header.stamp.t = stamp;
+        msg->cloud.points.resize( hdr[ 0 ] );
+        for ( int i = 0; i < hdr[ 0 ]; i++ )
+        {
+            float v[ 4 ];
+            if ( fread( v, sizeof( float ), 4, f ) != 4 ) return 3;
+            msg->cloud.points[ i ].x = v[ 0 ]; msg->cloud.points[ i ].y = v[ 1 ]; msg->cloud.points[ i ].z = v[ 2 ]; msg->cloud.points[ i ].intensity = v[ 3 ];
+        }
+        node.out_full.clear(); node.out_surface.clear(); node.out_corners.clear();
+        node.laserCloudHandler_excerpt( msg, hdr[ 1 ] );
+        const int n_pub = ( int ) node.out_full.size();
+        fwrite( &n_pub, sizeof( int ), 1, out );
+        for ( int j = 0; j < n_pub; j++ )
+            for ( auto *cl : { &node.out_full[ j ], &node.out_surface[ j ], &node.out_corners[ j ] } )
+            {
+                const int n = ( int ) cl->points.size();
+                fwrite( &n, sizeof( int ), 1, out );
+                for ( auto &p : cl->points )
+                {
+                    const float v[ 4 ] = { p.x, p.y, p.z, p.intensity };
+                    fwrite( v, sizeof( float ), 4, out );
+                }
+            }
+    }
+    fclose( out );
+    return 0;
+}
+'''
+
+
+def build_feature(force=False):
+    """-> (adapter exe, reference exe) of the feature-node harness; like build()"""
+    if not have_reference():
+        return (EXE_FA if os.path.exists(EXE_FA) else None, EXE_FB if os.path.exists(EXE_FB) else None)
+    from loam_livox_amd import build as libbuild
+    lib = libbuild.build()
+    deps = [os.path.abspath(__file__), os.path.join(ROOT, "include", "loam_livox_adapter.hpp"), os.path.join(ROOT, "include", "loam_livox_hip.h"), lib]
+    deps += [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(ROOT, "oracle", "ref_stubs")) for f in fs]
+    if not force and all(os.path.exists(e) and all(os.path.getmtime(d) <= os.path.getmtime(e) for d in deps) for e in (EXE_FA, EXE_FB)):
+        return EXE_FA, EXE_FB
+    os.makedirs(OUT, exist_ok=True)
+    tu = FEAT_HEAD + FEAT_HARNESS.replace("@HANDLER@", _lines("source/laser_feature_extractor.hpp", 256, 392))
+    stubs = os.path.join(ROOT, "oracle", "ref_stubs")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_feature.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        inc = ["-I", os.path.join(stubs, "override"), "-I-", "-I", stubs, "-I", os.path.join(REF, "source"), "-I", os.path.join(REF, "include"),
+               "-I", os.path.join(REF, "include", "tools"), "-I", os.path.join(ROOT, "include")]
+        common = ["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w"]
+        subprocess.check_call(common + ["-DLL_USE_ADAPTER"] + inc + [src, "-o", EXE_FA, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+        subprocess.check_call(common + inc + [src, "-o", EXE_FB, "-lpthread"])
+    return EXE_FA, EXE_FB
