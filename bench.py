@@ -263,11 +263,17 @@ def main():
         barrier()
         ts = time.perf_counter()
         pair[0].upload(scans, times, wait=False)  # the first batch's copy is inside the timed region too
+        t_sync = t_up = 0.0
         for i in range(args.steps):
             cur, nxt = pair[i % 2], pair[(i + 1) % 2]
+            ta = time.perf_counter()
             cur.sync()                                # batch i has arrived
+            tb = time.perf_counter()
             if i + 1 < args.steps:
                 nxt.upload(scans, times, wait=False)  # batch i+1 crosses PCIe while batch i is processed
+            tc = time.perf_counter()
+            t_sync += tb - ta
+            t_up += tc - tb
             run_on(cur)
         barrier()
         el_s = time.perf_counter() - ts
@@ -277,6 +283,8 @@ def main():
             el_s = float(t.item())
         streamed = {"value": round(total_scans / el_s, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el_s / args.steps, 3),
                     "h2d_bytes_per_step": int(B * N * 16),
+                    "host_ms_per_step_waiting_for_the_upload": round(1e3 * t_sync / args.steps, 3),
+                    "host_ms_per_step_in_the_upload_call": round(1e3 * t_up / args.steps, 3),
                     "note": "every batch uploaded from page-locked host memory inside the timed region (asynchronous copies, two extractor "
                             "handles: batch i+1 crosses PCIe while batch i runs)"}
         fe.upload(scans, times)  # leave the first handle as the resident configuration left it

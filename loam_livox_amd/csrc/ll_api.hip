@@ -73,6 +73,11 @@ struct ll_fe {
     int *d_npts = nullptr;
     double *d_time0 = nullptr;
     std::vector<int> h_npts;
+    // page-locked staging of the per-scan point counts and time bases: an asynchronous copy from pageable memory makes the host
+    // wait for everything queued on the stream before it -- behind the 98 MB scan upload that was 1.5 ms per step during which no
+    // kernel of the batch in flight could be enqueued
+    int *hp_npts = nullptr;
+    double *hp_time0 = nullptr;
 };
 
 extern "C" void ll_fe_default_params(ll_fe_params *p)
@@ -161,6 +166,8 @@ static int fe_create_impl(const ll_fe_params *p, ll_fe *h)
     HC(hipMemset(d.n_full, 0, B * sizeof(int)));
     HC(hipMemset(d.info, 0, B * sizeof(FeScanInfo)));
     h->h_npts.assign(B, 0);
+    HC(hipHostMalloc((void **)&h->hp_npts, B * sizeof(int), hipHostMallocDefault));
+    HC(hipHostMalloc((void **)&h->hp_time0, B * sizeof(double), hipHostMallocDefault));
     return 0;
 }
 
@@ -190,6 +197,8 @@ extern "C" void ll_fe_destroy(ll_fe *h)
                     d.n_ambig, d.ambig_list};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->hp_npts) (void)hipHostFree(h->hp_npts);
+    if (h->hp_time0) (void)hipHostFree(h->hp_time0);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -224,12 +233,20 @@ static int fe_upload_impl(ll_fe *h, int32_t first_scan, int32_t n_scans, const f
     if (n_points < 0 || n_points > h->prm.max_points) return set_err("ll_fe_upload", "n_points exceeds max_points");
     HC(hipSetDevice(h->prm.device));
     const size_t N = h->prm.max_points;
-    if (n_points > 0)
+    // (the staging slots of an upload still in flight are not rewritten: a second upload on a busy handle waits for it first)
+    if (hipStreamQuery(h->stream) != hipSuccess) HC(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n_scans; i++) {
+        h->h_npts[first_scan + i] = n_points;
+        h->hp_npts[first_scan + i] = n_points;
+        h->hp_time0[first_scan + i] = current_time[i];
+    }
+    HC(hipMemcpyAsync(h->d_npts + first_scan, h->hp_npts + first_scan, n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HC(hipMemcpyAsync(h->d_time0 + first_scan, h->hp_time0 + first_scan, n_scans * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (n_points > 0 && (size_t)n_points == N)  // full slots: one linear copy (a pitched copy of the same bytes does not run at link speed)
+        HC(hipMemcpyAsync(h->d_xyzi + (size_t)first_scan * N, xyzi, (size_t)n_scans * N * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    else if (n_points > 0)
         HC(hipMemcpy2DAsync(h->d_xyzi + (size_t)first_scan * N, N * sizeof(float4), xyzi, (size_t)n_points * sizeof(float4),
                             (size_t)n_points * sizeof(float4), n_scans, hipMemcpyHostToDevice, h->stream));
-    for (int i = 0; i < n_scans; i++) h->h_npts[first_scan + i] = n_points;
-    HC(hipMemcpyAsync(h->d_npts + first_scan, h->h_npts.data() + first_scan, n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HC(hipMemcpyAsync(h->d_time0 + first_scan, current_time, n_scans * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (wait) HC(hipStreamSynchronize(h->stream));  // the caller's buffers may be reused right away
     return 0;
 }
