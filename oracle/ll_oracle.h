@@ -188,6 +188,7 @@ typedef struct {
 /* test instrumentation: most contractions any projected line search has taken since the last reset (>= 2: the three-sample
  * interpolation ran) */
 int orc_dbg_ls_max_contractions(int reset);
+long long orc_dbg_ls_quintic_fits(int reset);
 int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_t n_map_corner,
                   const orc_kdtree *tree_surf, const float *map_surf, int64_t n_map_surf, int map_stride,
                   const float *scan_corner, int n_corner, const float *scan_surf, int n_surf,

@@ -447,99 +447,78 @@ static double gradient_max_norm(const double x[7], const double g[6], double bou
 /* Ceres 1.14 LineSearch::InterpolatingPolynomialMinimizingStepSize with interpolation_type = CUBIC from the SECOND contraction
  * of a line search on: three samples with value and gradient -- the start (0, f0, g0), the current trial (x1, f1, g1) and the
  * previous one (x2, f2, g2) -- give six constraints, i.e. the interpolating QUINTIC (polynomial.cc FindInterpolatingPolynomial:
- * rows [x^5 .. 1] for a value, [5 x^4 .. 0] for a gradient, solved with a fully pivoted LU), minimised over [lo, hi]
+ * rows [x^5 .. 1] for a value, [5 x^4 .. 0] for a gradient, solved with a fully pivoted LU; this restatement builds the same
+ * interpolant in Newton form by divided differences -- the two agree to rounding, checked against a dense solve in
+ * tests/test_hostcheck.py), minimised over [lo, hi]
  * (MinimizePolynomial: the better end point, then every real root of the derivative inside the interval).  Ceres takes the roots
  * from the eigenvalues of the companion matrix; here the quartic derivative is bracketed on a fixed grid of the interval and each
  * sign change refined by bisection (a real root without a sign change is no minimum; real parts of complex roots, which Ceres
  * also evaluates, can never beat the stationary points and end points).  The first contraction keeps the two-sample cubic below. */
 static int g_ls_max_contractions = 0; /* test instrumentation: deepest line search seen */
+static long long g_ls_quintic_fits = 0; /* ... and how many three-sample fits ran */
 int orc_dbg_ls_max_contractions(int reset)
 {
     int v = g_ls_max_contractions;
     if (reset) g_ls_max_contractions = 0;
     return v;
 }
-static double poly_eval(const double *c, int deg, double x)
+long long orc_dbg_ls_quintic_fits(int reset)
 {
-    double v = c[0];
-    for (int i = 1; i <= deg; i++) v = v * x + c[i];
+    long long v = g_ls_quintic_fits;
+    if (reset) g_ls_quintic_fits = 0;
     return v;
 }
 static double quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi)
 {
-    double A[6][7];
-    const double xs[3] = {0.0, x1, x2}, fs[3] = {f0, f1, f2}, gs[3] = {g0, g1, g2};
-    for (int sidx = 0; sidx < 3; sidx++) {
-        double pw[6];
-        pw[0] = 1.0;
-        for (int k = 1; k < 6; k++) pw[k] = pw[k - 1] * xs[sidx];
-        for (int j = 0; j <= 5; j++) A[2 * sidx][j] = pw[5 - j];
-        A[2 * sidx][6] = fs[sidx];
-        for (int j = 0; j < 5; j++) A[2 * sidx + 1][j] = (double)(5 - j) * pw[5 - j - 1];
-        A[2 * sidx + 1][5] = 0.0;
-        A[2 * sidx + 1][6] = gs[sidx];
+    /* Newton form on the nodes z = {0, 0, x1, x1, x2} (the sixth, x2 again, closes the table): divided differences with the
+     * derivative in place of the quotient at a repeated node */
+    const double h1 = x1, h2 = x2, h21 = x2 - x1;
+    if (!(h1 != 0.0) || !(h2 != 0.0) || !(h21 != 0.0)) return fmin(fmax(0.5 * x1, lo), hi); /* coincident samples: bisect like an invalid sample */
+    const double e01 = g0, e12 = (f1 - f0) / h1, e23 = g1, e34 = (f2 - f1) / h21, e45 = g2;
+    const double a0 = (e12 - e01) / h1, a1 = (e23 - e12) / h1, a2 = (e34 - e23) / h21, a3 = (e45 - e34) / h21;
+    const double b0 = (a1 - a0) / h1, b1 = (a2 - a1) / h2, b2 = (a3 - a2) / h21;
+    const double c0 = (b1 - b0) / h2, c1 = (b2 - b1) / h2;
+    const double d0 = (c1 - c0) / h2;
+    /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep */
+#define LL_Q_EVAL(X, PV, DV)                         \
+    do {                                             \
+        const double x_ = (X);                       \
+        double b_ = d0, db_ = 0.0;                   \
+        db_ = b_ + (x_ - x2) * db_;                  \
+        b_ = c0 + (x_ - x2) * b_;                    \
+        db_ = b_ + (x_ - x1) * db_;                  \
+        b_ = b0 + (x_ - x1) * b_;                    \
+        db_ = b_ + (x_ - x1) * db_;                  \
+        b_ = a0 + (x_ - x1) * b_;                    \
+        db_ = b_ + x_ * db_;                         \
+        b_ = e01 + x_ * b_;                          \
+        db_ = b_ + x_ * db_;                         \
+        b_ = f0 + x_ * b_;                           \
+        (PV) = b_;                                   \
+        (DV) = db_;                                  \
+    } while (0)
+    double best_x = lo, best_v, vh, da, dh;
+    LL_Q_EVAL(lo, best_v, da);
+    LL_Q_EVAL(hi, vh, dh);
+    (void)dh;
+    if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
+        best_v = vh;
+        best_x = hi;
     }
-    /* Gaussian elimination with complete pivoting */
-    int colperm[6] = {0, 1, 2, 3, 4, 5};
-    for (int k = 0; k < 6; k++) {
-        int pr = k, pc = k;
-        double best = -1.0;
-        for (int i = k; i < 6; i++)
-            for (int j = k; j < 6; j++)
-                if (fabs(A[i][j]) > best) {
-                    best = fabs(A[i][j]);
-                    pr = i;
-                    pc = j;
-                }
-        if (!(best > 0.0)) return fmin(fmax(0.5 * x1, lo), hi); /* singular (coincident samples): bisect like an invalid sample */
-        if (pr != k)
-            for (int j = 0; j < 7; j++) {
-                double t = A[k][j];
-                A[k][j] = A[pr][j];
-                A[pr][j] = t;
-            }
-        if (pc != k) {
-            for (int i = 0; i < 6; i++) {
-                double t = A[i][k];
-                A[i][k] = A[i][pc];
-                A[i][pc] = t;
-            }
-            int t = colperm[k];
-            colperm[k] = colperm[pc];
-            colperm[pc] = t;
-        }
-        for (int i = k + 1; i < 6; i++) {
-            double m = A[i][k] / A[k][k];
-            for (int j = k; j < 7; j++) A[i][j] -= m * A[k][j];
-        }
-    }
-    double y[6], c[6];
-    for (int i = 5; i >= 0; i--) {
-        double v = A[i][6];
-        for (int j = i + 1; j < 6; j++) v -= A[i][j] * y[j];
-        y[i] = v / A[i][i];
-    }
-    for (int i = 0; i < 6; i++) c[colperm[i]] = y[i];
-    double d[5];
-    for (int j = 0; j < 5; j++) d[j] = (double)(5 - j) * c[j];
-    double best_x = lo, best_v = poly_eval(c, 5, lo);
-    {
-        double vh = poly_eval(c, 5, hi);
-        if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
-            best_v = vh;
-            best_x = hi;
-        }
-    }
-    const int NG = 1024;
-    double xa = lo, da = poly_eval(d, 4, lo);
+    const int NG = 32; /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
+    double xa = lo;
     for (int k = 1; k <= NG; k++) {
-        double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
-        double db = poly_eval(d, 4, xb);
+        const double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
+        double pb, db;
+        LL_Q_EVAL(xb, pb, db);
         if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
             double l = xa, r = xb, dl = da;
             if (db != 0.0) {
-                for (int it = 0; it < 80; it++) {
-                    double m = 0.5 * (l + r), dm = poly_eval(d, 4, m);
+                for (int it = 0; it < 40; it++) {
+                    const double m = 0.5 * (l + r);
+                    double pm, dm;
+                    LL_Q_EVAL(m, pm, dm);
+                    (void)pm;
                     if (dm == 0.0) {
                         l = r = m;
                         break;
@@ -554,15 +533,20 @@ static double quintic_min_step(double f0, double g0, double x1, double f1, doubl
             } else {
                 l = r = xb;
             }
-            double root = 0.5 * (l + r), v = poly_eval(c, 5, root);
+            const double root = 0.5 * (l + r);
+            double v, dv;
+            LL_Q_EVAL(root, v, dv);
+            (void)dv;
             if (v < best_v) {
                 best_v = v;
                 best_x = root;
             }
         }
+        (void)pb;
         xa = xb;
         da = db;
     }
+#undef LL_Q_EVAL
     return best_x;
 }
 
@@ -711,6 +695,7 @@ static void lm_solve(const orc_block *blocks, const unsigned char *active, int n
                     new_step = fmin(fmax(step_size * 0.5, 1e-3 * step_size), 0.6 * step_size);
                 } else {
                     for (int j = 0; j < 6; j++) cg += cur_g[j] * delta[j];
+                    if (prev_valid) g_ls_quintic_fits++;
                     if (prev_valid)
                         new_step = quintic_min_step(cost, gd, step_size, cur_cost, cg, prev_x, prev_f, prev_g, 1e-3 * step_size, 0.6 * step_size);
                     else

@@ -198,125 +198,92 @@ inline bool cholesky_solve( int n, std::vector<double> A, const std::vector<doub
 }
 
 // LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC, with a valid `previous` sample (line_search.cc): three samples
-// with value and gradient -> FindInterpolatingPolynomial's 6 x 6 system (polynomial.cc: a row [x^5 .. 1] per value, [5 x^4 .. 0]
-// per gradient; fully pivoted LU) -> the quintic, minimised over [lo, hi] by MinimizePolynomial: the better end point, then the
-// real roots of the derivative inside the interval.  (Ceres: companion-matrix eigenvalues; here: sign changes of the quartic on a
-// grid of the interval, bisected -- a root without a sign change is no minimum, and the real parts of complex roots that Ceres
-// also tries cannot beat the stationary points.)
+// with value and gradient -> the quintic interpolant (polynomial.cc FindInterpolatingPolynomial solves the 6 x 6 system with a
+// row [x^5 .. 1] per value and [5 x^4 .. 0] per gradient by fully pivoted LU; here the same polynomial in Newton form by divided
+// differences, the arithmetic the oracle and the device share), minimised over [lo, hi] by MinimizePolynomial: the better end
+// point, then the real roots of the derivative inside the interval.  (Ceres: companion-matrix eigenvalues; here: sign changes of
+// the derivative on a grid of the interval, bisected -- a root without a sign change is no minimum, and the real parts of complex
+// roots that Ceres also tries cannot beat the stationary points.)
 inline double quintic_min( double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi )
 {
-    double       A[ 6 ][ 7 ];
-    const double xs[ 3 ] = { 0.0, x1, x2 }, fs[ 3 ] = { f0, f1, f2 }, gs[ 3 ] = { g0, g1, g2 };
-    for ( int s = 0; s < 3; s++ )
-    {
-        double pw[ 6 ];
-        pw[ 0 ] = 1.0;
-        for ( int k = 1; k < 6; k++ )
-            pw[ k ] = pw[ k - 1 ] * xs[ s ];
-        for ( int j = 0; j <= 5; j++ )
-            A[ 2 * s ][ j ] = pw[ 5 - j ];
-        A[ 2 * s ][ 6 ] = fs[ s ];
-        for ( int j = 0; j < 5; j++ )
-            A[ 2 * s + 1 ][ j ] = ( double ) ( 5 - j ) * pw[ 5 - j - 1 ];
-        A[ 2 * s + 1 ][ 5 ] = 0.0;
-        A[ 2 * s + 1 ][ 6 ] = gs[ s ];
+    /* Newton form on the nodes z = {0, 0, x1, x1, x2} (the sixth, x2 again, closes the table): divided differences with the
+     * derivative in place of the quotient at a repeated node */
+    const double h1 = x1, h2 = x2, h21 = x2 - x1;
+    if (!(h1 != 0.0) || !(h2 != 0.0) || !(h21 != 0.0)) return std::min(std::max(0.5 * x1, lo), hi); /* coincident samples: bisect like an invalid sample */
+    const double e01 = g0, e12 = (f1 - f0) / h1, e23 = g1, e34 = (f2 - f1) / h21, e45 = g2;
+    const double a0 = (e12 - e01) / h1, a1 = (e23 - e12) / h1, a2 = (e34 - e23) / h21, a3 = (e45 - e34) / h21;
+    const double b0 = (a1 - a0) / h1, b1 = (a2 - a1) / h2, b2 = (a3 - a2) / h21;
+    const double c0 = (b1 - b0) / h2, c1 = (b2 - b1) / h2;
+    const double d0 = (c1 - c0) / h2;
+    /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep */
+#define LL_Q_EVAL(X, PV, DV)                         \
+    do {                                             \
+        const double x_ = (X);                       \
+        double b_ = d0, db_ = 0.0;                   \
+        db_ = b_ + (x_ - x2) * db_;                  \
+        b_ = c0 + (x_ - x2) * b_;                    \
+        db_ = b_ + (x_ - x1) * db_;                  \
+        b_ = b0 + (x_ - x1) * b_;                    \
+        db_ = b_ + (x_ - x1) * db_;                  \
+        b_ = a0 + (x_ - x1) * b_;                    \
+        db_ = b_ + x_ * db_;                         \
+        b_ = e01 + x_ * b_;                          \
+        db_ = b_ + x_ * db_;                         \
+        b_ = f0 + x_ * b_;                           \
+        (PV) = b_;                                   \
+        (DV) = db_;                                  \
+    } while (0)
+    double best_x = lo, best_v, vh, da, dh;
+    LL_Q_EVAL(lo, best_v, da);
+    LL_Q_EVAL(hi, vh, dh);
+    (void)dh;
+    if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
+        best_v = vh;
+        best_x = hi;
     }
-    int perm[ 6 ] = { 0, 1, 2, 3, 4, 5 };
-    for ( int k = 0; k < 6; k++ )
-    {
-        int    pr = k, pc = k;
-        double best = -1.0;
-        for ( int i = k; i < 6; i++ )
-            for ( int j = k; j < 6; j++ )
-                if ( std::fabs( A[ i ][ j ] ) > best )
-                {
-                    best = std::fabs( A[ i ][ j ] );
-                    pr = i;
-                    pc = j;
-                }
-        if ( !( best > 0.0 ) )
-            return std::min( std::max( 0.5 * x1, lo ), hi );
-        if ( pr != k )
-            for ( int j = 0; j < 7; j++ )
-                std::swap( A[ k ][ j ], A[ pr ][ j ] );
-        if ( pc != k )
-        {
-            for ( int i = 0; i < 6; i++ )
-                std::swap( A[ i ][ k ], A[ i ][ pc ] );
-            std::swap( perm[ k ], perm[ pc ] );
-        }
-        for ( int i = k + 1; i < 6; i++ )
-        {
-            const double m = A[ i ][ k ] / A[ k ][ k ];
-            for ( int j = k; j < 7; j++ )
-                A[ i ][ j ] -= m * A[ k ][ j ];
-        }
-    }
-    double y[ 6 ], c[ 6 ], d[ 5 ];
-    for ( int i = 5; i >= 0; i-- )
-    {
-        double v = A[ i ][ 6 ];
-        for ( int j = i + 1; j < 6; j++ )
-            v -= A[ i ][ j ] * y[ j ];
-        y[ i ] = v / A[ i ][ i ];
-    }
-    for ( int i = 0; i < 6; i++ )
-        c[ perm[ i ] ] = y[ i ];
-    for ( int j = 0; j < 5; j++ )
-        d[ j ] = ( double ) ( 5 - j ) * c[ j ];
-    auto P = [&]( const double *q, int deg, double x ) {
-        double v = q[ 0 ];
-        for ( int i = 1; i <= deg; i++ )
-            v = v * x + q[ i ];
-        return v;
-    };
-    double bx = lo, bv = P( c, 5, lo );
-    if ( !( bv < P( c, 5, hi ) ) )
-    {
-        bv = P( c, 5, hi );
-        bx = hi;
-    }
-    const int NG = 1024;
-    double    xa = lo, da = P( d, 4, lo );
-    for ( int k = 1; k <= NG; k++ )
-    {
-        const double xb = ( k == NG ) ? hi : lo + ( hi - lo ) * ( ( double ) k / ( double ) NG );
-        const double db = P( d, 4, xb );
-        if ( ( da < 0.0 && db > 0.0 ) || ( da > 0.0 && db < 0.0 ) || db == 0.0 )
-        {
+    const int NG = 32; /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
+    double xa = lo;
+    for (int k = 1; k <= NG; k++) {
+        const double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
+        double pb, db;
+        LL_Q_EVAL(xb, pb, db);
+        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
             double l = xa, r = xb, dl = da;
-            if ( db != 0.0 )
-            {
-                for ( int it = 0; it < 80; it++ )
-                {
-                    const double m = 0.5 * ( l + r ), dm = P( d, 4, m );
-                    if ( dm == 0.0 )
-                    {
+            if (db != 0.0) {
+                for (int it = 0; it < 40; it++) {
+                    const double m = 0.5 * (l + r);
+                    double pm, dm;
+                    LL_Q_EVAL(m, pm, dm);
+                    (void)pm;
+                    if (dm == 0.0) {
                         l = r = m;
                         break;
                     }
-                    if ( ( dl < 0.0 ) == ( dm < 0.0 ) )
-                    {
+                    if ((dl < 0.0) == (dm < 0.0)) {
                         l = m;
                         dl = dm;
-                    }
-                    else
+                    } else {
                         r = m;
+                    }
                 }
-            }
-            else
+            } else {
                 l = r = xb;
-            const double root = 0.5 * ( l + r ), v = P( c, 5, root );
-            if ( v < bv )
-            {
-                bv = v;
-                bx = root;
+            }
+            const double root = 0.5 * (l + r);
+            double v, dv;
+            LL_Q_EVAL(root, v, dv);
+            (void)dv;
+            if (v < best_v) {
+                best_v = v;
+                best_x = root;
             }
         }
+        (void)pb;
         xa = xb;
         da = db;
     }
-    return bx;
+#undef LL_Q_EVAL
+    return best_x;
 }
 
 // minimiser on [lo, hi] of the cubic through (0, f0, g0), (x1, f1, g1)

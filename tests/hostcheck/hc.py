@@ -242,3 +242,11 @@ class CellMap:
         last = np.zeros(max(nc, 1), np.int32)
         self.L.hc_cellmap_dump(self.h, xyzi.ctypes.data, ijk.ctypes.data, start.ctypes.data, last.ctypes.data)
         return xyzi[:npts, :3].copy(), ijk[:nc].copy(), start, last[:nc].copy()
+
+
+def quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi):
+    """ll_reg_core.h lm_quintic_min_step compiled for the host"""
+    L = lib()
+    L.hc_quintic_min_step.restype = C.c_double
+    L.hc_quintic_min_step.argtypes = [C.c_double] * 10
+    return L.hc_quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi)

@@ -176,6 +176,12 @@ int hc_grid_set_guard(hc_grid *G, float guard)
     return 0;
 }
 
+/* the three-sample line-search interpolation of ll_reg_core.h, for the check against a dense Vandermonde solve */
+double hc_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi)
+{
+    return ll::lm_quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi);
+}
+
 int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx, float *d2)
 {
     for (int i = 0; i < nq; i++) {

@@ -368,3 +368,36 @@ def test_registration_with_subsampling_matches_oracle(small_world, scans, max_bl
     prm.subsample_seed = 8
     _, pc2, _, rep2 = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
     assert not np.array_equal(pc2, pc)
+
+
+def test_three_sample_interpolation_matches_a_dense_vandermonde_solve():
+    """Ceres (polynomial.cc FindInterpolatingPolynomial + MinimizePolynomial) solves the 6 x 6 system and takes companion-matrix
+    roots; the shared restatement uses divided differences and bracketed bisection.  Same minimiser on [lo, hi] to rounding."""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for trial in range(300):
+        x1 = 10.0 ** rng.uniform(-4, 0)
+        x2 = x1 * rng.uniform(1.5, 12.0)                      # the previous (larger) trial step
+        f0, g0 = rng.uniform(0.1, 10.0), -rng.uniform(0.1, 10.0) / x2
+        f1, f2 = f0 * rng.uniform(0.9, 1.5), f0 * rng.uniform(1.0, 4.0)
+        g1, g2 = rng.normal(0, 3.0) / x2, rng.uniform(0.0, 20.0) / x2
+        lo, hi = 1e-3 * x1, 0.6 * x1
+        # dense solve in u = x / x2 (keeps the Vandermonde matrix well scaled): rows [u^5 .. 1] per value, [5 u^4 .. 0] per gradient
+        rows, rhs = [], []
+        for x, f, g in ((0.0, f0, g0), (x1, f1, g1), (x2, f2, g2)):
+            u = x / x2
+            rows.append([u ** k for k in range(5, -1, -1)]); rhs.append(f)
+            rows.append([k * u ** (k - 1) if k > 0 else 0.0 for k in range(5, -1, -1)]); rhs.append(g * x2)
+        coef_u = np.linalg.solve(np.array(rows), np.array(rhs))
+        coef = coef_u / x2 ** np.arange(5, -1, -1)
+        cand = [lo, hi] + [float(r.real) * x2 for r in np.roots(np.polyder(coef_u)) if abs(r.imag) < 1e-12 and lo < r.real * x2 < hi]
+        vals = [np.polyval(coef, c) for c in cand]
+        want_v = min(vals)
+        got = hc.quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi)
+        assert lo <= got <= hi
+        # the minimum VALUE is what the line search acts on (two near-equal minima may swap places under rounding)
+        got_v = float(np.polyval(coef, got))
+        scale = max(abs(f0), abs(f1), abs(f2))
+        worst = max(worst, (got_v - want_v) / scale)
+        assert got_v - want_v <= 1e-9 * scale, (trial, got, cand, vals)
+    assert worst < 1e-9
