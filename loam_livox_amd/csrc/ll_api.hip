@@ -698,7 +698,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.work_build, B * d.cap);
     d.n_chunks = (int)((F + 255) / 256);  // must match RQ_THREADS in ll_reg_kernels.hip
     DM(d.work_cnt, B * 4);
-    DM(d.work_off, 2 * 2049);  // 2 lists x (RL_MAX_SEG + 1), ll_reg_kernels.hip
+    DM(d.work_off, 3 * 2049);  // 3 prefix tables x (RL_MAX_SEG + 1), ll_reg_kernels.hip
     DM(d.grp_ctl, 2 * B + 1);
     DM(d.grp_part, B * 2 * LL_GRP * 28);
     DM(d.blk_l1, B * d.cap);
@@ -789,6 +789,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->solve_group = (debug & 32) ? 1 : 0;    // bit 5: never spread a scan over a group of workgroups (A/B); 0 = decide per batch size
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
+    c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)

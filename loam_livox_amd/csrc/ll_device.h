@@ -14,6 +14,9 @@ namespace ll {
 #define LL_GRP 8             // workgroups per scan of the grouped solver
 #define LL_GRP_MIN_BLOCKS 6000  // ... whose largest scan has at least this many features (below, one CU's LDS cache holds most of a scan)
 #define LL_GRP_MAX_SCANS 16  // batches up to this size use it (LL_GRP * LL_GRP_MAX_SCANS workgroups stay below the CU count)
+// One wavefront per query (ll_knn_coop.h) where a launch is bound by its longest single-lane search chain:
+#define LL_KNN_COOP_MAX_QUERIES 8192  // ll_map_knn5 batches up to this size; corner searches of a late ICP iteration's work lists
+#define LL_KNN_COOP_MAX_SCANS 16      // all corner queries of ICP iterations 0 / 1 for batches up to this size
 
 struct FeScanInfo {
     int n_split;         // entries in split_idx (incl. the closing n-1)
@@ -111,6 +114,7 @@ struct RegConst {
     int solve_group;     // workgroups per scan of the compact solver (1, or LL_GRP for small batches: ll_reg_kernels.hip, group_*)
     int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
+    int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
     unsigned int subsample_seed;  // a13 (0 = off)
     int max_blocks;               // maximum_allow_residual_block
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
@@ -147,7 +151,8 @@ struct RegDev {
     unsigned char *blk_flag0;     // [B][cap]  block flag as built; the solver prunes a copy (LDS, or blk_flag in the general path)
     int *work_search;             // [B][cap]  slots that need a full search this iteration
     int *work_build;              // [B][cap]  slots that were re-sorted (block must be rebuilt)
-    int *work_off;                // [2][2 B + 1] exclusive prefix sums of work_cnt per list (reg_list_offsets_kernel)
+    int *work_off;                // [3][2 B + 1] exclusive prefix sums of work_cnt per list (reg_list_offsets_kernel): searches, re-sorts, and
+                                  // the searches of the corner segments alone (their surface segments counted as empty)
     int *work_cnt;                // [B][2 kinds][2] lengths of this ICP iteration's work lists (search, re-sorted) per scan and kind:
                                   // work_search / work_build hold (scan * cap + slot) entries, dense inside the scan-and-kind's own
                                   // segment [scan * cap + kind * cap_c, ...); one atomic per re-query workgroup and list reserves a range

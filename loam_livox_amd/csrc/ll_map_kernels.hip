@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "ll_device.h"
+#include "ll_knn_coop.h"
 
 namespace ll {
 
@@ -362,10 +363,29 @@ __global__ void knn5_kernel(Grid g, const float *q, int nq, float max_d2, int *i
     }
 }
 
+// one wavefront per query (ll_knn_coop.h): a small batch of queries is bound by the longest dependent-load chain of a single
+// lane's search, not by throughput
+__global__ __launch_bounds__(256) void knn5_coop_kernel(Grid g, const float *q, int nq, float max_d2, int *idx, float *d2)
+{
+    const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= nq) return;  // (whole wavefronts)
+    Knn5 r;
+    knn5_search_coop(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+            d2[5 * i + k] = r.d2[k];
+        }
+    }
+}
+
 void launch_knn5(const Grid &g, const float *d_q, int nq, float max_d2, int *d_idx, float *d_d2, hipStream_t s)
 {
     if (nq <= 0) return;
-    if (g.pts16)
+    if (!g.pts16 && nq <= LL_KNN_COOP_MAX_QUERIES)
+        hipLaunchKernelGGL(knn5_coop_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, g, d_q, nq, max_d2, d_idx, d_d2);
+    else if (g.pts16)
         hipLaunchKernelGGL(knn5_f16_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, g, d_q, nq, max_d2, d_idx, d_d2);
     else
         hipLaunchKernelGGL(knn5_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, g, d_q, nq, max_d2, d_idx, d_d2);

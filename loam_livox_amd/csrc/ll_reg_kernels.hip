@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ll_device.h"
+#include "ll_knn_coop.h"
 #include "ll_reg_core.h"
 
 namespace ll {
@@ -197,6 +198,17 @@ __device__ __forceinline__ void resort_one(const RegDev &rd, const RegConst &rc,
     knn_store(rd, rc, sb, slot, kind, iter, r);
 }
 
+__device__ __forceinline__ void knn_finish(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const float4 &pw,
+                                           float max_d2, const Knn5 &r)
+{
+    if (rc.knn_reuse || rc.check_line_pca || rc.check_plane_pca) {  // the PCA checks need all five positions
+        KnnRef ref;
+        knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
+        ref_store(rd, sb, slot, ref);
+    }
+    knn_store(rd, rc, sb, slot, kind, iter, r);
+}
+
 __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
 {
     const int kind = slot >= rd.cap_c ? 1 : 0;
@@ -205,12 +217,17 @@ __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, co
     const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
     Knn5 r;
     knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
-    if (rc.knn_reuse || rc.check_line_pca || rc.check_plane_pca) {  // the PCA checks need all five positions
-        KnnRef ref;
-        knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
-        ref_store(rd, sb, slot, ref);
-    }
-    knn_store(rd, rc, sb, slot, kind, iter, r);
+    knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
+}
+
+// The same for one CORNER query per wavefront (ll_knn_coop.h); lane 0 stores.  All 64 lanes call it with the same arguments.
+__device__ __forceinline__ void knn_one_coop(const RegDev &rd, const RegConst &rc, const Grid &gc, int b, int slot, int iter)
+{
+    const size_t sb = (size_t)b * rd.cap;
+    const float4 pw = rd.qw[sb + slot];
+    Knn5 r;
+    knn5_search_coop(gc, pw.x, pw.y, pw.z, rc.max_d2_line, r);
+    if ((threadIdx.x & 63) == 0) knn_finish(rd, rc, sb, slot, 0, iter, pw, rc.max_d2_line, r);
 }
 
 // K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
@@ -220,15 +237,29 @@ __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, co
 #define KNN_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
-void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int skip_corner)
 {
     const int b = blockIdx.y, kind = blockIdx.z;
+    if (skip_corner && kind == 0) return;  // reg_knn_corner_coop_kernel has them
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
     const int q = blockIdx.x * KB_THREADS + threadIdx.x;
     if (q >= n) return;
     knn_one(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q, iter);
+}
+
+// K6a for small batches: the corner queries one per wavefront.  A few hundred corner queries per scan, a quarter of them
+// searching rings of the sparse corner map: per lane that is the longest dependent chain of the launch (header of ll_knn_coop.h).
+#define KC_THREADS 256
+__global__ __launch_bounds__(KC_THREADS) void reg_knn_corner_coop_kernel(RegDev rd, RegConst rc, Grid gc, int iter)
+{
+    const int b = blockIdx.y;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int q = (int)((blockIdx.x * KC_THREADS + threadIdx.x) >> 6);
+    if (q >= rd.n_corner[b]) return;  // (whole wavefronts)
+    knn_one_coop(rd, rc, gc, b, q, iter);
 }
 
 // K6r: transform + reuse test (ICP iteration >= 1)
@@ -527,12 +558,13 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
 // exclusive prefix sums of the per-segment list lengths (segment = scan * 2 + kind) -> work_off[list][0 .. n_seg]; one workgroup
 __global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int seg0, int n_seg)
 {
-    __shared__ int s_wave[2][16];
+    __shared__ int s_wave[3][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sg0 = 2 * tid, sg1 = 2 * tid + 1;  // two segments per thread (n_seg <= 2048)
-    for (int w = 0; w < 2; w++) {
-        const int c0 = sg0 < n_seg ? rd.work_cnt[(size_t)(seg0 + sg0) * 2 + w] : 0;
-        const int c1 = sg1 < n_seg ? rd.work_cnt[(size_t)(seg0 + sg1) * 2 + w] : 0;
+    const int sg0 = 2 * tid, sg1 = 2 * tid + 1;  // two segments per thread (n_seg <= 2048): a scan's corner and surface segment
+    for (int w = 0; w < 3; w++) {
+        // (w = 2: the search list again with every surface segment -- odd: segment = scan * 2 + kind -- counted as empty)
+        const int c0 = sg0 < n_seg ? rd.work_cnt[(size_t)(seg0 + sg0) * 2 + (w & 1)] : 0;
+        const int c1 = (sg1 < n_seg && w < 2) ? rd.work_cnt[(size_t)(seg0 + sg1) * 2 + w] : 0;
         int incl = c0 + c1;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -552,12 +584,35 @@ __global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int s
     }
 }
 
-__global__ __launch_bounds__(RL_THREADS) void reg_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int seg0, int n_seg)
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void reg_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int seg0, int n_seg)
 {
     // The offsets table (<= 16 KB) is searched where it lies: it stays in L1 / L2, and a copy in LDS would cap the
     // occupancy of this latency-bound kernel (16 KB per 128-thread workgroup: 36 -> 99 us per late iteration at B = 256).
     const int tid = threadIdx.x;
     const int stride = gridDim.x * RL_THREADS;
+    // Corner searches first, one per WAVEFRONT while there are few of them (round 3): a late iteration searches a handful of
+    // corner queries per scan, each a chain of 100+ dependent loads for a single lane -- the floor of this launch (~100 us at
+    // B = 256 for ~1.5 k of them beside 75 k surface searches of ~15 round trips each; 49 us for a single scan).
+    const int *off_c = rd.work_off + (size_t)2 * (RL_MAX_SEG + 1);
+    const int total_c = off_c[n_seg];
+    const bool coop = rc.knn_coop && total_c <= LL_KNN_COOP_MAX_QUERIES;
+    if (coop) {
+        // (handed out from the LAST wavefront of the grid backwards: the per-lane lists below fill the grid from the front, so
+        // with short lists a wavefront has either a corner search or per-lane entries and the two chains overlap)
+        const int n_waves = stride >> 6;
+        for (int t = n_waves - 1 - (int)((blockIdx.x * RL_THREADS + tid) >> 6); t < total_c; t += n_waves) {
+            int lo = 0, hi = n_seg;  // largest segment with off_c[segment] <= t: a corner segment (the empty surface ones tie with their successor)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off_c[mid] <= t) lo = mid; else hi = mid;
+            }
+            const int b = (seg0 + lo) >> 1;
+            const int e = rd.work_search[(size_t)b * rd.cap + (t - off_c[lo])];
+            const int slot = e - b * rd.cap;
+            knn_one_coop(rd, rc, gc, b, slot, iter);
+            if ((tid & 63) == 0) build_one(rd, rc, gc, gs, b, slot);
+        }
+    }
     // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
     // to 99 us but cost 25 % at the long early lists -- profiles/r02 runs U / V -- and was dropped)
     for (int w = 0; w < 2; w++) {
@@ -571,6 +626,7 @@ __global__ __launch_bounds__(RL_THREADS) void reg_list_kernel(RegDev rd, RegCons
                 if (off[mid] <= t) lo = mid; else hi = mid;
             }
             const int sgg = seg0 + lo, b = sgg >> 1, kind = sgg & 1;
+            if (w == 0 && coop && kind == 0) continue;  // done above
             const int e = list[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off[lo])];
             const int slot = e - b * rd.cap;
             if (w == 0) knn_one(rd, rc, gc, gs, b, slot, iter);
@@ -3076,7 +3132,7 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         for (int seg0 = 0; seg0 < 2 * n_scans; seg0 += RL_MAX_SEG) {
             const int n_seg = 2 * n_scans - seg0 < RL_MAX_SEG ? 2 * n_scans - seg0 : RL_MAX_SEG;
             hipLaunchKernelGGL(reg_list_offsets_kernel, dim3(1), dim3(1024), 0, s, rd, seg0, n_seg);
-            hipLaunchKernelGGL(reg_list_kernel, dim3(n_scans >= 64 ? RL_BLOCKS : 64), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+            hipLaunchKernelGGL(reg_list_kernel, dim3(n_scans >= 64 ? RL_BLOCKS : 256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
         }
         return;
     }
@@ -3086,7 +3142,10 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     if (mx <= 0) return;
     dim3 grid((mx + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
     hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
-    hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter);
+    const int coop_corner = (rc.knn_coop && n_scans <= LL_KNN_COOP_MAX_SCANS && max_nc > 0) ? 1 : 0;
+    if (coop_corner)
+        hipLaunchKernelGGL(reg_knn_corner_coop_kernel, dim3((max_nc * 64 + KC_THREADS - 1) / KC_THREADS, n_scans), dim3(KC_THREADS), 0, s, rd, rc, gc, iter);
+    hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, coop_corner);
     hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s)

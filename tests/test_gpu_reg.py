@@ -39,10 +39,18 @@ def test_knn5_identical_to_oracle(dev_map, small_world, scans):
         assert np.array_equal(oi, gi) and np.array_equal(od, gd)
         qc = synth.transform_points(sc.pose_init, fc[:, :3])
         oi, od = small_world["tree_c"].knn(qc, 5)
-        gi, gd = dev_map.nearestKSearch(Map_buffer.CORNER, qc, 2.0)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.CORNER, qc, 2.0)   # a few hundred queries: one WAVEFRONT per query (ll_knn_coop.h)
         inside = od < 2.0
         assert np.array_equal(np.where(inside, oi, -1), gi)
         assert np.array_equal(np.where(inside, od, np.inf), gd)
+        # both forms of the search on both maps: batches of up to 8192 queries go one per wavefront, larger ones one per lane
+        reps = 8192 // len(qc) + 1
+        gi2, gd2 = dev_map.nearestKSearch(Map_buffer.CORNER, np.tile(qc, (reps, 1)), 2.0)
+        assert np.array_equal(gi2.reshape(reps, -1, 5), np.broadcast_to(gi, (reps,) + gi.shape))
+        assert np.array_equal(gd2.reshape(reps, -1, 5), np.broadcast_to(gd, (reps,) + gd.shape))
+        oi, od = small_world["tree_s"].knn(qs[:3000], 5)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.SURF, qs[:3000], 50.0)
+        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
 
 
 def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
@@ -54,10 +62,14 @@ def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
     m.setInputCloud(Map_buffer.SURF, pts, 0.7)
     tree = orc.KdTree(np.where(np.isfinite(pts), pts, 1e9).astype(np.float32))
     q = np.concatenate([rng.uniform(-8, 38, (500, 3)), pts[100:101], [[1e6, 0, 0]], [[np.nan, 0, 0]]]).astype(np.float32)
-    gi, gd = m.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    gi, gd = m.nearestKSearch(Map_buffer.SURF, q, 50.0)      # 503 queries: one wavefront per query, rings and the cube sweep included
     oi, od = tree.knn(np.nan_to_num(q, nan=1e9), 5)
     inside = od < 50.0
     assert np.array_equal(np.where(inside, oi, -1)[:-2], gi[:-2])
+    assert np.array_equal(np.where(inside, od, np.inf)[:-2], gd[:-2])
+    gi_l, gd_l = m.nearestKSearch(Map_buffer.SURF, np.tile(q, (17, 1)), 50.0)   # 8551 queries: one lane per query
+    assert np.array_equal(gi_l.reshape(17, -1, 5), np.broadcast_to(gi, (17,) + gi.shape))
+    assert np.array_equal(gd_l.reshape(17, -1, 5), np.broadcast_to(gd, (17,) + gd.shape))
     assert np.all(gi[-2:] == -1)
     assert gi[500].tolist()[:4] == [100, 101, 102, 103]
     # xyzi stride-4 input gives the same answer
@@ -318,6 +330,24 @@ def test_knn_reuse_is_exact(dev_map, small_world, scans, mode):
         poses.append((reg.m_pose_w_curr.copy(), reg.report.lm_iterations_total, reg.report.n_blocks_last))
         reg.close()
     assert np.array_equal(poses[0][0], poses[1][0]) and poses[0][1:] == poses[1][1:]
+
+
+@pytest.mark.parametrize("n", [1, 20])
+def test_wavefront_corner_search_changes_nothing(dev_map, scans, n):
+    """Corner searches by whole wavefronts (ll_knn_coop.h: every corner query of ICP iterations 0 / 1 for batches of up to 16
+    scans, the corner entries of the late iterations' search lists for every batch) return the neighbour lists of the per-lane
+    search; only the reuse budgets differ (larger), i.e. which queries are searched again later.  Same pose bits."""
+    feats = [oracle_features(sc)[4:] for sc in scans]
+    outs = []
+    for kw in ({}, {"no_knn_coop": True}):
+        reg = Point_cloud_registration(max_scans=n, max_features=24000)
+        reg.set_debug(False, **kw)
+        set_params(reg, 10, 20, 1)
+        pl = np.stack([scans[i % len(scans)].pose_init for i in range(n)])
+        res, pc, _, reps = reg.solve_batch(dev_map, [feats[i % len(scans)][0] for i in range(n)], [feats[i % len(scans)][1] for i in range(n)], pl, pl)
+        outs.append((res.copy(), pc.copy(), [(r.lm_iterations_total, r.n_blocks_last, r.icp_iterations) for r in reps]))
+        reg.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
 
 
 def test_run_to_run_determinism(dev_map, scans):
