@@ -157,8 +157,8 @@ __device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, 
     if (rc.debug_knn && iter == 0 && rd.dbg_idx) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            rd.dbg_idx[(sb + slot) * 5 + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
-            rd.dbg_d2[(sb + slot) * 5 + k] = r.d2[k];
+            rd.dbg_idx[(sb + slot) * 5 + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
+            rd.dbg_d2[(sb + slot) * 5 + k] = knn5_d2(r, k);
         }
     }
 }

@@ -188,8 +188,8 @@ int hc_knn5(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx
         Knn5 r;
         knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
         for (int k = 0; k < 5; k++) {
-            idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
-            d2[5 * i + k] = r.d2[k];
+            idx[5 * i + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
+            d2[5 * i + k] = knn5_d2(r, k);
         }
     }
     return 0;
@@ -223,7 +223,7 @@ int hc_knn5_bounds(const hc_grid *G, const float *q, int nq, float max_d2, int32
         knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
         KnnRef ref;
         knn5_make_ref(r, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, ref);
-        for (int k = 0; k < HC_KNN_K; k++) cand[HC_KNN_K * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+        for (int k = 0; k < HC_KNN_K; k++) cand[HC_KNN_K * i + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
         lb2[i] = r.lb2;
         out2[i] = r.out2;
         m_set[i] = ref.m_set;
@@ -255,7 +255,7 @@ int hc_knn5_reuse_chain(const hc_grid *G, const float *path, int n_hops, int nq,
                 knn5_make_ref(r, p[0], p[1], p[2], max_d2, ref);
             }
             if (st != 0)
-                for (int k = 0; k < 5; k++) cur[k] = (r.count >= 5) ? r.idx[k] : -1;
+                for (int k = 0; k < 5; k++) cur[k] = (r.count >= 5) ? knn5_idx(r, k) : -1;
             for (int k = 0; k < 5; k++) idx5[((size_t)h * nq + i) * 5 + k] = cur[k];
             state[(size_t)h * nq + i] = st;
         }

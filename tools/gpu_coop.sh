@@ -5,11 +5,11 @@ TAG=${1:-x}
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 600 python -m pytest tests/test_gpu_reg.py -m gpu -x -q -k "knn5 or wavefront or reuse or determinism or (registration_matches and not legacy) or batch_pipeline or grouped_and" 2>&1 | tail -25 ) > gpurun_out/${TAG}_tests.log 2>&1
+( timeout 600 python -m pytest tests/test_gpu_reg.py -m gpu -x -q -k "knn5 or wavefront or flat or reuse or determinism or (registration_matches and not legacy) or batch_pipeline or grouped_and" 2>&1 | tail -25 ) > gpurun_out/${TAG}_tests.log 2>&1
 tail -6 gpurun_out/${TAG}_tests.log
 C="--steps 5 --warmup 2 --no-cpu-baseline --no-q-pipe --no-streamed"
 timeout 400 python bench.py $C > gpurun_out/${TAG}_bench_a.json 2> gpurun_out/${TAG}_bench_a.err
-timeout 400 python bench.py $C --no-knn-coop > gpurun_out/${TAG}_bench_b.json 2> gpurun_out/${TAG}_bench_b.err
+timeout 400 python bench.py $C ${BFLAG:---no-knn-coop} > gpurun_out/${TAG}_bench_b.json 2> gpurun_out/${TAG}_bench_b.err
 for f in bench_a bench_b; do python - gpurun_out/${TAG}_$f.json <<'PY'
 import json,sys
 try:
