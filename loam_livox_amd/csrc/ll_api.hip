@@ -701,6 +701,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.work_off, 3 * 2049);  // 3 prefix tables x (RL_MAX_SEG + 1), ll_reg_kernels.hip
     DM(d.grp_ctl, 2 * B + 1);
     DM(d.grp_part, B * 2 * LL_GRP * 28);
+    DM(d.grp_xch, B * 2 * LL_GRP * 56);
     DM(d.blk_l1, B * d.cap);
     DM(d.hash, B * (size_t)d.hash_cap);
     DM(r->d_corner, B * F);
@@ -736,7 +737,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -836,6 +837,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     if (n_scans < 1 || n_scans > r->max_scans) return set_err("ll_reg", "n_scans out of range");
     if (prm->icp_max_iterations < 0 || prm->ceres_max_iterations < 0 || prm->ceres_prerun_times < 0)
         return set_err("ll_reg", "negative iteration count");
+    if (prm->icp_max_iterations > (1 << 19)) return set_err("ll_reg", "icp_max_iterations above 524288");  // (the grouped solver tags its exchanges with the launch number in 20 bits)
     if (map->device != r->device) return set_err("ll_reg", "map lives on another device");
     make_reg_const(prm, r->debug, &r->rc);
     // A solve enqueued earlier on this handle and never collected still reads its snapshots: let it finish before its pins are
@@ -908,7 +910,10 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         // candidates per search, displacement budgets set by the true 6th neighbour, a third fewer searches in the late iterations
         Grid g0 = mk0.grid, g1 = mk1.grid;
         g0.guard = g1.guard = r->rc.knn_reuse ? 0.05f : 0.0f;
+        if (r->rc.solve_group > 1)  // the exchange granules carry (launch number, exchange number) tags: none may survive from an earlier registration
+            HC(hipMemsetAsync(r->dev.grp_xch, 0, (size_t)n_scans * 2 * LL_GRP * 56 * sizeof(unsigned long long), r->stream));
         for (int it = 0; it < prm->icp_max_iterations; it++) {
+            r->rc.xch_epoch = it + 1;
             prof_begin(r, 0);
             launch_reg_knn_build(r->dev, r->rc, g0, g1, n_scans, it, max_nc, max_ns, r->stream);
             prof_end(r);

@@ -112,6 +112,7 @@ struct RegConst {
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
     int solver_legacy;   // A/B switch: round-1 fast path (49-byte fp64 plane blocks, no LDS block cache)
     int solve_group;     // workgroups per scan of the compact solver (1, or LL_GRP for small batches: ll_reg_kernels.hip, group_*)
+    int xch_epoch;       // ... number of this solver launch within its registration, from 1 (tags of the exchange granules, group_reduce)
     int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
@@ -147,7 +148,8 @@ struct RegDev {
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
     float2 *ref_s;                // [B][cap]  x = bits(neighbour 4, -1 when fewer than 5 inside the radius), y = m_set
     int *grp_ctl;                 // [1 + 2 B] grouped solver: [0] ticket counter, [1 + 2 b] arrival counter of scan b's group barrier, [2 + 2 b] its abort word (zeroed per launch)
-    double *grp_part;             // [B][2][LL_GRP][28] grouped solver: the workgroups' partial sums of one cost evaluation, double-buffered
+    double *grp_part;             // [B][2][LL_GRP][28] grouped solver: the workgroups' partial sums of the evaluation that also publishes the L1 values
+    unsigned long long *grp_xch;  // [B][2][LL_GRP][56] ... of every other evaluation, as self-validating 8-byte granules {32-bit half, tag}; zeroed per registration
     unsigned char *blk_flag0;     // [B][cap]  block flag as built; the solver prunes a copy (LDS, or blk_flag in the general path)
     int *work_search;             // [B][cap]  slots that need a full search this iteration
     int *work_build;              // [B][cap]  slots that were re-sorted (block must be rebuilt)

@@ -264,6 +264,7 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
         if (x1 >= g.nx) x1 = g.nx - 1;
         if (x0 > x1) continue;
         const int base = (z * g.ny + y) * g.nx;
+        LL_KNN_STAT(4, ri);
         scan_run_t<PT>(g, base + x0, base + x1, qx, qy, qz, max_d2, r);
     }
 

@@ -695,6 +695,8 @@ struct SolveShared {
     int pt_T, pt_Tl, pt_kc, pt_priv;  // plane-table path: distinct triples, table entries in LDS, record rounds cached in LDS, private entries
     double thr;
     int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
+    int xch_seq, xch_epoch;                // ... exchanges of partial sums made in this launch, and the launch's number in its registration (granule tags)
+    unsigned int xch[LL_GRP][2 * LL_NACC]; // ... the members' partial sums of one exchange, as 32-bit halves
 };
 
 __device__ __forceinline__ int slot_of(int j, int nC, int cap_c) { return j < nC ? j : cap_c + (j - nC); }
@@ -739,20 +741,70 @@ __device__ __forceinline__ void group_barrier(const RegDev &rd, int b, SolveShar
     if (FULL) __threadfence();
 }
 
-// sh.sum (this workgroup's share) -> sh.sum (the scan's totals), the same value in every member.  FULL as above.
+// sh.sum (this workgroup's share) -> sh.sum (the scan's totals), the same value in every member.
+// FULL (the one evaluation per launch that also publishes the L1 values): partial sums through rd.grp_part behind the counter
+// barrier with its fences.  Otherwise (every other evaluation, ~8 per launch) a fence-free exchange of self-validating
+// GRANULES (MI355X_MICROARCH.md, hand-off price list: 8-byte {data, tag} written by one agent-scope store, polled with
+// agent-scope loads -- about one memory round trip, against four for store / release / counter / poll / load): every double
+// travels as two granules {32-bit half, tag}, tag = launch epoch << 12 | exchange number, so a reader that sees the tag has
+// the data and nothing needs ordering.  Slots alternate by exchange parity: a member that posts exchange s + 2 has read all
+// of s + 1, which every member posted only after reading all of s.  rd.grp_xch is zeroed per registration and the epoch is the
+// ICP iteration, so no tag repeats while a stale granule could still be seen.  Bounded polling like the barrier: a member
+// that gives up (or runs out of exchange numbers) raises the scan's abort word, the others see it.
 template <bool FULL>
 __device__ __forceinline__ void group_reduce(const RegDev &rd, int b, SolveShared &sh)
 {
     const int tid = threadIdx.x, G = sh.grp_G;
-    double *part = rd.grp_part + ((size_t)b * 2 + (sh.grp_seq & 1)) * LL_GRP * LL_NACC;
-    if (tid < LL_NACC) {
-        __hip_atomic_store(part + sh.grp_g * LL_NACC + tid, sh.sum[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!FULL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the storing wavefront's own stores have left before it reaches the barrier
+    if (FULL) {
+        double *part = rd.grp_part + ((size_t)b * 2 + (sh.grp_seq & 1)) * LL_GRP * LL_NACC;
+        if (tid < LL_NACC) __hip_atomic_store(part + sh.grp_g * LL_NACC + tid, sh.sum[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        group_barrier<true>(rd, b, sh);
+        if (tid < LL_NACC) {
+            double t = 0.0;
+            for (int k = 0; k < G; k++) t += __hip_atomic_load(part + k * LL_NACC + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh.sum[tid] = t;
+        }
+        __syncthreads();
+        return;
     }
-    group_barrier<FULL>(rd, b, sh);
-    if (tid < LL_NACC) {
+    constexpr int NG = 2 * LL_NACC;  // granules per member
+    static_assert(LL_GRP * NG <= RS_THREADS, "one polling thread per granule");
+    if (tid == 0) sh.xch_seq++;
+    __syncthreads();  // (sh.sum is complete; grp_abort as the last exchange left it)
+    const int seq = sh.xch_seq;
+    if (!sh.grp_abort && seq < 4096) {  // uniform
+        const unsigned int tag = ((unsigned int)sh.xch_epoch << 12) | (unsigned int)seq;
+        unsigned long long *slot = rd.grp_xch + ((size_t)b * 2 + (seq & 1)) * LL_GRP * NG;
+        if (tid < NG) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.sum[tid >> 1]);
+            const unsigned int half = (tid & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+            __hip_atomic_store(slot + sh.grp_g * NG + tid, ((unsigned long long)tag << 32) | (unsigned long long)half, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < G * NG) {
+            const int *abt = rd.grp_ctl + 2 + 2 * b;
+            unsigned long long v = __hip_atomic_load(slot + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ((unsigned int)(v >> 32) != tag) {
+                if (++spins > LL_GRP_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(abt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    sh.grp_abort = 1;  // (any thread may raise it; read again behind the barrier below)
+                    __hip_atomic_store(const_cast<int *>(abt), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(slot + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sh.xch[tid / NG][tid % NG] = (unsigned int)v;
+        }
+    } else if (tid == 0 && !sh.grp_abort) {  // out of exchange numbers: fail loudly rather than reuse a tag
+        sh.grp_abort = 1;
+        __hip_atomic_store(rd.grp_ctl + 2 + 2 * b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < LL_NACC && !sh.grp_abort) {  // (after an abort the sums stay the member's own: nothing of this launch is kept)
         double t = 0.0;
-        for (int k = 0; k < G; k++) t += __hip_atomic_load(part + k * LL_NACC + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < G; k++)
+            t += __longlong_as_double((long long)(((unsigned long long)sh.xch[k][2 * tid + 1] << 32) | (unsigned long long)sh.xch[k][2 * tid]));
         sh.sum[tid] = t;
     }
     __syncthreads();
@@ -3069,6 +3121,8 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
         sh.grp_g = g;
         sh.grp_G = G;
         sh.grp_seq = 0;
+        sh.xch_seq = 0;
+        sh.xch_epoch = rc.xch_epoch;
         sh.grp_abort = (rc.test_group_abort && G > 1) ? 1 : 0;  // test switch: behave as if the first barrier had timed out
     }
     __syncthreads();

@@ -105,6 +105,15 @@ class Grid:
         lib().hc_knn5(self.h, _p(q), q.shape[0], max_d2, _p(idx), _p(d2))
         return idx, d2
 
+    def knn5_run_cands(self, q, max_d2):
+        """candidates examined per run of the 3x3x3 block, [nq][9] (-1 = run not scanned)"""
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        out = np.zeros((q.shape[0], 9), np.int32)
+        L = lib()
+        L.hc_knn5_run_cands.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.hc_knn5_run_cands(self.h, _p(q), q.shape[0], max_d2, _p(out))
+        return out
+
     def knn5_work(self, q, max_d2):
         """(rows looked up, candidates examined, deepest phase) per query -- instrumentation of the device search"""
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)

@@ -15,7 +15,16 @@
 #include <vector>
 
 static long long g_knn_stat[4];  // row look-ups, candidates, queries reaching ring 2, queries reaching the cube sweep
-#define LL_KNN_STAT(counter, n) (g_knn_stat[counter] += (n))
+static int g_knn_run = -1;       // counter 4: the run of the 3x3x3 block being scanned (per-run candidate counts below)
+static int g_knn_run_cands[9];
+#define LL_KNN_STAT(counter, n)                                                          \
+    do {                                                                                 \
+        if ((counter) == 4) g_knn_run = (int)(n);                                        \
+        else {                                                                           \
+            g_knn_stat[(counter) & 3] += (n);                                            \
+            if ((counter) == 1 && g_knn_run >= 0) { g_knn_run_cands[g_knn_run] = (int)(n); g_knn_run = -1; } \
+        }                                                                                \
+    } while (0)
 #include "../../loam_livox_amd/csrc/ll_fe_core.h"
 #include "../../loam_livox_amd/csrc/ll_knn_core.h"
 #include "../../loam_livox_amd/csrc/ll_reg_core.h"
@@ -206,6 +215,20 @@ int hc_knn5_work(const hc_grid *G, const float *q, int nq, float max_d2, int32_t
         rows[i] = (int32_t)(g_knn_stat[0] - before[0]);
         cands[i] = (int32_t)(g_knn_stat[1] - before[1]);
         phase[i] = g_knn_stat[3] > before[3] ? 3 : (g_knn_stat[2] > before[2] ? 2 : 1);
+    }
+    return 0;
+}
+
+// candidates examined per run of the 3x3x3 block (-1: run pruned or outside the grid), [nq][9]: input of the SIMT schedule model in
+// tools/knn_simt_model.py
+int hc_knn5_run_cands(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *cands9)
+{
+    for (int i = 0; i < nq; i++) {
+        for (int k = 0; k < 9; k++) g_knn_run_cands[k] = -1;
+        g_knn_run = -1;
+        Knn5 r;
+        knn5_search(G->g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
+        for (int k = 0; k < 9; k++) cands9[9 * i + k] = g_knn_run_cands[k];
     }
     return 0;
 }
