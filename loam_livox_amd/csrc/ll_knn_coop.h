@@ -80,37 +80,43 @@ __device__ __forceinline__ void coop_scan_seg(const Grid &g, int b, int e, int p
 // lb2: everything a lane rejected or pushed off its own list, and every entry still standing in some lane's list afterwards.
 __device__ __forceinline__ void coop_merge(const Knn5 &loc, Knn5 &r)
 {
-    unsigned long long ck[5];
-    int cp[5];
+    float cd[5];
+    int ci[5], cp[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        ck[i] = loc.key[i];
+        cd[i] = loc.d2[i];
+        ci[i] = loc.idx[i];
         cp[i] = loc.pos[i];
     }
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        const unsigned long long kmin = wave_min_u64(ck[0]);
-        const bool any = (unsigned int)(kmin >> 32) < 0x7f800000u;  // (an empty head is +inf)
-        const bool win = any && ck[0] == kmin;
+        // squared distances are >= +0: their bit patterns order like the values; an empty head is +inf
+        const unsigned long long key = ((unsigned long long)(unsigned int)as_int(cd[0]) << 32) | (unsigned long long)(unsigned int)ci[0];
+        const unsigned long long kmin = wave_min_u64(key);
+        const bool any = (unsigned int)(kmin >> 32) < 0x7f800000u;
+        const bool win = any && key == kmin;
         const unsigned long long wm = __ballot(win);
         const int src = any ? (int)__ffsll((long long)wm) - 1 : 0;
         const int wpos = __builtin_amdgcn_readlane(cp[0], src);
-        r.key[k] = any ? kmin : LL_KNN_EMPTY_KEY;
+        r.d2[k] = any ? __int_as_float((int)(unsigned int)(kmin >> 32)) : INFINITY;
+        r.idx[k] = any ? (int)(unsigned int)kmin : LL_KNN_EMPTY;
         r.pos[k] = any ? wpos : -1;
         cnt += any ? 1 : 0;
         if (win) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                ck[i] = ck[i + 1];
+                cd[i] = cd[i + 1];
+                ci[i] = ci[i + 1];
                 cp[i] = cp[i + 1];
             }
-            ck[4] = LL_KNN_EMPTY_KEY;
+            cd[4] = INFINITY;
+            ci[4] = LL_KNN_EMPTY;
             cp[4] = -1;
         }
     }
     r.count = cnt;
-    r.lb2 = wave_min_f32(fminf(loc.lb2, knn5_key_d2(ck[0])));
+    r.lb2 = wave_min_f32(fminf(loc.lb2, cd[0]));
     r.out2 = wave_min_f32(loc.out2);
 }
 
@@ -156,7 +162,7 @@ __device__ __forceinline__ void knn5_search_coop(const Grid &g, float qx, float 
         if (k == LL_KNN_CUBE_FROM) {
             int K = kmax;
             if (r.count == 5) {
-                const int kd = (int)ceilf(sqrtf(knn5_d2(r, 4)) * g.inv_h) + 1;
+                const int kd = (int)ceilf(sqrtf(r.d2[4]) * g.inv_h) + 1;
                 K = kd < kmax ? kd : kmax;
             }
             if (K < LL_KNN_CUBE_FROM) K = LL_KNN_CUBE_FROM;
@@ -207,7 +213,7 @@ __device__ __forceinline__ void knn5_search_coop(const Grid &g, float qx, float 
         if (cx - k <= 0 && cx + k >= g.nx - 1 && cy - k <= 0 && cy + k >= g.ny - 1 && cz - k <= 0 && cz + k >= g.nz - 1) return;
         const float bound = (float)k * g.h + m - ((k >= 2) ? slack : 0.0f);
         const float b2 = bound * bound;
-        if (b2 >= max_d2 || (r.count == 5 && knn5_d2(r, 4) < b2)) {
+        if (b2 >= max_d2 || (r.count == 5 && r.d2[4] < b2)) {
             r.lb2 = fminf(r.lb2, fminf(b2, max_d2));
             r.out2 = fminf(r.out2, fmaxf(b2, max_d2));
             return;

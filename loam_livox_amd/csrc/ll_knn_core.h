@@ -36,11 +36,8 @@ struct Grid {
 };
 
 struct Knn5 {
-    // The list, ascending: key = (bits of d2) << 32 | original index.  Squared distances are sums of squares (>= +0, never NaN in
-    // the list), so their bit patterns order like their values and ONE unsigned 64-bit comparison is the lexicographic (d2, index)
-    // order of FLANN's result set; the original (upload-order) index is the tie-break key and what callers see.  An empty place
-    // is (+inf, LL_KNN_EMPTY).  Accessors: knn5_d2 / knn5_idx.
-    unsigned long long key[5];
+    float d2[5];
+    int idx[5];  // original (upload-order) index: the tie-break key and what callers see
     int pos[5];  // position in the cell-sorted array (to fetch the coordinates again)
     int count;
     float out2;  // lower bound on the squared distance of every point at or beyond the match radius (INF if none);
@@ -51,12 +48,26 @@ struct Knn5 {
 };
 
 #define LL_KNN_EMPTY 0x7fffffff
-#define LL_KNN_EMPTY_KEY 0x7f8000007fffffffull
 // test-only instrumentation hook (tests/hostcheck counts row look-ups and candidates per query); nothing on the device
 #ifndef LL_KNN_STAT
 #define LL_KNN_STAT(counter, n)
 #endif
 #define LL_KNN_CUBE_FROM 5  // ring at which the search stops growing shells and sweeps the remaining cube (knn5_search_t)
+
+LL_HD float knn5_d2(const Knn5 &r, int i) { return r.d2[i]; }
+LL_HD int knn5_idx(const Knn5 &r, int i) { return r.idx[i]; }
+
+LL_HD void knn5_init(Knn5 &r)
+{
+    for (int i = 0; i < 5; i++) {
+        r.d2[i] = INFINITY;
+        r.idx[i] = LL_KNN_EMPTY;
+        r.pos[i] = -1;
+    }
+    r.count = 0;
+    r.lb2 = INFINITY;
+    r.out2 = INFINITY;
+}
 
 LL_HD int as_int(float f)
 {
@@ -67,58 +78,37 @@ LL_HD int as_int(float f)
     u.f = f;
     return u.i;
 }
-LL_HD float as_float_bits(unsigned int b)
-{
-    union {
-        float f;
-        unsigned int i;
-    } u;
-    u.i = b;
-    return u.f;
-}
-
-LL_HD unsigned long long knn5_key(float d2, int idx) { return ((unsigned long long)(unsigned int)as_int(d2) << 32) | (unsigned long long)(unsigned int)idx; }
-LL_HD float knn5_key_d2(unsigned long long k) { return as_float_bits((unsigned int)(k >> 32)); }
-LL_HD float knn5_d2(const Knn5 &r, int i) { return knn5_key_d2(r.key[i]); }
-LL_HD int knn5_idx(const Knn5 &r, int i) { return (int)(unsigned int)r.key[i]; }
-
-LL_HD void knn5_init(Knn5 &r)
-{
-    for (int i = 0; i < 5; i++) {
-        r.key[i] = LL_KNN_EMPTY_KEY;
-        r.pos[i] = -1;
-    }
-    r.count = 0;
-    r.lb2 = INFINITY;
-    r.out2 = INFINITY;
-}
 
 LL_HD bool lex_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
-// Ordered insertion by (d2, idx): the candidate is carried down the list, every place keeps the smaller of itself and the
-// carry -- one 64-bit compare and selects per place, static indices only, so the five places stay in registers.  (Measured
-// against the branchy two-compare form of round 2: 2.6 % fewer VALU instructions per search, same time; the insertion is not
-// where a search spends its issue slots -- the ~100 candidate slots a wavefront executes per lane for ~22 used are.)
+// Ordered insertion by (d2, idx): carry the displaced element down a fully unrolled compare-swap chain
+// (static indices only, so the five slots stay in registers on the GPU).  (Round 3 tried the list as packed 64-bit
+// (d2 bits, idx) keys, one compare and selects per place, no branches: 2.6 % fewer VALU instructions per search, 19 more
+// registers, the late-iteration list kernel 6 % slower -- the places a candidate does not reach are skipped by the branches
+// here; kept as it was.)
 LL_HD void knn5_push(Knn5 &r, float d2, int idx, int pos)
 {
-    unsigned long long c = knn5_key(d2, idx);
-    if (!(c < r.key[4])) {
+    if (!lex_less(d2, idx, r.d2[4], r.idx[4])) {
         r.lb2 = fminf(r.lb2, d2);  // rejected: it stays outside the list
         return;
     }
     if (r.count < 5) r.count++;
-    int cp = pos;
+    float cd = d2;
+    int ci = idx, cp = pos;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        const bool lt = c < r.key[i];
-        const unsigned long long tk = r.key[i];
-        const int tp = r.pos[i];
-        r.key[i] = lt ? c : tk;
-        r.pos[i] = lt ? cp : tp;
-        c = lt ? tk : c;
-        cp = lt ? tp : cp;
+        if (lex_less(cd, ci, r.d2[i], r.idx[i])) {
+            const float td = r.d2[i];
+            const int ti = r.idx[i], tp = r.pos[i];
+            r.d2[i] = cd;
+            r.idx[i] = ci;
+            r.pos[i] = cp;
+            cd = td;
+            ci = ti;
+            cp = tp;
+        }
     }
-    r.lb2 = fminf(r.lb2, knn5_key_d2(c));  // whatever fell off the end (INF while the list was not full)
+    r.lb2 = fminf(r.lb2, cd);  // whatever fell off the end (INF while the list was not full)
 }
 
 // FLANN L2_Simple<float>: result = 0; result += diff*diff for x, y, z.  No FMA contraction.
@@ -157,27 +147,6 @@ struct PtF32 {
     static LL_HD void push(const Grid &, Knn5 &r, float d2, int j, int tok) { knn5_push(r, d2, tok, j); }
 };
 
-// four candidates j .. j + 3 of a run ending at e: the four record loads are independent, so their latencies overlap
-template <class PT>
-LL_HD void scan_trip_t(const Grid &g, const typename PT::Row &row, int j, int e, float qx, float qy, float qz, float max_d2, Knn5 &r)
-{
-    const int j1 = (j + 1 < e) ? j + 1 : j, j2 = (j + 2 < e) ? j + 2 : j, j3 = (j + 3 < e) ? j + 3 : j;
-    float x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
-    int t0, t1, t2, t3;
-    PT::load(g, row, j, x0, y0, z0, t0);
-    PT::load(g, row, j1, x1, y1, z1, t1);
-    PT::load(g, row, j2, x2, y2, z2, t2);
-    PT::load(g, row, j3, x3, y3, z3, t3);
-    const float d0 = dist2_xyz(qx, qy, qz, x0, y0, z0);
-    const float d1 = dist2_xyz(qx, qy, qz, x1, y1, z1);
-    const float d2 = dist2_xyz(qx, qy, qz, x2, y2, z2);
-    const float d3 = dist2_xyz(qx, qy, qz, x3, y3, z3);
-    if (d0 < max_d2) PT::push(g, r, d0, j, t0); else r.out2 = fminf(r.out2, d0);
-    if (j1 != j) { if (d1 < max_d2) PT::push(g, r, d1, j1, t1); else r.out2 = fminf(r.out2, d1); }
-    if (j2 != j) { if (d2 < max_d2) PT::push(g, r, d2, j2, t2); else r.out2 = fminf(r.out2, d2); }
-    if (j3 != j) { if (d3 < max_d2) PT::push(g, r, d3, j3, t3); else r.out2 = fminf(r.out2, d3); }
-}
-
 template <class PT>
 LL_HD void scan_run_t(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of one x-run*/, float qx, float qy, float qz,
                       float max_d2, Knn5 &r)
@@ -186,7 +155,24 @@ LL_HD void scan_run_t(const Grid &g, int c_lo, int c_hi /*inclusive cell keys of
     LL_KNN_STAT(0, 1);
     LL_KNN_STAT(1, e - b);
     const typename PT::Row row = PT::row(g, c_lo);
-    for (int j = b; j < e; j += 4) scan_trip_t<PT>(g, row, j, e, qx, qy, qz, max_d2, r);
+    // four candidates per trip: the four record loads are independent, so their latencies overlap
+    for (int j = b; j < e; j += 4) {
+        const int j1 = (j + 1 < e) ? j + 1 : j, j2 = (j + 2 < e) ? j + 2 : j, j3 = (j + 3 < e) ? j + 3 : j;
+        float x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
+        int t0, t1, t2, t3;
+        PT::load(g, row, j, x0, y0, z0, t0);
+        PT::load(g, row, j1, x1, y1, z1, t1);
+        PT::load(g, row, j2, x2, y2, z2, t2);
+        PT::load(g, row, j3, x3, y3, z3, t3);
+        const float d0 = dist2_xyz(qx, qy, qz, x0, y0, z0);
+        const float d1 = dist2_xyz(qx, qy, qz, x1, y1, z1);
+        const float d2 = dist2_xyz(qx, qy, qz, x2, y2, z2);
+        const float d3 = dist2_xyz(qx, qy, qz, x3, y3, z3);
+        if (d0 < max_d2) PT::push(g, r, d0, j, t0); else r.out2 = fminf(r.out2, d0);
+        if (j1 != j) { if (d1 < max_d2) PT::push(g, r, d1, j1, t1); else r.out2 = fminf(r.out2, d1); }
+        if (j2 != j) { if (d2 < max_d2) PT::push(g, r, d2, j2, t2); else r.out2 = fminf(r.out2, d2); }
+        if (j3 != j) { if (d3 < max_d2) PT::push(g, r, d3, j3, t3); else r.out2 = fminf(r.out2, d3); }
+    }
 }
 
 LL_HD void scan_run(const Grid &g, int c_lo, int c_hi, float qx, float qy, float qz, float max_d2, Knn5 &r)
@@ -238,7 +224,7 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
         const float row2 = dy * dy + dz * dz;
         float lim = max_d2;
         if (r.count == 5) {
-            lim = knn5_d2(r, 4);
+            lim = r.d2[4];
             if (g.guard > 0.0f) {
                 const float d5g = sqrtf(lim) + g.guard;
                 lim = fminf(d5g * d5g, max_d2);  // (points at or beyond the match radius never count)
@@ -282,7 +268,7 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
             // result, and the cells of rings 1 .. LL_KNN_CUBE_FROM-1 are left out, so no point is offered twice.
             int K = kmax;
             if (r.count == 5) {
-                const int kd = (int)ceilf(sqrtf(knn5_d2(r, 4)) * g.inv_h) + 1;  // the 5th best can only come closer
+                const int kd = (int)ceilf(sqrtf(r.d2[4]) * g.inv_h) + 1;  // the 5th best can only come closer
                 K = kd < kmax ? kd : kmax;
             }
             if (K < LL_KNN_CUBE_FROM) K = LL_KNN_CUBE_FROM;
@@ -334,7 +320,7 @@ LL_HD void knn5_search_t(const Grid &g, float qx, float qy, float qz, float max_
         if (cx - k <= 0 && cx + k >= g.nx - 1 && cy - k <= 0 && cy + k >= g.ny - 1 && cz - k <= 0 && cz + k >= g.nz - 1) return;
         const float bound = (float)k * g.h + m - ((k >= 2) ? slack : 0.0f);
         const float b2 = bound * bound;
-        if (b2 >= max_d2 || (r.count == 5 && knn5_d2(r, 4) < b2)) {
+        if (b2 >= max_d2 || (r.count == 5 && r.d2[4] < b2)) {
             // done: every point within the match radius has been seen, or the 5 best cannot be displaced by an
             // unvisited point.  Unvisited points are farther than `bound`; points beyond the radius never count.
             r.lb2 = fminf(r.lb2, fminf(b2, max_d2));
@@ -352,7 +338,6 @@ LL_HD void knn5_search(const Grid &g, float qx, float qy, float qz, float max_d2
     knn5_search_t<PtF32>(g, qx, qy, qz, max_d2, r);
 }
 
-
 // How far the query may move before the result of knn5_search has to be recomputed (metres, conservative):
 //   5 found : the set is unchanged while  d5 + delta < lb - delta          ->  (lb - d5) / 2
 //   < 5     : still fewer than 5 inside the radius while  lb - delta >= R   ->  lb - R
@@ -362,7 +347,7 @@ LL_HD float knn5_reuse_margin(const Knn5 &r, float max_d2)
     float lb = sqrtf(r.lb2);
     float mg;
     if (r.count == 5) {
-        mg = 0.5f * (lb - sqrtf(knn5_d2(r, 4)));
+        mg = 0.5f * (lb - sqrtf(r.d2[4]));
     } else {
         // every point inside the radius is in the list (the search was exhaustive there); the state "< 5 inside"
         // persists while no outside point can enter: nearest outside point (or unvisited region) minus the radius.
@@ -393,7 +378,7 @@ LL_HD float knn5_order_margin(const Knn5 &r)
 {
     if (r.count != 5) return INFINITY;  // nothing to order
     float d[5];
-    for (int i = 0; i < 5; i++) d[i] = sqrtf(knn5_d2(r, i));
+    for (int i = 0; i < 5; i++) d[i] = sqrtf(r.d2[i]);
     float g = INFINITY;
     for (int i = 0; i < 4; i++) g = fminf(g, d[i + 1] - d[i]);
     g = 0.5f * g - 1e-5f * (1.0f + d[4]);

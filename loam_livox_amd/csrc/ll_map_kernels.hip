@@ -250,7 +250,7 @@ struct PtF16 {
     // the original index (the tie-break key) lives in a separate array and is only fetched for candidates that can enter
     static __device__ __forceinline__ void push(const Grid &g, Knn5 &r, float d2, int j, int)
     {
-        if (d2 > knn5_d2(r, 4))
+        if (d2 > r.d2[4])
             r.lb2 = fminf(r.lb2, d2);
         else
             knn5_push(r, d2, g.perm[j], j);
@@ -345,8 +345,8 @@ __global__ void knn5_f16_kernel(Grid g, const float *q, int nq, float max_d2, in
     knn5_search_t<PtF16>(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        idx[5 * i + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
-        d2[5 * i + k] = knn5_d2(r, k);
+        idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+        d2[5 * i + k] = r.d2[k];
     }
 }
 
@@ -358,8 +358,8 @@ __global__ void knn5_kernel(Grid g, const float *q, int nq, float max_d2, int *i
     knn5_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        idx[5 * i + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
-        d2[5 * i + k] = knn5_d2(r, k);
+        idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+        d2[5 * i + k] = r.d2[k];
     }
 }
 
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void knn5_coop_kernel(Grid g, const float *q, 
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            idx[5 * i + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
-            d2[5 * i + k] = knn5_d2(r, k);
+            idx[5 * i + k] = (r.idx[k] == LL_KNN_EMPTY) ? -1 : r.idx[k];
+            d2[5 * i + k] = r.d2[k];
         }
     }
 }
