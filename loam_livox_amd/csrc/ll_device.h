@@ -16,7 +16,8 @@ namespace ll {
 #define LL_GRP_MAX_SCANS 16  // batches up to this size use it (LL_GRP * LL_GRP_MAX_SCANS workgroups stay below the CU count)
 // One wavefront per query (ll_knn_coop.h) where a launch is bound by its longest single-lane search chain:
 #define LL_KNN_COOP_MAX_QUERIES 8192  // ll_map_knn5 batches up to this size; corner searches of a late ICP iteration's work lists
-#define LL_KNN_COOP_MAX_SCANS 16      // all corner queries of ICP iterations 0 / 1 for batches up to this size
+#define LL_KNN_COOP_MAX_SCANS 16      // all corner queries of ICP iterations 0 / 1 for batches up to this size ...
+#define LL_KNN_COOP_MAX_SURF 2048     // ... and the surface queries of scans with up to this many (voxel-filtered clouds)
 
 struct FeScanInfo {
     int n_split;         // entries in split_idx (incl. the closing n-1)

@@ -220,14 +220,16 @@ __device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, co
     knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
 }
 
-// The same for one CORNER query per wavefront (ll_knn_coop.h); lane 0 stores.  All 64 lanes call it with the same arguments.
-__device__ __forceinline__ void knn_one_coop(const RegDev &rd, const RegConst &rc, const Grid &gc, int b, int slot, int iter)
+// The same for one query per wavefront (ll_knn_coop.h); lane 0 stores.  All 64 lanes call it with the same arguments.
+__device__ __forceinline__ void knn_one_coop(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
 {
+    const int kind = slot >= rd.cap_c ? 1 : 0;
     const size_t sb = (size_t)b * rd.cap;
     const float4 pw = rd.qw[sb + slot];
+    const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
     Knn5 r;
-    knn5_search_coop(gc, pw.x, pw.y, pw.z, rc.max_d2_line, r);
-    if ((threadIdx.x & 63) == 0) knn_finish(rd, rc, sb, slot, 0, iter, pw, rc.max_d2_line, r);
+    knn5_search_coop(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);
+    if ((threadIdx.x & 63) == 0) knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
 }
 
 // K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
@@ -237,10 +239,10 @@ __device__ __forceinline__ void knn_one_coop(const RegDev &rd, const RegConst &r
 #define KNN_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(KB_THREADS) __attribute__((amdgpu_waves_per_eu(KNN_WAVES_PER_EU, 8)))
-void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int skip_corner)
+void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int skip_kinds)
 {
     const int b = blockIdx.y, kind = blockIdx.z;
-    if (skip_corner && kind == 0) return;  // reg_knn_corner_coop_kernel has them
+    if ((skip_kinds >> kind) & 1) return;  // reg_knn_coop_kernel has them
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
@@ -249,17 +251,20 @@ void reg_knn_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int skip
     knn_one(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q, iter);
 }
 
-// K6a for small batches: the corner queries one per wavefront.  A few hundred corner queries per scan, a quarter of them
-// searching rings of the sparse corner map: per lane that is the longest dependent chain of the launch (header of ll_knn_coop.h).
+// K6a for small batches: one query per wavefront -- the corner queries (a few hundred per scan, a quarter of them searching
+// rings of the sparse corner map: per lane the longest dependent chain of the launch, header of ll_knn_coop.h), and the
+// surface queries too when a scan has few of them (voxel-filtered clouds against a sparse local map: the sequential mapping
+// loop, where every search walks rings).  kinds: bit k set = kind k is searched here.
 #define KC_THREADS 256
-__global__ __launch_bounds__(KC_THREADS) void reg_knn_corner_coop_kernel(RegDev rd, RegConst rc, Grid gc, int iter)
+__global__ __launch_bounds__(KC_THREADS) void reg_knn_coop_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int kinds)
 {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, kind = blockIdx.z;
+    if (!((kinds >> kind) & 1)) return;
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int q = (int)((blockIdx.x * KC_THREADS + threadIdx.x) >> 6);
-    if (q >= rd.n_corner[b]) return;  // (whole wavefronts)
-    knn_one_coop(rd, rc, gc, b, q, iter);
+    if (q >= (kind ? rd.n_surf[b] : rd.n_corner[b])) return;  // (whole wavefronts)
+    knn_one_coop(rd, rc, gc, gs, b, (kind ? rd.cap_c : 0) + q, iter);
 }
 
 // K6r: transform + reuse test (ICP iteration >= 1)
@@ -593,29 +598,33 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     // Corner searches first, one per WAVEFRONT while there are few of them (round 3): a late iteration searches a handful of
     // corner queries per scan, each a chain of 100+ dependent loads for a single lane -- the floor of this launch (~100 us at
     // B = 256 for ~1.5 k of them beside 75 k surface searches of ~15 round trips each; 49 us for a single scan).
+    // With few searches altogether (a single scan, a small batch, voxel-filtered clouds) every search goes that way.
+    const int *off_s = rd.work_off;
     const int *off_c = rd.work_off + (size_t)2 * (RL_MAX_SEG + 1);
-    const int total_c = off_c[n_seg];
-    const bool coop = rc.knn_coop && total_c <= LL_KNN_COOP_MAX_QUERIES;
-    if (coop) {
+    const bool coop_all = rc.knn_coop && off_s[n_seg] <= LL_KNN_COOP_MAX_QUERIES;
+    const bool coop = rc.knn_coop && off_c[n_seg] <= LL_KNN_COOP_MAX_QUERIES;  // the corner ones at least
+    if (coop_all || coop) {
         // (handed out from the LAST wavefront of the grid backwards: the per-lane lists below fill the grid from the front, so
-        // with short lists a wavefront has either a corner search or per-lane entries and the two chains overlap)
+        // with short lists a wavefront has either a cooperative search or per-lane entries and the two chains overlap)
+        const int *off_w = coop_all ? off_s : off_c;
+        const int total_w = off_w[n_seg];
         const int n_waves = stride >> 6;
-        for (int t = n_waves - 1 - (int)((blockIdx.x * RL_THREADS + tid) >> 6); t < total_c; t += n_waves) {
-            int lo = 0, hi = n_seg;  // largest segment with off_c[segment] <= t: a corner segment (the empty surface ones tie with their successor)
+        for (int t = n_waves - 1 - (int)((blockIdx.x * RL_THREADS + tid) >> 6); t < total_w; t += n_waves) {
+            int lo = 0, hi = n_seg;  // largest segment with off_w[segment] <= t (in off_c the empty surface segments tie with their successor)
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (off_c[mid] <= t) lo = mid; else hi = mid;
+                if (off_w[mid] <= t) lo = mid; else hi = mid;
             }
-            const int b = (seg0 + lo) >> 1;
-            const int e = rd.work_search[(size_t)b * rd.cap + (t - off_c[lo])];
+            const int sgg = seg0 + lo, b = sgg >> 1, kind = sgg & 1;
+            const int e = rd.work_search[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off_w[lo])];
             const int slot = e - b * rd.cap;
-            knn_one_coop(rd, rc, gc, b, slot, iter);
+            knn_one_coop(rd, rc, gc, gs, b, slot, iter);
             if ((tid & 63) == 0) build_one(rd, rc, gc, gs, b, slot);
         }
     }
     // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
     // to 99 us but cost 25 % at the long early lists -- profiles/r02 runs U / V -- and was dropped)
-    for (int w = 0; w < 2; w++) {
+    for (int w = coop_all ? 1 : 0; w < 2; w++) {
         const int *off = rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
         const int total = off[n_seg];
         const int *list = w == 0 ? rd.work_search : rd.work_build;
@@ -3196,10 +3205,18 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     if (mx <= 0) return;
     dim3 grid((mx + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
     hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
-    const int coop_corner = (rc.knn_coop && n_scans <= LL_KNN_COOP_MAX_SCANS && max_nc > 0) ? 1 : 0;
-    if (coop_corner)
-        hipLaunchKernelGGL(reg_knn_corner_coop_kernel, dim3((max_nc * 64 + KC_THREADS - 1) / KC_THREADS, n_scans), dim3(KC_THREADS), 0, s, rd, rc, gc, iter);
-    hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, coop_corner);
+    // small batches: the corner queries one per wavefront, and the surface queries too when the scans are small
+    int coop_kinds = 0;
+    if (rc.knn_coop && n_scans <= LL_KNN_COOP_MAX_SCANS) {
+        if (max_nc > 0) coop_kinds |= 1;
+        if (max_ns > 0 && max_ns <= LL_KNN_COOP_MAX_SURF) coop_kinds |= 2;
+    }
+    if (coop_kinds) {
+        const int mq = (coop_kinds & 2) ? mx : max_nc;
+        hipLaunchKernelGGL(reg_knn_coop_kernel, dim3((mq * 64 + KC_THREADS - 1) / KC_THREADS, n_scans, 2), dim3(KC_THREADS), 0, s, rd, rc, gc, gs, iter, coop_kinds);
+    }
+    if (coop_kinds != 3 || max_nc <= 0 || max_ns <= 0)
+        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, coop_kinds);
     hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s)

@@ -332,12 +332,13 @@ def test_knn_reuse_is_exact(dev_map, small_world, scans, mode):
     assert np.array_equal(poses[0][0], poses[1][0]) and poses[0][1:] == poses[1][1:]
 
 
-@pytest.mark.parametrize("n", [1, 20])
-def test_wavefront_corner_search_changes_nothing(dev_map, scans, n):
-    """Corner searches by whole wavefronts (ll_knn_coop.h: every corner query of ICP iterations 0 / 1 for batches of up to 16
-    scans, the corner entries of the late iterations' search lists for every batch) return the neighbour lists of the per-lane
-    search; only the reuse budgets differ (larger), i.e. which queries are searched again later.  Same pose bits."""
-    feats = [oracle_features(sc)[4:] for sc in scans]
+@pytest.mark.parametrize("n,thin", [(1, 1), (20, 1), (1, 12), (16, 12)])
+def test_wavefront_search_changes_nothing(dev_map, scans, n, thin):
+    """Searches by whole wavefronts (ll_knn_coop.h: every corner query of ICP iterations 0 / 1 for batches of up to 16 scans --
+    and every surface query too when the scans are small, thin = 12 --, the late iterations' search lists while they are short,
+    their corner entries otherwise) return the neighbour lists of the per-lane search; only the reuse budgets differ (larger),
+    i.e. which queries are searched again later.  Same pose bits."""
+    feats = [(f[4][::thin], f[5][::thin]) for f in (oracle_features(sc) for sc in scans)]
     outs = []
     for kw in ({}, {"no_knn_coop": True}):
         reg = Point_cloud_registration(max_scans=n, max_features=24000)
