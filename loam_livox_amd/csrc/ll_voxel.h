@@ -9,6 +9,7 @@ namespace ll {
 struct VoxelDev {
     int max_clouds, stride;
     int out_stride;              // stride of `out` after the last filter call (= the input stride of that call)
+    int block_path;              // 1 (default): up to 16 clouds of up to 24 576 points are filtered by one workgroup each (vox_block_kernel); 0 = A/B off
     float4 *in;                  // [max_clouds][stride]  staging for host inputs
     float4 *out;                 // [n_clouds][out_stride] filtered clouds
     int *n, *n_out, *status;     // [max_clouds]

@@ -12,6 +12,7 @@
 //   vox_copy_kernel     pass-through clouds: output = input
 // HBM-bound integer/byte work; the sort (4 radix passes over 12-byte pairs) dominates.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <hipcub/hipcub.hpp>
 
 #include "ll_voxel.h"
@@ -217,6 +218,202 @@ __global__ __launch_bounds__(256) void vox_copy_kernel(const float4 *in, const i
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n[b]; i += gridDim.x * 256) out[(size_t)b * stride + i] = in[(size_t)b * stride + i];
 }
 
+// ---- one workgroup per cloud (round 3) -----------------------------------------------------------------------------------
+// The sequential mapping loop filters half a dozen SMALL clouds per frame (a frame's few hundred corner features, its ~17 k
+// surface features, the frame and the match-buffer clouds of the history: laser_mapping.hpp:1367-1373, 1434-1437, 533-537),
+// one cloud per call -- and the pipeline above costs ~16 launches per call whatever the size (its kernels take 2 - 15 us each;
+// the launches and their boundaries are the cost).  For a cloud of up to 1024 x ITEMS points one 1024-thread workgroup does
+// the whole filter: bounding box -> leaf indices -> block radix sort of (leaf index, point index) in LDS, stable, so the points
+// of a voxel stay in input order -> voxel heads -> one thread per voxel adds its points in input order.  Same arithmetic per
+// point and per voxel as the kernels above (voxel_params / voxel_index, float sums in input order, one division per
+// component), so the output is bit for bit the general path's (tests/test_gpu_voxel.py runs both).
+#define VB_THREADS 1024
+template <int ITEMS>
+__global__ __launch_bounds__(VB_THREADS) void vox_block_kernel(const float4 *in, const int *n, int stride, float inv0, float inv1, float inv2,
+                                                                float4 *out, int *n_out, int *status)
+{
+    typedef hipcub::BlockRadixSort<unsigned int, VB_THREADS, ITEMS, unsigned short> Sort;
+    constexpr int CAP = VB_THREADS * ITEMS;
+    __shared__ union {
+        typename Sort::TempStorage sort;
+        struct {
+            unsigned short vals[CAP];      // point index at every sorted position
+            unsigned short head_pos[CAP];  // sorted position of the v-th voxel's first point
+        } run;
+    } sm;
+    __shared__ float s_lo[3][VB_THREADS / 64], s_hi[3][VB_THREADS / 64];
+    __shared__ int s_cnt[VB_THREADS / 64], s_heads[VB_THREADS / 64];
+    __shared__ unsigned int s_last[VB_THREADS], s_maxkey[VB_THREADS / 64];
+    __shared__ VoxelParams s_prm;
+    __shared__ int s_bits, s_nvox, s_nvalid;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = n[b] < stride ? n[b] : stride;
+    const float4 *src = in + (size_t)b * stride;
+    float4 *dst = out + (size_t)b * stride;
+    const float inv[3] = {inv0, inv1, inv2};
+
+    // ---- bounding box of the finite points (min / max / count: order-independent) -------------------------------------------
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) {  // blocked: thread t owns points t * ITEMS .. (the sort keeps that order inside a voxel)
+        const int i = tid * ITEMS + u;
+        const float4 p = src[i < nb ? i : 0];
+        if (i < nb && ll_isfinite(p.x) && ll_isfinite(p.y) && ll_isfinite(p.z)) {
+            lo[0] = fminf(lo[0], p.x);
+            lo[1] = fminf(lo[1], p.y);
+            lo[2] = fminf(lo[2], p.z);
+            hi[0] = fmaxf(hi[0], p.x);
+            hi[1] = fmaxf(hi[1], p.y);
+            hi[2] = fmaxf(hi[2], p.z);
+            cnt++;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            lo[d] = fminf(lo[d], __shfl_down(lo[d], off));
+            hi[d] = fmaxf(hi[d], __shfl_down(hi[d], off));
+        }
+        cnt += __shfl_down(cnt, off);
+    }
+    if (lane == 0) {
+        for (int d = 0; d < 3; d++) {
+            s_lo[d][wave] = lo[d];
+            s_hi[d][wave] = hi[d];
+        }
+        s_cnt[wave] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int c = 0;
+        for (int w = 0; w < VB_THREADS / 64; w++) {
+            for (int d = 0; d < 3; d++) {
+                mn[d] = fminf(mn[d], s_lo[d][w]);
+                mx[d] = fmaxf(mx[d], s_hi[d][w]);
+            }
+            c += s_cnt[w];
+        }
+        VoxelParams prm;
+        voxel_params(mn, mx, c, inv, prm);
+        s_prm = prm;
+        s_nvalid = c;
+    }
+    __syncthreads();
+    const VoxelParams prm = s_prm;
+    if (prm.status != VOX_OK) {  // uniform: "leaf size is too small" -> output = input; no finite point -> empty output
+        if (prm.status == VOX_PASSTHROUGH)
+            for (int i = tid; i < nb; i += VB_THREADS) dst[i] = src[i];
+        if (tid == 0) {
+            status[b] = prm.status;
+            n_out[b] = prm.status == VOX_PASSTHROUGH ? n[b] : 0;
+        }
+        return;
+    }
+
+    // ---- (leaf index, point index), sorted by leaf index; non-finite points and the padding sort last ------------------------
+    unsigned int key[ITEMS];
+    unsigned short val[ITEMS];
+    unsigned int kmax = 0;
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) {
+        const int i = tid * ITEMS + u;
+        const float4 p = src[i < nb ? i : 0];  // (read again, from L1 / L2: 24 points per thread held in registers spilled)
+        const bool ok = i < nb && ll_isfinite(p.x) && ll_isfinite(p.y) && ll_isfinite(p.z);
+        key[u] = ok ? voxel_index(p.x, p.y, p.z, inv, prm) : 0xffffffffu;
+        val[u] = (unsigned short)i;
+        if (ok) kmax = key[u] > kmax ? key[u] : kmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int y = (unsigned int)__shfl_down((int)kmax, off);
+        kmax = y > kmax ? y : kmax;
+    }
+    if (lane == 0) s_maxkey[wave] = kmax;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int m = 0;
+        for (int w = 0; w < VB_THREADS / 64; w++) m = s_maxkey[w] > m ? s_maxkey[w] : m;
+        int bits = 1;
+        while (bits < 32 && (m + 1u) >> bits) bits++;  // the sentinel becomes m + 1: only these bits need sorting
+        s_bits = bits;
+        s_maxkey[0] = m;
+    }
+    __syncthreads();
+    const int bits = s_bits;
+    const unsigned int sentinel = s_maxkey[0] + 1u;  // (m <= 2^31 - 2: voxel_params caps the grid at 2^31 - 1 leaves)
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++)
+        if (key[u] == 0xffffffffu) key[u] = sentinel;
+    __syncthreads();
+    Sort(sm.sort).Sort(key, val, 0, bits);
+    __syncthreads();  // the sort's storage becomes the run arrays
+
+    // ---- voxel heads: a sorted position whose key differs from its predecessor's ----------------------------------------------
+    s_last[tid] = key[ITEMS - 1];
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) sm.run.vals[tid * ITEMS + u] = val[u];
+    __syncthreads();
+    unsigned int prev = tid > 0 ? s_last[tid - 1] : sentinel;  // (position 0 is a head whenever it holds a point)
+    int heads = 0;
+    unsigned int head_mask = 0;  // ITEMS <= 24
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) {
+        const bool head = key[u] != sentinel && (tid * ITEMS + u == 0 || key[u] != prev);
+        if (head) {
+            heads++;
+            head_mask |= 1u << u;
+        }
+        prev = key[u];
+    }
+    int incl = heads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) s_heads[wave] = incl;
+    __syncthreads();
+    int rank = incl - heads;
+    for (int w = 0; w < wave; w++) rank += s_heads[w];
+    if (tid == VB_THREADS - 1) s_nvox = rank + heads;
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++)
+        if (head_mask & (1u << u)) sm.run.head_pos[rank++] = (unsigned short)(tid * ITEMS + u);
+    __syncthreads();
+
+    // ---- one thread per voxel: float sums in input order, one division per component (vox_centroid_kernel) -----------------
+    const int n_vox = s_nvox, n_valid = s_nvalid;
+    for (int v = tid; v < n_vox; v += VB_THREADS) {
+        const int j0 = sm.run.head_pos[v], j1 = v + 1 < n_vox ? (int)sm.run.head_pos[v + 1] : n_valid;
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        int c = 0;
+        for (int j = j0; j < j1; j += 8) {
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = src[sm.run.vals[j + u < j1 ? j + u : j0]];  // (eight independent gathers)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (j + u < j1) {
+                    sx = sx + q[u].x;
+                    sy = sy + q[u].y;
+                    sz = sz + q[u].z;
+                    si = si + q[u].w;
+                    c++;
+                }
+            }
+        }
+        const float cf = (float)c;
+        dst[v] = make_float4(sx / cf, sy / cf, sz / cf, si / cf);
+    }
+    if (tid == 0) {
+        status[b] = VOX_OK;
+        n_out[b] = n_vox;
+    }
+}
+
 #define VXCHK(x)                              \
     do {                                      \
         hipError_t e_ = (x);                  \
@@ -231,6 +428,7 @@ int voxel_alloc(VoxelDev &v, int max_clouds, int stride, const char **err)
     memset(&v, 0, sizeof(v));
     v.max_clouds = max_clouds;
     v.stride = stride;
+    v.block_path = getenv("LL_VOXEL_GENERAL_PATH") ? 0 : 1;  // (A/B and test switch: every cloud through the multi-kernel pipeline)
     const size_t total = (size_t)max_clouds * stride;
     if (total >= 0x7fffffffull) {
         *err = "max_clouds * max_points_per_cloud must stay below 2^31";
@@ -282,6 +480,17 @@ int voxel_filter(VoxelDev &v, const float4 *in, const int *n, int in_stride, int
         return -1;
     }
     const float inv[3] = {1.0f / leaf[0], 1.0f / leaf[1], 1.0f / leaf[2]};  // inverse_leaf_size_ = 1 / leaf_size_ (float)
+    if (v.block_path && n_clouds <= 16 && in_stride <= VB_THREADS * 24) {  // few small clouds: one workgroup per cloud, one launch
+        if (in_stride <= VB_THREADS * 4)
+            hipLaunchKernelGGL(vox_block_kernel<4>, dim3(n_clouds), dim3(VB_THREADS), 0, s, in, n, in_stride, inv[0], inv[1], inv[2], v.out, v.n_out, v.status);
+        else if (in_stride <= VB_THREADS * 8)
+            hipLaunchKernelGGL(vox_block_kernel<8>, dim3(n_clouds), dim3(VB_THREADS), 0, s, in, n, in_stride, inv[0], inv[1], inv[2], v.out, v.n_out, v.status);
+        else
+            hipLaunchKernelGGL(vox_block_kernel<24>, dim3(n_clouds), dim3(VB_THREADS), 0, s, in, n, in_stride, inv[0], inv[1], inv[2], v.out, v.n_out, v.status);
+        VXCHK(hipGetLastError());
+        v.out_stride = in_stride;
+        return 0;
+    }
     // the sort works on the compact [n_clouds][in_stride] index space
     const size_t total = (size_t)n_clouds * in_stride;
     hipLaunchKernelGGL(vox_init_kernel, dim3((n_clouds + 63) / 64), dim3(64), 0, s, v.mm, v.n_vox, n_clouds);

@@ -83,6 +83,36 @@ def test_batch_of_ragged_clouds(gpu_lib):
     vg.close()
 
 
+def test_one_workgroup_path_equals_the_kernel_pipeline(gpu_lib, monkeypatch):
+    """up to 16 clouds of up to 24 576 points are filtered by one workgroup each (vox_block_kernel: block radix sort in LDS);
+    everything else, and every cloud when LL_VOXEL_GENERAL_PATH is set at creation, by the multi-kernel pipeline: same bits"""
+    rng = np.random.default_rng(9)
+    cases = []
+    for stride, B in ((300, 1), (4096, 3), (4097, 2), (8192, 16), (24000, 2), (24576, 1)):
+        n = rng.integers(0, stride + 1, B).astype(np.int32)
+        n[0] = stride
+        clouds = rng.uniform(-20, 20, (B, stride, 4)).astype(np.float32)
+        clouds[rng.random((B, stride)) < 0.01, 1] = np.inf
+        cases.append((stride, B, n, clouds))
+    outs = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("LL_VOXEL_GENERAL_PATH", "1")
+        res = []
+        for stride, B, n, clouds in cases:
+            vg = VoxelGrid(max_points=stride, max_clouds=B)
+            vg.setLeafSize(0.35, 0.5, 0.35)
+            out, n_out, st = vg.filter_batch(clouds, n)
+            res.append((n_out.copy(), st.copy(), [bits(out[b, :n_out[b]]).copy() for b in range(B)]))
+            vg.close()
+        outs.append(res)
+    for a, b_ in zip(*outs):
+        assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1])
+        assert all(np.array_equal(x, y) for x, y in zip(a[2], b_[2]))
+    s, ref = orc.voxel_grid(cases[4][3][0, :cases[4][2][0]], (0.35, 0.5, 0.35))
+    assert np.array_equal(outs[0][4][2][0], bits(ref))
+
+
 def test_properties_at_map_scale(gpu_lib):
     """1 M points (a map refresh, LM:533-537): count conservation, centroids inside their leaf, ascending leaf order"""
     rng = np.random.default_rng(6)
