@@ -2886,10 +2886,17 @@ __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int n
             }
         }
     }
+    // A wavefront none of whose threads owns an active block (voxel-filtered scans of a few hundred blocks: half of the eight)
+    // has nothing but +0.0 to add: it writes the zeros instead of running 28 six-step reductions beside the wavefront that
+    // shares its SIMD (the 504 data-parallel moves and adds are half of such an evaluation's cycles).  Same sums, bit for bit.
+    if (__ballot(act != 0ull) != 0ull) {
 #pragma unroll
-    for (int i = 0; i < LL_NACC; i++) {
-        const double s = wave_sum(acc[i]);
-        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
+        for (int i = 0; i < LL_NACC; i++) {
+            const double s = wave_sum(acc[i]);
+            if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
+        }
+    } else if (lane < LL_NACC) {
+        sh.red[wave][lane] = 0.0;
     }
     __syncthreads();
     if (tid < LL_NACC) {
