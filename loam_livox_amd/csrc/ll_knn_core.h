@@ -83,9 +83,9 @@ LL_HD bool lex_less(float da, int ia, float db, int ib) { return da < db || (da 
 
 // Ordered insertion by (d2, idx): carry the displaced element down a fully unrolled compare-swap chain
 // (static indices only, so the five slots stay in registers on the GPU).  (Round 3 tried the list as packed 64-bit
-// (d2 bits, idx) keys, one compare and selects per place, no branches: 2.6 % fewer VALU instructions per search, 19 more
-// registers, the late-iteration list kernel 6 % slower -- the places a candidate does not reach are skipped by the branches
-// here; kept as it was.)
+// (d2 bits, idx) keys, one compare and selects per place, no branches: 12 % fewer VALU instructions per full search, the same
+// time -- 64-bit compares do not issue at the 32-bit rate --, 19 more registers, the late-iteration list kernel 6 - 8 % slower;
+// kept as it was.)
 LL_HD void knn5_push(Knn5 &r, float d2, int idx, int pos)
 {
     if (!lex_less(d2, idx, r.d2[4], r.idx[4])) {
