@@ -24,6 +24,7 @@
 // No MFMA: 6x6 systems are reduced, not multiplied.  Plane blocks live in HBM as three 16-byte planes (48 B + 1 flag per
 // block), line blocks as 65 B; every cost evaluation streams the part of them that does not fit the LDS record cache.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "ll_device.h"
 #include "ll_knn_coop.h"
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegCon
 #define RL_THREADS 128
 #define RL_BLOCKS 2048  // x 128 threads; 4096 (every wavefront slot at 64 VGPRs) measured the same, the lists are bound by dependent misses
 #define RL_MAX_SEG 2048  // scan-and-kind segments of one offsets table (max_scans <= 1024); larger batches run in slices
+#define RL_LOCAL_SEG 64  // up to this many segments (32 scans) the list kernel builds the offsets itself
 // exclusive prefix sums of the per-segment list lengths (segment = scan * 2 + kind) -> work_off[list][0 .. n_seg]; one workgroup
 __global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int seg0, int n_seg)
 {
@@ -589,6 +591,9 @@ __global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int s
     }
 }
 
+// LOCAL: the offsets tables are built in LDS by every workgroup (small batches); a template constant so that the large-batch
+// form keeps plain global loads in its binary searches
+template <bool LOCAL>
 __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void reg_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int seg0, int n_seg)
 {
     // The offsets table (<= 16 KB) is searched where it lies: it stays in L1 / L2, and a copy in LDS would cap the
@@ -599,8 +604,28 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     // corner queries per scan, each a chain of 100+ dependent loads for a single lane -- the floor of this launch (~100 us at
     // B = 256 for ~1.5 k of them beside 75 k surface searches of ~15 round trips each; 49 us for a single scan).
     // With few searches altogether (a single scan, a small batch, voxel-filtered clouds) every search goes that way.
-    const int *off_s = rd.work_off;
-    const int *off_c = rd.work_off + (size_t)2 * (RL_MAX_SEG + 1);
+    // Small batches (<= RL_LOCAL_SEG segments) skip the offsets kernel: every workgroup sums the few counters itself
+    // (one launch and one kernel boundary less per ICP iteration: ~6 us of a single scan's ~40 per iteration).
+    __shared__ int s_cnt[2][LOCAL ? RL_LOCAL_SEG : 1];
+    __shared__ int s_off[3][LOCAL ? RL_LOCAL_SEG + 1 : 1];
+    if (LOCAL) {
+        if (tid < n_seg) {
+            s_cnt[0][tid] = rd.work_cnt[(size_t)(seg0 + tid) * 2 + 0];
+            s_cnt[1][tid] = rd.work_cnt[(size_t)(seg0 + tid) * 2 + 1];
+        }
+        __syncthreads();
+        if (tid < 3) {  // (as reg_list_offsets_kernel: searches, re-sorts, the searches of the corner segments alone)
+            int acc = 0;
+            for (int sg = 0; sg < n_seg; sg++) {
+                s_off[tid][sg] = acc;
+                acc += tid == 2 ? ((sg & 1) ? 0 : s_cnt[0][sg]) : s_cnt[tid][sg];
+            }
+            s_off[tid][n_seg] = acc;
+        }
+        __syncthreads();
+    }
+    const int *off_s = LOCAL ? s_off[0] : rd.work_off;
+    const int *off_c = LOCAL ? s_off[2] : rd.work_off + (size_t)2 * (RL_MAX_SEG + 1);
     const bool coop_all = rc.knn_coop && off_s[n_seg] <= LL_KNN_COOP_MAX_QUERIES;
     const bool coop = rc.knn_coop && off_c[n_seg] <= LL_KNN_COOP_MAX_QUERIES;  // the corner ones at least
     if (coop_all || coop) {
@@ -625,7 +650,7 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
     // to 99 us but cost 25 % at the long early lists -- profiles/r02 runs U / V -- and was dropped)
     for (int w = coop_all ? 1 : 0; w < 2; w++) {
-        const int *off = rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
+        const int *off = LOCAL ? s_off[w] : rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
         const int total = off[n_seg];
         const int *list = w == 0 ? rd.work_search : rd.work_build;
         for (int t = blockIdx.x * RL_THREADS + tid; t < total; t += stride) {
@@ -3201,8 +3226,13 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         hipLaunchKernelGGL(reg_requery_kernel, cgrid, dim3(RQ_THREADS), 0, s, rd, rc, gc, gs, iter);
         for (int seg0 = 0; seg0 < 2 * n_scans; seg0 += RL_MAX_SEG) {
             const int n_seg = 2 * n_scans - seg0 < RL_MAX_SEG ? 2 * n_scans - seg0 : RL_MAX_SEG;
-            hipLaunchKernelGGL(reg_list_offsets_kernel, dim3(1), dim3(1024), 0, s, rd, seg0, n_seg);
-            hipLaunchKernelGGL(reg_list_kernel, dim3(n_scans >= 64 ? RL_BLOCKS : 256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+            static const int local_seg = getenv("LL_LIST_NO_LOCAL_OFFSETS") ? 0 : RL_LOCAL_SEG;  // (A/B switch)
+            if (n_seg <= local_seg) {
+                hipLaunchKernelGGL(reg_list_kernel<true>, dim3(256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+            } else {
+                hipLaunchKernelGGL(reg_list_offsets_kernel, dim3(1), dim3(1024), 0, s, rd, seg0, n_seg);
+                hipLaunchKernelGGL(reg_list_kernel<false>, dim3(n_scans >= 64 ? RL_BLOCKS : 256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+            }
         }
         return;
     }
