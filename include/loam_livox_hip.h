@@ -257,6 +257,11 @@ int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corne
  * each cover an eighth of the blocks, resident in LDS; the sums are then grouped differently, so results agree with the
  * one-workgroup form to rounding, not bit for bit). */
 int ll_reg_set_debug(ll_reg *r, int32_t enable);
+/* Further A/B switches of ll_reg_set_debug (measurement and tests only): bit 8 = searches one per lane everywhere (no
+ * wavefront-per-query search where the work is small).  Environment switches read by the library, same purpose:
+ * LL_LIST_NO_LOCAL_OFFSETS (small batches launch the work-list offsets kernel like large ones), LL_VOXEL_GENERAL_PATH (read
+ * when a voxel filter is created: every cloud through the multi-kernel pipeline instead of one workgroup per small cloud).
+ * None of them changes a result bit. */
 
 /* ------------------------------------------------------------------------------------------------------------
  * VoxelGrid  (SURVEY 8(f) row 1).  pcl::VoxelGrid<pcl::PointXYZI> as hku-mars/loam_livox uses it:
