@@ -215,21 +215,24 @@ inline double quintic_min( double f0, double g0, double x1, double f1, double g1
     const double b0 = (a1 - a0) / h1, b1 = (a2 - a1) / h2, b2 = (a3 - a2) / h21;
     const double c0 = (b1 - b0) / h2, c1 = (b2 - b1) / h2;
     const double d0 = (c1 - c0) / h2;
-    /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep */
+    /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep of
+     * explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and on the device; half the dependent
+     * chain of a multiply and an add per step, and the sweep runs ~100 times per fit on the controller lane) */
 #define LL_Q_EVAL(X, PV, DV)                         \
     do {                                             \
         const double x_ = (X);                       \
+        const double u1_ = x_ - x1, u2_ = x_ - x2;   \
         double b_ = d0, db_ = 0.0;                   \
-        db_ = b_ + (x_ - x2) * db_;                  \
-        b_ = c0 + (x_ - x2) * b_;                    \
-        db_ = b_ + (x_ - x1) * db_;                  \
-        b_ = b0 + (x_ - x1) * b_;                    \
-        db_ = b_ + (x_ - x1) * db_;                  \
-        b_ = a0 + (x_ - x1) * b_;                    \
-        db_ = b_ + x_ * db_;                         \
-        b_ = e01 + x_ * b_;                          \
-        db_ = b_ + x_ * db_;                         \
-        b_ = f0 + x_ * b_;                           \
+        db_ = std::fma(u2_, db_, b_);                     \
+        b_ = std::fma(u2_, b_, c0);                       \
+        db_ = std::fma(u1_, db_, b_);                     \
+        b_ = std::fma(u1_, b_, b0);                       \
+        db_ = std::fma(u1_, db_, b_);                     \
+        b_ = std::fma(u1_, b_, a0);                       \
+        db_ = std::fma(x_, db_, b_);                      \
+        b_ = std::fma(x_, b_, e01);                       \
+        db_ = std::fma(x_, db_, b_);                      \
+        b_ = std::fma(x_, b_, f0);                        \
         (PV) = b_;                                   \
         (DV) = db_;                                  \
     } while (0)
