@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--legacy-solver", action="store_true", help="A/B: round-1 solver fast path (49-byte fp64 plane blocks, no LDS block cache)")
     ap.add_argument("--packed48-solver", action="store_true", help="A/B: round-2 compact solver path (48-byte packed plane records) instead of the plane table")
     ap.add_argument("--no-knn-coop", action="store_true", help="A/B: corner searches one per lane everywhere (no wavefront-cooperative search)")
+    ap.add_argument("--no-knn-tile", action="store_true", help="A/B: per-lane search of the surface queries + neighbour reuse (round 3) instead of the tile search")
+    ap.add_argument("--knn-tile-with-reuse", action="store_true", help="A/B: tile search at ICP iterations 0 / 1, neighbour reuse + work lists afterwards")
     ap.add_argument("--no-solver-groups", action="store_true", help="A/B for the single-scan latency figure: one solver workgroup per scan "
                     "even for small batches (default: batches of <= 16 scans spread every scan over 8 workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,9 +204,9 @@ def main():
     p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
     p.maximum_allow_residual_block = N
     reg.set_profiling(True)
-    if args.force_general or args.legacy_solver or args.packed48_solver or args.no_knn_coop:
+    if args.force_general or args.legacy_solver or args.packed48_solver or args.no_knn_coop or args.no_knn_tile or args.knn_tile_with_reuse:
         reg.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver, packed48_solver=args.packed48_solver,
-                      no_knn_coop=args.no_knn_coop)
+                      no_knn_coop=args.no_knn_coop, no_knn_tile=args.no_knn_tile, knn_tile_with_reuse=args.knn_tile_with_reuse)
 
     vox = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
 
@@ -299,8 +301,9 @@ def main():
     for f_ in ("icp_max_iterations", "ceres_max_iterations", "force_all_iterations", "para_max_angular_rate", "para_max_speed",
                "max_final_cost", "current_frame_index", "mapping_init_accumulate_frames", "maximum_allow_residual_block"):
         setattr(reg1.params, f_, getattr(p, f_))
-    if args.no_solver_groups or args.no_knn_coop:
-        reg1.set_debug(False, no_solver_groups=args.no_solver_groups, no_knn_coop=args.no_knn_coop)
+    if args.no_solver_groups or args.no_knn_coop or args.no_knn_tile or args.knn_tile_with_reuse:
+        reg1.set_debug(False, no_solver_groups=args.no_solver_groups, no_knn_coop=args.no_knn_coop, no_knn_tile=args.no_knn_tile,
+                       knn_tile_with_reuse=args.knn_tile_with_reuse)
     vox1 = (VoxelGrid(N, 1, device=dev), VoxelGrid(N, 1, device=dev)) if vox else None
     for i in range(5):
         torch.cuda.synchronize()

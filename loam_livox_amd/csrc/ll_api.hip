@@ -689,6 +689,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.pl_tab, B * (size_t)d.tab_cap * 2);
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
+    DM(d.qperm, B * d.cap_s);
     DM(d.qw, B * d.cap);
     DM(d.ref_q, B * d.cap);
     DM(d.ref_p, B * d.cap);
@@ -737,7 +738,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -791,6 +792,8 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
+    c->knn_tile = (debug & 512) ? 0 : ((debug & 1024) ? 1 : 2);  // bit 9: no tile search of the surface queries (A/B, ll_knn_tile.h); bit 10: tile
+                                                                 // search only where all queries are searched, the reuse machinery for the rest
     c->max_d2_line_d = p->maximum_dis_line_for_match;
     c->max_d2_plane_d = p->maximum_dis_plane_for_match;
     // fp32 distances are compared against the double thresholds (PCR:254,353): d2 < thr  <=>  d2 < ceil_f32(thr)
@@ -898,6 +901,10 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
                                  "339-345,438-458) with a reproducible random stream");
     if (prm->subsample_seed && (max_nc > 2 * prm->maximum_allow_residual_block || max_ns > 2 * prm->maximum_allow_residual_block))
         r->rc.knn_reuse = 0;  // skipped features change from iteration to iteration: every iteration searches
+    // Scans of thousands of surface queries: the tile search (ll_knn_kernels.hip) takes them, in every ICP iteration -- searching
+    // all of them costs less than classifying them against reuse records and searching the lists that leaves
+    if (max_ns < LL_KNN_TILE_MIN_SURF || max_ns > LL_KNN_TILE_MAX_SURF) r->rc.knn_tile = 0;
+    if (r->rc.knn_tile == 2) r->rc.knn_reuse = 0;
     // Small batches leave most of the chip idle with one workgroup per scan: spread each scan's cost evaluations over a
     // group of LL_GRP workgroups (ll_reg_kernels.hip, group_*).  Compact scans only; the others run on the group's first.
     // A scan whose records (nearly) fit one CU's LDS cache gains nothing from it and pays ~3.5 us per exchange: voxel-filtered

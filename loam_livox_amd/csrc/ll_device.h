@@ -18,6 +18,10 @@ namespace ll {
 #define LL_KNN_COOP_MAX_QUERIES 8192  // ll_map_knn5 batches up to this size; corner searches of a late ICP iteration's work lists
 #define LL_KNN_COOP_MAX_SCANS 16      // all corner queries of ICP iterations 0 / 1 for batches up to this size ...
 #define LL_KNN_COOP_MAX_SURF 2048     // ... and the surface queries of scans with up to this many (voxel-filtered clouds)
+// Tile search of the surface queries (ll_knn_tile.h, ll_knn_kernels.hip): queries sorted by map cell once per registration, one
+// wavefront per 64 of them against the LDS-staged points of their cells' common neighbourhood
+#define LL_KNN_TILE_MIN_SURF 1024   // batches whose largest scan has at least this many surface queries (below: the wavefront-per-query search)
+#define LL_KNN_TILE_MAX_SURF 24576  // ... and at most this many (one sorting workgroup per scan holds them: 1024 threads x 24)
 
 struct FeScanInfo {
     int n_split;         // entries in split_idx (incl. the closing n-1)
@@ -117,6 +121,9 @@ struct RegConst {
     int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
+    int knn_tile;        // surface searches by the tile kernel (ll_knn_tile.h): 0 = off (A/B), 1 = wherever the per-lane search of ALL surface
+                         // queries would run (ICP iterations before knn_reuse_from, or every iteration without reuse), 2 = every ICP iteration
+                         // (the reuse machinery is then off: a tile search of everything costs less than classifying + searching the lists)
     unsigned int subsample_seed;  // a13 (0 = off)
     int max_blocks;               // maximum_allow_residual_block
     float max_d2_line, max_d2_plane;      // compared against fp32 squared distances (PCR:254,353)
@@ -161,6 +168,7 @@ struct RegDev {
                                   // segment [scan * cap + kind * cap_c, ...); one atomic per re-query workgroup and list reserves a range
     int n_chunks;                 // chunks of 256 queries (RQ_THREADS) per (scan, kind): the re-query kernel's grid
     int4 *nn;                     // [B][cap]  neighbour positions (cell-sorted order) + found flag (K6a -> K6b)
+    unsigned short *qperm;        // [B][cap_s] surface queries of a scan ordered by the map cell they fall into at ICP iteration 0 (reg_qsort_kernel)
     unsigned char *blk_flag;      // [B][cap]  BLK_* bits
     double *blk_l1;               // [B][cap]  scratch for the inlier threshold
     unsigned long long *hash;     // [B][hash_cap] dedup table for the std::set semantics of PCR:155-160
@@ -172,6 +180,8 @@ struct RegDev {
 
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
                           int max_nc, int max_ns, hipStream_t s);
+void launch_reg_qsort(const RegDev &rd, const Grid &gs, int n_scans, int max_ns, hipStream_t s);
+void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_ns, hipStream_t s);
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);

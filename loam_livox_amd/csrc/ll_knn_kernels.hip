@@ -1,0 +1,159 @@
+// ll_knn_kernels.hip -- tile search of the surface queries (gfx950, wave64): the 5-NN call site of
+// hku-mars/loam_livox source/point_cloud_registration.hpp:351-353 for scans whose queries share map cells by the hundred.
+//
+//   reg_qsort_kernel    : once per registration (ICP iteration 0): the surface queries of a scan, transformed with the start
+//                         pose, sorted by the map cell they fall into (one workgroup per scan, block radix sort in LDS over
+//                         the bits of the scan's own cell box) -> rd.qperm.  The order is only a grouping: every result goes
+//                         to its query's own slot, so nothing depends on it, and it is kept for all ICP iterations (a pose
+//                         update of centimetres moves the queries of a cell together).
+//   reg_knn_tile_kernel : one wavefront per 64 consecutive queries of that order: the map points of the cells' common
+//                         neighbourhood staged in LDS, every lane offers every staged point to its top five (ll_knn_tile.h),
+//                         then the residual-block constants of the same slot (build_one).  Lanes the tile cannot settle
+//                         (0.1 % on the C2 map) run the per-lane search.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <limits.h>
+
+#include "ll_knn_tile.h"
+#include "ll_reg_query.h"
+
+namespace ll {
+
+#define QS_THREADS 1024
+template <int ITEMS>
+__global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, Grid gs)
+{
+    typedef hipcub::BlockRadixSort<unsigned int, QS_THREADS, ITEMS, unsigned short> Sort;
+    __shared__ typename Sort::TempStorage sort;
+    __shared__ int s_lo[3][QS_THREADS / 64], s_hi[3][QS_THREADS / 64];
+    __shared__ int s_box[6];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rd.state[b].done) return;
+    const int nS = rd.n_surf[b];
+    const float4 *qw = rd.qw + (size_t)b * rd.cap + rd.cap_c;
+    // ---- box of the cells the scan's queries fall into (striped reads: coalesced; any initial order is as good as another)
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) {
+        const int i = u * QS_THREADS + tid;
+        if (i < nS) {
+            const float4 p = qw[i];
+            TileQ tq;
+            tile_query(gs, p.x, p.y, p.z, tq);
+            if (tq.ingrid) {
+                lo[0] = min(lo[0], tq.cx);
+                lo[1] = min(lo[1], tq.cy);
+                lo[2] = min(lo[2], tq.cz);
+                hi[0] = max(hi[0], tq.cx);
+                hi[1] = max(hi[1], tq.cy);
+                hi[2] = max(hi[2], tq.cz);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            lo[d] = min(lo[d], __shfl_down(lo[d], off));
+            hi[d] = max(hi[d], __shfl_down(hi[d], off));
+        }
+    }
+    if (lane == 0) {
+        for (int d = 0; d < 3; d++) {
+            s_lo[d][wave] = lo[d];
+            s_hi[d][wave] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        int mn = INT_MAX, mx = -1;
+        for (int w = 0; w < QS_THREADS / 64; w++) {
+            mn = min(mn, s_lo[tid][w]);
+            mx = max(mx, s_hi[tid][w]);
+        }
+        s_box[tid] = mn;
+        s_box[3 + tid] = mx;
+    }
+    __syncthreads();
+    const int bx0 = s_box[0], by0 = s_box[1], bz0 = s_box[2];
+    const long long ex = (long long)s_box[3] - bx0 + 1, ey = (long long)s_box[4] - by0 + 1, ez = (long long)s_box[5] - bz0 + 1;
+    const bool any = s_box[3] >= 0;
+    // keys are cell indices inside the box, x fastest like the map's own order (neighbours in the order are neighbours in a
+    // row); a box too large for 30 bits (a scan scattered over kilometres) degrades to one key: correct, just not grouped
+    const bool wide = !any || ex * ey * ez > (1ll << 30);
+    const unsigned int kmax = wide ? 0u : (unsigned int)(ex * ey * ez - 1);
+    unsigned int key[ITEMS];
+    unsigned short val[ITEMS];
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) {
+        const int i = u * QS_THREADS + tid;
+        unsigned int k = kmax + 2u;  // padding: behind everything
+        if (i < nS) {
+            const float4 p = qw[i];  // (read again from L2: ITEMS points held in registers would spill)
+            TileQ tq;
+            tile_query(gs, p.x, p.y, p.z, tq);
+            k = kmax + 1u;  // not in the grid / not finite: behind the grouped ones (they take the per-lane search anyway)
+            if (tq.ingrid) k = wide ? 0u : (unsigned int)(((long long)(tq.cz - bz0) * ey + (tq.cy - by0)) * ex + (tq.cx - bx0));
+        }
+        key[u] = k;
+        val[u] = (unsigned short)i;
+    }
+    int bits = 1;
+    while (bits < 32 && ((kmax + 2u) >> bits)) bits++;
+    Sort(sort).Sort(key, val, 0, bits);
+    unsigned short *perm = rd.qperm + (size_t)b * rd.cap_s;
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) {
+        const int pos = tid * ITEMS + u;  // (blocked arrangement after the sort)
+        if (pos < nS) perm[pos] = val[u];
+    }
+}
+
+#define KT_THREADS 256
+__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+{
+    __shared__ float4 s_tile[KT_THREADS / 64][68];
+    const int b = blockIdx.y;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const int nS = rd.n_surf[b];
+    const int i = blockIdx.x * KT_THREADS + threadIdx.x;  // position in the scan's cell order
+    if ((i & ~63) >= nS) return;                           // (whole wavefronts)
+    const bool valid = i < nS;
+    const size_t sb = (size_t)b * rd.cap;
+    const int slot = rd.cap_c + (valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0);
+    const float4 pw = rd.qw[sb + slot];
+    const float max_d2 = rc.max_d2_plane;
+    Knn5 r;
+    bool fin;
+    knn5_tile_wave(gs, valid, pw.x, pw.y, pw.z, max_d2, s_tile[threadIdx.x >> 6], r, fin);
+    if (!valid) return;
+    if (fin) {
+        if (rc.debug_knn && iter == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
+        }
+        knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
+    } else {
+        knn_one(rd, rc, gc, gs, b, slot, iter);  // sparse surroundings, an exact tie, a query outside the grid or not finite
+    }
+    build_one(rd, rc, gc, gs, b, slot);
+}
+
+void launch_reg_qsort(const RegDev &rd, const Grid &gs, int n_scans, int max_ns, hipStream_t s)
+{
+    if (max_ns <= QS_THREADS * 4)
+        hipLaunchKernelGGL(reg_qsort_kernel<4>, dim3(n_scans), dim3(QS_THREADS), 0, s, rd, gs);
+    else if (max_ns <= QS_THREADS * 8)
+        hipLaunchKernelGGL(reg_qsort_kernel<8>, dim3(n_scans), dim3(QS_THREADS), 0, s, rd, gs);
+    else
+        hipLaunchKernelGGL(reg_qsort_kernel<24>, dim3(n_scans), dim3(QS_THREADS), 0, s, rd, gs);
+}
+
+void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_ns, hipStream_t s)
+{
+    hipLaunchKernelGGL(reg_knn_tile_kernel, dim3((max_ns + KT_THREADS - 1) / KT_THREADS, n_scans), dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter);
+}
+
+}  // namespace ll

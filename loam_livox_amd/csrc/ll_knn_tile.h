@@ -1,0 +1,226 @@
+// ll_knn_tile.h -- the exact 5-NN search of ll_knn_core.h for a WAVEFRONT OF QUERIES THAT SHARE A MAP TILE.
+//
+// Stands in for pcl::KdTreeFLANN::nearestKSearch at hku-mars/loam_livox source/point_cloud_registration.hpp:351 (and :249)
+// like knn5_search does: exact k-NN, squared L2 accumulated in fp32 in x,y,z order, ties by original index.
+//
+// Why: one lane per query walking its own nine x-runs (knn5_search_t) keeps the VALU issue port busy at ~50 % lane utilisation --
+// a wavefront executes every run any of its lanes needs and every ordered insertion any of its lanes makes.  The workload is
+// far more redundant than that schedule can use: the ~17 k surface queries of a Mid-40 scan fall into 60 - 100 cells of the
+// 0.6 m grid (hundreds of queries per cell), and a query's whole 27-cell neighbourhood holds ~25 map points.  So the queries
+// of a scan are sorted by map cell once per registration (reg_qsort_kernel), a wavefront takes 64 consecutive queries of that
+// order -- one or two neighbouring cells --, stages the map points of the cells' common neighbourhood (the TILE: bounding box of
+// the lanes' cells +- 1, at most 5 x 5 x 5 cells, a few contiguous x-runs of the cell-sorted array, ~35 points) in LDS with
+// one coalesced load, and every lane offers EVERY tile point to its sorted top five through a branch-free min / med3 network
+// (tile5_offer: 21 instructions, no divergence, no dependent loads).  Afterwards a lane's answer is exact iff its 5th best lies
+// inside the distance every unvisited point must exceed (one full ring of cells around its own cell: the k = 1 termination test
+// of knn5_search_t) and no exact distance tie touches the list; the other lanes (0.1 % on the C2 map: sparse surroundings, ties,
+// queries outside the grid) run knn5_search.  Same lists as knn5_search, bit for bit; the reuse bounds are valid and
+// tighter (nothing inside the tile is pruned, so lb2 is the true 6th-nearest distance or the ring bound).
+#pragma once
+#include "ll_knn_core.h"
+
+namespace ll {
+
+// median of three (device: v_med3_f32).  Distances are never NaN here (finite queries, finite map points, +inf padding).
+LL_HD float tile_med3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    const float lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c < hi ? c : hi);
+#endif
+}
+
+// a lane's running result: the five smallest squared distances seen so far, ascending, with the candidates' positions in the
+// cell-sorted array, and the smallest distance of everything that was offered and is not (or no longer) in the list
+struct Tile5 {
+    float d[5];
+    int p[5];
+    float lb;
+};
+
+LL_HD void tile5_init(Tile5 &t)
+{
+    for (int i = 0; i < 5; i++) {
+        t.d[i] = INFINITY;
+        t.p[i] = -1;
+    }
+    t.lb = INFINITY;
+}
+
+// Offer one candidate (squared distance c, position pc).  Equal distances keep their order of arrival (strict compares); the
+// caller detects afterwards whether a tie could have mattered (tile5_has_tie) and searches again with the exact tie rule.
+// No branches: place i of the new list is med3(d[i-1], c, d[i]) of the old one.
+LL_HD void tile5_offer(Tile5 &t, float c, int pc)
+{
+    const bool m0 = c < t.d[0], m1 = c < t.d[1], m2 = c < t.d[2], m3 = c < t.d[3], m4 = c < t.d[4];
+    t.lb = fminf(t.lb, fmaxf(t.d[4], c));  // what falls off the end, or the candidate itself
+    const float n4 = tile_med3(t.d[3], c, t.d[4]);
+    const float n3 = tile_med3(t.d[2], c, t.d[3]);
+    const float n2 = tile_med3(t.d[1], c, t.d[2]);
+    const float n1 = tile_med3(t.d[0], c, t.d[1]);
+    const float n0 = fminf(t.d[0], c);
+    const int q4 = m4 ? (m3 ? t.p[3] : pc) : t.p[4];
+    const int q3 = m3 ? (m2 ? t.p[2] : pc) : t.p[3];
+    const int q2 = m2 ? (m1 ? t.p[1] : pc) : t.p[2];
+    const int q1 = m1 ? (m0 ? t.p[0] : pc) : t.p[1];
+    const int q0 = m0 ? pc : t.p[0];
+    t.d[0] = n0;
+    t.d[1] = n1;
+    t.d[2] = n2;
+    t.d[3] = n3;
+    t.d[4] = n4;
+    t.p[0] = q0;
+    t.p[1] = q1;
+    t.p[2] = q2;
+    t.p[3] = q3;
+    t.p[4] = q4;
+}
+
+// An exact tie among the six smallest distances seen (the five kept + the best one left out): only then can the order of
+// arrival differ from the (distance, original index) order of knn5_push.  Ties among +inf (fewer than five candidates) count
+// too -- such a lane is not final anyway.
+LL_HD bool tile5_has_tie(const Tile5 &t)
+{
+    return t.d[0] == t.d[1] || t.d[1] == t.d[2] || t.d[2] == t.d[3] || t.d[3] == t.d[4] || t.d[4] == t.lb;
+}
+
+// Where a query sits in the grid: the quantities knn5_search_t derives at its start, operation for operation.
+struct TileQ {
+    int cx, cy, cz;
+    float m;      // distance (metres, shrunk by slack) from the query to the nearest wall of its own cell
+    bool ingrid;  // finite, and its cell is a cell of the grid (otherwise the query goes to knn5_search)
+};
+
+LL_HD void tile_query(const Grid &g, float qx, float qy, float qz, TileQ &o)
+{
+    o.cx = o.cy = o.cz = 0;
+    o.m = 0.0f;
+    o.ingrid = false;
+    if (!ll_isfinite(qx) || !ll_isfinite(qy) || !ll_isfinite(qz)) return;
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.nx && fy < (float)g.ny && fz < (float)g.nz)) return;
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    if (cx >= g.nx || cy >= g.ny || cz >= g.nz) return;  // (rounding of the int -> float conversions above)
+    const float slack = g.slack;
+    const float xm = fmaxf((fx - (float)cx) * g.h - slack, 0.0f), xp = fmaxf(((float)(cx + 1) - fx) * g.h - slack, 0.0f);
+    const float ym = fmaxf((fy - (float)cy) * g.h - slack, 0.0f), yp = fmaxf(((float)(cy + 1) - fy) * g.h - slack, 0.0f);
+    const float zm = fmaxf((fz - (float)cz) * g.h - slack, 0.0f), zp = fmaxf(((float)(cz + 1) - fz) * g.h - slack, 0.0f);
+    o.cx = cx;
+    o.cy = cy;
+    o.cz = cz;
+    o.m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));
+    o.ingrid = true;
+}
+
+// The lane has been offered every point of a tile that contains the 3 x 3 x 3 block of cells around its own cell (clipped to
+// the grid).  Returns true and fills r (the list and bounds knn5_search would be allowed to return) when that settles the
+// answer: five neighbours inside the match radius, the fifth closer than anything outside the block can be (the k = 1 test of
+// knn5_search_t: bound = h + m), no tie.  Otherwise false: search again with knn5_search.  r.idx is not filled (callers that
+// need original indices read pts[pos].w).
+LL_HD bool tile5_finish(const Grid &g, const Tile5 &t, const TileQ &tq, float max_d2, Knn5 &r)
+{
+    if (!(t.d[4] < max_d2)) return false;  // fewer than five inside the radius: only the rings can tell (7 m at the plane radius)
+    if (tile5_has_tie(t)) return false;
+    const float bound = g.h + tq.m;
+    const float b2 = bound * bound;
+    // (when the block covers the whole grid every point has been offered and the test below is only conservative)
+    if (!(t.d[4] < b2)) return false;
+    for (int i = 0; i < 5; i++) {
+        r.d2[i] = t.d[i];
+        r.pos[i] = t.p[i];
+        r.idx[i] = 0;
+    }
+    r.count = 5;
+    r.lb2 = fminf(t.lb, fminf(b2, max_d2));
+    r.out2 = fmaxf(b2, max_d2);
+    return true;
+}
+
+// ---- tile geometry shared by the kernel and its host model --------------------------------------------------------------
+// The x-runs of a tile: rows (y, z) in [y0, y1] x [z0, z1], cells x0 .. x1 of each, all inside the grid.
+#define LL_TILE_MAX_ROWS 25  // participants of a round lie within +-1 cell of the round's leader: at most 5 x 5 rows of <= 5 cells
+
+#if defined(__HIPCC__)
+// ---- device: one round-based search for the 64 queries of a wavefront ------------------------------------------------------
+// All 64 lanes call it together (whole wavefronts, one-dimensional blocks).  q*: the lane's query (any value when !active);
+// tile: this wavefront's LDS staging buffer, 64 + 4 entries {x, y, z, bits(position)}.  On return `final` says whether r holds
+// the lane's exact result; lanes with active && !final must run knn5_search.
+__device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float qx, float qy, float qz, float max_d2, float4 *tile,
+                                               Knn5 &r, bool &final)
+{
+    const int lane = threadIdx.x & 63;
+    TileQ tq;
+    tile_query(g, qx, qy, qz, tq);
+    const bool ingrid = active && tq.ingrid;
+    Tile5 t;
+    tile5_init(t);
+    final = false;
+    unsigned long long todo = __ballot(ingrid);
+    while (todo != 0ull) {  // (uniform) one round per group of lanes whose cells lie within +-1 of the leader's: 1.05 rounds on C2
+        const int leader = (int)__ffsll((long long)todo) - 1;
+        const int lx = __builtin_amdgcn_readlane(tq.cx, leader), ly = __builtin_amdgcn_readlane(tq.cy, leader),
+                  lz = __builtin_amdgcn_readlane(tq.cz, leader);
+        const int dx = tq.cx - lx, dy = tq.cy - ly, dz = tq.cz - lz;
+        const bool part = ingrid && ((todo >> lane) & 1ull) && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+        todo &= ~__ballot(part);
+        // bounding box of the participants' cells, +-1, clipped to the grid (uniform)
+        int x0 = lx - 1 - (__ballot(part && dx < 0) ? 1 : 0), x1 = lx + 1 + (__ballot(part && dx > 0) ? 1 : 0);
+        int y0 = ly - 1 - (__ballot(part && dy < 0) ? 1 : 0), y1 = ly + 1 + (__ballot(part && dy > 0) ? 1 : 0);
+        int z0 = lz - 1 - (__ballot(part && dz < 0) ? 1 : 0), z1 = lz + 1 + (__ballot(part && dz > 0) ? 1 : 0);
+        x0 = x0 < 0 ? 0 : x0;
+        y0 = y0 < 0 ? 0 : y0;
+        z0 = z0 < 0 ? 0 : z0;
+        x1 = x1 >= g.nx ? g.nx - 1 : x1;
+        y1 = y1 >= g.ny ? g.ny - 1 : y1;
+        z1 = z1 >= g.nz ? g.nz - 1 : z1;
+        const int nyt = y1 - y0 + 1, nrows = nyt * (z1 - z0 + 1);  // <= LL_TILE_MAX_ROWS
+        // row table: lane r holds row r's first candidate and count; inclusive prefix sums over the rows
+        int rb = 0, cnt = 0;
+        if (lane < nrows) {
+            const int rz = lane / nyt, ry = lane - rz * nyt;
+            const int base = ((z0 + rz) * g.ny + (y0 + ry)) * g.nx;
+            rb = g.cell_start[base + x0];
+            cnt = g.cell_start[base + x1 + 1] - rb;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        const int T = __builtin_amdgcn_readlane(incl, LL_TILE_MAX_ROWS - 1);  // (rows beyond nrows count 0)
+        const int excl = incl - cnt;
+        for (int c0 = 0; c0 < T; c0 += 64) {  // (uniform) one chunk of 64 candidates at a time: T <= 64 for 95 % of the C2 tiles
+            const int j = c0 + lane;
+            int row = 0;
+            for (int rr = 0; rr < nrows - 1; rr++) row += (j >= __builtin_amdgcn_readlane(incl, rr)) ? 1 : 0;  // (scalar operand)
+            const int addr = __shfl(rb, row) + (j - __shfl(excl, row));
+            float4 e = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);  // padding: distance +inf, never enters a list
+            if (j < T) {
+                const f4 pt = g.pts[addr];
+                e = make_float4(pt.x, pt.y, pt.z, __int_as_float(addr));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the previous chunk's reads are done)
+            tile[lane] = e;
+            if (lane < 4) tile[64 + lane] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int n = (T - c0) < 64 ? (T - c0) : 64;
+            for (int jj = 0; jj < n; jj += 4) {  // (uniform) four broadcast reads and four independent offers per trip
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float4 cnd = tile[jj + u];
+                    float dd = dist2_xyz(qx, qy, qz, cnd.x, cnd.y, cnd.z);
+                    dd = part ? dd : INFINITY;
+                    tile5_offer(t, dd, __float_as_int(cnd.w));
+                }
+            }
+        }
+        if (part) final = tile5_finish(g, t, tq, max_d2, r);
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace ll

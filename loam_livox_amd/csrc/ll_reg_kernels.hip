@@ -26,18 +26,12 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
-#include "ll_device.h"
-#include "ll_knn_coop.h"
-#include "ll_reg_core.h"
+#include "ll_reg_query.h"
 
 namespace ll {
 
-#define KB_THREADS 128
 #define RQ_THREADS 256  // queries per requery workgroup = work-list segment size
 #define RQ_WAVES (RQ_THREADS / 64)
-#ifndef RS_THREADS
-#define RS_THREADS 512
-#endif
 #ifndef RS_PREFETCH
 #define RS_PREFETCH 2  // blocks in flight per thread in the fast-path sweep (0 = none, 1, 2)
 #endif
@@ -90,43 +84,6 @@ __device__ __forceinline__ double wave_sum(double v)
 // 48 k workgroups with three busy lanes each, and its ~110 us floor (186 us average) was the cost of scheduling them.
 // The order of the entries depends on the order of the atomics; every entry is processed independently, so results do not.
 
-__device__ __forceinline__ void transform_query(const RegState *st, const RegConst &rc, const float4 &f, float pw[3])
-{
-    pw[0] = pw[1] = pw[2] = NAN;  // non-finite features are skipped (PCR:242-245; surface: defined deviation)
-    if (!(ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z))) return;
-    const float sblur = refine_blur(rc.if_motion_deblur, f.w, rc.min_ts, rc.max_ts);  // PCR:247
-    if (rc.if_motion_deblur == 0 || (double)sblur == 1.0) {
-        point_to_map(st->pose_curr, f.x, f.y, f.z, pw);  // PCR:629
-    } else {
-        // Rodrigues interpolation, PCR:641-646
-        const double s = (double)sblur;
-        const double T[3] = {st->inc[4] * (s * 1.0), st->inc[5] * (s * 1.0), st->inc[6] * (s * 1.0)};
-        const double th = st->interp_theta * s;
-        const double sn = sin(th), cs1 = 1.0 - cos(th);
-        const double pc[3] = {(double)f.x, (double)f.y, (double)f.z};
-        double inner[3], o[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const double rij = ((i == j) ? 1.0 : 0.0) + sn * st->hat[i * 3 + j] + cs1 * st->hat_sq[i * 3 + j];
-                acc += rij * pc[j];
-            }
-            inner[i] = acc + T[i];
-        }
-        quat_rot(st->pose_last, inner, o);
-        pw[0] = (float)(o[0] + st->pose_last[4]);
-        pw[1] = (float)(o[1] + st->pose_last[5]);
-        pw[2] = (float)(o[2] + st->pose_last[6]);
-    }
-}
-
-__device__ __forceinline__ float4 load_feature(const RegDev &rd, int b, int kind, int q)
-{
-    return kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
-}
-
 // K6t: pose transform of every query (pointAssociateToMap, fp64 math -> fp32 store like the reference).  A
 // kernel of its own so that the double-precision sin/cos of the motion-deblur branch does not set the register
 // footprint of the k-NN kernel.
@@ -144,93 +101,6 @@ __global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, Re
     // a13: a skipped feature is handed on as a non-finite query -- no neighbours, no block (PCR:232-238, 339-345)
     if (subsample_skip_feature(rc.subsample_seed, kind, st->icp_iters, q, n, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
     rd.qw[(size_t)b * rd.cap + slot] = make_float4(pw[0], pw[1], pw[2], 0.f);
-}
-
-__device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r)
-{
-    // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
-    int4 nn;
-    nn.w = (r.count == 5) ? 1 : 0;
-    nn.x = r.pos[0];
-    nn.y = kind ? r.pos[2] : r.pos[1];  // plane: 0, k/2, k-1 (PCR:416-418); line: 0, 1 (PCR:300-301)
-    nn.z = r.pos[4];
-    rd.nn[sb + slot] = nn;
-    if (rc.debug_knn && iter == 0 && rd.dbg_idx) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            rd.dbg_idx[(sb + slot) * 5 + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
-            rd.dbg_d2[(sb + slot) * 5 + k] = knn5_d2(r, k);
-        }
-    }
-}
-
-__device__ __forceinline__ void ref_store(const RegDev &rd, size_t sb, int slot, const KnnRef &ref)
-{
-    rd.ref_q[sb + slot] = make_float4(ref.qx, ref.qy, ref.qz, ref.m_strong);
-    rd.ref_p[sb + slot] = make_int4(ref.pos[0], ref.pos[1], ref.pos[2], ref.pos[3]);
-    rd.ref_s[sb + slot] = make_float2(__int_as_float(ref.pos[4]), ref.m_set);
-}
-
-// Set-stable query (re-query state 1): the same five neighbours, re-evaluated and re-sorted at the new position; the
-// reuse record moves there with shrunken budgets (knn5_resort).
-__device__ __forceinline__ void resort_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
-{
-    const int kind = slot >= rd.cap_c ? 1 : 0;
-    const size_t sb = (size_t)b * rd.cap;
-    const float4 pw = rd.qw[sb + slot];
-    const float4 rq = rd.ref_q[sb + slot];
-    const float2 rs = rd.ref_s[sb + slot];
-    const int4 rp = rd.ref_p[sb + slot];
-    KnnRef ref;
-    ref.qx = rq.x;
-    ref.qy = rq.y;
-    ref.qz = rq.z;
-    ref.m_strong = rq.w;
-    ref.m_set = rs.y;
-    ref.pos[0] = rp.x;
-    ref.pos[1] = rp.y;
-    ref.pos[2] = rp.z;
-    ref.pos[3] = rp.w;
-    ref.pos[4] = __float_as_int(rs.x);
-    const float delta = knn5_ref_delta(ref, pw.x, pw.y, pw.z);  // the value the re-query kernel classified with
-    Knn5 r;
-    knn5_resort(kind ? gs : gc, ref, delta, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);
-    ref_store(rd, sb, slot, ref);
-    knn_store(rd, rc, sb, slot, kind, iter, r);
-}
-
-__device__ __forceinline__ void knn_finish(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const float4 &pw,
-                                           float max_d2, const Knn5 &r)
-{
-    if (rc.knn_reuse || rc.check_line_pca || rc.check_plane_pca) {  // the PCA checks need all five positions
-        KnnRef ref;
-        knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
-        ref_store(rd, sb, slot, ref);
-    }
-    knn_store(rd, rc, sb, slot, kind, iter, r);
-}
-
-__device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
-{
-    const int kind = slot >= rd.cap_c ? 1 : 0;
-    const size_t sb = (size_t)b * rd.cap;
-    const float4 pw = rd.qw[sb + slot];
-    const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
-    Knn5 r;
-    knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
-    knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
-}
-
-// The same for one query per wavefront (ll_knn_coop.h); lane 0 stores.  All 64 lanes call it with the same arguments.
-__device__ __forceinline__ void knn_one_coop(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
-{
-    const int kind = slot >= rd.cap_c ? 1 : 0;
-    const size_t sb = (size_t)b * rd.cap;
-    const float4 pw = rd.qw[sb + slot];
-    const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
-    Knn5 r;
-    knn5_search_coop(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);
-    if ((threadIdx.x & 63) == 0) knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
 }
 
 // K6a: one lane per query: exact 5-NN of the transformed point (fp32 only -> small register footprint, so
@@ -370,184 +240,10 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
     }
 }
 
-// Loads through an explicit global (address space 1) pointer.  Inside a non-inlined device function the compiler cannot
-// tell that a pointer taken from RegDev is global and emits flat_load, which also counts on lgkmcnt: the wait in front
-// of every LDS flag read then drained the whole software pipeline of record loads (round-2 profile of solver_eval2).
-typedef int ll_v4i __attribute__((ext_vector_type(4)));
-typedef float ll_v4f __attribute__((ext_vector_type(4)));
-typedef double ll_v2d __attribute__((ext_vector_type(2)));
-#define LL_AS_GLOBAL __attribute__((address_space(1)))
-__device__ __forceinline__ int4 gload_i4(const int4 *p)
-{
-    const ll_v4i v = *(const LL_AS_GLOBAL ll_v4i *)p;
-    return make_int4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float4 gload_f4(const float4 *p)
-{
-    const ll_v4f v = *(const LL_AS_GLOBAL ll_v4f *)p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-// x, y, z of a float4 record as a 12-byte load: with the 16-byte form the register allocator parks another in-flight value
-// in the unused w lane, and the write-after-write hazard on that register drains the load pipeline (solver_eval3)
-typedef float ll_v3f __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void gload_f3(const float4 *p, float &x, float &y, float &z)
-{
-    const ll_v3f v = *(const LL_AS_GLOBAL ll_v3f *)p;
-    x = v.x;
-    y = v.y;
-    z = v.z;
-}
-__device__ __forceinline__ double2 gload_d2(const double2 *p)
-{
-    const ll_v2d v = *(const LL_AS_GLOBAL ll_v2d *)p;
-    return make_double2(v.x, v.y);
-}
-// ... and through an explicit LDS (address space 3) pointer: a generic pointer into a __shared__ array that crossed a
-// function boundary becomes flat_load / flat_store / flat_atomic, which count on both wait counters
-#define LL_AS_LDS __attribute__((address_space(3)))
-__device__ __forceinline__ int4 lds_load_i4(const int4 *p)
-{
-    const ll_v4i v = *(const LL_AS_LDS ll_v4i *)p;
-    return make_int4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void lds_store_i4(int4 *p, const int4 &v)
-{
-    ll_v4i w;
-    w.x = v.x;
-    w.y = v.y;
-    w.z = v.z;
-    w.w = v.w;
-    *(LL_AS_LDS ll_v4i *)p = w;
-}
-__device__ __forceinline__ void gstore_f64(double *p, double v) { *(LL_AS_GLOBAL double *)p = v; }
-__device__ __forceinline__ unsigned char gload_u8(const unsigned char *p) { return *(const LL_AS_GLOBAL unsigned char *)p; }
-__device__ __forceinline__ void gstore_u16(unsigned short *p, unsigned short v) { *(LL_AS_GLOBAL unsigned short *)p = v; }
-__device__ __forceinline__ void gstore_i4(int4 *p, const int4 &v)
-{
-    ll_v4i w;
-    w.x = v.x;
-    w.y = v.y;
-    w.z = v.z;
-    w.w = v.w;
-    *(LL_AS_GLOBAL ll_v4i *)p = w;
-}
-__device__ __forceinline__ f4 gload_pt(const f4 *p)
-{
-    const ll_v4f v = *(const LL_AS_GLOBAL ll_v4f *)p;
-    f4 o;
-    o.x = v.x;
-    o.y = v.y;
-    o.z = v.z;
-    o.w = v.w;
-    return o;
-}
-__device__ __forceinline__ double gload_f64(const double *p) { return *(const LL_AS_GLOBAL double *)p; }
-
-// Block constants of one scan (blk_av, 6 * cap doubles) as three arrays of 16-byte pairs: {a0, v0}[cap], {v1, v2}[cap] and
-// {a1, a2}[cap] (line slots only; a plane block folds a' into a0 = n'.a').  A plane block is then one float4 and two
-// 16-byte loads per lane instead of one float4 and four 8-byte loads.  cap is even and the base 256-byte aligned.
-__device__ __forceinline__ void av_store(double *av, int cap, int slot, bool line, const double a[3], const double v[3])
-{
-    reinterpret_cast<double2 *>(av)[slot] = make_double2(a[0], v[0]);
-    reinterpret_cast<double2 *>(av + (size_t)2 * cap)[slot] = make_double2(v[1], v[2]);
-    if (line) reinterpret_cast<double2 *>(av + (size_t)4 * cap)[slot] = make_double2(a[1], a[2]);
-}
-__device__ __forceinline__ void av_load(const double *av, int cap, int slot, bool line, double &a0, double &a1, double &a2, double &v0,
-                                        double &v1, double &v2)
-{
-    const double2 x = gload_d2(reinterpret_cast<const double2 *>(av) + slot);
-    const double2 y = gload_d2(reinterpret_cast<const double2 *>(av + (size_t)2 * cap) + slot);
-    a0 = x.x;
-    v0 = x.y;
-    v1 = y.x;
-    v2 = y.y;
-    a1 = a2 = 0.0;
-    if (line) {
-        const double2 z = gload_d2(reinterpret_cast<const double2 *>(av + (size_t)4 * cap) + slot);
-        a1 = z.x;
-        a2 = z.y;
-    }
-}
-
-// Scans whose blocks go to the round-2 fast path of the solver (solve_fast2): no motion deblur (its blocks carry a blur
-// ratio and take the round-1 path), planes padded to whole 512-thread rounds + lines within the register budget of the
-// L1 phase.
-#define FAST_MAX_BLOCKS 24576
-__device__ __forceinline__ bool scan_is_compact(const RegDev &rd, const RegConst &rc, int b)
-{
-    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
-    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
-    return !rc.if_motion_deblur && !rc.force_general && !rc.solver_legacy && nSp + nC <= FAST_MAX_BLOCKS;
-}
-
-// K6b: residual-block constants (fp64) from the neighbours found by K6a.
-__device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot)
-{
-    const int kind = slot >= rd.cap_c ? 1 : 0;
-    const int q = slot - (kind ? rd.cap_c : 0);
-    const RegState *st = rd.state + b;
-    const size_t sb = (size_t)b * rd.cap;
-    const int4 nn = rd.nn[sb + slot];
-    unsigned char flag = BLK_NONE;
-    bool feature_ok = true;
-    if (nn.w && (kind ? rc.check_plane_pca : rc.check_line_pca)) {
-        // K7: PCA check of the five neighbours (PCR:259-292, 357-389); their positions live in the reuse record
-        const Grid &g5 = kind ? gs : gc;
-        const int4 rp = rd.ref_p[sb + slot];
-        const int p5[5] = {rp.x, rp.y, rp.z, rp.w, __float_as_int(rd.ref_s[sb + slot].x)};
-        double pts[5][3];
-        for (int j = 0; j < 5; j++) {
-            const f4 pj = g5.pts[p5[j]];
-            pts[j][0] = (double)pj.x;
-            pts[j][1] = (double)pj.y;
-            pts[j][2] = (double)pj.z;
-        }
-        feature_ok = pca_check(kind, pts);
-    }
-    if (nn.w && feature_ok) {
-        const Grid &g = kind ? gs : gc;
-        double a_out[3], v_out[3];
-        const f4 p0 = g.pts[nn.x], p1 = g.pts[nn.y];
-        const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
-        const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
-        if (kind == 0) {
-            if (rc.icp_line && block_line(st->pose_last, pa, pb, a_out, v_out)) flag = BLK_LINE | BLK_ACTIVE | 8;
-        } else {
-            flag = 8;  // surf_avail counts even when ICP_PLANE == 0 (PCR:425)
-            if (rc.icp_plane) {
-                const f4 p2 = g.pts[nn.z];
-                const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
-                if (!rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
-                    // plane-table path: only the flag is decided here; the solver computes {n', c} once per distinct
-                    // (nn0, nn2, nn4) triple from rd.nn (solve_fast3)
-                    rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
-                    return;
-                }
-                flag = block_plane(st->pose_last, pa, pb, pc, a_out, v_out) ? (BLK_PLANE | BLK_ACTIVE | 8) : BLK_NONE;
-            }
-        }
-        if (flag & BLK_ACTIVE) {
-            const float4 f = load_feature(rd, b, kind, q);
-            if (kind == 1 && scan_is_compact(rd, rc, b)) {
-                // packed plane block: 48 bytes in three coalesced 16-byte planes (ll_device.h blk_pa / blk_pb / blk_pc)
-                const size_t ps = (size_t)b * rd.cap_s + q;
-                rd.blk_pa[ps] = make_int4(__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), 0);
-                rd.blk_pb[ps] = make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1]));
-                rd.blk_pc[ps] = make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0]));
-            } else {
-                const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
-                rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
-                double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-                av_store(av, rd.cap, slot, kind == 0, a_out, v_out);  // line blocks keep the full a'; plane blocks only the scalar n'.a'
-            }
-        }
-    }
-    rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)
-}
-
-__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs)
+__global__ __launch_bounds__(KB_THREADS) void reg_build_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int skip_kinds)
 {
     const int b = blockIdx.y, kind = blockIdx.z;
+    if ((skip_kinds >> kind) & 1) return;  // (the tile kernel builds the blocks of its own slots)
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
@@ -3242,19 +2938,32 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     if (mx <= 0) return;
     dim3 grid((mx + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
     hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
+    // large scans: the surface queries go to the tile kernel (ll_knn_kernels.hip) in the order of the map cells they fell into
+    // at ICP iteration 0; it also builds their blocks
+    const bool tile = rc.knn_tile && max_ns >= LL_KNN_TILE_MIN_SURF && max_ns <= LL_KNN_TILE_MAX_SURF;
+    if (tile && iter == 0) launch_reg_qsort(rd, gs, n_scans, max_ns, s);
     // small batches: the corner queries one per wavefront, and the surface queries too when the scans are small
     int coop_kinds = 0;
     if (rc.knn_coop && n_scans <= LL_KNN_COOP_MAX_SCANS) {
         if (max_nc > 0) coop_kinds |= 1;
-        if (max_ns > 0 && max_ns <= LL_KNN_COOP_MAX_SURF) coop_kinds |= 2;
+        if (max_ns > 0 && max_ns <= LL_KNN_COOP_MAX_SURF && !tile) coop_kinds |= 2;
     }
     if (coop_kinds) {
         const int mq = (coop_kinds & 2) ? mx : max_nc;
         hipLaunchKernelGGL(reg_knn_coop_kernel, dim3((mq * 64 + KC_THREADS - 1) / KC_THREADS, n_scans, 2), dim3(KC_THREADS), 0, s, rd, rc, gc, gs, iter, coop_kinds);
     }
-    if (coop_kinds != 3 || max_nc <= 0 || max_ns <= 0)
-        hipLaunchKernelGGL(reg_knn_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, coop_kinds);
-    hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs);
+    const int done_kinds = coop_kinds | (tile ? 2 : 0);  // kinds that do not need the per-lane kernel
+    if ((max_nc > 0 && !(done_kinds & 1)) || (max_ns > 0 && !(done_kinds & 2))) {
+        const int mk = (done_kinds & 2) ? max_nc : ((done_kinds & 1) ? max_ns : mx);
+        hipLaunchKernelGGL(reg_knn_kernel, dim3((mk + KB_THREADS - 1) / KB_THREADS, n_scans, 2), dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, done_kinds);
+    }
+    if (tile) {
+        launch_reg_knn_tile(rd, rc, gc, gs, n_scans, iter, max_ns, s);
+        if (max_nc > 0)
+            hipLaunchKernelGGL(reg_build_kernel, dim3((max_nc + KB_THREADS - 1) / KB_THREADS, n_scans, 2), dim3(KB_THREADS), 0, s, rd, rc, gc, gs, 2);
+    } else {
+        hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, 0);
+    }
 }
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s)
 {

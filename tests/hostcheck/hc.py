@@ -14,7 +14,7 @@ _CSRC = os.path.join(_HERE, "..", "..", "loam_livox_amd", "csrc")
 
 
 def build():
-    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("ll_fe_core.h", "ll_knn_core.h", "ll_reg_core.h", "ll_cellmap_core.h", "ll_voxel_core.h")]
+    deps = [_SRC] + [os.path.join(_CSRC, f) for f in ("ll_fe_core.h", "ll_knn_core.h", "ll_knn_tile.h", "ll_reg_core.h", "ll_cellmap_core.h", "ll_voxel_core.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
                                "-o", _LIB, _SRC])
@@ -104,6 +104,20 @@ class Grid:
         d2 = np.zeros((q.shape[0], 5), np.float32)
         lib().hc_knn5(self.h, _p(q), q.shape[0], max_d2, _p(idx), _p(d2))
         return idx, d2
+
+    def knn5_tile(self, q, max_d2):
+        """host model of the wavefront tile search (ll_knn_tile.h), 64 queries per wavefront in the order given:
+        (idx5, d2, lb2, stats = [rounds, candidates staged, lanes that fell back to the per-lane search, wavefronts])"""
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        idx = np.zeros((q.shape[0], 5), np.int32)
+        d2 = np.zeros((q.shape[0], 5), np.float32)
+        lb2 = np.zeros(q.shape[0], np.float32)
+        stats = np.zeros(4, np.int64)
+        L = lib()
+        L.hc_knn5_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
+        rc = L.hc_knn5_tile(self.h, _p(q), q.shape[0], max_d2, _p(idx), _p(d2), _p(lb2), _p(stats))
+        assert rc == 0, "tile of more than 25 rows"
+        return idx, d2, lb2, stats
 
     def knn5_run_cands(self, q, max_d2):
         """candidates examined per run of the 3x3x3 block, [nq][9] (-1 = run not scanned)"""

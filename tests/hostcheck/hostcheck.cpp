@@ -27,6 +27,7 @@ static int g_knn_run_cands[9];
     } while (0)
 #include "../../loam_livox_amd/csrc/ll_fe_core.h"
 #include "../../loam_livox_amd/csrc/ll_knn_core.h"
+#include "../../loam_livox_amd/csrc/ll_knn_tile.h"
 #include "../../loam_livox_amd/csrc/ll_reg_core.h"
 #include "../../loam_livox_amd/csrc/ll_cellmap_core.h"
 #include "../../loam_livox_amd/csrc/ll_voxel_core.h"
@@ -281,6 +282,86 @@ int hc_knn5_reuse_chain(const hc_grid *G, const float *path, int n_hops, int nq,
                 for (int k = 0; k < 5; k++) cur[k] = (r.count >= 5) ? knn5_idx(r, k) : -1;
             for (int k = 0; k < 5; k++) idx5[((size_t)h * nq + i) * 5 + k] = cur[k];
             state[(size_t)h * nq + i] = st;
+        }
+    }
+    return 0;
+}
+
+// Host model of knn5_tile_wave (ll_knn_tile.h): the queries are taken 64 at a time in the order given (the kernel's order is the
+// cell order of reg_qsort_kernel); per "wavefront" the rounds, tiles and candidate order of the device code, the per-lane
+// arithmetic from the shared header (tile_query / tile5_offer / tile5_finish); lanes the tile does not settle run knn5_search.
+// idx: original indices (-1 where fewer than five inside the radius); stats[0] rounds, [1] candidates staged, [2] lanes that
+// fell back, [3] wavefronts.
+int hc_knn5_tile(const hc_grid *G, const float *q, int nq, float max_d2, int32_t *idx, float *d2, float *lb2, int64_t *stats)
+{
+    const Grid &g = G->g;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    for (int w0 = 0; w0 < nq; w0 += 64) {
+        const int nl = nq - w0 < 64 ? nq - w0 : 64;
+        stats[3]++;
+        TileQ tq[64];
+        Tile5 t[64];
+        Knn5 r[64];
+        bool fin[64], todo[64];
+        for (int l = 0; l < nl; l++) {
+            tile_query(g, q[3 * (w0 + l)], q[3 * (w0 + l) + 1], q[3 * (w0 + l) + 2], tq[l]);
+            tile5_init(t[l]);
+            fin[l] = false;
+            todo[l] = tq[l].ingrid;
+        }
+        for (;;) {
+            int leader = -1;
+            for (int l = 0; l < nl; l++)
+                if (todo[l]) { leader = l; break; }
+            if (leader < 0) break;
+            stats[0]++;
+            const int lx = tq[leader].cx, ly = tq[leader].cy, lz = tq[leader].cz;
+            bool part[64];
+            int x0 = lx - 1, x1 = lx + 1, y0 = ly - 1, y1 = ly + 1, z0 = lz - 1, z1 = lz + 1;
+            for (int l = 0; l < nl; l++) {
+                const int dx = tq[l].cx - lx, dy = tq[l].cy - ly, dz = tq[l].cz - lz;
+                part[l] = todo[l] && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                if (!part[l]) continue;
+                todo[l] = false;
+                if (dx < 0) x0 = lx - 2;
+                if (dx > 0) x1 = lx + 2;
+                if (dy < 0) y0 = ly - 2;
+                if (dy > 0) y1 = ly + 2;
+                if (dz < 0) z0 = lz - 2;
+                if (dz > 0) z1 = lz + 2;
+            }
+            x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
+            x1 = x1 >= g.nx ? g.nx - 1 : x1; y1 = y1 >= g.ny ? g.ny - 1 : y1; z1 = z1 >= g.nz ? g.nz - 1 : z1;
+            if ((y1 - y0 + 1) * (z1 - z0 + 1) > LL_TILE_MAX_ROWS) return -1;
+            for (int z = z0; z <= z1; z++)
+                for (int y = y0; y <= y1; y++) {  // rows in the device's order: y fastest
+                    const int base = (z * g.ny + y) * g.nx;
+                    for (int j = g.cell_start[base + x0]; j < g.cell_start[base + x1 + 1]; j++) {
+                        stats[1]++;
+                        const f4 pt = g.pts[j];
+                        for (int l = 0; l < nl; l++) {
+                            if (!part[l]) continue;
+                            const float dd = dist2_xyz(q[3 * (w0 + l)], q[3 * (w0 + l) + 1], q[3 * (w0 + l) + 2], pt.x, pt.y, pt.z);
+                            tile5_offer(t[l], dd, j);
+                        }
+                    }
+                }
+            for (int l = 0; l < nl; l++)
+                if (part[l]) fin[l] = tile5_finish(g, t[l], tq[l], max_d2, r[l]);
+        }
+        for (int l = 0; l < nl; l++) {
+            const int i = w0 + l;
+            if (fin[l]) {
+                for (int k = 0; k < 5; k++) r[l].idx[k] = as_int(g.pts[r[l].pos[k]].w);
+            } else {
+                stats[2]++;
+                knn5_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r[l]);
+            }
+            for (int k = 0; k < 5; k++) {
+                idx[5 * i + k] = (knn5_idx(r[l], k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r[l], k);
+                d2[5 * i + k] = knn5_d2(r[l], k);
+            }
+            lb2[i] = r[l].lb2;
         }
     }
     return 0;

@@ -317,19 +317,85 @@ def test_grouped_and_single_workgroup_solver_agree_across_batch_sizes(dev_map, s
 @pytest.mark.parametrize("mode", ["no_reuse", "reuse_from_iter1"])
 def test_knn_reuse_is_exact(dev_map, small_world, scans, mode):
     """the neighbour reuse across ICP iterations must not change anything: same pose bits as with a full search in
-    every iteration, whether it starts at iteration 1 or 2"""
+    every iteration, whether it starts at iteration 1 or 2 (per-lane search: the tile search is switched off here)"""
     sc = scans[2]
     _, _, _, _, fc, fs = oracle_features(sc)
     poses = []
     for kw in ({}, {"no_knn_reuse": True} if mode == "no_reuse" else {"reuse_from_iter1": True}):
         reg = Point_cloud_registration()
-        reg.set_debug(False, **kw)
+        reg.set_debug(False, no_knn_tile=True, **kw)
         set_params(reg, 10, 20, 1)
         reg.m_pose_w_last = sc.pose_init.copy(); reg.m_pose_w_curr = sc.pose_init.copy()
         reg.find_out_incremental_transfrom(dev_map, fc, fs)
         poses.append((reg.m_pose_w_curr.copy(), reg.report.lm_iterations_total, reg.report.n_blocks_last))
         reg.close()
     assert np.array_equal(poses[0][0], poses[1][0]) and poses[0][1:] == poses[1][1:]
+
+
+@pytest.mark.parametrize("n", [1, 3, 20])
+def test_tile_search_changes_nothing(dev_map, small_world, scans, n):
+    """The tile search of the surface queries (ll_knn_tile.h: queries sorted by map cell, one wavefront per 64 of them against the
+    LDS-staged points of their cells' neighbourhood; default: in every ICP iteration, no reuse records) returns the neighbour lists
+    of the per-lane search -- same pose bits, same counts, with the reuse machinery behind it (tile at iterations 0 / 1 only) or
+    without, and the neighbour lists of iteration 0 equal to the k-d tree's."""
+    feats = [(f[4], f[5]) for f in (oracle_features(sc) for sc in scans)]
+    outs = []
+    for kw in ({}, {"knn_tile_with_reuse": True}, {"no_knn_tile": True}, {"no_knn_tile": True, "no_knn_reuse": True}):
+        reg = Point_cloud_registration(max_scans=n, max_features=24000)
+        reg.set_debug(True, **kw)
+        set_params(reg, 10, 20, 1)
+        pl = np.stack([scans[i % len(scans)].pose_init for i in range(n)])
+        res, pc, _, reps = reg.solve_batch(dev_map, [feats[i % len(scans)][0] for i in range(n)], [feats[i % len(scans)][1] for i in range(n)], pl, pl)
+        knn = [reg.debug_knn(i, len(feats[i % len(scans)][0]), len(feats[i % len(scans)][1])) for i in range(min(n, 3))]
+        outs.append((res.copy(), pc.copy(), [(r.lm_iterations_total, r.n_blocks_last, r.icp_iterations) for r in reps], knn))
+        reg.close()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2]
+        for a, b in zip(outs[0][3], o[3]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for i in range(min(n, 3)):
+        qs = synth.transform_points(scans[i % len(scans)].pose_init, feats[i % len(scans)][1][:, :3])
+        oi, od = small_world["tree_s"].knn(qs, 5)
+        assert np.array_equal(oi, outs[0][3][i][2]) and np.array_equal(od, outs[0][3][i][3])
+
+
+def test_tile_search_sparse_map_ties_and_strays(gpu_lib):
+    """a uniform random cloud (most lanes need the rings), exact duplicates among the map points (ties by index) and queries outside
+    the grid / not finite: the tile kernel's fall-back lanes; checked against the k-d tree through the registrar's debug tap"""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 20, (60000, 3)).astype(np.float32)
+    pts[100:104] = pts[100]
+    corner = rng.uniform(0, 20, (500, 3)).astype(np.float32)
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, corner)
+    m.setInputCloud(Map_buffer.SURF, pts, 0.6)
+    tree = orc.KdTree(pts)
+    fs = np.zeros((5000, 4), np.float32)
+    fs[:, :3] = rng.uniform(-1, 21, (5000, 3))
+    fs[0, :3] = pts[100]
+    fs[1, :3] = [1e5, 0, 0]
+    fs[2, 0] = np.nan
+    fc = np.zeros((10, 4), np.float32)
+    fc[:, :3] = rng.uniform(0, 20, (10, 3))
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+    res = []
+    for kw in ({}, {"no_knn_tile": True}):
+        reg = Point_cloud_registration(max_scans=1, max_features=8192)
+        reg.set_debug(True, **kw)
+        set_params(reg, 1, 4, 1)
+        reg.m_pose_w_last = ident.copy(); reg.m_pose_w_curr = ident.copy()
+        reg.find_out_incremental_transfrom(m, fc, fs)
+        res.append(reg.debug_knn(0, len(fc), len(fs)))
+        reg.close()
+    si, sd = res[0][2], res[0][3]
+    assert np.array_equal(si, res[1][2]) and np.array_equal(sd, res[1][3])
+    ok = np.isfinite(fs[:, 0])
+    oi, od = tree.knn(fs[ok, :3], 5)
+    inside = od < 50.0
+    assert np.array_equal(np.where(inside, oi, -1), si[ok]) and np.array_equal(np.where(inside, od, np.inf), sd[ok])
+    assert np.all(si[2] == -1) and np.all(si[1] == -1)
+    assert si[0].tolist()[:4] == [100, 101, 102, 103]
+    m.close()
 
 
 @pytest.mark.parametrize("n,thin", [(1, 1), (20, 1), (1, 12), (16, 12)])
@@ -340,7 +406,7 @@ def test_wavefront_search_changes_nothing(dev_map, scans, n, thin):
     i.e. which queries are searched again later.  Same pose bits."""
     feats = [(f[4][::thin], f[5][::thin]) for f in (oracle_features(sc) for sc in scans)]
     outs = []
-    for kw in ({}, {"no_knn_coop": True}):
+    for kw in ({"no_knn_tile": True}, {"no_knn_tile": True, "no_knn_coop": True}, {}, {"no_knn_coop": True}):
         reg = Point_cloud_registration(max_scans=n, max_features=24000)
         reg.set_debug(False, **kw)
         set_params(reg, 10, 20, 1)
@@ -348,7 +414,8 @@ def test_wavefront_search_changes_nothing(dev_map, scans, n, thin):
         res, pc, _, reps = reg.solve_batch(dev_map, [feats[i % len(scans)][0] for i in range(n)], [feats[i % len(scans)][1] for i in range(n)], pl, pl)
         outs.append((res.copy(), pc.copy(), [(r.lm_iterations_total, r.n_blocks_last, r.icp_iterations) for r in reps]))
         reg.close()
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2]
 
 
 def test_run_to_run_determinism(dev_map, scans):

@@ -86,6 +86,74 @@ def test_grid_knn_sparse_outside_and_ties():
     assert hi[500].tolist()[:4] == [100, 101, 102, 103]
 
 
+def _cell_order(q, cell, origin):
+    """queries grouped by grid cell, x fastest (what reg_qsort_kernel produces; any order is valid, this one is the efficient one)"""
+    c = np.floor((np.nan_to_num(q, nan=0.0) - origin) / cell).astype(np.int64)
+    key = (c[:, 2] * 100003 + c[:, 1]) * 100003 + c[:, 0]
+    return np.argsort(key, kind="stable")
+
+
+def test_tile_search_equals_per_lane_search_on_the_scan_workload(small_world, scans):
+    """ll_knn_tile.h (host model of the wavefront: rounds, tiles, min / med3 network, k = 1 termination test, fall-back): the same
+    lists as knn5_search, index for index and bit for bit, valid lb2, and nearly every lane settled by its tile"""
+    gs = hc.Grid(small_world["surf"], 0.6)
+    for sc in scans[:2]:
+        _, _, _, _, fc, fs = oracle_features(sc)
+        q = synth.transform_points(sc.pose_init, fs[:, :3]).astype(np.float32)
+        q = q[_cell_order(q, 0.6, small_world["surf"][:, :3].min(axis=0))]
+        hi, hd = gs.knn5(q, 50.0)
+        ti, td, lb2, stats = gs.knn5_tile(q, 50.0)
+        assert np.array_equal(hi, ti) and np.array_equal(hd, td)
+        assert stats[2] < 0.2 * len(q), stats  # (the small test map is sparser than C2's: more lanes need the rings)
+        # also in scan order (many cells per wavefront -> several rounds per wavefront): still exact
+        q2 = synth.transform_points(sc.pose_init, fs[:, :3]).astype(np.float32)
+        hi2, hd2 = gs.knn5(q2, 50.0)
+        ti2, td2, _, stats2 = gs.knn5_tile(q2, 50.0)
+        assert np.array_equal(hi2, ti2) and np.array_equal(hd2, td2)
+        assert stats2[0] >= stats[0]
+
+
+@pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500), (0.6, 50.0, 200000)])
+def test_tile_search_sparse_dense_ties_and_outside(cell, max_d2, npts):
+    rng = np.random.default_rng(21)
+    pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
+    pts[100:104] = pts[100]          # exact duplicates: ties by original index, decided by the fall-back
+    pts[200:206, :] = pts[200] + np.float32(0.0)
+    pts[7, 0] = np.nan
+    g = hc.Grid(pts, cell)
+    q = np.concatenate([rng.uniform(-3, 33, (3000, 3)), pts[100:101], pts[200:201] + 1e-3, [[1e6, 0, 0]], [[np.nan, 0, 0]],
+                        rng.uniform(10, 12, (1000, 3))]).astype(np.float32)
+    for order in (np.arange(len(q)), _cell_order(q, cell, np.nanmin(pts, axis=0))):
+        qq = q[order]
+        hi, hd = g.knn5(qq, max_d2)
+        ti, td, lb2, stats = g.knn5_tile(qq, max_d2)
+        assert np.array_equal(hi, ti) and np.array_equal(hd, td)
+        # lb2 bounds every point outside a full list
+        fin = np.isfinite(qq).all(axis=1) & (ti[:, 4] >= 0)
+        sel = np.flatnonzero(fin)[:300]
+        P = np.where(np.isfinite(pts), pts, 1e9).astype(np.float64)
+        for i in sel:
+            d2_all = ((qq[i].astype(np.float64) - P) ** 2).sum(-1)
+            rest = np.delete(d2_all, ti[i])
+            assert lb2[i] <= rest.min() * (1 + 1e-5) + 1e-6
+    if npts >= 200000:
+        assert stats[2] < 0.5 * len(q)  # a dense cloud: the tiles settle most lanes
+
+
+def test_tile_offer_network_equals_ordered_insertion():
+    """tile5_offer against a sort: random streams with repeated values"""
+    rng = np.random.default_rng(5)
+    pts = np.zeros((600, 3), np.float32)
+    pts[:, 0] = rng.integers(0, 40, 600).astype(np.float32) * 0.01   # many equal distances along one axis
+    pts[:, 1:] = rng.uniform(0, 0.3, (600, 2)).astype(np.float32) * 0
+    g = hc.Grid(pts + np.float32(5.0), 0.6)
+    q = np.array([[5.2, 5.0, 5.0], [5.0, 5.0, 5.0], [5.39, 5.0, 5.0]], np.float32)
+    hi, hd = g.knn5(q, 50.0)
+    ti, td, _, stats = g.knn5_tile(q, 50.0)
+    assert np.array_equal(hi, ti) and np.array_equal(hd, td)
+    assert stats[2] == 3  # every list has ties: all three lanes fall back
+
+
 @pytest.mark.parametrize("guard", [0.0, 0.05, 0.5])
 @pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500)])
 def test_grid_knn_reuse_bounds_are_valid(cell, max_d2, npts, guard):
