@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--knn-tile-with-reuse", action="store_true", help="A/B: tile search at ICP iterations 0 / 1, neighbour reuse + work lists afterwards")
     ap.add_argument("--no-solver-groups", action="store_true", help="A/B for the single-scan latency figure: one solver workgroup per scan "
                     "even for small batches (default: batches of <= 16 scans spread every scan over 8 workgroups)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / collective plumbing only (gloo, no GPU work): the CPU test of the --gpus path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive figure")
@@ -149,11 +150,53 @@ def pmc_knn_issue(batch: int):
             "sources": [os.path.relpath(pv, ROOT), os.path.relpath(pt, ROOT)]}
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def relaunch_under_torchrun(n, script=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command line under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and hand back their exit code.  Under a launcher (WORLD_SIZE set) nothing happens
+    here: the ranks already exist."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(script or __file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def dry_run(args, rank, world):
+    """Launcher / collective plumbing without the hot path (the CPU test of the --gpus path: gloo, no GPU): every rank reports a
+    made-up elapsed time, the line is assembled exactly as the real one is (MAX over ranks, per-rank rates gathered)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    elapsed = 0.010 * (rank + 1)
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(per, torch.tensor([args.batch * args.steps / elapsed], dtype=torch.float64))
+    if rank == 0:
+        print(json.dumps({"metric": "scans_per_s", "dry_run": True, "n_gpus": dist.get_world_size(), "requested_gpus": args.gpus,
+                          "value": round(args.batch * args.steps * world / float(t.item()), 2),
+                          "per_rank_scans_per_s": [round(float(x.item()), 2) for x in per]}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
 
     dist = None
@@ -242,10 +285,16 @@ def main():
         k_n += n
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [round(B * args.steps / elapsed, 2)]
     if dist is not None:
+        mine = torch.tensor([B * args.steps / elapsed], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(float(x.item()), 2) for x in allr]
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        world = dist.get_world_size()  # what RCCL saw
     res, pc, pi, reps = out
     nc, ns, nf, n_amb = fe.counts(B)
     nc_fe, ns_fe = nc, ns
@@ -369,6 +418,9 @@ def main():
                 "traffic_source": traffic_src,  # a committed rocprofv3 PMC summary of this command, not measured in this run
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "plane_block_bytes": plane_bytes,
+                # the contract's roofline is bytes against the HBM peak; what the counters say limits this kernel (profiles/):
+                "limited_by": ("fp64 VALU issue of the cost evaluations + per-launch table build + serial phases, not HBM bandwidth"
+                               if dom == 1 else "VALU issue of the searches (map patch is cache resident), not HBM bandwidth"),
                 # what the kernel really moves (rocprofv3 PMC passes, profiles/) against the same peak
                 "traffic_frac": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 8e12, 4)}
 
@@ -415,6 +467,10 @@ def main():
                    "map_surf": int(len(surf)), "icp_iters": args.icp_iters, "batch_scans_per_step_per_gpu": B,
                    "distinct_scans_in_batch": n_distinct,
                    "parallelism": f"replicas x{world} (independent scans, no data-path collective)"},
+        "per_rank_scans_per_s": per_rank,
+        # a device-side clock beside the wall clock: HIP events on the registrar's stream around every launch class, summed (the
+        # extraction kernels run on the extractor's stream and are not in it: ~0.3 ms per step)
+        "device_ms_per_step_hip_events": {"registrar_kernels": round(float(k_ms.sum() / args.steps), 3), "wall": round(ms_per_step, 3)},
         "roofline": roofline,
         "roofline_path": roofline_path,
         "roofline_knn": pmc_knn_issue(B),  # the other half of the step: instruction-bound (committed counters, labelled)
@@ -425,16 +481,18 @@ def main():
         "per_iter_ms_split_per_batch": {"transform_knn_build": round(float(k_ms[0] / args.steps / max(1, args.icp_iters)), 4),
                                         "solve": round(float(k_ms[1] / args.steps / max(1, args.icp_iters)), 4)},
         "single_scan_latency_ms": round(latency_ms, 3),
-        "single_scan_solver_phase_cycles": [int(v) for v in reg1.debug_cycles(0)],
         "single_scan_solver": "one workgroup per scan" if args.no_solver_groups else "group of 8 workgroups per scan (batches <= 16)",
         "features_per_scan": {"corner": float(nc.mean()), "surface": float(ns.mean())},
         "knn_reuse_last_iter": dict(zip(("searched", "resorted"), reg.debug_worklists(B)), queries=int(nc.sum() + ns.sum()),
                                     corner_searched_resorted=reg.debug_worklists_by_kind(B)[0], corner_queries=int(nc.sum())),
-        "solver_phase_cycles_scan0": [int(v) for v in reg.debug_cycles(0)],
         "accepted_frac": float(np.mean(res)), "lm_iters_per_scan": float(np.mean([r.lm_iterations_total for r in reps])),
         "ambiguous_labels": int(n_amb), "setup_s": {"synthetic_data": round(t_data, 1), "map_upload_grid_build": round(t_map, 2)},
     }
 
+    cyc1, cycB = [int(v) for v in reg1.debug_cycles(0)], [int(v) for v in reg.debug_cycles(0)]
+    if any(cyc1) or any(cycB):  # only the -DLL_SOLVE_TIMING build (LOAM_LIVOX_LIB=...timing.so) fills these
+        result["single_scan_solver_phase_cycles"] = cyc1
+        result["solver_phase_cycles_scan0"] = cycB
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg belongs to the N = 1 line only
         result.update(cpu_legs(args, synth, corner, surf, scans, init, B, vox, pc, res, reps, nc, ns, nc_fe, ns_fe))
     if rank == 0:
@@ -535,6 +593,27 @@ def cpu_legs(args, synth, corner, surf, scans, init, B, vox, pc, res, reps, nc, 
                                           "ms_per_scan_median": round(1e3 * med_s, 2),
                                           "sample": f"median of {n_runs} runs: voxel-filtered features (0.1 / 0.4 m) and maximum_residual_blocks = 200 "
                                                     "(the shipped configs), the reference's real operating point"}
+    # -- (iv) the shipped operating point on all host cores, one scan per thread at a time (laser_mapping.hpp:1737): the honest
+    #         neighbour of the device's Q-pipe figure
+    per_thread_s = 16
+    done_s = [0] * n_thr
+
+    def worker_s(t):
+        for j in range(per_thread_s):
+            one_scan((t * per_thread_s + j) % B, prm_s, True)
+            done_s[t] += 1
+
+    threads = [threading.Thread(target=worker_s, args=(t,)) for t in range(n_thr)]
+    tb = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    t_all_s = time.perf_counter() - tb
+    out["cpu_baseline_shipped_config_allcores"] = {"value": round(sum(done_s) / t_all_s, 3), "unit": "scans/s", "cores": n_thr, "kind": "port",
+                                                   "sample": f"{sum(done_s)} scans on {n_thr} threads ({per_thread_s} each, one scan per thread at a time): "
+                                                             f"voxel-filtered features, maximum_residual_blocks = 200; {t_all_s:.1f} s wall",
+                                                   "host_cores_available": os.cpu_count()}
     seen = set(range(min(n_runs, B)))
     for lst in audit:
         for b, e, s_sets, s_blocks, s_lm, s_res in lst:

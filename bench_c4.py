@@ -44,6 +44,9 @@ def main():
                     "out-and-back trajectory) and replay them: frame k uses scan k mod D, whose pose is frame k's; 0 = every frame its own scan")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of rank 0's sequence also run through the CPU oracle (0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: start the ranks ourselves (bench.py's helper), one per GPU
+        from bench import relaunch_under_torchrun
+        sys.exit(relaunch_under_torchrun(args.gpus, __file__))
     import torch
     from loam_livox_amd import synth
     from loam_livox_amd.mapping import Laser_mapping
@@ -104,6 +107,9 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        world = dist.get_world_size()  # what RCCL saw
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         merged, counts = gather_submaps(sub, dist)
         torch.cuda.synchronize()
     t_gather = time.perf_counter() - t1
@@ -114,6 +120,7 @@ def main():
                                f"{args.line_res}/{args.plane_res}, 10 ICP iters max", "history": args.history},
         "accepted": accepted, "final_drift_m": float(errs[-1][0]), "final_drift_rad": float(errs[-1][1]),
         "max_drift_m": float(max(e[0] for e in errs)), "submap_points_per_rank": counts, "gather_s": round(t_gather, 4),
+        "gather_gb_per_s_received_per_rank": round((sum(counts) - counts[rank if rank < len(counts) else 0]) * 16 / max(t_gather, 1e-9) / 1e9, 3) if len(counts) > 1 else None,
         "match_buffer": {"corner": lm.map_sizes[0], "surface": lm.map_sizes[1]},
         "ms_per_frame_by_stage": dict(zip(("extract_register", "history_add", "match_buffer_refresh"), [round(1e3 * float(v) / F, 3) for v in lm.stage_s[:3]])),
         "icp_iterations_last_frame": int(lm.last_report.icp_iterations),

@@ -66,3 +66,23 @@ def test_summarize_rocprof_reads_register_counts_from_the_code_object():
     sol = rows["ll::reg_solve_kernel<0>"]
     assert int(sol[1]) == 256 and int(sol[7]) > 150000 and int(sol[8]) == 2   # one 512-thread workgroup per CU, two waves per SIMD
     assert 64 <= int(rows["ll::reg_knn_kernel"][1]) <= 128 and int(rows["ll::reg_knn_kernel"][6]) == 0
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks under torch.distributed.run itself (the flag was
+    parsed and ignored); --dry-run keeps the hot path out so the plumbing -- rendezvous on 127.0.0.1, MAX over ranks, gathered
+    per-rank rates, n_gpus = the world size the process group saw -- runs on the CPU tier with gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--batch", "4", "--steps", "2"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["requested_gpus"] == 2 and len(d["per_rank_scans_per_s"]) == 2
+    assert d["value"] == 2 * 4 * 2 / 0.020  # all ranks' scans over the slowest rank's time
