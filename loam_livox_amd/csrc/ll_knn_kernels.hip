@@ -8,8 +8,11 @@
 //                         update of centimetres moves the queries of a cell together).
 //   reg_knn_tile_kernel : one wavefront per 64 consecutive queries of that order: the map points of the cells' common
 //                         neighbourhood staged in LDS, every lane offers every staged point to its top five (ll_knn_tile.h),
-//                         then the residual-block constants of the same slot (build_one).  Lanes the tile cannot settle
-//                         (0.1 % on the C2 map) run the per-lane search.
+//                         then the residual-block constants of the same slot.  Lanes the tile cannot settle (0.1 % on the
+//                         C2 map) run the per-lane search.  Without motion deblur the pose transform of the query
+//                         (pointAssociateToMap, :622-661) happens in here too, and the scan's corner queries (a few hundred,
+//                         per-lane ring searches on the sparse corner map) ride in the first workgroups of the same launch:
+//                         one launch per ICP iteration instead of transform + corner search + surface search + build.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <limits.h>
@@ -20,24 +23,45 @@
 namespace ll {
 
 #define QS_THREADS 1024
-template <int ITEMS>
-__global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, Grid gs)
+// the query position the sort and the tile kernel agree on: FUSED = transformed here from the extractor's feature cloud with the
+// scan's current pose (no motion deblur), else read from rd.qw (reg_transform_kernel has run)
+// transform_query without motion deblur (the only case the fused kernels serve): pointAssociateToMap's plain branch, PCR:629
+__device__ __forceinline__ void transform_plain(const RegState *st, const float4 &f, float pw[3])
+{
+    pw[0] = pw[1] = pw[2] = NAN;  // non-finite features are skipped like in transform_query
+    if (!(ll_isfinite(f.x) && ll_isfinite(f.y) && ll_isfinite(f.z))) return;
+    point_to_map(st->pose_curr, f.x, f.y, f.z, pw);
+}
+
+template <bool FUSED>
+__device__ __forceinline__ float4 tile_query_pos(const RegDev &rd, const RegConst &rc, const RegState *st, int b, int q, int nS)
+{
+    if (!FUSED) return rd.qw[(size_t)b * rd.cap + rd.cap_c + q];
+    float pw[3];
+    transform_plain(st, load_feature(rd, b, 1, q), pw);
+    // a13: a skipped feature is handed on as a non-finite query -- no neighbours, no block (PCR:339-345)
+    if (subsample_skip_feature(rc.subsample_seed, 1, st->icp_iters, q, nS, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
+    return make_float4(pw[0], pw[1], pw[2], 0.f);
+}
+
+template <int ITEMS, bool FUSED>
+__global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegConst rc, Grid gs)
 {
     typedef hipcub::BlockRadixSort<unsigned int, QS_THREADS, ITEMS, unsigned short> Sort;
     __shared__ typename Sort::TempStorage sort;
     __shared__ int s_lo[3][QS_THREADS / 64], s_hi[3][QS_THREADS / 64];
     __shared__ int s_box[6];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (rd.state[b].done) return;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
     const int nS = rd.n_surf[b];
-    const float4 *qw = rd.qw + (size_t)b * rd.cap + rd.cap_c;
     // ---- box of the cells the scan's queries fall into (striped reads: coalesced; any initial order is as good as another)
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const int i = u * QS_THREADS + tid;
         if (i < nS) {
-            const float4 p = qw[i];
+            const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);
             TileQ tq;
             tile_query(gs, p.x, p.y, p.z, tq);
             if (tq.ingrid) {
@@ -89,7 +113,7 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, Grid g
         const int i = u * QS_THREADS + tid;
         unsigned int k = kmax + 2u;  // padding: behind everything
         if (i < nS) {
-            const float4 p = qw[i];  // (read again from L2: ITEMS points held in registers would spill)
+            const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);  // (again: ITEMS points held in registers would spill)
             TileQ tq;
             tile_query(gs, p.x, p.y, p.z, tq);
             k = kmax + 1u;  // not in the grid / not finite: behind the grouped ones (they take the per-lane search anyway)
@@ -110,20 +134,37 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, Grid g
 }
 
 #define KT_THREADS 256
+// grid (corner_blocks + surface blocks, scans).  corner_blocks > 0: the first workgroups of a scan search its corner queries one
+// per lane (and build their blocks) -- their long ring searches overlap the tiles instead of forming a launch of their own.
+template <bool FUSED>
 __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
+void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int corner_blocks)
 {
-    __shared__ float4 s_tile[KT_THREADS / 64][68];
+    __shared__ float4 s_tile[KT_THREADS / 64][LL_TILE_CAP + 4];
     const int b = blockIdx.y;
     const RegState *st = rd.state + b;
     if (st->done) return;
-    const int nS = rd.n_surf[b];
-    const int i = blockIdx.x * KT_THREADS + threadIdx.x;  // position in the scan's cell order
-    if ((i & ~63) >= nS) return;                           // (whole wavefronts)
-    const bool valid = i < nS;
     const size_t sb = (size_t)b * rd.cap;
-    const int slot = rd.cap_c + (valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0);
-    const float4 pw = rd.qw[sb + slot];
+    if ((int)blockIdx.x < corner_blocks) {
+        const int q = blockIdx.x * KT_THREADS + threadIdx.x, nC = rd.n_corner[b];
+        if (q >= nC) return;
+        if (FUSED) {
+            float pw[3];
+            transform_plain(st, load_feature(rd, b, 0, q), pw);
+            if (subsample_skip_feature(rc.subsample_seed, 0, st->icp_iters, q, nC, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
+            rd.qw[sb + q] = make_float4(pw[0], pw[1], pw[2], 0.f);
+        }
+        knn_one(rd, rc, gc, gs, b, q, iter);
+        build_one(rd, rc, gc, gs, b, q);
+        return;
+    }
+    const int nS = rd.n_surf[b];
+    const int i = ((int)blockIdx.x - corner_blocks) * KT_THREADS + threadIdx.x;  // position in the scan's cell order
+    if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
+    const bool valid = i < nS;
+    const int q = valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
+    const int slot = rd.cap_c + q;
+    const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
     const float max_d2 = rc.max_d2_plane;
     Knn5 r;
     bool fin;
@@ -135,25 +176,52 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
             for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
         }
         knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
+        if (!rc.check_plane_pca && rc.icp_plane && !rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
+            // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
+            // still knows -- no second look at rd.nn
+            const f4 p0 = gs.pts[r.pos[0]], p1 = gs.pts[r.pos[2]], p2 = gs.pts[r.pos[4]];
+            const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
+            const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
+            const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
+            rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
+            return;
+        }
     } else {
-        knn_one(rd, rc, gc, gs, b, slot, iter);  // sparse surroundings, an exact tie, a query outside the grid or not finite
+        // sparse surroundings, an exact tie, a query outside the grid or not finite
+        if (FUSED) rd.qw[sb + slot] = pw;
+        knn_one(rd, rc, gc, gs, b, slot, iter);
     }
     build_one(rd, rc, gc, gs, b, slot);
 }
 
-void launch_reg_qsort(const RegDev &rd, const Grid &gs, int n_scans, int max_ns, hipStream_t s)
+void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s)
 {
+#define LL_QSORT(ITEMS)                                                                                                        \
+    do {                                                                                                                       \
+        if (fused)                                                                                                             \
+            hipLaunchKernelGGL((reg_qsort_kernel<ITEMS, true>), dim3(n_scans), dim3(QS_THREADS), 0, s, rd, rc, gs);           \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((reg_qsort_kernel<ITEMS, false>), dim3(n_scans), dim3(QS_THREADS), 0, s, rd, rc, gs);          \
+    } while (0)
     if (max_ns <= QS_THREADS * 4)
-        hipLaunchKernelGGL(reg_qsort_kernel<4>, dim3(n_scans), dim3(QS_THREADS), 0, s, rd, gs);
+        LL_QSORT(4);
     else if (max_ns <= QS_THREADS * 8)
-        hipLaunchKernelGGL(reg_qsort_kernel<8>, dim3(n_scans), dim3(QS_THREADS), 0, s, rd, gs);
+        LL_QSORT(8);
     else
-        hipLaunchKernelGGL(reg_qsort_kernel<24>, dim3(n_scans), dim3(QS_THREADS), 0, s, rd, gs);
+        LL_QSORT(24);
+#undef LL_QSORT
 }
 
-void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_ns, hipStream_t s)
+// max_nc > 0: the corner queries are searched (per lane) and built by the first workgroups of the same launch
+void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
+                         bool fused, hipStream_t s)
 {
-    hipLaunchKernelGGL(reg_knn_tile_kernel, dim3((max_ns + KT_THREADS - 1) / KT_THREADS, n_scans), dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter);
+    const int cb = (max_nc + KT_THREADS - 1) / KT_THREADS;
+    const dim3 grid(cb + (max_ns + KT_THREADS - 1) / KT_THREADS, n_scans);
+    if (fused)
+        hipLaunchKernelGGL(reg_knn_tile_kernel<true>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, cb);
+    else
+        hipLaunchKernelGGL(reg_knn_tile_kernel<false>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, cb);
 }
 
 }  // namespace ll

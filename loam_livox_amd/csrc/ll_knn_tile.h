@@ -10,8 +10,11 @@
 // of a scan are sorted by map cell once per registration (reg_qsort_kernel), a wavefront takes 64 consecutive queries of that
 // order -- one or two neighbouring cells --, stages the map points of the cells' common neighbourhood (the TILE: bounding box of
 // the lanes' cells +- 1, at most 5 x 5 x 5 cells, a few contiguous x-runs of the cell-sorted array, ~35 points) in LDS with
-// one coalesced load, and every lane offers EVERY tile point to its sorted top five through a branch-free min / med3 network
-// (tile5_offer: 21 instructions, no divergence, no dependent loads).  Afterwards a lane's answer is exact iff its 5th best lies
+// coalesced loads, and every lane offers EVERY tile point to its sorted top five through a branch-free min / med3 network on
+// 32-bit KEYS {squared distance with its low 8 mantissa bits replaced by the point's place in the tile} (tilek_offer: 8
+// instructions per point besides the distance, no payload moves, no divergence, no dependent loads); the five winners are then
+// evaluated again exactly.  Truncating the distance is harmless unless two of the six smallest keys agree in all their distance
+// bits -- then (and for true ties) the lane searches again.  Afterwards a lane's answer is exact iff its 5th best lies
 // inside the distance every unvisited point must exceed (one full ring of cells around its own cell: the k = 1 termination test
 // of knn5_search_t) and no exact distance tie touches the list; the other lanes (0.1 % on the C2 map: sparse surroundings, ties,
 // queries outside the grid) run knn5_search.  Same lists as knn5_search, bit for bit; the reuse bounds are valid and
@@ -86,6 +89,66 @@ LL_HD bool tile5_has_tie(const Tile5 &t)
     return t.d[0] == t.d[1] || t.d[1] == t.d[2] || t.d[2] == t.d[3] || t.d[3] == t.d[4] || t.d[4] == t.lb;
 }
 
+// ---- the key network -------------------------------------------------------------------------------------------------------
+// One pass covers up to LL_TILE_CAP staged points.  key = bits(d2) with the low LL_TILE_IDX_BITS bits replaced by the point's index
+// in the pass: squared distances are >= +0, so their bit patterns order like the values and the keys order by (truncated distance,
+// index).  Unsigned integer min / max / med3 throughout: no NaN or denormal rules to think about.
+#define LL_TILE_IDX_BITS 8
+#define LL_TILE_CAP (1 << LL_TILE_IDX_BITS)
+#define LL_TILE_KEY_EMPTY 0xffffffffu
+
+LL_HD unsigned int tile_umin(unsigned int a, unsigned int b) { return a < b ? a : b; }
+LL_HD unsigned int tile_umax(unsigned int a, unsigned int b) { return a < b ? b : a; }
+// (the compiler turns this shape into v_med3_u32)
+LL_HD unsigned int tile_umed3(unsigned int a, unsigned int b, unsigned int c) { return tile_umax(tile_umin(a, b), tile_umin(tile_umax(a, b), c)); }
+
+struct TileK {
+    unsigned int k[5];  // the five smallest keys so far, ascending
+    unsigned int lb;    // the smallest key that was offered and is not (or no longer) among them
+};
+
+LL_HD void tilek_init(TileK &t)
+{
+    for (int i = 0; i < 5; i++) t.k[i] = LL_TILE_KEY_EMPTY;
+    t.lb = LL_TILE_KEY_EMPTY;
+}
+
+LL_HD unsigned int tile_key(float d2, int j) { return ((unsigned int)as_int(d2) & ~(unsigned int)(LL_TILE_CAP - 1)) | (unsigned int)j; }
+
+LL_HD void tilek_offer(TileK &t, unsigned int c)
+{
+    t.lb = tile_umin(t.lb, tile_umax(t.k[4], c));
+    const unsigned int n4 = tile_umed3(t.k[3], c, t.k[4]);
+    const unsigned int n3 = tile_umed3(t.k[2], c, t.k[3]);
+    const unsigned int n2 = tile_umed3(t.k[1], c, t.k[2]);
+    const unsigned int n1 = tile_umed3(t.k[0], c, t.k[1]);
+    t.k[0] = tile_umin(t.k[0], c);
+    t.k[1] = n1;
+    t.k[2] = n2;
+    t.k[3] = n3;
+    t.k[4] = n4;
+}
+
+// two of the six smallest keys share all their distance bits: the truncated order may not be the true one (or it is a true tie)
+LL_HD bool tilek_collision(const TileK &t)
+{
+    const int s = LL_TILE_IDX_BITS;
+    return (t.k[0] >> s) == (t.k[1] >> s) || (t.k[1] >> s) == (t.k[2] >> s) || (t.k[2] >> s) == (t.k[3] >> s) ||
+           (t.k[3] >> s) == (t.k[4] >> s) || (t.k[4] >> s) == (t.lb >> s);
+}
+
+// a lower bound on the squared distance behind a key (truncation rounds towards zero); +inf for "nothing"
+LL_HD float tile_key_lower(unsigned int k)
+{
+    if (k == LL_TILE_KEY_EMPTY) return INFINITY;
+    union {
+        unsigned int u;
+        float f;
+    } v;
+    v.u = k & ~(unsigned int)(LL_TILE_CAP - 1);
+    return v.f;
+}
+
 // Where a query sits in the grid: the quantities knn5_search_t derives at its start, operation for operation.
 struct TileQ {
     int cx, cy, cz;
@@ -145,8 +208,9 @@ LL_HD bool tile5_finish(const Grid &g, const Tile5 &t, const TileQ &tq, float ma
 #if defined(__HIPCC__)
 // ---- device: one round-based search for the 64 queries of a wavefront ------------------------------------------------------
 // All 64 lanes call it together (whole wavefronts, one-dimensional blocks).  q*: the lane's query (any value when !active);
-// tile: this wavefront's LDS staging buffer, 64 + 4 entries {x, y, z, bits(position)}.  On return `final` says whether r holds
-// the lane's exact result; lanes with active && !final must run knn5_search.
+// tile: this wavefront's LDS staging buffer, LL_TILE_CAP + 4 entries {x, y, z, bits(position)}.  On return `final` says whether r
+// holds the lane's exact result; lanes with active && !final must run knn5_search.
+#define LL_TILE_FAR 1.0e18f  // coordinate of a padding entry: its distance is huge and finite or +inf, never NaN
 __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float qx, float qy, float qz, float max_d2, float4 *tile,
                                                Knn5 &r, bool &final)
 {
@@ -154,8 +218,6 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
     TileQ tq;
     tile_query(g, qx, qy, qz, tq);
     const bool ingrid = active && tq.ingrid;
-    Tile5 t;
-    tile5_init(t);
     final = false;
     unsigned long long todo = __ballot(ingrid);
     while (todo != 0ull) {  // (uniform) one round per group of lanes whose cells lie within +-1 of the leader's: 1.05 rounds on C2
@@ -192,33 +254,58 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
         }
         const int T = __builtin_amdgcn_readlane(incl, LL_TILE_MAX_ROWS - 1);  // (rows beyond nrows count 0)
         const int excl = incl - cnt;
-        for (int c0 = 0; c0 < T; c0 += 64) {  // (uniform) one chunk of 64 candidates at a time: T <= 64 for 95 % of the C2 tiles
-            const int j = c0 + lane;
-            int row = 0;
-            for (int rr = 0; rr < nrows - 1; rr++) row += (j >= __builtin_amdgcn_readlane(incl, rr)) ? 1 : 0;  // (scalar operand)
-            const int addr = __shfl(rb, row) + (j - __shfl(excl, row));
-            float4 e = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);  // padding: distance +inf, never enters a list
-            if (j < T) {
-                const f4 pt = g.pts[addr];
-                e = make_float4(pt.x, pt.y, pt.z, __int_as_float(addr));
+        Tile5 t;  // the round's exact result (participants); every lane starts a round empty
+        tile5_init(t);
+        bool collided = false;
+        for (int c0 = 0; c0 < T; c0 += LL_TILE_CAP) {  // (uniform) one pass per LL_TILE_CAP candidates: one pass for every C2 tile
+            const int np = (T - c0) < LL_TILE_CAP ? (T - c0) : LL_TILE_CAP;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the previous pass's reads are done)
+            for (int s0 = 0; s0 < np; s0 += 64) {  // stage 64 candidates per trip, one per lane, each lane finds its row
+                const int j = c0 + s0 + lane;
+                int row = 0;
+                for (int rr = 0; rr < nrows - 1; rr++) row += (j >= __builtin_amdgcn_readlane(incl, rr)) ? 1 : 0;  // (scalar operand)
+                const int addr = __shfl(rb, row) + (j - __shfl(excl, row));
+                float4 e = make_float4(LL_TILE_FAR, 0.0f, 0.0f, __int_as_float(-1));  // padding: never among five real neighbours
+                if (j < T) {
+                    const f4 pt = g.pts[addr];
+                    e = make_float4(pt.x, pt.y, pt.z, __int_as_float(addr));
+                }
+                tile[s0 + lane] = e;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the previous chunk's reads are done)
-            tile[lane] = e;
-            if (lane < 4) tile[64 + lane] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+            if (lane < 4) tile[((np + 63) & ~63) + lane] = make_float4(LL_TILE_FAR, 0.0f, 0.0f, __int_as_float(-1));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int n = (T - c0) < 64 ? (T - c0) : 64;
-            for (int jj = 0; jj < n; jj += 4) {  // (uniform) four broadcast reads and four independent offers per trip
+            TileK tk;
+            tilek_init(tk);
+            for (int jj = 0; jj < np; jj += 4) {  // (uniform) four broadcast reads and four independent offers per trip
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const float4 cnd = tile[jj + u];
-                    float dd = dist2_xyz(qx, qy, qz, cnd.x, cnd.y, cnd.z);
-                    dd = part ? dd : INFINITY;
-                    tile5_offer(t, dd, __float_as_int(cnd.w));
+                    tilek_offer(tk, tile_key(dist2_xyz(qx, qy, qz, cnd.x, cnd.y, cnd.z), jj + u));
                 }
             }
+            collided = collided || tilek_collision(tk);
+            // the five winners again, exactly (their order is the true one unless `collided`)
+            const float lbv = tile_key_lower(tk.lb);
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                float d = INFINITY;
+                int pos = -1;
+                if (tk.k[k] != LL_TILE_KEY_EMPTY) {
+                    const float4 cnd = tile[tk.k[k] & (LL_TILE_CAP - 1)];
+                    pos = __float_as_int(cnd.w);
+                    d = pos >= 0 ? dist2_xyz(qx, qy, qz, cnd.x, cnd.y, cnd.z) : INFINITY;
+                }
+                if (c0 == 0) {  // (uniform) the first pass fills the list, later ones (tiles of > LL_TILE_CAP points) merge into it
+                    t.d[k] = d;
+                    t.p[k] = pos;
+                } else {
+                    tile5_offer(t, d, pos);
+                }
+            }
+            t.lb = fminf(t.lb, lbv);
         }
-        if (part) final = tile5_finish(g, t, tq, max_d2, r);
+        if (part) final = !collided && tile5_finish(g, t, tq, max_d2, r);
     }
 }
 #endif  // __HIPCC__

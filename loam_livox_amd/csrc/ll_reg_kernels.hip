@@ -87,9 +87,10 @@ __device__ __forceinline__ double wave_sum(double v)
 // K6t: pose transform of every query (pointAssociateToMap, fp64 math -> fp32 store like the reference).  A
 // kernel of its own so that the double-precision sin/cos of the motion-deblur branch does not set the register
 // footprint of the k-NN kernel.
-__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc)
+__global__ __launch_bounds__(KB_THREADS) void reg_transform_kernel(RegDev rd, RegConst rc, int skip_kinds)
 {
     const int b = blockIdx.y, kind = blockIdx.z;
+    if ((skip_kinds >> kind) & 1) return;  // (the tile kernel transforms its own queries)
     const RegState *st = rd.state + b;
     if (st->done) return;
     const int n = kind ? rd.n_surf[b] : rd.n_corner[b];
@@ -2937,29 +2938,38 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
     const int mx = max_nc > max_ns ? max_nc : max_ns;
     if (mx <= 0) return;
     dim3 grid((mx + KB_THREADS - 1) / KB_THREADS, n_scans, 2);
-    hipLaunchKernelGGL(reg_transform_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc);
-    // large scans: the surface queries go to the tile kernel (ll_knn_kernels.hip) in the order of the map cells they fell into
-    // at ICP iteration 0; it also builds their blocks
+    // large scans: the surface queries go to the tile kernel (ll_knn_kernels.hip) in the order of the map cells they fall into (sorted at
+    // ICP iterations 0 and 1: the first pose update moves the queries by a good part of a cell, the later ones by centimetres); it also
+    // builds their blocks and, without motion deblur, transforms them itself
     const bool tile = rc.knn_tile && max_ns >= LL_KNN_TILE_MIN_SURF && max_ns <= LL_KNN_TILE_MAX_SURF;
-    if (tile && iter == 0) launch_reg_qsort(rd, gs, n_scans, max_ns, s);
+    const bool fused = tile && !rc.if_motion_deblur;
     // small batches: the corner queries one per wavefront, and the surface queries too when the scans are small
     int coop_kinds = 0;
     if (rc.knn_coop && n_scans <= LL_KNN_COOP_MAX_SCANS) {
         if (max_nc > 0) coop_kinds |= 1;
         if (max_ns > 0 && max_ns <= LL_KNN_COOP_MAX_SURF && !tile) coop_kinds |= 2;
     }
+    const bool corner_in_tile = tile && max_nc > 0 && !(coop_kinds & 1);  // ... otherwise they ride in the tile launch
+    {
+        const int skip = fused ? (corner_in_tile ? 3 : 2) : 0;
+        if (skip != 3 && (skip == 0 || max_nc > 0)) {
+            const int mt = skip == 2 ? max_nc : mx;
+            hipLaunchKernelGGL(reg_transform_kernel, dim3((mt + KB_THREADS - 1) / KB_THREADS, n_scans, 2), dim3(KB_THREADS), 0, s, rd, rc, skip);
+        }
+    }
+    if (tile && iter <= 1) launch_reg_qsort(rd, rc, gs, n_scans, max_ns, fused, s);
     if (coop_kinds) {
         const int mq = (coop_kinds & 2) ? mx : max_nc;
         hipLaunchKernelGGL(reg_knn_coop_kernel, dim3((mq * 64 + KC_THREADS - 1) / KC_THREADS, n_scans, 2), dim3(KC_THREADS), 0, s, rd, rc, gc, gs, iter, coop_kinds);
     }
-    const int done_kinds = coop_kinds | (tile ? 2 : 0);  // kinds that do not need the per-lane kernel
+    const int done_kinds = coop_kinds | (tile ? 2 : 0) | (corner_in_tile ? 1 : 0);  // kinds that do not need the per-lane kernel
     if ((max_nc > 0 && !(done_kinds & 1)) || (max_ns > 0 && !(done_kinds & 2))) {
         const int mk = (done_kinds & 2) ? max_nc : ((done_kinds & 1) ? max_ns : mx);
         hipLaunchKernelGGL(reg_knn_kernel, dim3((mk + KB_THREADS - 1) / KB_THREADS, n_scans, 2), dim3(KB_THREADS), 0, s, rd, rc, gc, gs, iter, done_kinds);
     }
     if (tile) {
-        launch_reg_knn_tile(rd, rc, gc, gs, n_scans, iter, max_ns, s);
-        if (max_nc > 0)
+        launch_reg_knn_tile(rd, rc, gc, gs, n_scans, iter, corner_in_tile ? max_nc : 0, max_ns, fused, s);
+        if (max_nc > 0 && !corner_in_tile)
             hipLaunchKernelGGL(reg_build_kernel, dim3((max_nc + KB_THREADS - 1) / KB_THREADS, n_scans, 2), dim3(KB_THREADS), 0, s, rd, rc, gc, gs, 2);
     } else {
         hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, 0);

@@ -333,21 +333,59 @@ int hc_knn5_tile(const hc_grid *G, const float *q, int nq, float max_d2, int32_t
             x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
             x1 = x1 >= g.nx ? g.nx - 1 : x1; y1 = y1 >= g.ny ? g.ny - 1 : y1; z1 = z1 >= g.nz ? g.nz - 1 : z1;
             if ((y1 - y0 + 1) * (z1 - z0 + 1) > LL_TILE_MAX_ROWS) return -1;
+            std::vector<f4> cand;  // the tile in the device's staging order: rows y fastest, then z; w = bits(position)
             for (int z = z0; z <= z1; z++)
-                for (int y = y0; y <= y1; y++) {  // rows in the device's order: y fastest
+                for (int y = y0; y <= y1; y++) {
                     const int base = (z * g.ny + y) * g.nx;
                     for (int j = g.cell_start[base + x0]; j < g.cell_start[base + x1 + 1]; j++) {
-                        stats[1]++;
-                        const f4 pt = g.pts[j];
-                        for (int l = 0; l < nl; l++) {
-                            if (!part[l]) continue;
-                            const float dd = dist2_xyz(q[3 * (w0 + l)], q[3 * (w0 + l) + 1], q[3 * (w0 + l) + 2], pt.x, pt.y, pt.z);
-                            tile5_offer(t[l], dd, j);
-                        }
+                        f4 e = g.pts[j];
+                        union { int i; float f; } u;
+                        u.i = j;
+                        e.w = u.f;
+                        cand.push_back(e);
                     }
                 }
-            for (int l = 0; l < nl; l++)
-                if (part[l]) fin[l] = tile5_finish(g, t[l], tq[l], max_d2, r[l]);
+            stats[1] += (int64_t)cand.size();
+            const int T = (int)cand.size();
+            for (int l = 0; l < nl; l++) {
+                if (!part[l]) continue;
+                const float qx = q[3 * (w0 + l)], qy = q[3 * (w0 + l) + 1], qz = q[3 * (w0 + l) + 2];
+                tile5_init(t[l]);
+                bool collided = false;
+                for (int c0 = 0; c0 < T; c0 += LL_TILE_CAP) {  // passes of LL_TILE_CAP candidates, as on the device
+                    const int np = T - c0 < LL_TILE_CAP ? T - c0 : LL_TILE_CAP;
+                    TileK tk;
+                    tilek_init(tk);
+                    const int np4 = (np + 3) & ~3;  // the device offers whole groups of four; the surplus are padding entries
+                    for (int jj = 0; jj < np4; jj++) {
+                        float dd;
+                        if (jj < np) dd = dist2_xyz(qx, qy, qz, cand[c0 + jj].x, cand[c0 + jj].y, cand[c0 + jj].z);
+                        else dd = dist2_xyz(qx, qy, qz, 1.0e18f, 0.0f, 0.0f);
+                        tilek_offer(tk, tile_key(dd, jj));
+                    }
+                    collided = collided || tilek_collision(tk);
+                    const float lbv = tile_key_lower(tk.lb);
+                    for (int k = 0; k < 5; k++) {
+                        float d = INFINITY;
+                        int pos = -1;
+                        if (tk.k[k] != LL_TILE_KEY_EMPTY) {
+                            const int jj = (int)(tk.k[k] & (LL_TILE_CAP - 1));
+                            if (jj < np) {
+                                pos = as_int(cand[c0 + jj].w);
+                                d = dist2_xyz(qx, qy, qz, cand[c0 + jj].x, cand[c0 + jj].y, cand[c0 + jj].z);
+                            }
+                        }
+                        if (c0 == 0) {
+                            t[l].d[k] = d;
+                            t[l].p[k] = pos;
+                        } else {
+                            tile5_offer(t[l], d, pos);
+                        }
+                    }
+                    t[l].lb = fminf(t[l].lb, lbv);
+                }
+                fin[l] = !collided && tile5_finish(g, t[l], tq[l], max_d2, r[l]);
+            }
         }
         for (int l = 0; l < nl; l++) {
             const int i = w0 + l;

@@ -113,7 +113,8 @@ def test_tile_search_equals_per_lane_search_on_the_scan_workload(small_world, sc
         assert stats2[0] >= stats[0]
 
 
-@pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500), (0.6, 50.0, 200000)])
+@pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500), (0.6, 50.0, 200000),
+                                               (1.5, 9.0, 200000)])  # (the last one: tiles of more than 256 points, several passes)
 def test_tile_search_sparse_dense_ties_and_outside(cell, max_d2, npts):
     rng = np.random.default_rng(21)
     pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
