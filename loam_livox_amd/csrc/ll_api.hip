@@ -903,7 +903,9 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         r->rc.knn_reuse = 0;  // skipped features change from iteration to iteration: every iteration searches
     // Scans of thousands of surface queries: the tile search (ll_knn_kernels.hip) takes them, in every ICP iteration -- searching
     // all of them costs less than classifying them against reuse records and searching the lists that leaves
-    if (max_ns < LL_KNN_TILE_MIN_SURF || max_ns > LL_KNN_TILE_MAX_SURF) r->rc.knn_tile = 0;
+    // (small batches are latency chains, not issue-bound: the wavefront-per-query searches and the short work lists serve them better --
+    //  single scan 2.24 ms against 2.49 with a tile launch per iteration; debug bit 11 forces the tile search for tests)
+    if (max_ns < LL_KNN_TILE_MIN_SURF || max_ns > LL_KNN_TILE_MAX_SURF || (n_scans <= LL_KNN_COOP_MAX_SCANS && !(r->debug & 2048))) r->rc.knn_tile = 0;
     if (r->rc.knn_tile == 2) r->rc.knn_reuse = 0;
     // Small batches leave most of the chip idle with one workgroup per scan: spread each scan's cost evaluations over a
     // group of LL_GRP workgroups (ll_reg_kernels.hip, group_*).  Compact scans only; the others run on the group's first.

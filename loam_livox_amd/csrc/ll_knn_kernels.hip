@@ -134,19 +134,22 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 }
 
 #define KT_THREADS 256
-// grid (corner_blocks + surface blocks, scans).  corner_blocks > 0: the first workgroups of a scan search its corner queries one
-// per lane (and build their blocks) -- their long ring searches overlap the tiles instead of forming a launch of their own.
+// One-dimensional grid: first corner_blocks workgroups for every scan (scan fastest), then surf_blocks workgroups per scan.
+// corner_blocks > 0: those first workgroups search the scans' corner queries one per lane (and build their blocks) -- dispatched
+// before any tile, their long ring searches (~100 dependent loads per lane) overlap the tiles instead of forming a launch of their
+// own or a tail behind the last tile.
 template <bool FUSED>
 __global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int corner_blocks)
+void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int n_scans, int corner_blocks, int surf_blocks)
 {
     __shared__ float4 s_tile[KT_THREADS / 64][LL_TILE_CAP + 4];
-    const int b = blockIdx.y;
-    const RegState *st = rd.state + b;
-    if (st->done) return;
-    const size_t sb = (size_t)b * rd.cap;
-    if ((int)blockIdx.x < corner_blocks) {
-        const int q = blockIdx.x * KT_THREADS + threadIdx.x, nC = rd.n_corner[b];
+    const int bid = blockIdx.x, n_corner_wg = corner_blocks * n_scans;
+    if (bid < n_corner_wg) {
+        const int b = bid % n_scans, cblk = bid / n_scans;
+        const RegState *st = rd.state + b;
+        if (st->done) return;
+        const size_t sb = (size_t)b * rd.cap;
+        const int q = cblk * KT_THREADS + threadIdx.x, nC = rd.n_corner[b];
         if (q >= nC) return;
         if (FUSED) {
             float pw[3];
@@ -158,8 +161,12 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
         build_one(rd, rc, gc, gs, b, q);
         return;
     }
+    const int b = (bid - n_corner_wg) / surf_blocks, sblk = (bid - n_corner_wg) - b * surf_blocks;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const size_t sb = (size_t)b * rd.cap;
     const int nS = rd.n_surf[b];
-    const int i = ((int)blockIdx.x - corner_blocks) * KT_THREADS + threadIdx.x;  // position in the scan's cell order
+    const int i = sblk * KT_THREADS + threadIdx.x;  // position in the scan's cell order
     if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
     const bool valid = i < nS;
     const int q = valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
@@ -179,11 +186,10 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
         if (!rc.check_plane_pca && rc.icp_plane && !rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
             // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
             // still knows -- no second look at rd.nn
+            // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)
             const f4 p0 = gs.pts[r.pos[0]], p1 = gs.pts[r.pos[2]], p2 = gs.pts[r.pos[4]];
-            const double pa[3] = {(double)p0.x, (double)p0.y, (double)p0.z};
-            const double pb[3] = {(double)p1.x, (double)p1.y, (double)p1.z};
-            const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
-            rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
+            const bool degenerate = (p1.x == p0.x && p1.y == p0.y && p1.z == p0.z) || (p2.x == p0.x && p2.y == p0.y && p2.z == p0.z);
+            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
             return;
         }
     } else {
@@ -216,12 +222,12 @@ void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int 
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
                          bool fused, hipStream_t s)
 {
-    const int cb = (max_nc + KT_THREADS - 1) / KT_THREADS;
-    const dim3 grid(cb + (max_ns + KT_THREADS - 1) / KT_THREADS, n_scans);
+    const int cb = (max_nc + KT_THREADS - 1) / KT_THREADS, sbk = (max_ns + KT_THREADS - 1) / KT_THREADS;
+    const dim3 grid((unsigned int)((cb + sbk) * n_scans));
     if (fused)
-        hipLaunchKernelGGL(reg_knn_tile_kernel<true>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, cb);
+        hipLaunchKernelGGL(reg_knn_tile_kernel<true>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, sbk);
     else
-        hipLaunchKernelGGL(reg_knn_tile_kernel<false>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, cb);
+        hipLaunchKernelGGL(reg_knn_tile_kernel<false>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, sbk);
 }
 
 }  // namespace ll

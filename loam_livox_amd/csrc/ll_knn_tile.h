@@ -241,7 +241,7 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
         // row table: lane r holds row r's first candidate and count; inclusive prefix sums over the rows
         int rb = 0, cnt = 0;
         if (lane < nrows) {
-            const int rz = lane / nyt, ry = lane - rz * nyt;
+            const int rz = (lane >= nyt) + (lane >= 2 * nyt) + (lane >= 3 * nyt) + (lane >= 4 * nyt), ry = lane - rz * nyt;  // lane / nyt, nyt <= 5
             const int base = ((z0 + rz) * g.ny + (y0 + ry)) * g.nx;
             rb = g.cell_start[base + x0];
             cnt = g.cell_start[base + x1 + 1] - rb;

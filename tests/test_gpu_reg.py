@@ -340,7 +340,8 @@ def test_tile_search_changes_nothing(dev_map, small_world, scans, n):
     without, and the neighbour lists of iteration 0 equal to the k-d tree's."""
     feats = [(f[4], f[5]) for f in (oracle_features(sc) for sc in scans)]
     outs = []
-    for kw in ({}, {"knn_tile_with_reuse": True}, {"no_knn_tile": True}, {"no_knn_tile": True, "no_knn_reuse": True}):
+    for kw in ({"knn_tile_small_batches": True}, {"knn_tile_small_batches": True, "knn_tile_with_reuse": True}, {"no_knn_tile": True},
+               {"no_knn_tile": True, "no_knn_reuse": True}):
         reg = Point_cloud_registration(max_scans=n, max_features=24000)
         reg.set_debug(True, **kw)
         set_params(reg, 10, 20, 1)
@@ -379,7 +380,7 @@ def test_tile_search_sparse_map_ties_and_strays(gpu_lib):
     fc[:, :3] = rng.uniform(0, 20, (10, 3))
     ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
     res = []
-    for kw in ({}, {"no_knn_tile": True}):
+    for kw in ({"knn_tile_small_batches": True}, {"no_knn_tile": True}):
         reg = Point_cloud_registration(max_scans=1, max_features=8192)
         reg.set_debug(True, **kw)
         set_params(reg, 1, 4, 1)
@@ -406,7 +407,8 @@ def test_wavefront_search_changes_nothing(dev_map, scans, n, thin):
     i.e. which queries are searched again later.  Same pose bits."""
     feats = [(f[4][::thin], f[5][::thin]) for f in (oracle_features(sc) for sc in scans)]
     outs = []
-    for kw in ({"no_knn_tile": True}, {"no_knn_tile": True, "no_knn_coop": True}, {}, {"no_knn_coop": True}):
+    for kw in ({"no_knn_tile": True}, {"no_knn_tile": True, "no_knn_coop": True}, {"knn_tile_small_batches": True},
+               {"knn_tile_small_batches": True, "no_knn_coop": True}):
         reg = Point_cloud_registration(max_scans=n, max_features=24000)
         reg.set_debug(False, **kw)
         set_params(reg, 10, 20, 1)
