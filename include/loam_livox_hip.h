@@ -352,6 +352,12 @@ typedef struct ll_cellmap ll_cellmap;
 int ll_cellmap_create(int32_t device, int64_t max_points, float resolution, int32_t minimum_revisit_threshold, ll_cellmap **out);
 void ll_cellmap_destroy(ll_cellmap *c);
 int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n);
+/* append_cloud( pts, &cell_vec ) (cell_map_keyframe.hpp:619-672, the form the mapping node calls when loop closure is on,
+ * laser_mapping.hpp:1527): the append, plus the cells that received at least min_points of this cloud's points (3 in the
+ * reference, :646; on an empty map every cell that received a point, set_point_cloud :596-607), as cell indices [n][3] in
+ * ascending cell order.  cell_ijk == NULL only counts. */
+int ll_cellmap_append_touched(ll_cellmap *c, const float *xyzi, int32_t n, int32_t min_points, int32_t *cell_ijk, int64_t capacity_cells,
+                              int64_t *n_touched);
 int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], float radius, float maximum_in_fov_angle, float leaf,
                             int32_t down_sample_replace, int64_t *n_cells_selected, int64_t *n_out);
 /* the concatenated cloud of the last query (host copy); xyzi == NULL returns its size */

@@ -323,6 +323,17 @@ class Cell_map:
         cloud = capi.as_f32(cloud, 4)
         check(self.L.ll_cellmap_append(self.h, ptr(cloud), cloud.shape[0]), "ll_cellmap_append")
 
+    def append_cloud_touched(self, cloud, min_points: int = 3) -> np.ndarray:
+        """append_cloud( pts, &cell_vec ) (cell_map_keyframe.hpp:619-672): the append, and the indices [n,3] of the cells that received
+        at least min_points of this cloud's points (every touched cell on an empty map)."""
+        cloud = capi.as_f32(cloud, 4)
+        cap = max(1, cloud.shape[0])
+        ijk = np.zeros((cap, 3), np.int32)
+        n = C.c_int64(0)
+        check(self.L.ll_cellmap_append_touched(self.h, ptr(cloud), cloud.shape[0], int(min_points), ptr(ijk), cap, C.byref(n)),
+              "ll_cellmap_append_touched")
+        return ijk[:n.value].copy()
+
     def stats(self):
         """(cells, points, m_current_frame_idx)"""
         nc, npts, fr = C.c_int64(0), C.c_int64(0), C.c_int32(0)

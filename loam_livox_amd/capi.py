@@ -108,6 +108,7 @@ SYMBOLS = {
     "ll_cellmap_create": (_i32, [_i32, _i64, C.c_float, _i32, _vp]),
     "ll_cellmap_destroy": (None, [_vp]),
     "ll_cellmap_append": (_i32, [_vp, _vp, _i32]),
+    "ll_cellmap_append_touched": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, C.POINTER(_i64)]),
     "ll_cellmap_query_filter": (_i32, [_vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),
     "ll_cellmap_result": (_i64, [_vp, _vp, _i64]),
     "ll_cellmap_stats": (_i32, [_vp, _vp, _vp, _vp]),

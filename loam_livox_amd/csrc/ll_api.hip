@@ -1205,6 +1205,40 @@ extern "C" int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n)
     return 0;
 }
 
+extern "C" int ll_cellmap_append_touched(ll_cellmap *c, const float *xyzi, int32_t n, int32_t min_points, int32_t *cell_ijk,
+                                         int64_t capacity_cells, int64_t *n_touched)
+{
+    if (!c || (n > 0 && !xyzi) || !n_touched) return set_err("ll_cellmap_append_touched", "null argument");
+    if (n < 0 || n > c->dev.cap) return set_err("ll_cellmap_append_touched", "cloud exceeds max_points");
+    HC(hipSetDevice(c->device));
+    const bool first = c->dev.n_cells == 0;  // set_point_cloud: every cell that received a point (CMK:596-607)
+    const int n_before = c->dev.n_pts;
+    if (n > 0) HC(hipMemcpyAsync(c->d_in, xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    const char *err = nullptr;
+    if (cellmap_append(c->dev, c->d_in, n, c->stream, &err)) return set_err("ll_cellmap_append_touched", err);
+    if (cellmap_touch_counts(c->dev, n_before, n, c->stream, &err)) return set_err("ll_cellmap_append_touched", err);
+    const int nc = c->dev.n_cells;
+    std::vector<unsigned int> cnt(nc);
+    std::vector<unsigned long long> keys(nc);
+    if (nc > 0) {
+        HC(hipMemcpyAsync(cnt.data(), c->dev.csel, (size_t)nc * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HC(hipMemcpyAsync(keys.data(), c->dev.ckey, (size_t)nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    }
+    HC(hipStreamSynchronize(c->stream));
+    const unsigned int need = first ? 1u : (unsigned int)(min_points > 1 ? min_points : 1);
+    int64_t k = 0;
+    for (int i = 0; i < nc; i++) {
+        if (cnt[i] < need) continue;
+        if (cell_ijk) {
+            if (k >= capacity_cells) return set_err("ll_cellmap_append_touched", "buffer too small");
+            cell_unpack(keys[i], cell_ijk + 3 * (size_t)k);
+        }
+        k++;
+    }
+    *n_touched = k;
+    return 0;
+}
+
 extern "C" int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], float radius, float maximum_in_fov_angle, float leaf,
                                        int32_t down_sample_replace, int64_t *n_cells_selected, int64_t *n_out)
 {

@@ -36,6 +36,8 @@ int cellmap_alloc(CellMapDev &m, int cap, float resolution, int revisit_threshol
 void cellmap_free(CellMapDev &m);
 // append_cloud (CMK:619-672): n points at d_src (device)
 int cellmap_append(CellMapDev &m, const float4 *d_src, int n, hipStream_t s, const char **err);
+// after cellmap_append of n_appended points onto n_before stored ones: points received per cell of the new table -> m.csel
+int cellmap_touch_counts(CellMapDev &m, int n_before, int n_appended, hipStream_t s, const char **err);
 // find_cells_in_radius + if_pt_in_fov + per-cell VoxelGrid (+ set_pointcloud), LM:475-513 for one feature kind;
 // d_pose: device copy of {qx, qy, qz, qw, tx, ty, tz}.  Result in m.filt[0 .. m.n_filt)
 int cellmap_query_filter(CellMapDev &m, const double *d_pose, float radius, float max_fov_deg, float leaf, int replace, hipStream_t s,

@@ -137,6 +137,17 @@ __global__ __launch_bounds__(256) void cm_touch_kernel(const u64 *pkey_new, int 
     if (c >= 0) clast[c] = frame;  // every writer stores the same value
 }
 
+// how many of the points appended last fell in each cell (append_cloud's appeared_cell_count, CMK:638-651)
+__global__ __launch_bounds__(256) void cm_touch_count_kernel(const u64 *pkey_new, int n, const u64 *ckey, int n_cells, u32 *cnt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = pkey_new[i];
+    if (k == LL_CELL_KEY_NONE) return;
+    const int c = cell_find(ckey, n_cells, k);
+    if (c >= 0) atomicAdd(&cnt[c], 1u);
+}
+
 // ----------------------------------------------------------------------------------------------------------- query
 __global__ __launch_bounds__(256) void cm_select_kernel(const u64 *ckey, int n_cells, CellGeom g, const double *pose, float radius,
                                                         double max_fov_deg, u32 *csel)
@@ -602,6 +613,19 @@ static int cellmap_resort(CellMapDev &m, int total, int n_appended, hipStream_t 
     std::swap(m.clast, m.clast2);
     m.n_pts = n_valid;
     m.n_cells = n_cells;
+    return 0;
+}
+
+// Per cell of the table (after the append that brought n_appended points): how many of those points it received -> m.csel
+// (the query's selection flags: free between queries).  The appended points' keys still sit behind the old ones in the unsorted
+// key array, which the re-sort left in pkey2.
+int cellmap_touch_counts(CellMapDev &m, int n_before, int n_appended, hipStream_t s, const char **err)
+{
+    if (m.n_cells <= 0) return 0;
+    CMCHK(hipMemsetAsync(m.csel, 0, (size_t)m.n_cells * sizeof(u32), s));
+    if (n_appended > 0)
+        hipLaunchKernelGGL(cm_touch_count_kernel, dim3(blocks(n_appended)), dim3(256), 0, s, m.pkey2 + n_before, n_appended, m.ckey, m.n_cells, m.csel);
+    CMCHK(hipGetLastError());
     return 0;
 }
 

@@ -6,7 +6,8 @@ This is the unit of BASELINE config C4 (one sequence per GPU, local map growth).
   * the match buffer is refreshed synchronously after every accepted frame; the node refreshes it on a service thread
     and registers against whichever buffer is newest (laser_mapping.hpp:568-594, 1395-1403), which makes its output
     depend on thread timing;
-  * no ROS, logging, full-cloud cell map, key frames or loop closure (out of scope).
+  * no ROS or logging; the full-cloud cell map, the key frames and the front half of loop detection are optional
+    (loop_closure_if_enable, keyframes.py); the pose graph and the map refinement behind them are out of scope.
 """
 from __future__ import annotations
 
@@ -23,7 +24,8 @@ class Laser_mapping:
                  minimum_icp_R_diff: float = 0.01, minimum_icp_T_diff: float = 0.01, maximum_residual_blocks: int = 0,
                  subsample_seed: int = 1, matching_mode: int = 0, cell_resolution: float = 1.0, threshold_cell_revisit: int = 5000,
                  maximum_search_range_corner: float = 100.0, maximum_search_range_surface: float = 100.0,
-                 maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1, cell_map_max_points: int = 1 << 21):
+                 maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1, cell_map_max_points: int = 1 << 21,
+                 loop_closure_if_enable: int = 0, loop_closure: dict | None = None):
         self.fe = Livox_laser(max_points=scan_points, max_scans=1, device=device, piecewise_number=1)
         self.reg = Point_cloud_registration(max_scans=1, max_features=scan_points, device=device)
         self.map = Map_buffer(device=device)
@@ -54,10 +56,29 @@ class Laser_mapping:
         self.stage_s = np.zeros(4)  # cumulative wall time: extract+register, history add, match-buffer refresh, frames
         self.m_last_time_stamp = 0.0
         self._host_vox = None
+        # loop_closure/if_enable_loop_closure (laser_mapping.hpp:698; 0 in the shipped Mid-40 configs): the full-cloud cell map, the key frames
+        # and the front half of loop detection (keyframes.py; laser_mapping.hpp:626, 1524-1562, 919-1060)
+        self.keyframes = None
+        self.loops = []
+        if loop_closure_if_enable:
+            from .keyframes import Keyframe_assembly
+            self.keyframes = Keyframe_assembly(device=device, cell_resolution=cell_resolution, threshold_cell_revisit=threshold_cell_revisit,
+                                               **(loop_closure or {}))
 
     def close(self):
         for h in (self.fe, self.reg, self.map, self.vox[0], self.vox[1], self.history):
             h.close()
+        if self.keyframes is not None:
+            self.keyframes.close()
+
+    def _keyframe_step(self, full_xyzi: np.ndarray) -> None:
+        """laser_mapping.hpp:1442 + 1524-1562 (+ the detector's loop body for whatever key frame that closed): the scan's full cloud,
+        moved into the map frame with the accepted pose, goes into the full cell map and the open key frames"""
+        full = np.ascontiguousarray(full_xyzi, np.float32)
+        full = full[np.isfinite(full[:, :3]).all(axis=1)]
+        cloud = self.reg.pointcloudAssociateToMap(full, self.pose) if len(full) else full
+        self.keyframes.add_scan(cloud, self.pose, self.m_current_frame_index)
+        self.loops += self.keyframes.process_waiting()
 
     def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0) -> int:
         """One frame (laser_mapping.hpp:1311-1520).  Returns the registration result (1 accepted, 0 rejected)."""
@@ -88,6 +109,8 @@ class Laser_mapping:
         else:
             self.history.add_fe(fe, 0, pc[0], self.history_add_t_step, self.history_add_angle_step)
         self.pose = pc[0].copy()  # :1496-1500
+        if self.keyframes is not None:
+            self._keyframe_step(np.asarray(xyzi, np.float32)[fe.get_features(0.0, 1.0)["full_idx"]])  # /pc2_full of this scan
         t2 = time.perf_counter()
         if self.m_matching_mode:  # update_buff_for_matching (service thread in the node), synchronous here
             self.map_sizes = self.history.refresh_cells(self.map, self.pose, self.m_maximum_search_range[0], self.m_maximum_search_range[1],
@@ -135,5 +158,7 @@ class Laser_mapping:
         self.history.set_gate_pose(self.pose)  # m_q_w_curr is still the pre-registration pose at LM:1439-1451
         self.pose = np.array(reg.m_pose_w_curr, np.float64)
         self.history.add(corner_stack, surf_stack, self.pose, self.history_add_t_step, self.history_add_angle_step)
+        if self.keyframes is not None:
+            self._keyframe_step(full)
         self.map_sizes = self.history.refresh(self.map)
         return 1

@@ -1,0 +1,112 @@
+"""Key-frame assembly of the mapping loop (second half; loam_livox_amd/keyframes.py).
+
+CPU tier: the bookkeeping -- which key frames are open, which cells they hold, when one is closed / opened / dropped from the waiting
+list -- against the REFERENCE'S OWN TEXT: laser_mapping.hpp:1524-1564 and Maps_keyframe::add_cells (cell_map_keyframe.hpp:1243-1261)
+compiled verbatim into a small harness (tests/verbatim_build.py, build_keyframes) and driven with scripted touched-cell sets.
+GPU tier: the whole chain on the device -- cells touched per scan (ll_cellmap_append_touched) against the oracle cell map, and an
+out-and-back sequence whose revisit is detected and aligned."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import verbatim_build
+
+
+class ScriptedMap:
+    """stands in for the device cell map: append_cloud_touched returns the scripted cells of the scan"""
+
+    def __init__(self, script):
+        self.script, self.k = script, 0
+
+    def append_cloud_touched(self, cloud, min_points=3):
+        ids = self.script[self.k]
+        self.k += 1
+        return np.array([[i, 0, 0] for i in ids], np.int32).reshape(-1, 3)
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("each,between,waiting,frames", [(300, 100, 3, 1200), (30, 10, 3, 200), (12, 5, 1, 150), (9, 7, 2, 60), (20, 3, 0, 90)])  # (each <= between empties the open list: the reference dereferences back() of an empty list there)
+def test_assembly_bookkeeping_equals_the_reference_text(tmp_path, each, between, waiting, frames):
+    from loam_livox_amd.keyframes import Keyframe_assembly
+    exe = verbatim_build.build_keyframes()
+    if not exe:
+        pytest.skip("verbatim key-frame harness not built (no /root/reference here and none travelled)")
+    rng = np.random.default_rng(each * 1000 + between)
+    script = [sorted(set(int(v) for v in rng.integers(k // 3, k // 3 + 40, rng.integers(0, 25)))) for k in range(frames)]
+    inp, out = str(tmp_path / "script.txt"), str(tmp_path / "state.txt")
+    with open(inp, "w") as f:
+        f.write(f"{frames}\n")
+        for ids in script:
+            f.write(" ".join(str(v) for v in [len(ids)] + ids) + "\n")
+    subprocess.check_call([exe, str(each), str(between), str(waiting), inp, out], timeout=120)
+    ref = [l.split(" ", 1)[1] for l in open(out).read().strip().split("\n")]
+    ka = Keyframe_assembly(scans_of_each_keyframe=each, scans_between_two_keyframe=between, maximum_keyframe_in_waiting_list=waiting,
+                           full_cell_map=ScriptedMap(script))
+    pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+    mine = []
+    for k in range(frames):
+        ka.add_scan(np.zeros((0, 4), np.float32), pose, k + 1)
+        mine.append(ka.state())
+    assert mine == ref
+    assert any(" W " in l for l in ref)  # key frames were closed along the way
+
+
+@pytest.mark.gpu
+def test_touched_cells_equal_the_oracle_cell_map(gpu_lib):
+    """ll_cellmap_append_touched: append_cloud( pts, &cell_vec ) -- every cell on an empty map, then the cells with >= 3 points of the scan"""
+    from loam_livox_amd.api import Cell_map
+    from oracle.orc_cellmap import CellMap
+    rng = np.random.default_rng(8)
+    cm, om = Cell_map(1 << 18, 1.0), CellMap(1.0)
+    for k in range(6):
+        n = [4000, 2500, 1, 3000, 0, 5000][k]
+        cloud = np.zeros((n, 4), np.float32)
+        cloud[:, :3] = rng.normal(0, 3.0 + k, (n, 3))
+        if n > 10:
+            cloud[5, 0] = np.nan
+        got = cm.append_cloud_touched(cloud, 3)
+        first = om.n_points() == 0
+        idx = om.cell_index(cloud[:, :3])
+        ok = np.isfinite(cloud[:, :3]).all(axis=1)
+        om.append(cloud)
+        keys, counts = np.unique(idx[ok], axis=0, return_counts=True)
+        want = keys[counts >= (1 if first else 3)]
+        assert np.array_equal(np.array(sorted(map(tuple, got))), np.array(sorted(map(tuple, want)))), k
+    cm.close()
+
+
+@pytest.mark.gpu
+def test_out_and_back_sequence_closes_a_loop(gpu_lib):
+    """A sensor that looks at a scene, leaves and comes back with a pose error: the key frame of the revisit matches the first one
+    (direction images), and the scene alignment recovers the offset between the two (SA:269-391 through keyframes.py)."""
+    from loam_livox_amd import synth
+    from loam_livox_amd.keyframes import Keyframe_assembly
+    world = synth.world_for_map_size(200_000)
+    rng = np.random.default_rng(77)
+    start = synth.sensor_pose_in_world(world, rng)
+    ka = Keyframe_assembly(scans_of_each_keyframe=8, scans_between_two_keyframe=8, minimum_keyframe_differen=2, maximum_keyframe_in_waiting_list=3,
+                           map_alignment_inlier_threshold=0.35, map_alignment_maximum_icp_iteration=4, max_points=1 << 21)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+    # 8 scans here, 8 scans from a pose that looks elsewhere, 8 scans back here -- the last group drifted by `drift`
+    away = synth.pose_compose(start, np.r_[synth.quat_from_axis_angle(np.array([0.0, 0.0, 1.0]), np.deg2rad(170.0)), np.zeros(3)])
+    drift = np.r_[synth.quat_from_axis_angle(np.array([0.0, 0.0, 1.0]), np.deg2rad(0.5)), np.array([0.6, -0.4, 0.1])]
+    loops, k = [], 0
+    for grp, (true_pose, est_err) in enumerate([(start, ident), (away, ident), (start, drift)]):
+        for j in range(8):
+            sc = synth.make_moving_scan(world, 9100 + 10 * grp + j, 24000, inc_true=ident, pose_start=true_pose, t_phase=0.07 * j)
+            est = synth.pose_compose(est_err, true_pose)  # the pose the mapping loop believes: the truth with the accumulated drift on top
+            cloud = np.c_[synth.transform_points(est, sc.xyzi[:, :3]), np.zeros(len(sc.xyzi), np.float32)].astype(np.float32)
+            cloud = cloud[np.isfinite(cloud).all(axis=1) & (np.abs(sc.xyzi[:, :3]).sum(axis=1) > 0)]
+            k += 1
+            ka.add_scan(cloud, est, k)
+            loops += ka.process_waiting()
+    assert len(ka.keyframe_vec) == 3
+    assert len(loops) == 1 and loops[0]["his"] == 0 and loops[0]["last"] == 2
+    # the alignment maps key frame `last` (drifted) onto key frame `his`: it undoes the drift (to the resolution of a 0.2 m voxel alignment)
+    t = loops[0]["icp_t"]
+    assert np.linalg.norm(t - drift[4:7]) < 0.15 or np.linalg.norm(t + drift[4:7]) < 0.15, (t, drift[4:7])
+    ka.close()

@@ -634,3 +634,143 @@ def build_feature(force=False):
         subprocess.check_call(common + ["-DLL_USE_ADAPTER"] + inc + [src, "-o", EXE_FA, lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
         subprocess.check_call(common + inc + [src, "-o", EXE_FB, "-lpthread"])
     return EXE_FA, EXE_FB
+
+
+# ---- key-frame assembly of the mapping loop (laser_mapping.hpp:1524-1562 + Maps_keyframe::add_cells, cell_map_keyframe.hpp:1243-1261) ----
+# The two excerpts run on scripted "touched cell" sets against minimal stand-ins of the classes around them (no PCL / Eigen needed for
+# list bookkeeping); tests/test_keyframes.py holds loam_livox_amd.keyframes.Keyframe_assembly to the state the reference's text reaches.
+EXE_KF = os.path.join(OUT, "verbatim_keyframes")
+KF_HARNESS = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <vector>
+using namespace std;
+#define screen_out std::cout
+#define FUNC_T
+struct PointType {};
+struct Cloud_stub {
+    int n_added = 0;
+    std::shared_ptr<Cloud_stub> makeShared() const { return std::make_shared<Cloud_stub>( *this ); }
+    Cloud_stub &operator+=( const Cloud_stub & ) { n_added++; return *this; }
+    void clear() {}
+};
+namespace pcl { struct PointXYZ { float x, y, z; PointXYZ( float a, float b, float c ) : x( a ), y( b ), z( c ) {} }; }
+namespace PCL_TOOLS { template <class T, class P> std::vector<int> pcl_pts_to_eigen_pts( std::shared_ptr<Cloud_stub> ) { return std::vector<int>(); } }
+struct Center_stub { int id; float operator()( int ) const { return ( float ) id; } bool operator<( const Center_stub &o ) const { return id < o.id; } };
+struct Mapping_cell { Center_stub m_center; Center_stub get_center() const { return m_center; } };
+struct Quat_stub { double v[ 4 ]; };
+struct Vec3_stub { double v[ 3 ]; };
+template <typename T> struct Points_cloud_map
+{
+    typedef std::shared_ptr<Mapping_cell> Mapping_cell_ptr;
+    std::vector<std::vector<int>> script;  // the cells each scan touches
+    size_t frame = 0;
+    std::map<int, Mapping_cell_ptr> cells;
+    Mapping_cell_ptr cell( int id )
+    {
+        auto it = cells.find( id );
+        if ( it != cells.end() ) return it->second;
+        Mapping_cell_ptr c = std::make_shared<Mapping_cell>();
+        c->m_center.id = id;
+        cells[ id ] = c;
+        return c;
+    }
+    template <class V> void append_cloud( const V &, std::set<Mapping_cell_ptr> *cell_vec = nullptr )
+    {
+        if ( cell_vec )
+        {
+            cell_vec->clear();
+            for ( int id : script[ frame ] ) cell_vec->insert( cell( id ) );
+        }
+        frame++;
+    }
+};
+template <typename T> struct Maps_keyframe
+{
+    typedef std::shared_ptr<Mapping_cell> Mapping_cell_ptr;
+    std::set<Mapping_cell_ptr>              m_set_cell;
+    std::map<Center_stub, Mapping_cell_ptr> m_map_pt_cell;
+    std::shared_ptr<std::vector<pcl::PointXYZ>> m_pcl_cells_center = std::make_shared<std::vector<pcl::PointXYZ>>();
+    unsigned int m_accumulate_frames = 0;
+    int          m_ending_frame_idx = 0;
+    Quat_stub    m_pose_q;
+    Vec3_stub    m_pose_t;
+    Cloud_stub   m_accumulated_point_cloud;
+@ADD_CELLS@
+};
+struct Laser_mapping_kf_harness
+{
+    int m_loop_closure_if_enable = 1, m_para_scans_of_each_keyframe = 300, m_para_scans_between_two_keyframe = 100, m_current_frame_index = 0;
+    size_t m_loop_closure_maximum_keyframe_in_wating_list = 3;
+    Quat_stub m_q_w_curr;
+    Vec3_stub m_t_w_curr;
+    std::mutex m_mutex_keyframe, m_mutex_dump_full_history;
+    Points_cloud_map<float> m_pt_cell_map_full;
+    std::list<std::shared_ptr<Maps_keyframe<float>>> m_keyframe_of_updating_list, m_keyframe_need_precession_list;
+    std::list<Cloud_stub> m_laser_cloud_full_history;
+    Laser_mapping_kf_harness() { m_keyframe_of_updating_list.push_back( std::make_shared<Maps_keyframe<float>>() ); }  // laser_mapping.hpp:626
+    void one_scan()
+    {
+        Cloud_stub current_laser_cloud_full;
+        m_laser_cloud_full_history.push_back( current_laser_cloud_full );
+@ASSEMBLY@
+    }
+};
+int main( int argc, char **argv )
+{
+    if ( argc < 6 ) return 2;
+    Laser_mapping_kf_harness node;
+    node.m_para_scans_of_each_keyframe = atoi( argv[ 1 ] );
+    node.m_para_scans_between_two_keyframe = atoi( argv[ 2 ] );
+    node.m_loop_closure_maximum_keyframe_in_wating_list = ( size_t ) atoi( argv[ 3 ] );
+    FILE *f = fopen( argv[ 4 ], "r" ), *out = fopen( argv[ 5 ], "w" );
+    if ( !f || !out ) return 3;
+    int n_frames = 0;
+    if ( fscanf( f, "%d", &n_frames ) != 1 ) return 4;
+    for ( int k = 0; k < n_frames; k++ )
+    {
+        int n = 0;
+        if ( fscanf( f, "%d", &n ) != 1 ) return 4;
+        std::vector<int> ids( n );
+        for ( int i = 0; i < n; i++ ) if ( fscanf( f, "%d", &ids[ i ] ) != 1 ) return 4;
+        node.m_pt_cell_map_full.script.push_back( ids );
+    }
+    std::cout.setstate( std::ios_base::failbit );  // (the excerpt's own chatter)
+    for ( int k = 0; k < n_frames; k++ )
+    {
+        node.m_current_frame_index = k + 1;
+        node.one_scan();
+        fprintf( out, "%d U", k );
+        for ( auto &kf : node.m_keyframe_of_updating_list ) fprintf( out, " %u:%d", kf->m_accumulate_frames, ( int ) kf->m_set_cell.size() );
+        fprintf( out, " W" );
+        for ( auto &kf : node.m_keyframe_need_precession_list ) fprintf( out, " %u:%d:%d", kf->m_accumulate_frames, ( int ) kf->m_set_cell.size(), kf->m_ending_frame_idx );
+        fprintf( out, "\n" );
+    }
+    fclose( out );
+    return 0;
+}
+'''
+
+
+def build_keyframes(force=False):
+    """-> exe of the key-frame assembly harness (None where neither /root/reference nor a travelled binary exists)"""
+    if not have_reference():
+        return EXE_KF if os.path.exists(EXE_KF) else None
+    deps = [os.path.abspath(__file__)]
+    if not force and os.path.exists(EXE_KF) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_KF) for d in deps):
+        return EXE_KF
+    os.makedirs(OUT, exist_ok=True)
+    tu = (KF_HARNESS.replace("@ADD_CELLS@", _lines("source/cell_map_keyframe.hpp", 1243, 1261))
+                    .replace("@ASSEMBLY@", _lines("source/laser_mapping.hpp", 1524, 1564)))
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_keyframes.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-o", EXE_KF, src])
+    return EXE_KF
