@@ -11,8 +11,8 @@
 // order -- one or two neighbouring cells --, stages the map points of the cells' common neighbourhood (the TILE: bounding box of
 // the lanes' cells +- 1, at most 5 x 5 x 5 cells, a few contiguous x-runs of the cell-sorted array, ~35 points) in LDS with
 // coalesced loads, and every lane offers EVERY tile point to its sorted top five through a branch-free min / med3 network on
-// 32-bit KEYS {squared distance with its low 8 mantissa bits replaced by the point's place in the tile} (tilek_offer: 8
-// instructions per point besides the distance, no payload moves, no divergence, no dependent loads); the five winners are then
+// 32-bit KEYS {squared distance with its low 8 mantissa bits replaced by the point's place in the tile} (tilek_offer: 6
+// instructions per point besides the distance, which packed two-float arithmetic computes for two points at a time; no payload moves, no divergence, no dependent loads); the five winners are then
 // evaluated again exactly.  Truncating the distance is harmless unless two of the six smallest keys agree in all their distance
 // bits -- then (and for true ties) the lane searches again.  Afterwards a lane's answer is exact iff its 5th best lies
 // inside the distance every unvisited point must exceed (one full ring of cells around its own cell: the k = 1 termination test
@@ -103,21 +103,20 @@ LL_HD unsigned int tile_umax(unsigned int a, unsigned int b) { return a < b ? b 
 LL_HD unsigned int tile_umed3(unsigned int a, unsigned int b, unsigned int c) { return tile_umax(tile_umin(a, b), tile_umin(tile_umax(a, b), c)); }
 
 struct TileK {
-    unsigned int k[5];  // the five smallest keys so far, ascending
-    unsigned int lb;    // the smallest key that was offered and is not (or no longer) among them
+    unsigned int k[6];  // the six smallest keys so far, ascending: five for the list, the sixth bounds everything that is not in it
 };
 
 LL_HD void tilek_init(TileK &t)
 {
-    for (int i = 0; i < 5; i++) t.k[i] = LL_TILE_KEY_EMPTY;
-    t.lb = LL_TILE_KEY_EMPTY;
+    for (int i = 0; i < 6; i++) t.k[i] = LL_TILE_KEY_EMPTY;
 }
 
 LL_HD unsigned int tile_key(float d2, int j) { return ((unsigned int)as_int(d2) & ~(unsigned int)(LL_TILE_CAP - 1)) | (unsigned int)j; }
 
+// place i of the new list is med3(k[i-1], c, k[i]) of the old one: six instructions, no branches
 LL_HD void tilek_offer(TileK &t, unsigned int c)
 {
-    t.lb = tile_umin(t.lb, tile_umax(t.k[4], c));
+    const unsigned int n5 = tile_umed3(t.k[4], c, t.k[5]);
     const unsigned int n4 = tile_umed3(t.k[3], c, t.k[4]);
     const unsigned int n3 = tile_umed3(t.k[2], c, t.k[3]);
     const unsigned int n2 = tile_umed3(t.k[1], c, t.k[2]);
@@ -127,6 +126,7 @@ LL_HD void tilek_offer(TileK &t, unsigned int c)
     t.k[2] = n2;
     t.k[3] = n3;
     t.k[4] = n4;
+    t.k[5] = n5;
 }
 
 // two of the six smallest keys share all their distance bits: the truncated order may not be the true one (or it is a true tie)
@@ -134,7 +134,7 @@ LL_HD bool tilek_collision(const TileK &t)
 {
     const int s = LL_TILE_IDX_BITS;
     return (t.k[0] >> s) == (t.k[1] >> s) || (t.k[1] >> s) == (t.k[2] >> s) || (t.k[2] >> s) == (t.k[3] >> s) ||
-           (t.k[3] >> s) == (t.k[4] >> s) || (t.k[4] >> s) == (t.lb >> s);
+           (t.k[3] >> s) == (t.k[4] >> s) || (t.k[4] >> s) == (t.k[5] >> s);
 }
 
 // a lower bound on the squared distance behind a key (truncation rounds towards zero); +inf for "nothing"
@@ -257,6 +257,14 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
         Tile5 t;  // the round's exact result (participants); every lane starts a round empty
         tile5_init(t);
         bool collided = false;
+        // LDS layout of a pass: candidates in PAIRS {x0, x1, y0, y1, z0, z1, bits(pos0), bits(pos1)} (32 bytes), so that a pair's
+        // coordinates arrive as the two-float operands of the packed subtract / multiply / add: 8 instructions per two distances
+        typedef float ll_tv2 __attribute__((ext_vector_type(2)));
+        float *tile_f = reinterpret_cast<float *>(tile);
+        const ll_tv2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        unsigned int keep;  // ~(LL_TILE_CAP - 1) in a register: (bits & keep) | index is then one v_and_or_b32 (a literal would not fit beside the scalar index)
+        asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keep));
+        static_assert(LL_TILE_IDX_BITS == 8, "the literal above");
         for (int c0 = 0; c0 < T; c0 += LL_TILE_CAP) {  // (uniform) one pass per LL_TILE_CAP candidates: one pass for every C2 tile
             const int np = (T - c0) < LL_TILE_CAP ? (T - c0) : LL_TILE_CAP;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the previous pass's reads are done)
@@ -265,36 +273,58 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
                 int row = 0;
                 for (int rr = 0; rr < nrows - 1; rr++) row += (j >= __builtin_amdgcn_readlane(incl, rr)) ? 1 : 0;  // (scalar operand)
                 const int addr = __shfl(rb, row) + (j - __shfl(excl, row));
-                float4 e = make_float4(LL_TILE_FAR, 0.0f, 0.0f, __int_as_float(-1));  // padding: never among five real neighbours
+                float ex = LL_TILE_FAR, ey = 0.0f, ez = 0.0f;  // padding: never among five real neighbours
+                int ep = -1;
                 if (j < T) {
                     const f4 pt = g.pts[addr];
-                    e = make_float4(pt.x, pt.y, pt.z, __int_as_float(addr));
+                    ex = pt.x;
+                    ey = pt.y;
+                    ez = pt.z;
+                    ep = addr;
                 }
-                tile[s0 + lane] = e;
+                float *e = tile_f + ((s0 + lane) >> 1) * 8 + (lane & 1);
+                e[0] = ex;
+                e[2] = ey;
+                e[4] = ez;
+                e[6] = __int_as_float(ep);
             }
-            if (lane < 4) tile[((np + 63) & ~63) + lane] = make_float4(LL_TILE_FAR, 0.0f, 0.0f, __int_as_float(-1));
+            if (lane < 4) {  // (two more pairs of padding behind a full last trip)
+                float *e = tile_f + ((((np + 63) & ~63) + lane) >> 1) * 8 + (lane & 1);
+                e[0] = LL_TILE_FAR;
+                e[2] = 0.0f;
+                e[4] = 0.0f;
+                e[6] = __int_as_float(-1);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             TileK tk;
             tilek_init(tk);
-            for (int jj = 0; jj < np; jj += 4) {  // (uniform) four broadcast reads and four independent offers per trip
+            for (int jj = 0; jj < np; jj += 4) {  // (uniform) two pairs per trip: broadcast reads, four independent offers
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float4 cnd = tile[jj + u];
-                    tilek_offer(tk, tile_key(dist2_xyz(qx, qy, qz, cnd.x, cnd.y, cnd.z), jj + u));
+                for (int u = 0; u < 4; u += 2) {
+                    const float4 xy = *reinterpret_cast<const float4 *>(tile_f + ((jj + u) >> 1) * 8);
+                    const float2 zz = *reinterpret_cast<const float2 *>(tile_f + ((jj + u) >> 1) * 8 + 4);
+                    const ll_tv2 px = {xy.x, xy.y}, py = {xy.z, xy.w}, pz = {zz.x, zz.y};
+                    const ll_tv2 dx = qx2 - px, dy = qy2 - py, dz = qz2 - pz;  // dist2_xyz, two candidates at a time
+                    ll_tv2 rr2 = dx * dx;
+                    rr2 = rr2 + dy * dy;
+                    rr2 = rr2 + dz * dz;
+                    tilek_offer(tk, ((unsigned int)__float_as_int(rr2.x) & keep) | (unsigned int)(jj + u));
+                    tilek_offer(tk, ((unsigned int)__float_as_int(rr2.y) & keep) | (unsigned int)(jj + u + 1));
                 }
             }
             collided = collided || tilek_collision(tk);
             // the five winners again, exactly (their order is the true one unless `collided`)
-            const float lbv = tile_key_lower(tk.lb);
+            const float lbv = tile_key_lower(tk.k[5]);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 float d = INFINITY;
                 int pos = -1;
                 if (tk.k[k] != LL_TILE_KEY_EMPTY) {
-                    const float4 cnd = tile[tk.k[k] & (LL_TILE_CAP - 1)];
-                    pos = __float_as_int(cnd.w);
-                    d = pos >= 0 ? dist2_xyz(qx, qy, qz, cnd.x, cnd.y, cnd.z) : INFINITY;
+                    const int jw = (int)(tk.k[k] & (LL_TILE_CAP - 1));
+                    const float *e = tile_f + (jw >> 1) * 8 + (jw & 1);
+                    pos = __float_as_int(e[6]);
+                    d = pos >= 0 ? dist2_xyz(qx, qy, qz, e[0], e[2], e[4]) : INFINITY;
                 }
                 if (c0 == 0) {  // (uniform) the first pass fills the list, later ones (tiles of > LL_TILE_CAP points) merge into it
                     t.d[k] = d;

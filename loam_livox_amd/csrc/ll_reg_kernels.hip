@@ -26,7 +26,6 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
-#include "ll_knn_tile.h"
 #include "ll_reg_query.h"
 
 namespace ll {
@@ -149,9 +148,7 @@ __global__ __launch_bounds__(KC_THREADS) void reg_knn_coop_kernel(RegDev rd, Reg
 // contiguous range per list with one round of ballots per query slice, one barrier pair and two independent atomicAdds issued back
 // to back.  (Within a list the entries of a workgroup are ordered by slice, then wavefront, then lane; nothing depends on the order.)
 #define RQ_PER 4
-// use_perm: the surface queries are visited in the cell order of reg_qsort_kernel (rd.qperm) instead of scan order, so that the
-// entries a workgroup appends to the search list are neighbours in the map and the tile form of the list kernel can share tiles.
-__global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int use_perm)
+__global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter)
 {
     const int chunk = blockIdx.x, b = blockIdx.y, kind = blockIdx.z;
     const RegState *st = rd.state + b;
@@ -165,11 +162,10 @@ __global__ __launch_bounds__(RQ_THREADS) void reg_requery_kernel(RegDev rd, RegC
     __shared__ int s_base[2];
     float4 ft[RQ_PER], rq[RQ_PER];
     int qq[RQ_PER];  // the query of this thread's u-th place (-1: beyond the scan's queries)
-    const unsigned short *perm = (use_perm && kind == 1) ? rd.qperm + (size_t)b * rd.cap_s : nullptr;
 #pragma unroll
     for (int u = 0; u < RQ_PER; u++) {
         const int place = (chunk * RQ_PER + u) * RQ_THREADS + tid;
-        qq[u] = place < n ? (perm ? (int)perm[place] : place) : -1;
+        qq[u] = place < n ? place : -1;
     }
 #pragma unroll
     for (int u = 0; u < RQ_PER; u++) {
@@ -298,12 +294,9 @@ __global__ __launch_bounds__(1024) void reg_list_offsets_kernel(RegDev rd, int s
 
 // LOCAL: the offsets tables are built in LDS by every workgroup (small batches); a template constant so that the large-batch
 // form keeps plain global loads in its binary searches
-// TILE: the surface entries of the search list are searched 64 at a time by whole wavefronts against shared LDS tiles
-// (ll_knn_tile.h) -- the re-query kernel appended them in cell order, so neighbours in the list are neighbours in the map.
-template <bool LOCAL, bool TILE>
+template <bool LOCAL>
 __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void reg_list_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int seg0, int n_seg)
 {
-    __shared__ float4 s_tile[TILE ? RL_THREADS / 64 : 1][TILE ? LL_TILE_CAP + 4 : 1];
     // The offsets table (<= 16 KB) is searched where it lies: it stays in L1 / L2, and a copy in LDS would cap the
     // occupancy of this latency-bound kernel (16 KB per 128-thread workgroup: 36 -> 99 us per late iteration at B = 256).
     const int tid = threadIdx.x;
@@ -357,40 +350,7 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
     // to 99 us but cost 25 % at the long early lists -- profiles/r02 runs U / V -- and was dropped)
-    if (TILE && !coop_all) {
-        const int *off = LOCAL ? s_off[0] : rd.work_off;
-        const int total = off[n_seg];
-        const int lane = tid & 63;
-        for (int base = (int)(((blockIdx.x * RL_THREADS + tid) >> 6) << 6); base < total; base += stride) {  // (uniform per wavefront)
-            const int t = base + lane;
-            const bool valid = t < total;
-            int b = 0, kind = 0, slot = 0;
-            if (valid) {
-                int lo = 0, hi = n_seg;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (off[mid] <= t) lo = mid; else hi = mid;
-                }
-                const int sgg = seg0 + lo;
-                b = sgg >> 1;
-                kind = sgg & 1;
-                slot = rd.work_search[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off[lo])] - b * rd.cap;
-            }
-            const size_t sb = (size_t)b * rd.cap;
-            const float4 pw = rd.qw[sb + slot];
-            const bool surf = valid && kind == 1;
-            Knn5 r;
-            bool fin;
-            knn5_tile_wave(gs, surf, pw.x, pw.y, pw.z, rc.max_d2_plane, s_tile[tid >> 6], r, fin);
-            if (!valid || (coop && kind == 0)) continue;  // (corner entries: done above when there are few of them)
-            if (surf && fin)
-                knn_finish(rd, rc, sb, slot, 1, iter, pw, rc.max_d2_plane, r);
-            else
-                knn_one(rd, rc, gc, gs, b, slot, iter);
-            build_one(rd, rc, gc, gs, b, slot);
-        }
-    }
-    for (int w = (coop_all || TILE) ? 1 : 0; w < 2; w++) {
+    for (int w = coop_all ? 1 : 0; w < 2; w++) {
         const int *off = LOCAL ? s_off[w] : rd.work_off + (size_t)w * (RL_MAX_SEG + 1);
         const int total = off[n_seg];
         const int *list = w == 0 ? rd.work_search : rd.work_build;
@@ -2964,23 +2924,15 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         const int mx = max_nc > max_ns ? max_nc : max_ns;
         dim3 cgrid((mx + RQ_PER * RQ_THREADS - 1) / (RQ_PER * RQ_THREADS), n_scans, 2);
         (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);
-        const bool tile_lists = rc.knn_tile && max_ns >= LL_KNN_TILE_MIN_SURF && max_ns <= LL_KNN_TILE_MAX_SURF;  // (rd.qperm is the cell order)
-        hipLaunchKernelGGL(reg_requery_kernel, cgrid, dim3(RQ_THREADS), 0, s, rd, rc, gc, gs, iter, tile_lists ? 1 : 0);
+        hipLaunchKernelGGL(reg_requery_kernel, cgrid, dim3(RQ_THREADS), 0, s, rd, rc, gc, gs, iter);
         for (int seg0 = 0; seg0 < 2 * n_scans; seg0 += RL_MAX_SEG) {
             const int n_seg = 2 * n_scans - seg0 < RL_MAX_SEG ? 2 * n_scans - seg0 : RL_MAX_SEG;
             static const int local_seg = getenv("LL_LIST_NO_LOCAL_OFFSETS") ? 0 : RL_LOCAL_SEG;  // (A/B switch)
             if (n_seg <= local_seg) {
-                if (tile_lists)
-                    hipLaunchKernelGGL((reg_list_kernel<true, true>), dim3(256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
-                else
-                    hipLaunchKernelGGL((reg_list_kernel<true, false>), dim3(256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+                hipLaunchKernelGGL(reg_list_kernel<true>, dim3(256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
             } else {
                 hipLaunchKernelGGL(reg_list_offsets_kernel, dim3(1), dim3(1024), 0, s, rd, seg0, n_seg);
-                const dim3 lgrid(n_scans >= 64 ? RL_BLOCKS : 256);
-                if (tile_lists)
-                    hipLaunchKernelGGL((reg_list_kernel<false, true>), lgrid, dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
-                else
-                    hipLaunchKernelGGL((reg_list_kernel<false, false>), lgrid, dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
+                hipLaunchKernelGGL(reg_list_kernel<false>, dim3(n_scans >= 64 ? RL_BLOCKS : 256), dim3(RL_THREADS), 0, s, rd, rc, gc, gs, iter, seg0, n_seg);
             }
         }
         return;

@@ -364,7 +364,7 @@ int hc_knn5_tile(const hc_grid *G, const float *q, int nq, float max_d2, int32_t
                         tilek_offer(tk, tile_key(dd, jj));
                     }
                     collided = collided || tilek_collision(tk);
-                    const float lbv = tile_key_lower(tk.lb);
+                    const float lbv = tile_key_lower(tk.k[5]);
                     for (int k = 0; k < 5; k++) {
                         float d = INFINITY;
                         int pos = -1;
