@@ -687,6 +687,9 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
         d.tab_cap = (lim + 4095) / 4096 * 4096;
     }
     DM(d.pl_tab, B * (size_t)d.tab_cap * 2);
+    DM(d.pl_key, B * (size_t)d.tab_cap);
+    DM(d.pl_T, B);
+    HC(hipMemset(d.pl_T, 0, B * sizeof(int)));
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
     DM(d.qperm, B * d.cap_s);
@@ -738,7 +741,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.pl_key, d.pl_T, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -792,6 +795,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
+    c->table_persist = (debug & 4096) ? 0 : 1;  // bit 12: the solver rebuilds its plane table at every launch (A/B)
     c->knn_tile = (debug & 512) ? 0 : ((debug & 1024) ? 1 : 2);  // bit 9: no tile search of the surface queries (A/B, ll_knn_tile.h); bit 10: tile
                                                                  // search only where all queries are searched, the reuse machinery for the rest
     c->max_d2_line_d = p->maximum_dis_line_for_match;
@@ -842,7 +846,8 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         return set_err("ll_reg", "negative iteration count");
     if (prm->icp_max_iterations > (1 << 19)) return set_err("ll_reg", "icp_max_iterations above 524288");  // (the grouped solver tags its exchanges with the launch number in 20 bits)
     if (map->device != r->device) return set_err("ll_reg", "map lives on another device");
-    make_reg_const(prm, r->debug, &r->rc);
+    static const int debug_or = getenv("LL_DEBUG_OR") ? atoi(getenv("LL_DEBUG_OR")) : 0;  // (A/B runs of unmodified drivers: bits of ll_reg_set_debug)
+    make_reg_const(prm, r->debug | debug_or, &r->rc);
     // A solve enqueued earlier on this handle and never collected still reads its snapshots: let it finish before its pins are
     // replaced (the snapshots could otherwise be recycled and rebuilt under its kernels by a concurrent ll_map_upload / refresh).
     if (r->pinned[0] || r->pinned[1]) HC(hipStreamSynchronize(r->stream));
@@ -905,7 +910,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     // all of them costs less than classifying them against reuse records and searching the lists that leaves
     // (small batches are latency chains, not issue-bound: the wavefront-per-query searches and the short work lists serve them better --
     //  single scan 2.24 ms against 2.49 with a tile launch per iteration; debug bit 11 forces the tile search for tests)
-    if (max_ns < LL_KNN_TILE_MIN_SURF || max_ns > LL_KNN_TILE_MAX_SURF || (n_scans <= LL_KNN_COOP_MAX_SCANS && !(r->debug & 2048))) r->rc.knn_tile = 0;
+    if (max_ns < LL_KNN_TILE_MIN_SURF || max_ns > LL_KNN_TILE_MAX_SURF || (n_scans <= LL_KNN_COOP_MAX_SCANS && !((r->debug | debug_or) & 2048))) r->rc.knn_tile = 0;
     if (r->rc.knn_tile == 2) r->rc.knn_reuse = 0;
     // Small batches leave most of the chip idle with one workgroup per scan: spread each scan's cost evaluations over a
     // group of LL_GRP workgroups (ll_reg_kernels.hip, group_*).  Compact scans only; the others run on the group's first.

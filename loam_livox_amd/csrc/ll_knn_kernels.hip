@@ -157,8 +157,8 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
             if (subsample_skip_feature(rc.subsample_seed, 0, st->icp_iters, q, nC, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
             rd.qw[sb + q] = make_float4(pw[0], pw[1], pw[2], 0.f);
         }
-        knn_one(rd, rc, gc, gs, b, q, iter);
-        build_one(rd, rc, gc, gs, b, q);
+        const bool ch = knn_one(rd, rc, gc, gs, b, q, iter);
+        build_one(rd, rc, gc, gs, b, q, ch);
         return;
     }
     const int b = (bid - n_corner_wg) / surf_blocks, sblk = (bid - n_corner_wg) - b * surf_blocks;
@@ -177,27 +177,28 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
     bool fin;
     knn5_tile_wave(gs, valid, pw.x, pw.y, pw.z, max_d2, s_tile[threadIdx.x >> 6], r, fin);
     if (!valid) return;
+    bool changed;
     if (fin) {
         if (rc.debug_knn && iter == 0) {
 #pragma unroll
             for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
         }
-        knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
+        changed = knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
         if (!rc.check_plane_pca && rc.icp_plane && !rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
             // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
             // still knows -- no second look at rd.nn
             // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)
             const f4 p0 = gs.pts[r.pos[0]], p1 = gs.pts[r.pos[2]], p2 = gs.pts[r.pos[4]];
             const bool degenerate = (p1.x == p0.x && p1.y == p0.y && p1.z == p0.z) || (p2.x == p0.x && p2.y == p0.y && p2.z == p0.z);
-            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
+            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8 | (changed ? BLK_DIRTY : 0));
             return;
         }
     } else {
         // sparse surroundings, an exact tie, a query outside the grid or not finite
         if (FUSED) rd.qw[sb + slot] = pw;
-        knn_one(rd, rc, gc, gs, b, slot, iter);
+        changed = knn_one(rd, rc, gc, gs, b, slot, iter);
     }
-    build_one(rd, rc, gc, gs, b, slot);
+    build_one(rd, rc, gc, gs, b, slot, changed);
 }
 
 void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s)

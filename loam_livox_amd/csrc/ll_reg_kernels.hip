@@ -344,8 +344,8 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
             const int sgg = seg0 + lo, b = sgg >> 1, kind = sgg & 1;
             const int e = rd.work_search[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off_w[lo])];
             const int slot = e - b * rd.cap;
-            knn_one_coop(rd, rc, gc, gs, b, slot, iter);
-            if ((tid & 63) == 0) build_one(rd, rc, gc, gs, b, slot);
+            const bool ch = knn_one_coop(rd, rc, gc, gs, b, slot, iter);
+            if ((tid & 63) == 0) build_one(rd, rc, gc, gs, b, slot, ch);
         }
     }
     // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
@@ -364,9 +364,8 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
             if (w == 0 && coop && kind == 0) continue;  // done above
             const int e = list[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off[lo])];
             const int slot = e - b * rd.cap;
-            if (w == 0) knn_one(rd, rc, gc, gs, b, slot, iter);
-            else resort_one(rd, rc, gc, gs, b, slot, iter);
-            build_one(rd, rc, gc, gs, b, slot);
+            const bool ch = (w == 0) ? knn_one(rd, rc, gc, gs, b, slot, iter) : resort_one(rd, rc, gc, gs, b, slot, iter);
+            build_one(rd, rc, gc, gs, b, slot, ch);
         }
     }
 }
@@ -428,6 +427,7 @@ struct SolveShared {
     int n_active, n_corner_avail, n_surf_avail, n_unique;
     int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
     int pt_T, pt_Tl, pt_kc, pt_priv;  // plane-table path: distinct triples, table entries in LDS, record rounds cached in LDS, private entries
+    int pt_next, pt_fail;             // ... incremental update: next free table entry, "rebuild instead" (probe overflow, table region full)
     double thr;
     int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
     int xch_seq, xch_epoch;                // ... exchanges of partial sums made in this launch, and the launch's number in its registration (granule tags)
@@ -2133,8 +2133,10 @@ __device__ __forceinline__ unsigned int pt_hash(unsigned int p0, unsigned int p1
 // slot of the triple (inserting it if new), or PT_PRIVATE.  Lock-free and wait-free per probe: a slot belongs to the first
 // {p0, p1} that lands on its `a` word AND the first p2 that lands on its `b` word; a lane that loses either race (or finds
 // another key) probes on, and every lane with the same triple walks the same probe sequence to the same slot.
-__device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned int p0, unsigned int p1, unsigned int p2)
+// claimed: this call made the slot the triple's (exactly one caller per new triple sees it set)
+__device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned int p0, unsigned int p1, unsigned int p2, bool &claimed)
 {
+    claimed = false;
     const unsigned long long A = ((unsigned long long)p0 << 32) | (unsigned long long)p1;
     const unsigned int hh = pt_hash(p0, p1, p2);
     unsigned int h = hh & (PT_SLOTS - 1);
@@ -2155,7 +2157,10 @@ __device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned
         }
         if (a == A) {
             if (bb == PT_EMPTY_B) {
-                if (__hip_atomic_compare_exchange_strong(&ht[h].b, &bb, p2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) bb = p2;
+                if (__hip_atomic_compare_exchange_strong(&ht[h].b, &bb, p2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    bb = p2;
+                    claimed = true;
+                }
             }
             if (bb == p2) return h;
         }
@@ -2245,7 +2250,8 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             }
             if (!GROUPED || u == g) {
                 const int4 t = t8[GROUPED ? 0 : u];
-                const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z) : PT_INACTIVE;
+                bool claimed_;
+                const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed_) : PT_INACTIVE;
                 if (h == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
                 h8[GROUPED ? 0 : u] = h;
             }
@@ -2256,6 +2262,8 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         for (int u = 0; u < 8; u++) {
             const int j = tid + (k0 + u) * RS_THREADS;
             if ((!GROUPED || u == g) && j < nS) gstore_u16(ids + j, (unsigned short)h8[GROUPED ? 0 : u]);
+            // the dirty marks of the k-NN stage are consumed: every block is numbered afresh here
+            if (!GROUPED && j < nS && (fl8[u] & BLK_DIRTY)) gstore_u8(const_cast<unsigned char *>(flag0) + rd.cap_c + j, (unsigned char)(fl8[u] & ~BLK_DIRTY));
         }
 #ifdef LL_SOLVE_TIMING
         LL_TACC(11, t_ins);
@@ -2331,12 +2339,14 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
     for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
     for (int i0 = tid; i0 < T; i0 += 4 * RS_THREADS) {
         f4 m[4][3];
+        int4 key4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int id = i0 + u * RS_THREADS;
             const unsigned int sl = slot_of_id[id < T ? id : i0];
             const unsigned long long sa = ht[sl].a;
             const unsigned int sb2 = ht[sl].b;
+            key4[u] = make_int4((int)(unsigned int)(sa >> 32), (int)(unsigned int)sa, (int)sb2, 0);
             m[u][0] = gload_pt(map_pts + (unsigned int)(sa >> 32));
             m[u][1] = gload_pt(map_pts + (unsigned int)sa);
             m[u][2] = gload_pt(map_pts + sb2);
@@ -2352,6 +2362,7 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             if (id < T) {
                 gstore_i4(tabG + 2 * id, make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1])));
                 gstore_i4(tabG + 2 * id + 1, make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0])));
+                if (!GROUPED && rc.table_persist) gstore_i4(rd.pl_key + (size_t)b * rd.tab_cap + id, key4[u]);  // the entry's triple: the next launches look it up again
             }
         }
     }
@@ -2433,11 +2444,199 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         sh.pt_T = sh.pt_priv > 0 ? PT_TCAP + 1 : T;
         sh.pt_Tl = Tl;
         sh.pt_kc = kc < kp ? kc : kp;
+        // what the next ICP iterations of this registration may build on (0: nothing -- private entries have no key)
+        if (!GROUPED) rd.pl_T[b] = (rc.table_persist && sh.pt_priv == 0 && T <= rd.tab_cap) ? T : 0;
     }
     __syncthreads();
     LL_TACC(15, t_p2);
     LL_TACC(8, t_tab);
     return act;
+}
+
+// ICP iterations >= 1 of a registration (one workgroup per scan): the table of the previous launch is still valid -- rd.pl_tab in the frame
+// of pose_last, rd.pl_key the triple behind every entry, rd.blk_id the entry of every block, rd.pl_T their number -- except for the
+// blocks whose neighbours the k-NN stage changed (BLK_DIRTY in their flag: a few per cent of a scan after the first iterations).
+// So: flags -> activity mask + census as in census_and_plane_table (no look at rd.nn: 1 byte per block instead of 17), and only if
+// something is dirty the LDS hash table is filled again from the T stored keys (7 inserts per thread instead of 34), the dirty
+// blocks' triples are looked up / appended behind the table, and their ids rewritten.  Returns false (uniformly) when the caller
+// must rebuild from scratch instead: no table to build on, too many dirty blocks to be worth it, a crowded probe sequence, a full
+// table region, a table that has just outgrown its LDS part (the rebuild drops the entries nobody uses any more).  Same table entry
+// for the same triple as a rebuild would compute (pt_plane = block_plane), so the evaluations see bit-identical planes.
+__device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst &rc, const f4 *map_pts, int b, const RegState *st, int nC, int nS,
+                                                uint4 *s_raw, SolveShared &sh, unsigned long long &act_out)
+{
+    const int tid = threadIdx.x;
+    const int T0 = rd.pl_T[b];
+    if (T0 <= 0) return false;
+    const int kp = (nS + RS_THREADS - 1) / RS_THREADS;
+    const int nSp = kp * RS_THREADS;
+    const int totp = nSp + nC;
+    const size_t sb = (size_t)b * rd.cap;
+    LL_AS_LDS PtSlot *ht = (LL_AS_LDS PtSlot *)s_raw;
+    const int4 *nn = rd.nn + sb + rd.cap_c;
+    unsigned char *flag0 = rd.blk_flag0 + sb;
+    unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
+    LL_T0(t_census);
+    unsigned long long act = 0, dirty = 0;
+    int na = 0, nca = 0, nsa = 0, nd = 0;
+    for (int k0 = 0; k0 * RS_THREADS < totp; k0 += 8) {
+        unsigned char fl8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = tid + (k0 + u) * RS_THREADS;
+            const int jc = j < totp ? j : 0;
+            const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
+            fl8[u] = gload_u8(flag0 + src);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = tid + (k0 + u) * RS_THREADS;
+            const unsigned char fl = (j < totp && (j < nS || j >= nSp)) ? fl8[u] : (unsigned char)0;
+            if (fl & BLK_ACTIVE) {
+                act |= 1ull << (k0 + u);
+                na++;
+            }
+            if (fl & 8) {
+                if (j >= nSp) nca++; else nsa++;
+            }
+            if (j < nS && (fl & BLK_DIRTY)) {
+                if (fl & BLK_ACTIVE) {
+                    dirty |= 1ull << (k0 + u);
+                    nd++;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // (the marks are consumed whatever happens next: a rebuild numbers every block anyway)
+            const int j = tid + (k0 + u) * RS_THREADS;
+            if (j < nS && (fl8[u] & BLK_DIRTY)) gstore_u8(flag0 + rd.cap_c + j, (unsigned char)(fl8[u] & ~BLK_DIRTY));
+        }
+    }
+    {
+        const unsigned long long tot = block_sum_u64((unsigned long long)na | ((unsigned long long)nca << 16) | ((unsigned long long)nsa << 32) |
+                                                     ((unsigned long long)nd << 48), sh);
+        na = (int)(tot & 0xffffull);
+        nca = (int)((tot >> 16) & 0xffffull);
+        nsa = (int)((tot >> 32) & 0xffffull);
+        nd = (int)((tot >> 48) & 0xffffull);
+    }
+    if (nd * 4 > nS) return false;  // (uniform) mostly new neighbours (ICP iteration 1 after a large correction): numbering everything is cheaper
+    if (rc.subsample_seed && na > rc.max_blocks) {  // a13 as in census_and_plane_table
+        int kept = 0;
+        for (int k = 0; k * RS_THREADS < totp; k++) {
+            if (!((act >> k) & 1ull)) continue;
+            const int j = tid + k * RS_THREADS;
+            const int jref = j >= nSp ? j - nSp : nC + j;
+            if (subsample_drop_block(rc.subsample_seed, st->icp_iters, jref, na, rc.max_blocks))
+                act &= ~(1ull << k);
+            else
+                kept++;
+        }
+        na = block_sum_int(kept, sh);
+    }
+    if (tid == 0) {
+        sh.n_active = na;
+        sh.n_corner_avail = nca;
+        sh.n_surf_avail = nsa;
+        sh.pt_next = T0;
+        sh.pt_fail = 0;
+        sh.pt_priv = 0;
+    }
+    __syncthreads();
+    LL_TACC(6, t_census);
+    LL_T0(t_tab);
+    int4 *tabG = pt_table_global(rd, b, 0, false);
+    int4 *keyG = rd.pl_key + (size_t)b * rd.tab_cap;
+    if (nd > 0) {  // (uniform)
+        for (int e = tid; e < PT_SLOTS; e += RS_THREADS) lds_store_i4((int4 *)s_raw + e, make_int4(-1, -1, -1, -1));
+        __syncthreads();
+        for (int i0 = tid; i0 < T0; i0 += 4 * RS_THREADS) {  // the stored keys back into the hash table, each under its old id
+            int4 k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int id = i0 + u * RS_THREADS;
+                k4[u] = gload_i4(keyG + (id < T0 ? id : i0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int id = i0 + u * RS_THREADS;
+                if (id >= T0) continue;
+                bool claimed;
+                const unsigned int h = pt_insert(ht, (unsigned int)k4[u].x, (unsigned int)k4[u].y, (unsigned int)k4[u].z, claimed);
+                if (h == PT_PRIVATE)
+                    sh.pt_fail = 1;
+                else
+                    ht[h].id = (unsigned int)id;
+            }
+        }
+        __syncthreads();
+        double pose_last[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
+        for (int k = 0; k < kp; k++) {  // dirty blocks: their triple's entry, appended behind the table when it is a new one
+            if (!((dirty >> k) & 1ull)) continue;
+            const int j = tid + k * RS_THREADS;
+            const int4 t = gload_i4(nn + j);
+            bool claimed;
+            const unsigned int h = pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed);
+            if (h == PT_PRIVATE) {
+                sh.pt_fail = 1;
+            } else if (claimed) {
+                const int id = atomicAdd(&sh.pt_next, 1);
+                if (id >= rd.tab_cap) {
+                    sh.pt_fail = 1;
+                } else {
+                    ht[h].id = (unsigned int)id;
+                    int4 ob, oc;
+                    pt_plane(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
+                    gstore_i4(tabG + 2 * id, ob);
+                    gstore_i4(tabG + 2 * id + 1, oc);
+                    gstore_i4(keyG + id, make_int4(t.x, t.y, t.z, 0));
+                }
+            }
+        }
+        __syncthreads();
+        if (sh.pt_fail) return false;  // (uniform)
+        for (int k = 0; k < kp; k++) {  // ... and the blocks' ids (every new entry has its id by now)
+            if (!((dirty >> k) & 1ull)) continue;
+            const int j = tid + k * RS_THREADS;
+            const int4 t = gload_i4(nn + j);
+            bool claimed;
+            const unsigned int h = pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed);  // (finds it)
+            gstore_u16(ids + j, (unsigned short)ht[h < PT_SLOTS ? h : 0u].id);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int T = sh.pt_next;
+    if (T > PT_TCAP && T0 <= PT_TCAP) return false;  // (uniform) just outgrew the LDS part: a rebuild drops the entries no block uses any more
+    // ---- the first PT_TCAP entries -> LDS; the rest of s_raw caches records (as census_and_plane_table) ----------------------------
+    const int Tl = T < PT_TCAP ? T : PT_TCAP;
+    int4 *s_tab = (int4 *)s_raw;
+    for (int e0 = tid; e0 < 2 * Tl; e0 += 8 * RS_THREADS) {
+        int4 v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * RS_THREADS;
+            v8[u] = gload_i4(tabG + (e < 2 * Tl ? e : e0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * RS_THREADS;
+            if (e < 2 * Tl) lds_store_i4(s_tab + e, v8[u]);
+        }
+    }
+    if (tid == 0) {
+        const int kc = ((PT_TCAP - Tl) * 2) / RS_THREADS;
+        sh.pt_T = T;
+        sh.pt_Tl = Tl;
+        sh.pt_kc = kc < kp ? kc : kp;
+        rd.pl_T[b] = T;
+    }
+    __syncthreads();
+    LL_TACC(8, t_tab);
+    act_out = act;
+    return true;
 }
 
 // after the inlier phase has used s_raw for its tables
@@ -2794,7 +2993,10 @@ __device__ void solve_fast3(const RegDev &rd, const RegConst &rc, const f4 *map_
 
     // ---- flags -> the thread's activity mask (bit k: block tid + k * RS_THREADS in the order planes, padding, lines), census
     //      (PCR:325,425), and the scan's plane table (this workgroup's share of it) ------------------------------------------
-    unsigned long long act = census_and_plane_table<GROUPED>(rd, rc, map_pts, b, st, nC, nS, s_raw, sh);
+    unsigned long long act = 0;
+    bool updated = false;
+    if (!GROUPED && rc.table_persist && st->icp_iters > 0) updated = plane_table_update(rd, rc, map_pts, b, st, nC, nS, s_raw, sh, act);
+    if (!updated) act = census_and_plane_table<GROUPED>(rd, rc, map_pts, b, st, nC, nS, s_raw, sh);
 
     // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------
     solver_lm3<true, GROUPED>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, act, s_raw, st->pose_last, sh);
