@@ -138,8 +138,11 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 // corner_blocks > 0: those first workgroups search the scans' corner queries one per lane (and build their blocks) -- dispatched
 // before any tile, their long ring searches (~100 dependent loads per lane) overlap the tiles instead of forming a launch of their
 // own or a tail behind the last tile.
+#ifndef KT_WAVES_PER_EU
+#define KT_WAVES_PER_EU 4  // (A/B: a register cap for more resident wavefronts spills in the per-lane fall-back)
+#endif
 template <bool FUSED>
-__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(KT_WAVES_PER_EU, 8)))
 void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int n_scans, int corner_blocks, int surf_blocks)
 {
     __shared__ float4 s_tile[KT_THREADS / 64][LL_TILE_CAP + 4];
@@ -172,6 +175,9 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
     const int q = valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
     const int slot = rd.cap_c + q;
     const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
+    // (what the slot holds from the previous ICP iteration, for knn_store's "did the neighbours change": loaded here, used at the end)
+    const bool want_old = rc.table_persist && iter > 0;
+    const int4 old_nn = want_old ? rd.nn[sb + slot] : make_int4(0, 0, 0, 0);
     const float max_d2 = rc.max_d2_plane;
     Knn5 r;
     bool fin;
@@ -183,7 +189,7 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
 #pragma unroll
             for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
         }
-        changed = knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
+        changed = knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r, want_old ? &old_nn : nullptr);
         if (!rc.check_plane_pca && rc.icp_plane && !rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
             // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
             // still knows -- no second look at rd.nn

@@ -2473,13 +2473,17 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
     const int totp = nSp + nC;
     const size_t sb = (size_t)b * rd.cap;
     LL_AS_LDS PtSlot *ht = (LL_AS_LDS PtSlot *)s_raw;
+    // the dirty blocks' indices, dense, behind the hash table (where the rebuild keeps its id -> slot map): <= PT_SLOTS entries
+    LL_AS_LDS unsigned short *dlist = (LL_AS_LDS unsigned short *)((LL_AS_LDS char *)s_raw + PT_MAP_OFF);
     const int4 *nn = rd.nn + sb + rd.cap_c;
     unsigned char *flag0 = rd.blk_flag0 + sb;
     unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
     LL_T0(t_census);
+    if (tid == 0) sh.pt_next = 0;  // (first the length of the dirty list)
+    __syncthreads();
     unsigned long long act = 0, dirty = 0;
-    int na = 0, nca = 0, nsa = 0, nd = 0;
-    for (int k0 = 0; k0 * RS_THREADS < totp; k0 += 8) {
+    int na = 0, nca = 0, nsa = 0;
+    for (int k0 = 0; k0 * RS_THREADS < totp; k0 += 8) {  // nothing but loads in here: a store between the trips makes every wait a wait for it
         unsigned char fl8[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -2499,28 +2503,22 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
             if (fl & 8) {
                 if (j >= nSp) nca++; else nsa++;
             }
-            if (j < nS && (fl & BLK_DIRTY)) {
-                if (fl & BLK_ACTIVE) {
-                    dirty |= 1ull << (k0 + u);
-                    nd++;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {  // (the marks are consumed whatever happens next: a rebuild numbers every block anyway)
-            const int j = tid + (k0 + u) * RS_THREADS;
-            if (j < nS && (fl8[u] & BLK_DIRTY)) gstore_u8(flag0 + rd.cap_c + j, (unsigned char)(fl8[u] & ~BLK_DIRTY));
+            if (j < nS && (fl & BLK_DIRTY) && (fl & BLK_ACTIVE)) dirty |= 1ull << (k0 + u);  // (an inactive block needs no id; its mark stays)
         }
     }
+    const int my_nd = __popcll(dirty);
+    int my_base = 0;
+    if (my_nd > 0) my_base = atomicAdd(&sh.pt_next, my_nd);
     {
-        const unsigned long long tot = block_sum_u64((unsigned long long)na | ((unsigned long long)nca << 16) | ((unsigned long long)nsa << 32) |
-                                                     ((unsigned long long)nd << 48), sh);
-        na = (int)(tot & 0xffffull);
-        nca = (int)((tot >> 16) & 0xffffull);
-        nsa = (int)((tot >> 32) & 0xffffull);
-        nd = (int)((tot >> 48) & 0xffffull);
+        const unsigned long long tot = block_sum_u64((unsigned long long)na | ((unsigned long long)nca << 20) | ((unsigned long long)nsa << 40), sh);
+        na = (int)(tot & 0xfffffull);
+        nca = (int)((tot >> 20) & 0xfffffull);
+        nsa = (int)((tot >> 40) & 0xfffffull);
     }
-    if (nd * 4 > nS) return false;  // (uniform) mostly new neighbours (ICP iteration 1 after a large correction): numbering everything is cheaper
+    const int nd = sh.pt_next;  // (block_sum's barriers have published it)
+    // (uniform) more than a tenth of the blocks changed (the first iterations after a large correction), or more than the list holds:
+    // numbering everything from scratch costs less than looking that many triples up one by one
+    if (nd * 10 > nS || nd > PT_SLOTS) return false;
     if (rc.subsample_seed && na > rc.max_blocks) {  // a13 as in census_and_plane_table
         int kept = 0;
         for (int k = 0; k * RS_THREADS < totp; k++) {
@@ -2534,6 +2532,7 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
         }
         na = block_sum_int(kept, sh);
     }
+    __syncthreads();
     if (tid == 0) {
         sh.n_active = na;
         sh.n_corner_avail = nca;
@@ -2542,13 +2541,21 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
         sh.pt_fail = 0;
         sh.pt_priv = 0;
     }
-    __syncthreads();
     LL_TACC(6, t_census);
     LL_T0(t_tab);
     int4 *tabG = pt_table_global(rd, b, 0, false);
     int4 *keyG = rd.pl_key + (size_t)b * rd.tab_cap;
     if (nd > 0) {  // (uniform)
         for (int e = tid; e < PT_SLOTS; e += RS_THREADS) lds_store_i4((int4 *)s_raw + e, make_int4(-1, -1, -1, -1));
+        {
+            int w = my_base;
+            for (int k = 0; k < kp; k++) {
+                if (!((dirty >> k) & 1ull)) continue;
+                const int j = tid + k * RS_THREADS;
+                dlist[w++] = (unsigned short)j;
+                gstore_u8(flag0 + rd.cap_c + j, (unsigned char)(BLK_PLANE | BLK_ACTIVE | 8));  // the mark is consumed (what an active plane block's flag is without it)
+            }
+        }
         __syncthreads();
         for (int i0 = tid; i0 < T0; i0 += 4 * RS_THREADS) {  // the stored keys back into the hash table, each under its old id
             int4 k4[4];
@@ -2573,41 +2580,62 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
         double pose_last[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
-        for (int k = 0; k < kp; k++) {  // dirty blocks: their triple's entry, appended behind the table when it is a new one
-            if (!((dirty >> k) & 1ull)) continue;
-            const int j = tid + k * RS_THREADS;
-            const int4 t = gload_i4(nn + j);
-            bool claimed;
-            const unsigned int h = pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed);
-            if (h == PT_PRIVATE) {
-                sh.pt_fail = 1;
-            } else if (claimed) {
-                const int id = atomicAdd(&sh.pt_next, 1);
-                if (id >= rd.tab_cap) {
+        // dirty blocks, spread evenly over the threads (list entry e -> thread e mod 512), four triples' loads in flight: the triple's
+        // entry, appended behind the table when it is a new one
+        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {
+            int4 t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * RS_THREADS;
+                t4[u] = gload_i4(nn + (int)dlist[e < nd ? e : e0]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * RS_THREADS;
+                if (e >= nd) continue;
+                const int4 t = t4[u];
+                bool claimed;
+                const unsigned int h = pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed);
+                if (h == PT_PRIVATE) {
                     sh.pt_fail = 1;
-                } else {
-                    ht[h].id = (unsigned int)id;
-                    int4 ob, oc;
-                    pt_plane(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
-                    gstore_i4(tabG + 2 * id, ob);
-                    gstore_i4(tabG + 2 * id + 1, oc);
-                    gstore_i4(keyG + id, make_int4(t.x, t.y, t.z, 0));
+                } else if (claimed) {
+                    const int id = atomicAdd(&sh.pt_next, 1);
+                    if (id >= rd.tab_cap) {
+                        sh.pt_fail = 1;
+                    } else {
+                        ht[h].id = (unsigned int)id;
+                        int4 ob, oc;
+                        pt_plane(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
+                        gstore_i4(tabG + 2 * id, ob);
+                        gstore_i4(tabG + 2 * id + 1, oc);
+                        gstore_i4(keyG + id, make_int4(t.x, t.y, t.z, 0));
+                    }
                 }
             }
         }
         __syncthreads();
-        if (sh.pt_fail) return false;  // (uniform)
-        for (int k = 0; k < kp; k++) {  // ... and the blocks' ids (every new entry has its id by now)
-            if (!((dirty >> k) & 1ull)) continue;
-            const int j = tid + k * RS_THREADS;
-            const int4 t = gload_i4(nn + j);
-            bool claimed;
-            const unsigned int h = pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed);  // (finds it)
-            gstore_u16(ids + j, (unsigned short)ht[h < PT_SLOTS ? h : 0u].id);
+        if (sh.pt_fail) return false;  // (uniform; the marks are gone, the rebuild numbers every block anyway)
+        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {  // ... and the blocks' ids (every new entry has its id by now)
+            int4 t4[4];
+            int j4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * RS_THREADS;
+                j4[u] = (int)dlist[e < nd ? e : e0];
+                t4[u] = gload_i4(nn + j4[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * RS_THREADS;
+                if (e >= nd) continue;
+                bool claimed;
+                const unsigned int h = pt_insert(ht, (unsigned int)t4[u].x, (unsigned int)t4[u].y, (unsigned int)t4[u].z, claimed);  // (finds it)
+                gstore_u16(ids + j4[u], (unsigned short)ht[h < PT_SLOTS ? h : 0u].id);
+            }
         }
         __threadfence_block();
-        __syncthreads();
     }
+    __syncthreads();
     const int T = sh.pt_next;
     if (T > PT_TCAP && T0 <= PT_TCAP) return false;  // (uniform) just outgrew the LDS part: a rebuild drops the entries no block uses any more
     // ---- the first PT_TCAP entries -> LDS; the rest of s_raw caches records (as census_and_plane_table) ----------------------------

@@ -166,7 +166,9 @@ __device__ __forceinline__ float4 load_feature(const RegDev &rd, int b, int kind
 
 // Returns whether the block's neighbours (what its constants are computed from) differ from what the slot held: the solver keeps the
 // plane constants of unchanged triples across the ICP iterations of a registration (BLK_DIRTY, ll_reg_kernels.hip).
-__device__ __forceinline__ bool knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r)
+// old_nn: what the slot held, when the caller has loaded it already (early, off the critical path)
+__device__ __forceinline__ bool knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r,
+                                          const int4 *old_nn = nullptr)
 {
     // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
     int4 nn;
@@ -176,7 +178,7 @@ __device__ __forceinline__ bool knn_store(const RegDev &rd, const RegConst &rc, 
     nn.z = r.pos[4];
     bool changed = true;
     if (kind == 1 && iter > 0 && rc.table_persist) {  // (iteration 0 rebuilds every table: what the slot holds is another registration's)
-        const int4 old = rd.nn[sb + slot];
+        const int4 old = old_nn ? *old_nn : rd.nn[sb + slot];
         changed = old.x != nn.x || old.y != nn.y || old.z != nn.z || old.w != nn.w;
     }
     rd.nn[sb + slot] = nn;
@@ -226,14 +228,14 @@ __device__ __forceinline__ bool resort_one(const RegDev &rd, const RegConst &rc,
 }
 
 __device__ __forceinline__ bool knn_finish(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const float4 &pw,
-                                           float max_d2, const Knn5 &r)
+                                           float max_d2, const Knn5 &r, const int4 *old_nn = nullptr)
 {
     if (rc.knn_reuse || rc.check_line_pca || rc.check_plane_pca) {  // the PCA checks need all five positions
         KnnRef ref;
         knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
         ref_store(rd, sb, slot, ref);
     }
-    return knn_store(rd, rc, sb, slot, kind, iter, r);
+    return knn_store(rd, rc, sb, slot, kind, iter, r, old_nn);
 }
 
 __device__ __forceinline__ bool knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
