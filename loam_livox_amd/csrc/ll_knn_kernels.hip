@@ -160,8 +160,8 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
             if (subsample_skip_feature(rc.subsample_seed, 0, st->icp_iters, q, nC, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
             rd.qw[sb + q] = make_float4(pw[0], pw[1], pw[2], 0.f);
         }
-        const bool ch = knn_one(rd, rc, gc, gs, b, q, iter);
-        build_one(rd, rc, gc, gs, b, q, ch);
+        knn_one(rd, rc, gc, gs, b, q, iter);
+        build_one(rd, rc, gc, gs, b, q);
         return;
     }
     const int b = (bid - n_corner_wg) / surf_blocks, sblk = (bid - n_corner_wg) - b * surf_blocks;
@@ -175,36 +175,32 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
     const int q = valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
     const int slot = rd.cap_c + q;
     const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
-    // (what the slot holds from the previous ICP iteration, for knn_store's "did the neighbours change": loaded here, used at the end)
-    const bool want_old = rc.table_persist && iter > 0;
-    const int4 old_nn = want_old ? rd.nn[sb + slot] : make_int4(0, 0, 0, 0);
     const float max_d2 = rc.max_d2_plane;
     Knn5 r;
     bool fin;
     knn5_tile_wave(gs, valid, pw.x, pw.y, pw.z, max_d2, s_tile[threadIdx.x >> 6], r, fin);
     if (!valid) return;
-    bool changed;
     if (fin) {
         if (rc.debug_knn && iter == 0) {
 #pragma unroll
             for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
         }
-        changed = knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r, want_old ? &old_nn : nullptr);
+        knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
         if (!rc.check_plane_pca && rc.icp_plane && !rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
             // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
             // still knows -- no second look at rd.nn
             // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)
             const f4 p0 = gs.pts[r.pos[0]], p1 = gs.pts[r.pos[2]], p2 = gs.pts[r.pos[4]];
             const bool degenerate = (p1.x == p0.x && p1.y == p0.y && p1.z == p0.z) || (p2.x == p0.x && p2.y == p0.y && p2.z == p0.z);
-            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8 | (changed ? BLK_DIRTY : 0));
+            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
             return;
         }
     } else {
         // sparse surroundings, an exact tie, a query outside the grid or not finite
         if (FUSED) rd.qw[sb + slot] = pw;
-        changed = knn_one(rd, rc, gc, gs, b, slot, iter);
+        knn_one(rd, rc, gc, gs, b, slot, iter);
     }
-    build_one(rd, rc, gc, gs, b, slot, changed);
+    build_one(rd, rc, gc, gs, b, slot);
 }
 
 void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s)

@@ -134,8 +134,7 @@ LL_HD bool subsample_drop_block(unsigned int seed, int iter, int j, int n_blocks
 
 // ---------------------------------------------------------------------------------------------- residual blocks
 
-enum : int { BLK_NONE = 0, BLK_LINE = 1, BLK_PLANE = 2, BLK_ACTIVE = 4, BLK_DIRTY = 16 };  // (8: counted as available, PCR:325,425; DIRTY: plane-table path,
-                                                                                         //  the block's neighbour triple changed since the solver last numbered it)
+enum : int { BLK_NONE = 0, BLK_LINE = 1, BLK_PLANE = 2, BLK_ACTIVE = 4 };  // (8: counted as available, PCR:325,425)
 
 // line block from the two nearest map points (point_cloud_registration.hpp:300-303, ceres_icp.hpp:255-256).
 // a_out / v_out are expressed in the frame of pose_last.  Returns false when |a-b| < 1e-4 (:302).

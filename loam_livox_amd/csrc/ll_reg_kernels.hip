@@ -38,30 +38,45 @@ namespace ll {
 #define RS_WAVES (RS_THREADS / 64)
 #define HASH_EMPTY 0xffffffffffffffffull
 
-// Wave-wide sum of a double, result valid in lane 63.  Data-parallel-primitive moves (row shifts inside each row of 16
-// lanes, then row broadcasts) instead of ds_bpermute shuffles: no LDS crossbar round trip per step, which is what a
-// 28-value reduction per cost evaluation spends its time on when a scan has only a few hundred residual blocks.
-// The addition tree is fixed, so results are reproducible run to run.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_shifted(double v)
+// The 28 accumulators of a cost evaluation summed over the wavefront -> red[0 .. 27].  Not 28 six-step trees (168 shifted adds, each
+// a pair of DPP moves per 64-bit operand plus the moves that feed them: ~850 VALU instructions per evaluation and wavefront, a
+// sixth of the evaluation's issue slots on a C2 scan and half of them on a voxel-filtered one) but ONE butterfly over the whole
+// set: at every step a lane keeps the half of its values whose index bit matches its lane bit and hands the other half to the
+// partner lane (ds_bpermute: the LDS crossbar, not a VALU slot), so the work halves with the distance -- 16 + 8 + 4 + 2 + 1 + 1 adds.
+// Value i ends up in lanes 2i and 2i + 1.  The addition tree is fixed (pairs 32 apart first, then 16, 8, 4, 2, 1), so sums are
+// reproducible run to run; a + b and b + a are the same bits, so both lanes of a pair agree.
+__device__ __forceinline__ void wave_sum_acc(const double (&acc)[LL_NACC], double *red, int lane)
 {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo));
+    static_assert(LL_NACC <= 32 && LL_NACC > 16, "butterfly over 32 value slots");
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+    double w16[16], w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const double hi = (16 + i < LL_NACC) ? acc[16 + i] : 0.0;
+        const double keep = b5 ? hi : acc[i], send = b5 ? acc[i] : hi;
+        w16[i] = keep + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double keep = b4 ? w16[8 + i] : w16[i], send = b4 ? w16[i] : w16[8 + i];
+        w8[i] = keep + __shfl_xor(send, 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double keep = b3 ? w8[4 + i] : w8[i], send = b3 ? w8[i] : w8[4 + i];
+        w4[i] = keep + __shfl_xor(send, 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const double keep = b2 ? w4[2 + i] : w4[i], send = b2 ? w4[i] : w4[2 + i];
+        w2[i] = keep + __shfl_xor(send, 4);
+    }
+    const double keep1 = b1 ? w2[1] : w2[0], send1 = b1 ? w2[0] : w2[1];
+    const double w1 = keep1 + __shfl_xor(send1, 2);
+    const double tot = w1 + __shfl_xor(w1, 1);
+    const int idx = (lane >> 1) & 31;
+    if (!(lane & 1) && idx < LL_NACC) red[idx] = tot;
 }
-__device__ __forceinline__ double wave_sum(double v)
-{
-    // lanes that receive nothing (row start, masked rows) add the `old` operand of update_dpp: +0.0
-    v += dpp_shifted<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_shifted<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_shifted<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_shifted<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
-    v += dpp_shifted<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold the half sums
-    v += dpp_shifted<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
-    return v;
-}
-#define WAVE_SUM_LANE 63
 
 // ---------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------
@@ -344,8 +359,8 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
             const int sgg = seg0 + lo, b = sgg >> 1, kind = sgg & 1;
             const int e = rd.work_search[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off_w[lo])];
             const int slot = e - b * rd.cap;
-            const bool ch = knn_one_coop(rd, rc, gc, gs, b, slot, iter);
-            if ((tid & 63) == 0) build_one(rd, rc, gc, gs, b, slot, ch);
+            knn_one_coop(rd, rc, gc, gs, b, slot, iter);
+            if ((tid & 63) == 0) build_one(rd, rc, gc, gs, b, slot);
         }
     }
     // (one index space over both lists, so that a lane never runs a re-sort after a search, brought the floor from 113 back
@@ -364,8 +379,9 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
             if (w == 0 && coop && kind == 0) continue;  // done above
             const int e = list[(size_t)b * rd.cap + (kind ? rd.cap_c : 0) + (t - off[lo])];
             const int slot = e - b * rd.cap;
-            const bool ch = (w == 0) ? knn_one(rd, rc, gc, gs, b, slot, iter) : resort_one(rd, rc, gc, gs, b, slot, iter);
-            build_one(rd, rc, gc, gs, b, slot, ch);
+            if (w == 0) knn_one(rd, rc, gc, gs, b, slot, iter);
+            else resort_one(rd, rc, gc, gs, b, slot, iter);
+            build_one(rd, rc, gc, gs, b, slot);
         }
     }
 }
@@ -582,11 +598,7 @@ __device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS
         if (fl & BLK_ACTIVE) LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
         j = jn;
     }
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) {
-        const double s = wave_sum(acc[i]);
-        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
-    }
+    wave_sum_acc(acc, sh.red[wave], lane);
     __syncthreads();
     if (tid < LL_NACC) {
         double s = 0.0;
@@ -1493,11 +1505,7 @@ __device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, i
         }
     }
 #endif
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) {
-        const double s = wave_sum(acc[i]);
-        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
-    }
+    wave_sum_acc(acc, sh.red[wave], lane);
     __syncthreads();
     if (tid < LL_NACC) {
         double s = 0.0;
@@ -1810,11 +1818,7 @@ __device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int n
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) {
-        const double s = wave_sum(acc[i]);
-        if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
-    }
+    wave_sum_acc(acc, sh.red[wave], lane);
     __syncthreads();
     if (tid < LL_NACC) {
         double s = 0.0;
@@ -2262,8 +2266,8 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         for (int u = 0; u < 8; u++) {
             const int j = tid + (k0 + u) * RS_THREADS;
             if ((!GROUPED || u == g) && j < nS) gstore_u16(ids + j, (unsigned short)h8[GROUPED ? 0 : u]);
-            // the dirty marks of the k-NN stage are consumed: every block is numbered afresh here
-            if (!GROUPED && j < nS && (fl8[u] & BLK_DIRTY)) gstore_u8(const_cast<unsigned char *>(flag0) + rd.cap_c + j, (unsigned char)(fl8[u] & ~BLK_DIRTY));
+            // the triples this numbering was made from: the next launches of the registration compare against them (plane_table_update)
+            if (!GROUPED && rc.table_persist && j < nS) gstore_i4(rd.nn_prev + (size_t)b * rd.cap_s + j, t8[u]);
         }
 #ifdef LL_SOLVE_TIMING
         LL_TACC(11, t_ins);
@@ -2454,14 +2458,21 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
 }
 
 // ICP iterations >= 1 of a registration (one workgroup per scan): the table of the previous launch is still valid -- rd.pl_tab in the frame
-// of pose_last, rd.pl_key the triple behind every entry, rd.blk_id the entry of every block, rd.pl_T their number -- except for the
-// blocks whose neighbours the k-NN stage changed (BLK_DIRTY in their flag: a few per cent of a scan after the first iterations).
-// So: flags -> activity mask + census as in census_and_plane_table (no look at rd.nn: 1 byte per block instead of 17), and only if
-// something is dirty the LDS hash table is filled again from the T stored keys (7 inserts per thread instead of 34), the dirty
-// blocks' triples are looked up / appended behind the table, and their ids rewritten.  Returns false (uniformly) when the caller
-// must rebuild from scratch instead: no table to build on, too many dirty blocks to be worth it, a crowded probe sequence, a full
-// table region, a table that has just outgrown its LDS part (the rebuild drops the entries nobody uses any more).  Same table entry
-// for the same triple as a rebuild would compute (pt_plane = block_plane), so the evaluations see bit-identical planes.
+// of pose_last, rd.pl_key the triple behind every entry, rd.blk_id the entry of every block, rd.nn_prev the triple every block was
+// numbered with, rd.pl_T the number of entries -- except for the blocks whose neighbours the k-NN stage has changed since (a few per
+// cent of a scan after the first iterations).  So instead of hashing all ~17 k triples again (34 dependent LDS insert chains per
+// thread: two thirds of the rebuild's time):
+//   1. the flag bytes come in through LDS in ONE round trip (whole dwords, 8 - 9 in flight per thread) -> activity mask + census;
+//   2. every active plane block's triple is compared with the one it was numbered with (two coalesced 16-byte streams, eight + eight
+//      loads in flight); the changed ones go to a dense list in LDS;
+//   3. only if there are any, the LDS hash table is filled again from the T stored keys (7 - 9 inserts per thread instead of 34), the
+//      changed blocks -- spread evenly over the threads, four in flight -- are looked up / appended behind the table, and their ids
+//      and remembered triples rewritten;
+//   4. table -> LDS as in the rebuild.
+// Returns false (uniformly) when the caller must rebuild from scratch instead: no table to build on, more than a tenth of the
+// blocks changed (numbering everything costs less than that many lookups), a crowded probe sequence, a full table region, a table
+// that has just outgrown its LDS part (the rebuild drops the entries nobody uses any more).  Same table entry for the same triple as
+// a rebuild computes (pt_plane = block_plane), so the evaluations see bit-identical planes.
 __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst &rc, const f4 *map_pts, int b, const RegState *st, int nC, int nS,
                                                 uint4 *s_raw, SolveShared &sh, unsigned long long &act_out)
 {
@@ -2473,40 +2484,75 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
     const int totp = nSp + nC;
     const size_t sb = (size_t)b * rd.cap;
     LL_AS_LDS PtSlot *ht = (LL_AS_LDS PtSlot *)s_raw;
-    // the dirty blocks' indices, dense, behind the hash table (where the rebuild keeps its id -> slot map): <= PT_SLOTS entries
+    // the changed blocks' indices, dense, behind the hash table (where the rebuild keeps its id -> slot map): <= PT_SLOTS entries
     LL_AS_LDS unsigned short *dlist = (LL_AS_LDS unsigned short *)((LL_AS_LDS char *)s_raw + PT_MAP_OFF);
     const int4 *nn = rd.nn + sb + rd.cap_c;
-    unsigned char *flag0 = rd.blk_flag0 + sb;
+    int4 *nnp = rd.nn_prev + (size_t)b * rd.cap_s;
     unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
     LL_T0(t_census);
-    if (tid == 0) sh.pt_next = 0;  // (first the length of the dirty list)
-    __syncthreads();
-    unsigned long long act = 0, dirty = 0;
-    int na = 0, nca = 0, nsa = 0;
-    for (int k0 = 0; k0 * RS_THREADS < totp; k0 += 8) {  // nothing but loads in here: a store between the trips makes every wait a wait for it
-        unsigned char fl8[8];
+    // ---- 1. flags through LDS: the surface blocks' bytes at s_raw[0 ..), the corner blocks' behind them ---------------------------
+    LL_AS_LDS unsigned char *lf = (LL_AS_LDS unsigned char *)s_raw;
+    const unsigned char *fs_g = rd.blk_flag0 + sb + rd.cap_c, *fc_g = rd.blk_flag0 + sb;
+    const int sh_s = (int)((size_t)fs_g & 3), sh_c = (int)((size_t)fc_g & 3);  // (the regions start wherever cap_c puts them)
+    const int nw_s = (sh_s + nS + 3) >> 2, nw_c = (sh_c + nC + 3) >> 2;
+    const int off_c = (nw_s << 2) + 16;  // byte offset of the corner bytes in LDS
+    {
+        const unsigned int *gs_w = (const unsigned int *)(fs_g - sh_s), *gc_w = (const unsigned int *)(fc_g - sh_c);
+        LL_AS_LDS unsigned int *lw = (LL_AS_LDS unsigned int *)s_raw;
+        for (int d0 = tid; d0 < nw_s; d0 += 8 * RS_THREADS) {
+            unsigned int w8[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int j = tid + (k0 + u) * RS_THREADS;
-            const int jc = j < totp ? j : 0;
-            const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
-            fl8[u] = gload_u8(flag0 + src);
+            for (int u = 0; u < 8; u++) {
+                const int d = d0 + u * RS_THREADS;
+                w8[u] = *(const LL_AS_GLOBAL unsigned int *)(gs_w + (d < nw_s ? d : d0));  // (the last word may reach up to 3 bytes past the scan's flags: blk_flag0 is padded)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int d = d0 + u * RS_THREADS;
+                if (d < nw_s) lw[d] = w8[u];
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int j = tid + (k0 + u) * RS_THREADS;
-            const unsigned char fl = (j < totp && (j < nS || j >= nSp)) ? fl8[u] : (unsigned char)0;
-            if (fl & BLK_ACTIVE) {
-                act |= 1ull << (k0 + u);
-                na++;
-            }
-            if (fl & 8) {
-                if (j >= nSp) nca++; else nsa++;
-            }
-            if (j < nS && (fl & BLK_DIRTY) && (fl & BLK_ACTIVE)) dirty |= 1ull << (k0 + u);  // (an inactive block needs no id; its mark stays)
+        for (int d = tid; d < nw_c; d += RS_THREADS) lw[(off_c >> 2) + d] = *(const LL_AS_GLOBAL unsigned int *)(gc_w + d);
+        if (tid == 0) sh.pt_next = 0;  // (first the length of the list of changed blocks)
+    }
+    __syncthreads();
+    unsigned long long act = 0, plane_act = 0;
+    int na = 0, nca = 0, nsa = 0;
+    for (int k = 0; k * RS_THREADS < totp; k++) {
+        const int j = tid + k * RS_THREADS;
+        unsigned char fl = 0;
+        if (j < nS)
+            fl = lf[sh_s + j];
+        else if (j >= nSp && j < totp)
+            fl = lf[off_c + sh_c + (j - nSp)];
+        if (fl & BLK_ACTIVE) {
+            act |= 1ull << k;
+            na++;
+            if (j < nS) plane_act |= 1ull << k;
+        }
+        if (fl & 8) {
+            if (j >= nSp) nca++; else nsa++;
         }
     }
-    const int my_nd = __popcll(dirty);
+    // ---- 2. which active plane blocks have new neighbours --------------------------------------------------------------------------
+    unsigned long long changed = 0;
+    for (int k0 = 0; k0 < kp; k0 += 8) {
+        int4 a8[8], p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = tid + (k0 + u) * RS_THREADS;
+            const int jc = j < nS ? j : 0;
+            a8[u] = gload_i4(nn + jc);
+            p8[u] = gload_i4(nnp + jc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (k0 + u < kp && ((plane_act >> (k0 + u)) & 1ull) &&
+                (a8[u].x != p8[u].x || a8[u].y != p8[u].y || a8[u].z != p8[u].z || a8[u].w != p8[u].w))  // (.w: a block that was not active then has no id)
+                changed |= 1ull << (k0 + u);
+        }
+    }
+    const int my_nd = __popcll(changed);
     int my_base = 0;
     if (my_nd > 0) my_base = atomicAdd(&sh.pt_next, my_nd);
     {
@@ -2515,10 +2561,8 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
         nca = (int)((tot >> 20) & 0xfffffull);
         nsa = (int)((tot >> 40) & 0xfffffull);
     }
-    const int nd = sh.pt_next;  // (block_sum's barriers have published it)
-    // (uniform) more than a tenth of the blocks changed (the first iterations after a large correction), or more than the list holds:
-    // numbering everything from scratch costs less than looking that many triples up one by one
-    if (nd * 10 > nS || nd > PT_SLOTS) return false;
+    const int nd = sh.pt_next;  // (block_sum's barriers have published it; they also end the reads of the staged flags)
+    if (nd * 10 > nS || nd > PT_SLOTS) return false;  // (uniform)
     if (rc.subsample_seed && na > rc.max_blocks) {  // a13 as in census_and_plane_table
         int kept = 0;
         for (int k = 0; k * RS_THREADS < totp; k++) {
@@ -2546,18 +2590,15 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
     int4 *tabG = pt_table_global(rd, b, 0, false);
     int4 *keyG = rd.pl_key + (size_t)b * rd.tab_cap;
     if (nd > 0) {  // (uniform)
+        // ---- 3. hash table from the stored keys, the changed blocks through it -----------------------------------------------------
         for (int e = tid; e < PT_SLOTS; e += RS_THREADS) lds_store_i4((int4 *)s_raw + e, make_int4(-1, -1, -1, -1));
         {
             int w = my_base;
-            for (int k = 0; k < kp; k++) {
-                if (!((dirty >> k) & 1ull)) continue;
-                const int j = tid + k * RS_THREADS;
-                dlist[w++] = (unsigned short)j;
-                gstore_u8(flag0 + rd.cap_c + j, (unsigned char)(BLK_PLANE | BLK_ACTIVE | 8));  // the mark is consumed (what an active plane block's flag is without it)
-            }
+            for (int k = 0; k < kp; k++)
+                if ((changed >> k) & 1ull) dlist[w++] = (unsigned short)(tid + k * RS_THREADS);
         }
         __syncthreads();
-        for (int i0 = tid; i0 < T0; i0 += 4 * RS_THREADS) {  // the stored keys back into the hash table, each under its old id
+        for (int i0 = tid; i0 < T0; i0 += 4 * RS_THREADS) {  // the stored keys, each under its old id
             int4 k4[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -2580,9 +2621,7 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
         double pose_last[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
-        // dirty blocks, spread evenly over the threads (list entry e -> thread e mod 512), four triples' loads in flight: the triple's
-        // entry, appended behind the table when it is a new one
-        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {
+        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {  // a changed block's triple: its entry, appended behind the table when new
             int4 t4[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -2614,8 +2653,8 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
             }
         }
         __syncthreads();
-        if (sh.pt_fail) return false;  // (uniform; the marks are gone, the rebuild numbers every block anyway)
-        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {  // ... and the blocks' ids (every new entry has its id by now)
+        if (sh.pt_fail) return false;  // (uniform; nothing of the scan's persistent state has been touched but appended entries nobody refers to)
+        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {  // ... and the blocks' ids and remembered triples (every new entry has its id by now)
             int4 t4[4];
             int j4[4];
 #pragma unroll
@@ -2631,14 +2670,17 @@ __device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst
                 bool claimed;
                 const unsigned int h = pt_insert(ht, (unsigned int)t4[u].x, (unsigned int)t4[u].y, (unsigned int)t4[u].z, claimed);  // (finds it)
                 gstore_u16(ids + j4[u], (unsigned short)ht[h < PT_SLOTS ? h : 0u].id);
+                gstore_i4(nnp + j4[u], t4[u]);
             }
         }
         __threadfence_block();
     }
     __syncthreads();
     const int T = sh.pt_next;
-    if (T > PT_TCAP && T0 <= PT_TCAP) return false;  // (uniform) just outgrew the LDS part: a rebuild drops the entries no block uses any more
-    // ---- the first PT_TCAP entries -> LDS; the rest of s_raw caches records (as census_and_plane_table) ----------------------------
+    if (T > PT_TCAP && T0 <= PT_TCAP) {  // (uniform) just outgrew the LDS part: a rebuild drops the entries no block uses any more
+        return false;
+    }
+    // ---- 4. the first PT_TCAP entries -> LDS; the rest of s_raw caches records (as census_and_plane_table) -------------------------
     const int Tl = T < PT_TCAP ? T : PT_TCAP;
     int4 *s_tab = (int4 *)s_raw;
     for (int e0 = tid; e0 < 2 * Tl; e0 += 8 * RS_THREADS) {
@@ -2843,11 +2885,7 @@ __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int n
     // has nothing but +0.0 to add: it writes the zeros instead of running 28 six-step reductions beside the wavefront that
     // shares its SIMD (the 504 data-parallel moves and adds are half of such an evaluation's cycles).  Same sums, bit for bit.
     if (__ballot(act != 0ull) != 0ull) {
-#pragma unroll
-        for (int i = 0; i < LL_NACC; i++) {
-            const double s = wave_sum(acc[i]);
-            if (lane == WAVE_SUM_LANE) sh.red[wave][i] = s;
-        }
+        wave_sum_acc(acc, sh.red[wave], lane);
     } else if (lane < LL_NACC) {
         sh.red[wave][lane] = 0.0;
     }
@@ -3023,7 +3061,8 @@ __device__ void solve_fast3(const RegDev &rd, const RegConst &rc, const f4 *map_
     //      (PCR:325,425), and the scan's plane table (this workgroup's share of it) ------------------------------------------
     unsigned long long act = 0;
     bool updated = false;
-    if (!GROUPED && rc.table_persist && st->icp_iters > 0) updated = plane_table_update(rd, rc, map_pts, b, st, nC, nS, s_raw, sh, act);
+    // (with the plane PCA check a block's activity also depends on its other two neighbours, which the remembered triple does not show)
+    if (!GROUPED && rc.table_persist && !rc.check_plane_pca && st->icp_iters > 0) updated = plane_table_update(rd, rc, map_pts, b, st, nC, nS, s_raw, sh, act);
     if (!updated) act = census_and_plane_table<GROUPED>(rd, rc, map_pts, b, st, nC, nS, s_raw, sh);
 
     // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------

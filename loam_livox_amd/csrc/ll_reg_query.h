@@ -164,11 +164,7 @@ __device__ __forceinline__ float4 load_feature(const RegDev &rd, int b, int kind
     return kind ? rd.surf_feat[(size_t)b * rd.feat_stride_s + q] : rd.corner_feat[(size_t)b * rd.feat_stride_c + q];
 }
 
-// Returns whether the block's neighbours (what its constants are computed from) differ from what the slot held: the solver keeps the
-// plane constants of unchanged triples across the ICP iterations of a registration (BLK_DIRTY, ll_reg_kernels.hip).
-// old_nn: what the slot held, when the caller has loaded it already (early, off the critical path)
-__device__ __forceinline__ bool knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r,
-                                          const int4 *old_nn = nullptr)
+__device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const Knn5 &r)
 {
     // 5 neighbours found inside the match radius  <=>  nearestKSearch == 5 and sq_dis[4] < thr (PCR:249-254,353)
     int4 nn;
@@ -176,11 +172,6 @@ __device__ __forceinline__ bool knn_store(const RegDev &rd, const RegConst &rc, 
     nn.x = r.pos[0];
     nn.y = kind ? r.pos[2] : r.pos[1];  // plane: 0, k/2, k-1 (PCR:416-418); line: 0, 1 (PCR:300-301)
     nn.z = r.pos[4];
-    bool changed = true;
-    if (kind == 1 && iter > 0 && rc.table_persist) {  // (iteration 0 rebuilds every table: what the slot holds is another registration's)
-        const int4 old = old_nn ? *old_nn : rd.nn[sb + slot];
-        changed = old.x != nn.x || old.y != nn.y || old.z != nn.z || old.w != nn.w;
-    }
     rd.nn[sb + slot] = nn;
     if (rc.debug_knn && iter == 0 && rd.dbg_idx) {
 #pragma unroll
@@ -189,7 +180,6 @@ __device__ __forceinline__ bool knn_store(const RegDev &rd, const RegConst &rc, 
             rd.dbg_d2[(sb + slot) * 5 + k] = knn5_d2(r, k);
         }
     }
-    return changed;
 }
 
 __device__ __forceinline__ void ref_store(const RegDev &rd, size_t sb, int slot, const KnnRef &ref)
@@ -201,7 +191,7 @@ __device__ __forceinline__ void ref_store(const RegDev &rd, size_t sb, int slot,
 
 // Set-stable query (re-query state 1): the same five neighbours, re-evaluated and re-sorted at the new position; the
 // reuse record moves there with shrunken budgets (knn5_resort).
-__device__ __forceinline__ bool resort_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
+__device__ __forceinline__ void resort_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
 {
     const int kind = slot >= rd.cap_c ? 1 : 0;
     const size_t sb = (size_t)b * rd.cap;
@@ -224,21 +214,21 @@ __device__ __forceinline__ bool resort_one(const RegDev &rd, const RegConst &rc,
     Knn5 r;
     knn5_resort(kind ? gs : gc, ref, delta, pw.x, pw.y, pw.z, kind ? rc.max_d2_plane : rc.max_d2_line, r);
     ref_store(rd, sb, slot, ref);
-    return knn_store(rd, rc, sb, slot, kind, iter, r);
+    knn_store(rd, rc, sb, slot, kind, iter, r);
 }
 
-__device__ __forceinline__ bool knn_finish(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const float4 &pw,
-                                           float max_d2, const Knn5 &r, const int4 *old_nn = nullptr)
+__device__ __forceinline__ void knn_finish(const RegDev &rd, const RegConst &rc, size_t sb, int slot, int kind, int iter, const float4 &pw,
+                                           float max_d2, const Knn5 &r)
 {
     if (rc.knn_reuse || rc.check_line_pca || rc.check_plane_pca) {  // the PCA checks need all five positions
         KnnRef ref;
         knn5_make_ref(r, pw.x, pw.y, pw.z, max_d2, ref);
         ref_store(rd, sb, slot, ref);
     }
-    return knn_store(rd, rc, sb, slot, kind, iter, r, old_nn);
+    knn_store(rd, rc, sb, slot, kind, iter, r);
 }
 
-__device__ __forceinline__ bool knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
+__device__ __forceinline__ void knn_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
 {
     const int kind = slot >= rd.cap_c ? 1 : 0;
     const size_t sb = (size_t)b * rd.cap;
@@ -246,12 +236,11 @@ __device__ __forceinline__ bool knn_one(const RegDev &rd, const RegConst &rc, co
     const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
     Knn5 r;
     knn5_search(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);  // NaN query -> empty
-    return knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
+    knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
 }
 
 // The same for one query per wavefront (ll_knn_coop.h); lane 0 stores.  All 64 lanes call it with the same arguments.
-// (lane 0's return value counts)
-__device__ __forceinline__ bool knn_one_coop(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
+__device__ __forceinline__ void knn_one_coop(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, int iter)
 {
     const int kind = slot >= rd.cap_c ? 1 : 0;
     const size_t sb = (size_t)b * rd.cap;
@@ -259,14 +248,11 @@ __device__ __forceinline__ bool knn_one_coop(const RegDev &rd, const RegConst &r
     const float max_d2 = kind ? rc.max_d2_plane : rc.max_d2_line;
     Knn5 r;
     knn5_search_coop(kind ? gs : gc, pw.x, pw.y, pw.z, max_d2, r);
-    bool changed = true;
-    if ((threadIdx.x & 63) == 0) changed = knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
-    return changed;
+    if ((threadIdx.x & 63) == 0) knn_finish(rd, rc, sb, slot, kind, iter, pw, max_d2, r);
 }
 
 // K6b: residual-block constants (fp64) from the neighbours found by K6a.
-// changed: the slot's neighbours differ from the previous ICP iteration's (knn_store); false only when the caller knows they do not
-__device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot, bool changed = true)
+__device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int b, int slot)
 {
     const int kind = slot >= rd.cap_c ? 1 : 0;
     const int q = slot - (kind ? rd.cap_c : 0);
@@ -305,7 +291,7 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
                 if (!rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
                     // plane-table path: only the flag is decided here; the solver computes {n', c} once per distinct
                     // (nn0, nn2, nn4) triple from rd.nn (solve_fast3)
-                    rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8 | (changed ? BLK_DIRTY : 0));
+                    rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
                     return;
                 }
                 flag = block_plane(st->pose_last, pa, pb, pc, a_out, v_out) ? (BLK_PLANE | BLK_ACTIVE | 8) : BLK_NONE;

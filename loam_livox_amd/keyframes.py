@@ -75,7 +75,7 @@ class Keyframe_assembly:
                  minimum_keyframe_differen: int = 200, minimum_similarity_linear: float = 0.65, minimum_similarity_planar: float = 0.95,
                  map_alignment_resolution: float = 0.2, map_alignment_inlier_threshold: float = 0.35,
                  map_alignment_maximum_icp_iteration: int = 2, scene_alignments_maximum_residual_block: int = 5000,
-                 keyframe_max_points: int = 1 << 20, full_cell_map=None):
+                 keyframe_max_points: int = 1 << 20, full_cell_map=None, avail_ratio_plane: float = 0.05, avail_ratio_line: float = 0.03):
         # parameter names and defaults: laser_mapping.hpp:698-710 (loop_closure/*), :686-687 (mapping/pt_cell_resolution, threshold_cell_revisit)
         self.device = device
         self.m_pt_cell_resolution = cell_resolution
@@ -93,6 +93,9 @@ class Keyframe_assembly:
         self.m_loop_closure_map_alignment_maximum_icp_iteration = map_alignment_maximum_icp_iteration
         self.m_para_scene_alignments_maximum_residual_block = scene_alignments_maximum_residual_block
         self.keyframe_max_points = keyframe_max_points
+        # locals of service_loop_detection (laser_mapping.hpp:887-888: "0.05 for 300 scans, 0.15 for 1000 scans"): a key frame whose direction
+        # images are emptier than this is not compared against
+        self.avail_ratio_plane, self.avail_ratio_line = avail_ratio_plane, avail_ratio_line
         self.m_keyframe_of_updating_list = deque([Maps_keyframe()])   # :626
         self.m_keyframe_need_precession_list = deque()
         self.keyframe_vec = []          # service_loop_detection's keyframe_vec
@@ -158,7 +161,7 @@ class Keyframe_assembly:
     def process_waiting(self):
         """Every waiting key frame through one pass of service_loop_detection's loop body.  Returns the loops found in this call."""
         found = []
-        avail_ratio_plane, avail_ratio_line = 0.05, 0.03   # :887-888
+        avail_ratio_plane, avail_ratio_line = self.avail_ratio_plane, self.avail_ratio_line   # :887-888
         while self.m_keyframe_need_precession_list and not self.if_end:
             last = self.m_keyframe_need_precession_list.popleft()
             last.cell_map = self.materialize(last)          # update_features_of_each_cells + analyze read the cells as they are now

@@ -80,32 +80,42 @@ def test_touched_cells_equal_the_oracle_cell_map(gpu_lib):
 
 @pytest.mark.gpu
 def test_out_and_back_sequence_closes_a_loop(gpu_lib):
-    """A sensor that looks at a scene, leaves and comes back with a pose error: the key frame of the revisit matches the first one
-    (direction images), and the scene alignment recovers the offset between the two (SA:269-391 through keyframes.py)."""
+    """A sensor sweeps a place, leaves for another one, and comes back with 0.6 m / 0.5 degrees of accumulated drift: three key frames;
+    the revisit's direction images match the first key frame's (not the other place's), the pair passes the detector's gates
+    (laser_mapping.hpp:990-1033) and the scene alignment (SA:269-391 through keyframes.py) ends below the loop threshold with a
+    transform that undoes the drift.  (40 scans per key frame instead of 300: the emptier direction images need a lower
+    avail_ratio_plane than the node's 0.05 "for 300 scans".)"""
     from loam_livox_amd import synth
     from loam_livox_amd.keyframes import Keyframe_assembly
     world = synth.world_for_map_size(200_000)
     rng = np.random.default_rng(77)
     start = synth.sensor_pose_in_world(world, rng)
-    ka = Keyframe_assembly(scans_of_each_keyframe=8, scans_between_two_keyframe=8, minimum_keyframe_differen=2, maximum_keyframe_in_waiting_list=3,
-                           map_alignment_inlier_threshold=0.35, map_alignment_maximum_icp_iteration=4, max_points=1 << 21)
+    per_kf = 40
+    ka = Keyframe_assembly(scans_of_each_keyframe=per_kf, scans_between_two_keyframe=per_kf, minimum_keyframe_differen=2,
+                           maximum_keyframe_in_waiting_list=3, map_alignment_inlier_threshold=0.35, map_alignment_maximum_icp_iteration=4,
+                           max_points=1 << 22, avail_ratio_plane=0.02, avail_ratio_line=0.0)
     ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
-    # 8 scans here, 8 scans from a pose that looks elsewhere, 8 scans back here -- the last group drifted by `drift`
-    away = synth.pose_compose(start, np.r_[synth.quat_from_axis_angle(np.array([0.0, 0.0, 1.0]), np.deg2rad(170.0)), np.zeros(3)])
-    drift = np.r_[synth.quat_from_axis_angle(np.array([0.0, 0.0, 1.0]), np.deg2rad(0.5)), np.array([0.6, -0.4, 0.1])]
+    zax, yax = np.array([0.0, 0.0, 1.0]), np.array([0.0, 1.0, 0.0])
+    away = synth.pose_compose(start, np.r_[synth.quat_from_axis_angle(zax, np.deg2rad(170.0)), np.array([12.0, 6.0, 0.0])])
+    drift = np.r_[synth.quat_from_axis_angle(zax, np.deg2rad(0.5)), np.array([0.6, -0.4, 0.1])]
     loops, k = [], 0
-    for grp, (true_pose, est_err) in enumerate([(start, ident), (away, ident), (start, drift)]):
-        for j in range(8):
-            sc = synth.make_moving_scan(world, 9100 + 10 * grp + j, 24000, inc_true=ident, pose_start=true_pose, t_phase=0.07 * j)
+    # (the revisit sweeps a little wider than the first visit: the detector skips a pair whose newer key frame has fewer cells, :1030)
+    for grp, (base, est_err, span, pitch) in enumerate([(start, ident, 300.0, 20.0), (away, ident, 300.0, 20.0), (start, drift, 360.0, 30.0)]):
+        for j in range(per_kf):
+            yaw, pit = np.deg2rad(span * (j / (per_kf - 1) - 0.5)), np.deg2rad(pitch * np.sin(3.1 * j))
+            rot = synth.quat_mul(synth.quat_from_axis_angle(zax, yaw), synth.quat_from_axis_angle(yax, pit))
+            true_pose = synth.pose_compose(base, np.r_[rot, np.zeros(3)])
+            sc = synth.make_moving_scan(world, 9100 + 100 * grp + j, 24000, inc_true=ident, pose_start=true_pose, t_phase=0.07 * j)
             est = synth.pose_compose(est_err, true_pose)  # the pose the mapping loop believes: the truth with the accumulated drift on top
-            cloud = np.c_[synth.transform_points(est, sc.xyzi[:, :3]), np.zeros(len(sc.xyzi), np.float32)].astype(np.float32)
-            cloud = cloud[np.isfinite(cloud).all(axis=1) & (np.abs(sc.xyzi[:, :3]).sum(axis=1) > 0)]
+            ok = np.isfinite(sc.xyzi[:, :3]).all(axis=1) & (np.abs(sc.xyzi[:, :3]).sum(axis=1) > 0)
+            cloud = np.c_[synth.transform_points(est, sc.xyzi[ok, :3]), np.zeros(int(ok.sum()), np.float32)].astype(np.float32)
             k += 1
             ka.add_scan(cloud, est, k)
             loops += ka.process_waiting()
-    assert len(ka.keyframe_vec) == 3
-    assert len(loops) == 1 and loops[0]["his"] == 0 and loops[0]["last"] == 2
-    # the alignment maps key frame `last` (drifted) onto key frame `his`: it undoes the drift (to the resolution of a 0.2 m voxel alignment)
+    info = [(len(kf.m_set_cell), np.round(kf.analysis["ratio_nonzero"], 4).tolist()) for kf in ka.keyframe_vec]
+    assert len(ka.keyframe_vec) == 3, info
+    assert len(loops) == 1 and loops[0]["his"] == 0 and loops[0]["last"] == 2, (info, ka.log)
+    # the alignment maps the drifted key frame onto the first one: its translation undoes the drift (to the resolution of a 0.2 m voxel alignment)
     t = loops[0]["icp_t"]
-    assert np.linalg.norm(t - drift[4:7]) < 0.15 or np.linalg.norm(t + drift[4:7]) < 0.15, (t, drift[4:7])
+    assert np.linalg.norm(t - drift[4:7]) < 0.2 or np.linalg.norm(t + drift[4:7]) < 0.2, (t, drift[4:7], ka.log)
     ka.close()

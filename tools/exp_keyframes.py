@@ -11,7 +11,7 @@ world = synth.world_for_map_size(200_000)
 rng = np.random.default_rng(77)
 start = synth.sensor_pose_in_world(world, rng)
 ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
-for per_kf, yaw_span in ((8, 0.0), (12, 120.0), (24, 300.0)):
+for per_kf, yaw_span in ((40, 300.0),):
     ka = Keyframe_assembly(scans_of_each_keyframe=per_kf, scans_between_two_keyframe=per_kf, minimum_keyframe_differen=2, maximum_keyframe_in_waiting_list=3,
                            map_alignment_inlier_threshold=0.35, map_alignment_maximum_icp_iteration=4, max_points=1 << 22)
     away = synth.pose_compose(start, np.r_[synth.quat_from_axis_angle(np.array([0.0, 0.0, 1.0]), np.deg2rad(170.0)), np.array([3.0, 1.0, 0.0])])
