@@ -687,10 +687,6 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
         d.tab_cap = (lim + 4095) / 4096 * 4096;
     }
     DM(d.pl_tab, B * (size_t)d.tab_cap * 2);
-    DM(d.pl_key, B * (size_t)d.tab_cap);
-    DM(d.nn_prev, B * d.cap_s);
-    DM(d.pl_T, B);
-    HC(hipMemset(d.pl_T, 0, B * sizeof(int)));
     DM(d.blk_flag, B * d.cap);
     DM(d.nn, B * d.cap);
     DM(d.qperm, B * d.cap_s);
@@ -698,7 +694,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.ref_q, B * d.cap);
     DM(d.ref_p, B * d.cap);
     DM(d.ref_s, B * d.cap);
-    DM(d.blk_flag0, B * d.cap + 16);  // (+16: plane_table_update reads the flags in whole dwords)
+    DM(d.blk_flag0, B * d.cap);
     DM(d.work_search, B * d.cap);
     DM(d.work_build, B * d.cap);
     d.n_chunks = (int)((F + 255) / 256);  // must match RQ_THREADS in ll_reg_kernels.hip
@@ -742,7 +738,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.pl_key, d.nn_prev, d.pl_T, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -796,7 +792,6 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
-    c->table_persist = (debug & 4096) ? 0 : 1;  // bit 12: the solver rebuilds its plane table at every launch (A/B)
     c->knn_tile = (debug & 512) ? 0 : ((debug & 1024) ? 1 : 2);  // bit 9: no tile search of the surface queries (A/B, ll_knn_tile.h); bit 10: tile
                                                                  // search only where all queries are searched, the reuse machinery for the rest
     c->max_d2_line_d = p->maximum_dis_line_for_match;

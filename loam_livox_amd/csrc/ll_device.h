@@ -121,8 +121,6 @@ struct RegConst {
     int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
-    int table_persist;   // the plane table of a scan is kept across the ICP iterations of a registration and only updated for the blocks whose
-                         // neighbours changed since the launch that numbered them; 0 = rebuilt by every solver launch (A/B)
     int knn_tile;        // surface searches by the tile kernel (ll_knn_tile.h): 0 = off (A/B), 1 = wherever the per-lane search of ALL surface
                          // queries would run (ICP iterations before knn_reuse_from, or every iteration without reuse), 2 = every ICP iteration
                          // (the reuse machinery is then off: a tile search of everything costs less than classifying + searching the lists)
@@ -152,10 +150,6 @@ struct RegDev {
     // (a scan's ~17 k plane blocks share 2.4 - 4.6 k triples), built by the solver itself at the start of every launch
     unsigned short *blk_id;       // [B][cap_s] plane id of every surface block (relative to its solver workgroup's table region)
     int4 *pl_tab;                 // [B][tab_cap][2] plane table: {n'.x, n'.y}, {n'.z, c = n'.a'} (fp64), frame of pose_last
-    int4 *pl_key;                 // [B][tab_cap] the neighbour triple {nn0, nn2, nn4, -} behind every table entry (the next launches of the registration
-                                  // fill their hash table from these instead of looking at every block again)
-    int4 *nn_prev;                // [B][cap_s] the neighbour triple every surface block was numbered with (what rd.nn held at that launch)
-    int *pl_T;                    // [B] entries of the scan's table that later ICP iterations may build on (0: none)
     int tab_cap;                  // entries per scan: min(cap_s, 24576) rounded up to 4096 (LL_GRP regions of whole 512-thread rounds)
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong

@@ -443,7 +443,6 @@ struct SolveShared {
     int n_active, n_corner_avail, n_surf_avail, n_unique;
     int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
     int pt_T, pt_Tl, pt_kc, pt_priv;  // plane-table path: distinct triples, table entries in LDS, record rounds cached in LDS, private entries
-    int pt_next, pt_fail;             // ... incremental update: next free table entry, "rebuild instead" (probe overflow, table region full)
     double thr;
     int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
     int xch_seq, xch_epoch;                // ... exchanges of partial sums made in this launch, and the launch's number in its registration (granule tags)
@@ -1189,29 +1188,48 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
             return (h2 ^ (h2 >> 16)) & (DD2B_SLOTS - 1);
         };
         unsigned long long valid_mask = 0, cont_mask = 0;
+        // The two marks of a key (landed / landed again) are a returning atomic and one that depends on what it returned.  Key by key
+        // that is one LDS round trip after the other (36 x 2 per pass and thread); in groups of DD_GRP keys the first marks of the whole
+        // group are in flight together before any second mark is formed.  Order within a group is irrelevant: the marks are ORs.
+        constexpr int DD_GRP = 12;
+        static_assert(NK % DD_GRP == 0, "whole groups");
 #pragma unroll
-        for (int k = 0; k < NK; k++) {
-            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
-            const double l1 = l1r[k];
-            const bool valid = l1 >= 0.0;  // inactive slot or NaN (NaN never enters the set)
-            const unsigned int slot = slot_a((unsigned long long)__double_as_longlong(l1));
-            const unsigned int bit0 = valid ? (1u << ((slot & 15u) * 2u)) : 0u;  // 0: a harmless no-op for padding lanes
-            const unsigned int old = atomicOr(&bmA[slot >> 4], bit0);
-            atomicOr(&bmA[slot >> 4], (old & bit0) << 1);
-            if (valid) valid_mask |= 1ull << k;
+        for (int k0 = 0; k0 < NK; k0 += DD_GRP) {
+            if (k0 >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
+            unsigned int word[DD_GRP], bit[DD_GRP], old[DD_GRP];
+#pragma unroll
+            for (int u = 0; u < DD_GRP; u++) {
+                const double l1 = l1r[k0 + u];
+                const bool valid = (k0 + u < kt) && l1 >= 0.0;  // inactive slot or NaN (NaN never enters the set)
+                const unsigned int slot = slot_a((unsigned long long)__double_as_longlong(l1));
+                word[u] = slot >> 4;
+                bit[u] = valid ? (1u << ((slot & 15u) * 2u)) : 0u;  // 0: a harmless no-op for padding lanes
+                if (valid) valid_mask |= 1ull << (k0 + u);
+            }
+#pragma unroll
+            for (int u = 0; u < DD_GRP; u++) old[u] = atomicOr(&bmA[word[u]], bit[u]);
+#pragma unroll
+            for (int u = 0; u < DD_GRP; u++) atomicOr(&bmA[word[u]], (old[u] & bit[u]) << 1);
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NK; k++) {
-            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
-            const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
-            const unsigned int slot = slot_a(key);
-            const bool contested = ((valid_mask >> k) & 1ull) && ((bmA[slot >> 4] >> ((slot & 15u) * 2u)) & 2u);
-            const unsigned int h2 = slot_b(key);
-            const unsigned int bit0 = contested ? (1u << ((h2 & 15u) * 2u)) : 0u;
-            const unsigned int old = atomicOr(&bmB[h2 >> 4], bit0);
-            atomicOr(&bmB[h2 >> 4], (old & bit0) << 1);
-            if (contested) cont_mask |= 1ull << k;
+        for (int k0 = 0; k0 < NK; k0 += DD_GRP) {
+            if (k0 >= kt) continue;
+            unsigned int word[DD_GRP], bit[DD_GRP], old[DD_GRP];
+#pragma unroll
+            for (int u = 0; u < DD_GRP; u++) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k0 + u]);
+                const unsigned int slot = slot_a(key);
+                const bool contested = ((valid_mask >> (k0 + u)) & 1ull) && ((bmA[slot >> 4] >> ((slot & 15u) * 2u)) & 2u);
+                const unsigned int h2 = slot_b(key);
+                word[u] = h2 >> 4;
+                bit[u] = contested ? (1u << ((h2 & 15u) * 2u)) : 0u;
+                if (contested) cont_mask |= 1ull << (k0 + u);
+            }
+#pragma unroll
+            for (int u = 0; u < DD_GRP; u++) old[u] = atomicOr(&bmB[word[u]], bit[u]);
+#pragma unroll
+            for (int u = 0; u < DD_GRP; u++) atomicOr(&bmB[word[u]], (old[u] & bit[u]) << 1);
         }
         __syncthreads();
         unsigned long long twice_mask = 0;
@@ -2137,10 +2155,8 @@ __device__ __forceinline__ unsigned int pt_hash(unsigned int p0, unsigned int p1
 // slot of the triple (inserting it if new), or PT_PRIVATE.  Lock-free and wait-free per probe: a slot belongs to the first
 // {p0, p1} that lands on its `a` word AND the first p2 that lands on its `b` word; a lane that loses either race (or finds
 // another key) probes on, and every lane with the same triple walks the same probe sequence to the same slot.
-// claimed: this call made the slot the triple's (exactly one caller per new triple sees it set)
-__device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned int p0, unsigned int p1, unsigned int p2, bool &claimed)
+__device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned int p0, unsigned int p1, unsigned int p2)
 {
-    claimed = false;
     const unsigned long long A = ((unsigned long long)p0 << 32) | (unsigned long long)p1;
     const unsigned int hh = pt_hash(p0, p1, p2);
     unsigned int h = hh & (PT_SLOTS - 1);
@@ -2161,16 +2177,69 @@ __device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned
         }
         if (a == A) {
             if (bb == PT_EMPTY_B) {
-                if (__hip_atomic_compare_exchange_strong(&ht[h].b, &bb, p2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    bb = p2;
-                    claimed = true;
-                }
+                if (__hip_atomic_compare_exchange_strong(&ht[h].b, &bb, p2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) bb = p2;
             }
             if (bb == p2) return h;
         }
         h = (h + step) & (PT_SLOTS - 1);
     }
     return PT_PRIVATE;
+}
+
+// Eight inserts of one thread in LOCKSTEP (the census' trip of eight blocks).  One after the other they were eight chains of
+// dependent LDS round trips -- read the slot, maybe claim its first word, maybe its second, maybe probe on -- and a wavefront paid
+// every chain in full for its slowest lane (two thirds of the table build).  Here every step of the protocol is issued for all
+// pending triples before any answer is looked at: 16 slot reads in flight, then the claims that are needed, then the probes move on
+// together; a trip costs the LONGEST probe sequence among its 8 x 64 inserts once, not eight of them one after the other.  Same
+// protocol as pt_insert (a slot belongs to the first {p0, p1} on its `a` word and the first p2 on its `b` word; losers probe on),
+// so lanes and threads racing for a slot still agree; which slot a triple gets may differ from the serial order, ids are dense
+// numbers of the occupied slots either way.  todo: bit u = insert t[u].  h8[u]: slot, PT_PRIVATE (no slot within PT_MAX_PROBE) or
+// PT_INACTIVE (bit not set).
+__device__ __forceinline__ void pt_insert8(LL_AS_LDS PtSlot *ht, const int4 (&t)[8], unsigned int todo, unsigned int (&h8)[8])
+{
+    unsigned int h[8], step[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const unsigned int hh = pt_hash((unsigned int)t[u].x, (unsigned int)t[u].y, (unsigned int)t[u].z);
+        h[u] = hh & (PT_SLOTS - 1);
+        step[u] = ((hh >> 13) | 1u) & (PT_SLOTS - 1);
+        h8[u] = ((todo >> u) & 1u) ? PT_PRIVATE : PT_INACTIVE;
+    }
+    for (int probe = 0; probe < PT_MAX_PROBE && todo != 0u; probe++) {
+        unsigned long long a[8];
+        unsigned int bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // (all reads first; a finished insert reads its own slot again: harmless, and no branch around the loads)
+            a[u] = __hip_atomic_load(&ht[h[u]].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bb[u] = __hip_atomic_load(&ht[h[u]].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // claims of the first word, where the slot looked empty
+            const unsigned long long A = ((unsigned long long)(unsigned int)t[u].x << 32) | (unsigned long long)(unsigned int)t[u].y;
+            if (((todo >> u) & 1u) && a[u] == PT_EMPTY_A) {
+                if (__hip_atomic_compare_exchange_strong(&ht[h[u]].a, &a[u], A, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) a[u] = A;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // ... of the second word, where the first is ours
+            const unsigned long long A = ((unsigned long long)(unsigned int)t[u].x << 32) | (unsigned long long)(unsigned int)t[u].y;
+            if (((todo >> u) & 1u) && a[u] == A && bb[u] == PT_EMPTY_B) {
+                if (__hip_atomic_compare_exchange_strong(&ht[h[u]].b, &bb[u], (unsigned int)t[u].z, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    bb[u] = (unsigned int)t[u].z;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (!((todo >> u) & 1u)) continue;
+            const unsigned long long A = ((unsigned long long)(unsigned int)t[u].x << 32) | (unsigned long long)(unsigned int)t[u].y;
+            if (a[u] == A && bb[u] == (unsigned int)t[u].z) {
+                h8[u] = h[u];
+                todo &= ~(1u << u);
+            } else {
+                h[u] = (h[u] + step[u]) & (PT_SLOTS - 1);
+            }
+        }
+    }
 }
 
 // {n', c} of one neighbour triple -> two int4 (the arithmetic of reg_build_kernel's plane blocks: block_plane)
@@ -2240,6 +2309,7 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         LL_TACC(10, t_trip);
         LL_T0(t_ins);
 #endif
+        unsigned int ins = 0;  // (one workgroup per scan: the trip's inserts, in lockstep below)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int j = tid + (k0 + u) * RS_THREADS;
@@ -2252,13 +2322,22 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             if (fl & 8) {
                 if (j >= nSp) nca++; else nsa++;
             }
-            if (!GROUPED || u == g) {
-                const int4 t = t8[GROUPED ? 0 : u];
-                bool claimed_;
-                const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed_) : PT_INACTIVE;
-                if (h == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
-                h8[GROUPED ? 0 : u] = h;
+            if (GROUPED) {
+                if (u == g) {
+                    const int4 t = t8[0];
+                    const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z) : PT_INACTIVE;
+                    if (h == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
+                    h8[0] = h;
+                }
+            } else if (active && j < nS) {
+                ins |= 1u << u;
             }
+        }
+        if constexpr (!GROUPED) {
+            pt_insert8(ht, t8, ins, h8);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (h8[u] == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
         }
         // the slot indices leave together at the end of the trip: a store between the inserts makes the wait for the next
         // flag byte a wait for that store (the counters are imprecise behind divergent code), one HBM round trip per block
@@ -2266,8 +2345,6 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         for (int u = 0; u < 8; u++) {
             const int j = tid + (k0 + u) * RS_THREADS;
             if ((!GROUPED || u == g) && j < nS) gstore_u16(ids + j, (unsigned short)h8[GROUPED ? 0 : u]);
-            // the triples this numbering was made from: the next launches of the registration compare against them (plane_table_update)
-            if (!GROUPED && rc.table_persist && j < nS) gstore_i4(rd.nn_prev + (size_t)b * rd.cap_s + j, t8[u]);
         }
 #ifdef LL_SOLVE_TIMING
         LL_TACC(11, t_ins);
@@ -2343,14 +2420,12 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
     for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
     for (int i0 = tid; i0 < T; i0 += 4 * RS_THREADS) {
         f4 m[4][3];
-        int4 key4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int id = i0 + u * RS_THREADS;
             const unsigned int sl = slot_of_id[id < T ? id : i0];
             const unsigned long long sa = ht[sl].a;
             const unsigned int sb2 = ht[sl].b;
-            key4[u] = make_int4((int)(unsigned int)(sa >> 32), (int)(unsigned int)sa, (int)sb2, 0);
             m[u][0] = gload_pt(map_pts + (unsigned int)(sa >> 32));
             m[u][1] = gload_pt(map_pts + (unsigned int)sa);
             m[u][2] = gload_pt(map_pts + sb2);
@@ -2366,7 +2441,6 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             if (id < T) {
                 gstore_i4(tabG + 2 * id, make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1])));
                 gstore_i4(tabG + 2 * id + 1, make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0])));
-                if (!GROUPED && rc.table_persist) gstore_i4(rd.pl_key + (size_t)b * rd.tab_cap + id, key4[u]);  // the entry's triple: the next launches look it up again
             }
         }
     }
@@ -2448,265 +2522,11 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         sh.pt_T = sh.pt_priv > 0 ? PT_TCAP + 1 : T;
         sh.pt_Tl = Tl;
         sh.pt_kc = kc < kp ? kc : kp;
-        // what the next ICP iterations of this registration may build on (0: nothing -- private entries have no key)
-        if (!GROUPED) rd.pl_T[b] = (rc.table_persist && sh.pt_priv == 0 && T <= rd.tab_cap) ? T : 0;
     }
     __syncthreads();
     LL_TACC(15, t_p2);
     LL_TACC(8, t_tab);
     return act;
-}
-
-// ICP iterations >= 1 of a registration (one workgroup per scan): the table of the previous launch is still valid -- rd.pl_tab in the frame
-// of pose_last, rd.pl_key the triple behind every entry, rd.blk_id the entry of every block, rd.nn_prev the triple every block was
-// numbered with, rd.pl_T the number of entries -- except for the blocks whose neighbours the k-NN stage has changed since (a few per
-// cent of a scan after the first iterations).  So instead of hashing all ~17 k triples again (34 dependent LDS insert chains per
-// thread: two thirds of the rebuild's time):
-//   1. the flag bytes come in through LDS in ONE round trip (whole dwords, 8 - 9 in flight per thread) -> activity mask + census;
-//   2. every active plane block's triple is compared with the one it was numbered with (two coalesced 16-byte streams, eight + eight
-//      loads in flight); the changed ones go to a dense list in LDS;
-//   3. only if there are any, the LDS hash table is filled again from the T stored keys (7 - 9 inserts per thread instead of 34), the
-//      changed blocks -- spread evenly over the threads, four in flight -- are looked up / appended behind the table, and their ids
-//      and remembered triples rewritten;
-//   4. table -> LDS as in the rebuild.
-// Returns false (uniformly) when the caller must rebuild from scratch instead: no table to build on, more than a tenth of the
-// blocks changed (numbering everything costs less than that many lookups), a crowded probe sequence, a full table region, a table
-// that has just outgrown its LDS part (the rebuild drops the entries nobody uses any more).  Same table entry for the same triple as
-// a rebuild computes (pt_plane = block_plane), so the evaluations see bit-identical planes.
-__device__ __noinline__ bool plane_table_update(const RegDev &rd, const RegConst &rc, const f4 *map_pts, int b, const RegState *st, int nC, int nS,
-                                                uint4 *s_raw, SolveShared &sh, unsigned long long &act_out)
-{
-    const int tid = threadIdx.x;
-    const int T0 = rd.pl_T[b];
-    if (T0 <= 0) return false;
-    const int kp = (nS + RS_THREADS - 1) / RS_THREADS;
-    const int nSp = kp * RS_THREADS;
-    const int totp = nSp + nC;
-    const size_t sb = (size_t)b * rd.cap;
-    LL_AS_LDS PtSlot *ht = (LL_AS_LDS PtSlot *)s_raw;
-    // the changed blocks' indices, dense, behind the hash table (where the rebuild keeps its id -> slot map): <= PT_SLOTS entries
-    LL_AS_LDS unsigned short *dlist = (LL_AS_LDS unsigned short *)((LL_AS_LDS char *)s_raw + PT_MAP_OFF);
-    const int4 *nn = rd.nn + sb + rd.cap_c;
-    int4 *nnp = rd.nn_prev + (size_t)b * rd.cap_s;
-    unsigned short *ids = rd.blk_id + (size_t)b * rd.cap_s;
-    LL_T0(t_census);
-    // ---- 1. flags through LDS: the surface blocks' bytes at s_raw[0 ..), the corner blocks' behind them ---------------------------
-    LL_AS_LDS unsigned char *lf = (LL_AS_LDS unsigned char *)s_raw;
-    const unsigned char *fs_g = rd.blk_flag0 + sb + rd.cap_c, *fc_g = rd.blk_flag0 + sb;
-    const int sh_s = (int)((size_t)fs_g & 3), sh_c = (int)((size_t)fc_g & 3);  // (the regions start wherever cap_c puts them)
-    const int nw_s = (sh_s + nS + 3) >> 2, nw_c = (sh_c + nC + 3) >> 2;
-    const int off_c = (nw_s << 2) + 16;  // byte offset of the corner bytes in LDS
-    {
-        const unsigned int *gs_w = (const unsigned int *)(fs_g - sh_s), *gc_w = (const unsigned int *)(fc_g - sh_c);
-        LL_AS_LDS unsigned int *lw = (LL_AS_LDS unsigned int *)s_raw;
-        for (int d0 = tid; d0 < nw_s; d0 += 8 * RS_THREADS) {
-            unsigned int w8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int d = d0 + u * RS_THREADS;
-                w8[u] = *(const LL_AS_GLOBAL unsigned int *)(gs_w + (d < nw_s ? d : d0));  // (the last word may reach up to 3 bytes past the scan's flags: blk_flag0 is padded)
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int d = d0 + u * RS_THREADS;
-                if (d < nw_s) lw[d] = w8[u];
-            }
-        }
-        for (int d = tid; d < nw_c; d += RS_THREADS) lw[(off_c >> 2) + d] = *(const LL_AS_GLOBAL unsigned int *)(gc_w + d);
-        if (tid == 0) sh.pt_next = 0;  // (first the length of the list of changed blocks)
-    }
-    __syncthreads();
-    unsigned long long act = 0, plane_act = 0;
-    int na = 0, nca = 0, nsa = 0;
-    for (int k = 0; k * RS_THREADS < totp; k++) {
-        const int j = tid + k * RS_THREADS;
-        unsigned char fl = 0;
-        if (j < nS)
-            fl = lf[sh_s + j];
-        else if (j >= nSp && j < totp)
-            fl = lf[off_c + sh_c + (j - nSp)];
-        if (fl & BLK_ACTIVE) {
-            act |= 1ull << k;
-            na++;
-            if (j < nS) plane_act |= 1ull << k;
-        }
-        if (fl & 8) {
-            if (j >= nSp) nca++; else nsa++;
-        }
-    }
-    // ---- 2. which active plane blocks have new neighbours --------------------------------------------------------------------------
-    unsigned long long changed = 0;
-    for (int k0 = 0; k0 < kp; k0 += 8) {
-        int4 a8[8], p8[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int j = tid + (k0 + u) * RS_THREADS;
-            const int jc = j < nS ? j : 0;
-            a8[u] = gload_i4(nn + jc);
-            p8[u] = gload_i4(nnp + jc);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (k0 + u < kp && ((plane_act >> (k0 + u)) & 1ull) &&
-                (a8[u].x != p8[u].x || a8[u].y != p8[u].y || a8[u].z != p8[u].z || a8[u].w != p8[u].w))  // (.w: a block that was not active then has no id)
-                changed |= 1ull << (k0 + u);
-        }
-    }
-    const int my_nd = __popcll(changed);
-    int my_base = 0;
-    if (my_nd > 0) my_base = atomicAdd(&sh.pt_next, my_nd);
-    {
-        const unsigned long long tot = block_sum_u64((unsigned long long)na | ((unsigned long long)nca << 20) | ((unsigned long long)nsa << 40), sh);
-        na = (int)(tot & 0xfffffull);
-        nca = (int)((tot >> 20) & 0xfffffull);
-        nsa = (int)((tot >> 40) & 0xfffffull);
-    }
-    const int nd = sh.pt_next;  // (block_sum's barriers have published it; they also end the reads of the staged flags)
-    if (nd * 10 > nS || nd > PT_SLOTS) return false;  // (uniform)
-    if (rc.subsample_seed && na > rc.max_blocks) {  // a13 as in census_and_plane_table
-        int kept = 0;
-        for (int k = 0; k * RS_THREADS < totp; k++) {
-            if (!((act >> k) & 1ull)) continue;
-            const int j = tid + k * RS_THREADS;
-            const int jref = j >= nSp ? j - nSp : nC + j;
-            if (subsample_drop_block(rc.subsample_seed, st->icp_iters, jref, na, rc.max_blocks))
-                act &= ~(1ull << k);
-            else
-                kept++;
-        }
-        na = block_sum_int(kept, sh);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        sh.n_active = na;
-        sh.n_corner_avail = nca;
-        sh.n_surf_avail = nsa;
-        sh.pt_next = T0;
-        sh.pt_fail = 0;
-        sh.pt_priv = 0;
-    }
-    LL_TACC(6, t_census);
-    LL_T0(t_tab);
-    int4 *tabG = pt_table_global(rd, b, 0, false);
-    int4 *keyG = rd.pl_key + (size_t)b * rd.tab_cap;
-    if (nd > 0) {  // (uniform)
-        // ---- 3. hash table from the stored keys, the changed blocks through it -----------------------------------------------------
-        for (int e = tid; e < PT_SLOTS; e += RS_THREADS) lds_store_i4((int4 *)s_raw + e, make_int4(-1, -1, -1, -1));
-        {
-            int w = my_base;
-            for (int k = 0; k < kp; k++)
-                if ((changed >> k) & 1ull) dlist[w++] = (unsigned short)(tid + k * RS_THREADS);
-        }
-        __syncthreads();
-        for (int i0 = tid; i0 < T0; i0 += 4 * RS_THREADS) {  // the stored keys, each under its old id
-            int4 k4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int id = i0 + u * RS_THREADS;
-                k4[u] = gload_i4(keyG + (id < T0 ? id : i0));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int id = i0 + u * RS_THREADS;
-                if (id >= T0) continue;
-                bool claimed;
-                const unsigned int h = pt_insert(ht, (unsigned int)k4[u].x, (unsigned int)k4[u].y, (unsigned int)k4[u].z, claimed);
-                if (h == PT_PRIVATE)
-                    sh.pt_fail = 1;
-                else
-                    ht[h].id = (unsigned int)id;
-            }
-        }
-        __syncthreads();
-        double pose_last[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
-        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {  // a changed block's triple: its entry, appended behind the table when new
-            int4 t4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int e = e0 + u * RS_THREADS;
-                t4[u] = gload_i4(nn + (int)dlist[e < nd ? e : e0]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int e = e0 + u * RS_THREADS;
-                if (e >= nd) continue;
-                const int4 t = t4[u];
-                bool claimed;
-                const unsigned int h = pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, claimed);
-                if (h == PT_PRIVATE) {
-                    sh.pt_fail = 1;
-                } else if (claimed) {
-                    const int id = atomicAdd(&sh.pt_next, 1);
-                    if (id >= rd.tab_cap) {
-                        sh.pt_fail = 1;
-                    } else {
-                        ht[h].id = (unsigned int)id;
-                        int4 ob, oc;
-                        pt_plane(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
-                        gstore_i4(tabG + 2 * id, ob);
-                        gstore_i4(tabG + 2 * id + 1, oc);
-                        gstore_i4(keyG + id, make_int4(t.x, t.y, t.z, 0));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (sh.pt_fail) return false;  // (uniform; nothing of the scan's persistent state has been touched but appended entries nobody refers to)
-        for (int e0 = tid; e0 < nd; e0 += 4 * RS_THREADS) {  // ... and the blocks' ids and remembered triples (every new entry has its id by now)
-            int4 t4[4];
-            int j4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int e = e0 + u * RS_THREADS;
-                j4[u] = (int)dlist[e < nd ? e : e0];
-                t4[u] = gload_i4(nn + j4[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int e = e0 + u * RS_THREADS;
-                if (e >= nd) continue;
-                bool claimed;
-                const unsigned int h = pt_insert(ht, (unsigned int)t4[u].x, (unsigned int)t4[u].y, (unsigned int)t4[u].z, claimed);  // (finds it)
-                gstore_u16(ids + j4[u], (unsigned short)ht[h < PT_SLOTS ? h : 0u].id);
-                gstore_i4(nnp + j4[u], t4[u]);
-            }
-        }
-        __threadfence_block();
-    }
-    __syncthreads();
-    const int T = sh.pt_next;
-    if (T > PT_TCAP && T0 <= PT_TCAP) {  // (uniform) just outgrew the LDS part: a rebuild drops the entries no block uses any more
-        return false;
-    }
-    // ---- 4. the first PT_TCAP entries -> LDS; the rest of s_raw caches records (as census_and_plane_table) -------------------------
-    const int Tl = T < PT_TCAP ? T : PT_TCAP;
-    int4 *s_tab = (int4 *)s_raw;
-    for (int e0 = tid; e0 < 2 * Tl; e0 += 8 * RS_THREADS) {
-        int4 v8[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * RS_THREADS;
-            v8[u] = gload_i4(tabG + (e < 2 * Tl ? e : e0));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * RS_THREADS;
-            if (e < 2 * Tl) lds_store_i4(s_tab + e, v8[u]);
-        }
-    }
-    if (tid == 0) {
-        const int kc = ((PT_TCAP - Tl) * 2) / RS_THREADS;
-        sh.pt_T = T;
-        sh.pt_Tl = Tl;
-        sh.pt_kc = kc < kp ? kc : kp;
-        rd.pl_T[b] = T;
-    }
-    __syncthreads();
-    LL_TACC(8, t_tab);
-    act_out = act;
-    return true;
 }
 
 // after the inlier phase has used s_raw for its tables
@@ -3059,11 +2879,7 @@ __device__ void solve_fast3(const RegDev &rd, const RegConst &rc, const f4 *map_
 
     // ---- flags -> the thread's activity mask (bit k: block tid + k * RS_THREADS in the order planes, padding, lines), census
     //      (PCR:325,425), and the scan's plane table (this workgroup's share of it) ------------------------------------------
-    unsigned long long act = 0;
-    bool updated = false;
-    // (with the plane PCA check a block's activity also depends on its other two neighbours, which the remembered triple does not show)
-    if (!GROUPED && rc.table_persist && !rc.check_plane_pca && st->icp_iters > 0) updated = plane_table_update(rd, rc, map_pts, b, st, nC, nS, s_raw, sh, act);
-    if (!updated) act = census_and_plane_table<GROUPED>(rd, rc, map_pts, b, st, nC, nS, s_raw, sh);
+    unsigned long long act = census_and_plane_table<GROUPED>(rd, rc, map_pts, b, st, nC, nS, s_raw, sh);
 
     // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------
     solver_lm3<true, GROUPED>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, act, s_raw, st->pose_last, sh);

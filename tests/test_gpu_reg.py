@@ -360,27 +360,6 @@ def test_tile_search_changes_nothing(dev_map, small_world, scans, n):
         assert np.array_equal(oi, outs[0][3][i][2]) and np.array_equal(od, outs[0][3][i][3])
 
 
-@pytest.mark.parametrize("n", [17, 40])
-def test_plane_table_persistence_changes_nothing(dev_map, scans, n):
-    """Batches of more than 16 scans (one solver workgroup per scan) keep a scan's plane table across the ICP iterations of a
-    registration and only renumber the blocks whose neighbour triple changed (BLK_DIRTY set by the k-NN stage, plane_table_update):
-    same table entry for the same triple, so every pose bit and every count equals the per-launch rebuild -- with the tile search,
-    with the per-lane search + neighbour reuse (stable queries keep their flag bytes), and with the per-lane search of everything."""
-    feats = [(f[4], f[5]) for f in (oracle_features(sc) for sc in scans)]
-    pl = np.stack([scans[i % len(scans)].pose_init for i in range(n)])
-    fcs, fss = [feats[i % len(scans)][0] for i in range(n)], [feats[i % len(scans)][1] for i in range(n)]
-    for base in ({}, {"no_knn_tile": True}, {"no_knn_tile": True, "no_knn_reuse": True}, {"knn_tile_with_reuse": True}):
-        outs = []
-        for kw in ({}, {"no_table_persist": True}):
-            reg = Point_cloud_registration(max_scans=n, max_features=24000)
-            reg.set_debug(False, **base, **kw)
-            set_params(reg, 10, 20, 1)
-            res, pc, _, reps = reg.solve_batch(dev_map, fcs, fss, pl, pl)
-            outs.append((res.copy(), pc.copy(), [(r.lm_iterations_total, r.n_blocks_last, r.icp_iterations, r.final_cost) for r in reps]))
-            reg.close()
-        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2], base
-
-
 def test_tile_search_sparse_map_ties_and_strays(gpu_lib):
     """a uniform random cloud (most lanes need the rings), exact duplicates among the map points (ties by index) and queries outside
     the grid / not finite: the tile kernel's fall-back lanes; checked against the k-d tree through the registrar's debug tap"""
