@@ -1188,48 +1188,29 @@ __device__ __forceinline__ void inlier_threshold_regs(const double (&l1r)[NK], i
             return (h2 ^ (h2 >> 16)) & (DD2B_SLOTS - 1);
         };
         unsigned long long valid_mask = 0, cont_mask = 0;
-        // The two marks of a key (landed / landed again) are a returning atomic and one that depends on what it returned.  Key by key
-        // that is one LDS round trip after the other (36 x 2 per pass and thread); in groups of DD_GRP keys the first marks of the whole
-        // group are in flight together before any second mark is formed.  Order within a group is irrelevant: the marks are ORs.
-        constexpr int DD_GRP = 12;
-        static_assert(NK % DD_GRP == 0, "whole groups");
 #pragma unroll
-        for (int k0 = 0; k0 < NK; k0 += DD_GRP) {
-            if (k0 >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
-            unsigned int word[DD_GRP], bit[DD_GRP], old[DD_GRP];
-#pragma unroll
-            for (int u = 0; u < DD_GRP; u++) {
-                const double l1 = l1r[k0 + u];
-                const bool valid = (k0 + u < kt) && l1 >= 0.0;  // inactive slot or NaN (NaN never enters the set)
-                const unsigned int slot = slot_a((unsigned long long)__double_as_longlong(l1));
-                word[u] = slot >> 4;
-                bit[u] = valid ? (1u << ((slot & 15u) * 2u)) : 0u;  // 0: a harmless no-op for padding lanes
-                if (valid) valid_mask |= 1ull << (k0 + u);
-            }
-#pragma unroll
-            for (int u = 0; u < DD_GRP; u++) old[u] = atomicOr(&bmA[word[u]], bit[u]);
-#pragma unroll
-            for (int u = 0; u < DD_GRP; u++) atomicOr(&bmA[word[u]], (old[u] & bit[u]) << 1);
+        for (int k = 0; k < NK; k++) {
+            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
+            const double l1 = l1r[k];
+            const bool valid = l1 >= 0.0;  // inactive slot or NaN (NaN never enters the set)
+            const unsigned int slot = slot_a((unsigned long long)__double_as_longlong(l1));
+            const unsigned int bit0 = valid ? (1u << ((slot & 15u) * 2u)) : 0u;  // 0: a harmless no-op for padding lanes
+            const unsigned int old = atomicOr(&bmA[slot >> 4], bit0);
+            atomicOr(&bmA[slot >> 4], (old & bit0) << 1);
+            if (valid) valid_mask |= 1ull << k;
         }
         __syncthreads();
 #pragma unroll
-        for (int k0 = 0; k0 < NK; k0 += DD_GRP) {
-            if (k0 >= kt) continue;
-            unsigned int word[DD_GRP], bit[DD_GRP], old[DD_GRP];
-#pragma unroll
-            for (int u = 0; u < DD_GRP; u++) {
-                const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k0 + u]);
-                const unsigned int slot = slot_a(key);
-                const bool contested = ((valid_mask >> (k0 + u)) & 1ull) && ((bmA[slot >> 4] >> ((slot & 15u) * 2u)) & 2u);
-                const unsigned int h2 = slot_b(key);
-                word[u] = h2 >> 4;
-                bit[u] = contested ? (1u << ((h2 & 15u) * 2u)) : 0u;
-                if (contested) cont_mask |= 1ull << (k0 + u);
-            }
-#pragma unroll
-            for (int u = 0; u < DD_GRP; u++) old[u] = atomicOr(&bmB[word[u]], bit[u]);
-#pragma unroll
-            for (int u = 0; u < DD_GRP; u++) atomicOr(&bmB[word[u]], (old[u] & bit[u]) << 1);
+        for (int k = 0; k < NK; k++) {
+            if (k >= kt) continue;  // not `break`: an early exit keeps the loop rolled and the register tile in scratch
+            const unsigned long long key = (unsigned long long)__double_as_longlong(l1r[k]);
+            const unsigned int slot = slot_a(key);
+            const bool contested = ((valid_mask >> k) & 1ull) && ((bmA[slot >> 4] >> ((slot & 15u) * 2u)) & 2u);
+            const unsigned int h2 = slot_b(key);
+            const unsigned int bit0 = contested ? (1u << ((h2 & 15u) * 2u)) : 0u;
+            const unsigned int old = atomicOr(&bmB[h2 >> 4], bit0);
+            atomicOr(&bmB[h2 >> 4], (old & bit0) << 1);
+            if (contested) cont_mask |= 1ull << k;
         }
         __syncthreads();
         unsigned long long twice_mask = 0;
@@ -2186,62 +2167,6 @@ __device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned
     return PT_PRIVATE;
 }
 
-// Eight inserts of one thread in LOCKSTEP (the census' trip of eight blocks).  One after the other they were eight chains of
-// dependent LDS round trips -- read the slot, maybe claim its first word, maybe its second, maybe probe on -- and a wavefront paid
-// every chain in full for its slowest lane (two thirds of the table build).  Here every step of the protocol is issued for all
-// pending triples before any answer is looked at: 16 slot reads in flight, then the claims that are needed, then the probes move on
-// together; a trip costs the LONGEST probe sequence among its 8 x 64 inserts once, not eight of them one after the other.  Same
-// protocol as pt_insert (a slot belongs to the first {p0, p1} on its `a` word and the first p2 on its `b` word; losers probe on),
-// so lanes and threads racing for a slot still agree; which slot a triple gets may differ from the serial order, ids are dense
-// numbers of the occupied slots either way.  todo: bit u = insert t[u].  h8[u]: slot, PT_PRIVATE (no slot within PT_MAX_PROBE) or
-// PT_INACTIVE (bit not set).
-__device__ __forceinline__ void pt_insert8(LL_AS_LDS PtSlot *ht, const int4 (&t)[8], unsigned int todo, unsigned int (&h8)[8])
-{
-    unsigned int h[8], step[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const unsigned int hh = pt_hash((unsigned int)t[u].x, (unsigned int)t[u].y, (unsigned int)t[u].z);
-        h[u] = hh & (PT_SLOTS - 1);
-        step[u] = ((hh >> 13) | 1u) & (PT_SLOTS - 1);
-        h8[u] = ((todo >> u) & 1u) ? PT_PRIVATE : PT_INACTIVE;
-    }
-    for (int probe = 0; probe < PT_MAX_PROBE && todo != 0u; probe++) {
-        unsigned long long a[8];
-        unsigned int bb[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {  // (all reads first; a finished insert reads its own slot again: harmless, and no branch around the loads)
-            a[u] = __hip_atomic_load(&ht[h[u]].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            bb[u] = __hip_atomic_load(&ht[h[u]].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {  // claims of the first word, where the slot looked empty
-            const unsigned long long A = ((unsigned long long)(unsigned int)t[u].x << 32) | (unsigned long long)(unsigned int)t[u].y;
-            if (((todo >> u) & 1u) && a[u] == PT_EMPTY_A) {
-                if (__hip_atomic_compare_exchange_strong(&ht[h[u]].a, &a[u], A, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) a[u] = A;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {  // ... of the second word, where the first is ours
-            const unsigned long long A = ((unsigned long long)(unsigned int)t[u].x << 32) | (unsigned long long)(unsigned int)t[u].y;
-            if (((todo >> u) & 1u) && a[u] == A && bb[u] == PT_EMPTY_B) {
-                if (__hip_atomic_compare_exchange_strong(&ht[h[u]].b, &bb[u], (unsigned int)t[u].z, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                    bb[u] = (unsigned int)t[u].z;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (!((todo >> u) & 1u)) continue;
-            const unsigned long long A = ((unsigned long long)(unsigned int)t[u].x << 32) | (unsigned long long)(unsigned int)t[u].y;
-            if (a[u] == A && bb[u] == (unsigned int)t[u].z) {
-                h8[u] = h[u];
-                todo &= ~(1u << u);
-            } else {
-                h[u] = (h[u] + step[u]) & (PT_SLOTS - 1);
-            }
-        }
-    }
-}
-
 // {n', c} of one neighbour triple -> two int4 (the arithmetic of reg_build_kernel's plane blocks: block_plane)
 __device__ __forceinline__ void pt_plane(const f4 *map_pts, const double *pose_last, unsigned int i0, unsigned int i1, unsigned int i2, int4 &ob, int4 &oc)
 {
@@ -2309,7 +2234,6 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
         LL_TACC(10, t_trip);
         LL_T0(t_ins);
 #endif
-        unsigned int ins = 0;  // (one workgroup per scan: the trip's inserts, in lockstep below)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int j = tid + (k0 + u) * RS_THREADS;
@@ -2322,22 +2246,12 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             if (fl & 8) {
                 if (j >= nSp) nca++; else nsa++;
             }
-            if (GROUPED) {
-                if (u == g) {
-                    const int4 t = t8[0];
-                    const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z) : PT_INACTIVE;
-                    if (h == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
-                    h8[0] = h;
-                }
-            } else if (active && j < nS) {
-                ins |= 1u << u;
+            if (!GROUPED || u == g) {
+                const int4 t = t8[GROUPED ? 0 : u];
+                const unsigned int h = (active && j < nS) ? pt_insert(ht, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z) : PT_INACTIVE;
+                if (h == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
+                h8[GROUPED ? 0 : u] = h;
             }
-        }
-        if constexpr (!GROUPED) {
-            pt_insert8(ht, t8, ins, h8);
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (h8[u] == PT_PRIVATE) atomicAdd(&sh.pt_priv, 1);
         }
         // the slot indices leave together at the end of the trip: a store between the inserts makes the wait for the next
         // flag byte a wait for that store (the counters are imprecise behind divergent code), one HBM round trip per block

@@ -57,6 +57,10 @@ template <typename T> inline T sum4( const T &e0, const T &e1, const T &e2, cons
 } // namespace ll_detail
 
 template <typename T, int R, int C> class Matrix;
+const int Dynamic = -1;  // (cell_map_keyframe.hpp's direction images: the specialisation lives in ll_stub_eigen_dyn.h)
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+template <typename T, int R, int C> class ColRef;
+template <typename T, int R, int C> struct ReverseHelper;
 
 template <typename T, int R, int C> class CommaInit
 {
@@ -259,6 +263,108 @@ template <typename T, int R, int C> class Matrix
                 os << "\n";
         }
         return os;
+    }
+
+    // ---- what source/cell_map_keyframe.hpp needs on top (Points_cloud_cell's moments, Maps_keyframe's eigen frames) ----------
+    template <typename S> Matrix &operator/=( const S &s )
+    {
+        for ( int i = 0; i < R * C; i++ )
+            d[ i ] = d[ i ] / T( s );  // (Eigen converts the scalar to the matrix's scalar type first)
+        return *this;
+    }
+    template <typename S> Matrix &operator*=( const S &s )
+    {
+        for ( int i = 0; i < R * C; i++ )
+            d[ i ] = d[ i ] * T( s );
+        return *this;
+    }
+    Matrix<T, R, R> asDiagonal() const
+    {
+        static_assert( C == 1, "asDiagonal of a vector" );
+        Matrix<T, R, R> o;
+        for ( int i = 0; i < R; i++ )
+            o( i, i ) = d[ i ];
+        return o;
+    }
+    // 3 x 3 inverse by cofactors (Eigen: compute_inverse_size3_helper -- cofactors over the determinant)
+    Matrix inverse() const
+    {
+        static_assert( R == 3 && C == 3, "inverse: 3 x 3 only" );
+        const Matrix &m = *this;
+        Matrix        o;
+        const T       c00 = m( 1, 1 ) * m( 2, 2 ) - m( 1, 2 ) * m( 2, 1 ), c10 = m( 1, 2 ) * m( 2, 0 ) - m( 1, 0 ) * m( 2, 2 ),
+                c20 = m( 1, 0 ) * m( 2, 1 ) - m( 1, 1 ) * m( 2, 0 );
+        const T det = ll_detail::sum3<T>( m( 0, 0 ) * c00, m( 0, 1 ) * c10, m( 0, 2 ) * c20 );
+        const T inv = T( 1 ) / det;
+        o( 0, 0 ) = c00 * inv;
+        o( 1, 0 ) = c10 * inv;
+        o( 2, 0 ) = c20 * inv;
+        o( 0, 1 ) = ( m( 0, 2 ) * m( 2, 1 ) - m( 0, 1 ) * m( 2, 2 ) ) * inv;
+        o( 1, 1 ) = ( m( 0, 0 ) * m( 2, 2 ) - m( 0, 2 ) * m( 2, 0 ) ) * inv;
+        o( 2, 1 ) = ( m( 0, 1 ) * m( 2, 0 ) - m( 0, 0 ) * m( 2, 1 ) ) * inv;
+        o( 0, 2 ) = ( m( 0, 1 ) * m( 1, 2 ) - m( 0, 2 ) * m( 1, 1 ) ) * inv;
+        o( 1, 2 ) = ( m( 0, 2 ) * m( 1, 0 ) - m( 0, 0 ) * m( 1, 2 ) ) * inv;
+        o( 2, 2 ) = ( m( 0, 0 ) * m( 1, 1 ) - m( 0, 1 ) * m( 1, 0 ) ) * inv;
+        return o;
+    }
+    template <int BR, int BC> Matrix<T, BR, BC> block( int i, int j ) const
+    {
+        Matrix<T, BR, BC> o;
+        for ( int r = 0; r < BR; r++ )
+            for ( int c = 0; c < BC; c++ )
+                o( r, c ) = ( *this )( i + r, j + c );
+        return o;
+    }
+    Matrix<T, R, 1> col( int j ) const
+    {
+        Matrix<T, R, 1> o;
+        for ( int r = 0; r < R; r++ )
+            o( r ) = ( *this )( r, j );
+        return o;
+    }
+    ColRef<T, R, C> col( int j ) { return ColRef<T, R, C>( *this, j ); }
+    ReverseHelper<T, R, C> rowwise() const { return ReverseHelper<T, R, C>( *this, 1 ); }  // .reverse(): every row reversed
+    ReverseHelper<T, R, C> colwise() const { return ReverseHelper<T, R, C>( *this, 0 ); }  // .reverse(): every column reversed
+    Matrix eval() const { return *this; }
+    T maxCoeff() const
+    {
+        T m = d[ 0 ];
+        for ( int i = 1; i < R * C; i++ )
+            if ( d[ i ] > m ) m = d[ i ];
+        return m;
+    }
+};
+
+// lvalue column of a fixed-size matrix: m.col( 2 ) = m.col( 0 ).cross( m.col( 1 ) )
+template <typename T, int R, int C> class ColRef
+{
+    Matrix<T, R, C> &m;
+    int              j;
+
+  public:
+    ColRef( Matrix<T, R, C> &mm, int jj ) : m( mm ), j( jj ) {}
+    operator Matrix<T, R, 1>() const { return const_cast<const Matrix<T, R, C> &>( m ).col( j ); }
+    ColRef &operator=( const Matrix<T, R, 1> &v )
+    {
+        for ( int r = 0; r < R; r++ )
+            m( r, j ) = v( r );
+        return *this;
+    }
+    Matrix<T, R, 1> cross( const Matrix<T, R, 1> &o ) const { return Matrix<T, R, 1>( *this ).cross( o ); }
+    Matrix<T, R, 1> cross( const ColRef &o ) const { return Matrix<T, R, 1>( *this ).cross( Matrix<T, R, 1>( o ) ); }
+};
+template <typename T, int R, int C> struct ReverseHelper
+{
+    Matrix<T, R, C> m;
+    int             rowwise;
+    ReverseHelper( const Matrix<T, R, C> &mm, int rw ) : m( mm ), rowwise( rw ) {}
+    Matrix<T, R, C> reverse() const
+    {
+        Matrix<T, R, C> o;
+        for ( int r = 0; r < R; r++ )
+            for ( int c = 0; c < C; c++ )
+                o( r, c ) = rowwise ? m( r, C - 1 - c ) : m( R - 1 - r, c );
+        return o;
     }
 };
 
@@ -542,19 +648,25 @@ template <typename T, int R, int C> class Map<Matrix<T, R, C>>
     }
 };
 
-// SelfAdjointEigenSolver<Matrix3d>: eigenvalues ascending.  Only the optional PCA checks (PCR:259-292, 357-389; off by
-// default) use it.  Cyclic Jacobi in double; Eigen's own closed-form/QR path differs in the last bits only.
+// SelfAdjointEigenSolver<Matrix<S, 3, 3>>, S = double (the optional PCA checks, PCR:259-292, 357-389) or float (the cell moments and
+// key-frame frames of cell_map_keyframe.hpp:239-249, 1554-1567): eigenvalues ascending, eigenvectors as columns in the same order.
+// Cyclic Jacobi in double on the symmetric input, results rounded to S; Eigen's own tridiagonal-QR path differs in the last bits,
+// and in the SIGN of an eigenvector (here: the component of largest magnitude is positive).
 template <typename M> class SelfAdjointEigenSolver
 {
-    Matrix<double, 3, 1> ev;
+    typedef typename M::Scalar S;
+    Matrix<S, 3, 1>            ev;
+    Matrix<S, 3, 3>            evec;
 
   public:
-    explicit SelfAdjointEigenSolver( const Matrix<double, 3, 3> &A )
+    SelfAdjointEigenSolver() {}
+    explicit SelfAdjointEigenSolver( const Matrix<S, 3, 3> &A ) { compute( A ); }
+    SelfAdjointEigenSolver &compute( const Matrix<S, 3, 3> &A )
     {
-        double a[ 3 ][ 3 ];
+        double a[ 3 ][ 3 ], v[ 3 ][ 3 ] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
         for ( int r = 0; r < 3; r++ )
             for ( int c = 0; c < 3; c++ )
-                a[ r ][ c ] = A( r, c );
+                a[ r ][ c ] = 0.5 * ( ( double ) A( r, c ) + ( double ) A( c, r ) );
         for ( int sweep = 0; sweep < 60; sweep++ )
         {
             double off = a[ 0 ][ 1 ] * a[ 0 ][ 1 ] + a[ 0 ][ 2 ] * a[ 0 ][ 2 ] + a[ 1 ][ 2 ] * a[ 1 ][ 2 ];
@@ -580,21 +692,40 @@ template <typename M> class SelfAdjointEigenSolver
                         a[ p ][ k ] = cs * apk - sn * aqk;
                         a[ q ][ k ] = sn * apk + cs * aqk;
                     }
+                    for ( int k = 0; k < 3; k++ )
+                    {
+                        double vkp = v[ k ][ p ], vkq = v[ k ][ q ];
+                        v[ k ][ p ] = cs * vkp - sn * vkq;
+                        v[ k ][ q ] = sn * vkp + cs * vkq;
+                    }
                 }
         }
+        int    idx[ 3 ] = { 0, 1, 2 };
         double e[ 3 ] = { a[ 0 ][ 0 ], a[ 1 ][ 1 ], a[ 2 ][ 2 ] };
         for ( int i = 0; i < 3; i++ )
             for ( int j = i + 1; j < 3; j++ )
-                if ( e[ j ] < e[ i ] )
+                if ( e[ idx[ j ] ] < e[ idx[ i ] ] )
                 {
-                    double t = e[ i ];
-                    e[ i ] = e[ j ];
-                    e[ j ] = t;
+                    int t = idx[ i ];
+                    idx[ i ] = idx[ j ];
+                    idx[ j ] = t;
                 }
-        ev = Matrix<double, 3, 1>( e[ 0 ], e[ 1 ], e[ 2 ] );
+        for ( int c = 0; c < 3; c++ )
+        {
+            ev( c ) = S( e[ idx[ c ] ] );
+            int big = 0;
+            for ( int r = 1; r < 3; r++ )
+                if ( std::fabs( v[ r ][ idx[ c ] ] ) > std::fabs( v[ big ][ idx[ c ] ] ) ) big = r;
+            const double sgn = v[ big ][ idx[ c ] ] < 0 ? -1.0 : 1.0;
+            for ( int r = 0; r < 3; r++ )
+                evec( r, c ) = S( sgn * v[ r ][ idx[ c ] ] );
+        }
+        return *this;
     }
-    const Matrix<double, 3, 1> &eigenvalues() const { return ev; }
+    const Matrix<S, 3, 1> &eigenvalues() const { return ev; }
+    const Matrix<S, 3, 3> &eigenvectors() const { return evec; }
 };
 
 } // namespace Eigen
+#include "ll_stub_eigen_dyn.h"
 #endif

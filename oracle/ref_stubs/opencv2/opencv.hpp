@@ -1,0 +1,1 @@
+#include "ll_stub_cv.h"

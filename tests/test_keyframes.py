@@ -99,12 +99,13 @@ def test_out_and_back_sequence_closes_a_loop(gpu_lib):
     away = synth.pose_compose(start, np.r_[synth.quat_from_axis_angle(zax, np.deg2rad(170.0)), np.array([12.0, 6.0, 0.0])])
     drift = np.r_[synth.quat_from_axis_angle(zax, np.deg2rad(0.5)), np.array([0.6, -0.4, 0.1])]
     loops, k = [], 0
-    # (the revisit sweeps a little wider than the first visit: the detector skips a pair whose newer key frame has fewer cells, :1030)
-    for grp, (base, est_err, span, pitch) in enumerate([(start, ident, 300.0, 20.0), (away, ident, 300.0, 20.0), (start, drift, 360.0, 30.0)]):
+    # (the revisit sweeps wider than the first visit and wanders half a metre: the detector skips a pair whose newer key frame has fewer
+    #  cells, :1030)
+    for grp, (base, est_err, span, pitch, jit) in enumerate([(start, ident, 220.0, 15.0, 0.0), (away, ident, 300.0, 20.0, 0.0), (start, drift, 360.0, 30.0, 0.5)]):
         for j in range(per_kf):
             yaw, pit = np.deg2rad(span * (j / (per_kf - 1) - 0.5)), np.deg2rad(pitch * np.sin(3.1 * j))
             rot = synth.quat_mul(synth.quat_from_axis_angle(zax, yaw), synth.quat_from_axis_angle(yax, pit))
-            true_pose = synth.pose_compose(base, np.r_[rot, np.zeros(3)])
+            true_pose = synth.pose_compose(base, np.r_[rot, jit * np.array([np.sin(1.7 * j), np.cos(2.3 * j), 0.0])])
             sc = synth.make_moving_scan(world, 9100 + 100 * grp + j, 24000, inc_true=ident, pose_start=true_pose, t_phase=0.07 * j)
             est = synth.pose_compose(est_err, true_pose)  # the pose the mapping loop believes: the truth with the accumulated drift on top
             ok = np.isfinite(sc.xyzi[:, :3]).all(axis=1) & (np.abs(sc.xyzi[:, :3]).sum(axis=1) > 0)
