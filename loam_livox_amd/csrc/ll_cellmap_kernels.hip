@@ -635,6 +635,7 @@ int cellmap_append(CellMapDev &m, const float4 *d_src, int n, hipStream_t s, con
         *err = "cell map is full (max_points)";
         return -1;
     }
+    const bool was_empty = m.n_cells == 0;
     if (n > 0) {
         if (m.n_cells > 0) CMCHK(hipMemsetAsync(m.csel, 0, (size_t)m.n_cells * sizeof(u32), s));
         hipLaunchKernelGGL(cm_new_points_kernel, dim3(blocks(n)), dim3(256), 0, s, d_src, n, m.n_pts, m.geom, m.ckey, m.clast, m.n_cells, m.frame,
@@ -643,7 +644,9 @@ int cellmap_append(CellMapDev &m, const float4 *d_src, int n, hipStream_t s, con
             hipLaunchKernelGGL(cm_drop_reset_kernel, dim3(blocks(m.n_pts)), dim3(256), 0, s, m.n_pts, m.ckey, m.n_cells, m.csel, m.pkey);
         if (cellmap_resort(m, m.n_pts + n, n, s, err)) return -1;
     }
-    m.frame++;  // CMK:667 (and :615 for the first cloud)
+    // m_current_frame_idx++ (CMK:667) -- and once more when the map was empty at the call: append_cloud then goes through
+    // set_point_cloud, which increments it too (CMK:615; pinned against the reference's own class, tests/test_ref_cells.py)
+    m.frame += was_empty ? 2 : 1;
     return 0;
 }
 

@@ -46,6 +46,8 @@ class CellMap:
         cloud = np.asarray(cloud, F)
         xyz = cloud.reshape(len(cloud), -1)[:, :3] if len(cloud) else np.zeros((0, 3), F)
         k, ok = self.cell_index(xyz)
+        was_empty = len(self.cells) == 0
+        hits = {}
         for i in np.nonzero(ok)[0]:
             key = (int(k[i, 0]), int(k[i, 1]), int(k[i, 2]))
             c = self.cells.get(key)
@@ -56,7 +58,13 @@ class CellMap:
             else:                                              # CMK:742-754: a fresh cell takes the place of the old one
                 c = self.cells[key] = {"pts": [], "last": self.frame}
             c["pts"].append(xyz[i].copy())
-        self.frame += 1
+            hits[key] = hits.get(key, 0) + 1
+        # m_current_frame_idx++ (CMK:667) -- and once more when the map was empty at the call: append_cloud then goes through
+        # set_point_cloud, which increments it too (CMK:615).  Pinned by oracle/ref_cells.py (tests/test_ref_cells.py).
+        self.frame += 2 if was_empty else 1
+        # cell_vec of append_cloud( pts, &cell_vec ): every cell of the first cloud (CMK:606-609), afterwards the cells that received
+        # at least 3 points of this cloud (CMK:640-662)
+        return sorted(k for k, n in hits.items() if was_empty or n >= 3)
 
     def cell_points(self, key):
         p = self.cells[key]["pts"]
@@ -83,18 +91,18 @@ class CellMap:
         return float(angle) * 57.3 < maximum_in_fov_angle
 
     # find_cells_in_radius (CMK:761-788) + if_pt_in_fov
-    def select(self, pose, radius, maximum_in_fov_angle):
-        sp = np.asarray(pose[4:], np.float64).astype(F)        # eigen_to_pcl_pt<pcl::PointXYZ>
+    def cells_in_radius(self, pt, radius):
+        sp = np.asarray(pt, np.float64).astype(F)              # eigen_to_pcl_pt<pcl::PointXYZ>
         out = []
         for key in sorted(self.cells):
-            c = self.centre(key)
-            d = c - sp
+            d = self.centre(key) - sp
             d2 = F(F(d[0] * d[0]) + F(d[1] * d[1])) + F(d[2] * d[2])
-            if float(d2) > float(F(radius)) * float(F(radius)):
-                continue
-            if self.in_fov(c, pose, maximum_in_fov_angle):
+            if not float(d2) > float(F(radius)) * float(F(radius)):
                 out.append(key)
         return out
+
+    def select(self, pose, radius, maximum_in_fov_angle):
+        return [key for key in self.cells_in_radius(pose[4:], radius) if self.in_fov(self.centre(key), pose, maximum_in_fov_angle)]
 
     # LM:481-497 (corners) / :499-513 (planes)
     def query_filter(self, pose, radius, maximum_in_fov_angle, leaf, down_sample_replace=1):

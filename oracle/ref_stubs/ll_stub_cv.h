@@ -145,6 +145,14 @@ inline void GaussianBlur( const Mat &src, Mat &dst, Size ksize, double sigmaX, d
         }
     dst = out;
 }
+// the normalised methods' division as OpenCV's matchTemplate documents / performs it: |num| < t -> num / t; within 12.5 % above t -> +-1
+// (rounding); anything else, including a zero denominator (an all-zero window or template) -> 0
+inline double normed( double num, double t )
+{
+    if ( std::fabs( num ) < t ) return num / t;
+    if ( std::fabs( num ) < t * 1.125 ) return num > 0 ? 1.0 : -1.0;
+    return 0.0;
+}
 inline void matchTemplate( const Mat &img, const Mat &templ, Mat &result, int method )
 {
     const int rr = img.rows - templ.rows + 1, rc = img.cols - templ.cols + 1;
@@ -166,9 +174,9 @@ inline void matchTemplate( const Mat &img, const Mat &templ, Mat &result, int me
                 }
             double v;
             if ( method == TM_CCORR_NORMED )
-                v = ti / std::sqrt( tt * ii );
+                v = normed( ti, std::sqrt( tt * ii ) );
             else if ( method == TM_CCOEFF_NORMED )
-                v = ( ti - tsum * isum / n ) / std::sqrt( ( tt - tsum * tsum / n ) * ( ii - isum * isum / n ) );
+                v = normed( ti - tsum * isum / n, std::sqrt( std::max( 0.0, ( tt - tsum * tsum / n ) * ( ii - isum * isum / n ) ) ) );
             else
                 v = ti;
             result.at( y, x ) = ( float ) v;

@@ -26,6 +26,8 @@ namespace pcl
 struct PointXYZ
 {
     float x = 0, y = 0, z = 0, data_w = 1.f;
+    PointXYZ() {}
+    PointXYZ( float xx, float yy, float zz ) : x( xx ), y( yy ), z( zz ) {}
 };
 struct PointXYZI
 {

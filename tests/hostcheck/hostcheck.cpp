@@ -821,8 +821,9 @@ int hc_cellmap_append(hc_cellmap *m, const float *xyzi, int n)
         const int c = hc_cell_find(m->ckey, pkey[i]);
         if (c >= 0 && reset[c]) pkey[i] = LL_CELL_KEY_NONE;
     }
+    const bool was_empty = m->ckey.empty();  // the reference bumps its frame counter twice for the first cloud (CMK:615 and :667)
     if (n > 0) hc_cellmap_resort(m, pts, pkey, n);
-    m->frame++;
+    m->frame += was_empty ? 2 : 1;
     return 0;
 }
 

@@ -55,13 +55,13 @@ def test_append_revisit_rule():
     m = CellMap(1.0, minimum_revisit_threshold=3)
     a = np.array([[0.3, 0.3, 0.3, 9.0]], np.float32)
     b = np.array([[5.3, 0.3, 0.3, 9.0]], np.float32)
-    m.append(a); m.append(a)                      # frames 0, 1: same cell, refreshed
-    assert len(m.cells) == 1 and len(m.cell_points((0, 0, 0))) == 2 and m.cells[(0, 0, 0)]["last"] == 1
-    m.append(b); m.append(b)                      # frames 2, 3
-    m.append(np.r_[a, a])                         # frame 4: 4 - 1 >= 3 -> a fresh cell replaces the old one (CMK:742-754)
-    assert len(m.cell_points((0, 0, 0))) == 2 and m.cells[(0, 0, 0)]["last"] == 4 and m.frame == 5
+    m.append(a); m.append(a)                      # frames 0, 2 (the first cloud advances the counter twice: CMK:615 + 667)
+    assert len(m.cells) == 1 and len(m.cell_points((0, 0, 0))) == 2 and m.cells[(0, 0, 0)]["last"] == 2
+    m.append(b); m.append(b)                      # frames 3, 4
+    m.append(np.r_[a, a])                         # frame 5: 5 - 2 >= 3 -> a fresh cell replaces the old one (CMK:742-754)
+    assert len(m.cell_points((0, 0, 0))) == 2 and m.cells[(0, 0, 0)]["last"] == 5 and m.frame == 6
     m.append(np.zeros((0, 4), np.float32))        # an empty cloud still advances m_current_frame_idx (CMK:667)
-    assert m.frame == 6
+    assert m.frame == 7
 
 
 def test_fov_and_radius_selection():
@@ -139,7 +139,7 @@ def test_history_feeds_cell_maps_every_frame():
         c = rng.uniform(-3, 3, (200, 4)).astype(np.float32)
         s = rng.uniform(-3, 3, (800, 4)).astype(np.float32)
         assert h.add(c, s, IDENT, t_step=0.5, angle_step=0.1) == (k < 2)   # history full and no motion -> not pushed ...
-    assert h.cells[0].frame == 4 and h.cells[1].frame == 4                # ... but appended to the cell maps (LM:1492-1493)
+    assert h.cells[0].frame == 5 and h.cells[1].frame == 5                # ... but appended to the cell maps (LM:1492-1493; +1: first cloud)
     mc, ms = h.refresh_cells(np.r_[0, 0, 0, 1, -6.0, 0, 0], (100.0, 100.0), 45.0, 1)
     assert 0 < len(mc) <= 800 and 0 < len(ms) <= 3200
 
