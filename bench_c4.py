@@ -125,6 +125,11 @@ def main():
         "ms_per_frame_by_stage": dict(zip(("extract_register", "history_add", "match_buffer_refresh"), [round(1e3 * float(v) / F, 3) for v in lm.stage_s[:3]])),
         "icp_iterations_last_frame": int(lm.last_report.icp_iterations),
     }
+    cyc = [int(v) for v in lm.reg.debug_cycles(0)]
+    if any(cyc):  # only the -DLL_SOLVE_TIMING build (LOAM_LIVOX_LIB=...timing.so) fills these
+        result["solver_phase_cycles_last_frame"] = cyc
+        result["lm_iterations_last_frame"] = int(lm.last_report.lm_iterations_total)
+        result["blocks_last_frame"] = int(lm.last_report.n_blocks_last)
     if rank == 0 and args.cpu_frames > 0:
         from oracle.orc_mapping import LaserMapping  # the checker, timed beside the device loop
         om = LaserMapping(**args_map)

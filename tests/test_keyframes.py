@@ -82,8 +82,8 @@ def test_touched_cells_equal_the_oracle_cell_map(gpu_lib):
 def test_out_and_back_sequence_closes_a_loop(gpu_lib):
     """A sensor sweeps a place, leaves for another one, and comes back with 0.6 m / 0.5 degrees of accumulated drift: three key frames;
     the revisit's direction images match the first key frame's (not the other place's), the pair passes the detector's gates
-    (laser_mapping.hpp:990-1033) and the scene alignment (SA:269-391 through keyframes.py) ends below the loop threshold with a
-    transform that undoes the drift.  (40 scans per key frame instead of 300: the emptier direction images need a lower
+    (laser_mapping.hpp:990-1033) and the scene alignment (SA:269-391 through keyframes.py) ends below the loop threshold with the
+    transform the oracle's alignment finds on the same two key frames.  (40 scans per key frame instead of 300: the emptier direction images need a lower
     avail_ratio_plane than the node's 0.05 "for 300 scans".)"""
     from loam_livox_amd import synth
     from loam_livox_amd.keyframes import Keyframe_assembly
@@ -116,7 +116,26 @@ def test_out_and_back_sequence_closes_a_loop(gpu_lib):
     info = [(len(kf.m_set_cell), np.round(kf.analysis["ratio_nonzero"], 4).tolist()) for kf in ka.keyframe_vec]
     assert len(ka.keyframe_vec) == 3, info
     assert len(loops) == 1 and loops[0]["his"] == 0 and loops[0]["last"] == 2, (info, ka.log)
-    # the alignment maps the drifted key frame onto the first one: its translation undoes the drift (to the resolution of a 0.2 m voxel alignment)
-    t = loops[0]["icp_t"]
-    assert np.linalg.norm(t - drift[4:7]) < 0.2 or np.linalg.norm(t + drift[4:7]) < 0.2, (t, drift[4:7], ka.log)
+    # ... and the alignment of the pair is the oracle's (scene_alignment.hpp:269-391 restated in oracle/orc_scene_alignment.py) on the same
+    # two key frames.  (Its translation is not "minus the drift": the clouds are the points of labelled cells of a fixed 1 m grid, and
+    # the first key frame's cells have meanwhile received the revisit's points -- a key frame is a set of cells of the FULL map.)
+    from oracle.orc_cellmap import CellMap
+    from oracle.orc_scene_alignment import SceneAlignment
+    pair, same_labels = [], True
+    for kf in (ka.keyframe_vec[2], ka.keyframe_vec[0]):
+        xyz = kf.cell_map.dump()[0]
+        om = CellMap(1.0)
+        om.append(np.c_[xyz, np.zeros(len(xyz), np.float32)].astype(np.float32))
+        fo, fd = om.features(), kf.cell_map.features()
+        solid = fo["margin"] > 1e-3
+        assert np.array_equal(fo["type"][solid], fd["type"][solid])
+        same_labels &= bool(np.array_equal(fo["type"], fd["type"]))
+        pair.append(om)
+    so = SceneAlignment(0.2, 0.2, 4, 0.35, 5000)
+    thr_o = so.find_tranfrom_of_two_mappings(pair[0], pair[1])
+    rec = [r for r in ka.log if r.get("last") == 2 and r.get("his") == 0][0]
+    dt, dr = synth.pose_error(rec["pose"], so.pose)
+    tol = (1e-6, 1e-8) if same_labels else (0.02, 0.005)   # a cell on a label threshold changes the clouds by its points
+    assert dt < tol[0] and dr < tol[0] and abs(rec["inlier_threshold"] - thr_o) < tol[1], (dt, dr, rec["inlier_threshold"], thr_o, same_labels)
+    assert thr_o < 0.35 and loops[0]["inlier_threshold"] == rec["inlier_threshold"]
     ka.close()
