@@ -211,6 +211,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
     torch.cuda.set_device(dev)
 
+    if (args.legacy_solver or args.packed48_solver) and "LOAM_LIVOX_LIB" not in os.environ:
+        # the older solver forms live in the A/B build of the library only (python -m loam_livox_amd.build --ab)
+        os.environ["LOAM_LIVOX_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loam_livox_amd", "libloamlivox_hip_ab.so")
     from loam_livox_amd import synth
     from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration, VoxelGrid
 

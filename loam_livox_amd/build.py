@@ -29,25 +29,29 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libloamlivox_hip.so)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+AB_LIB = os.path.join(HERE, "libloamlivox_hip_ab.so")  # the product sources + the round-1 / round-2 solver forms (-DLL_AB_PATHS): A/B references of tests / bench.py
+
+
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
+def build(force: bool = False, verbose: bool = False, lib: str = LIB, extra_flags=()) -> str:
+    if not force and not needs_build(lib):
+        return lib
     cc = hipcc()
-    objdir = os.path.join(HERE, "build" if not os.environ.get("LL_LIB_OUT") else "build_" + os.path.basename(LIB).replace(".so", ""))
+    default = os.path.join(HERE, "libloamlivox_hip.so")
+    objdir = os.path.join(HERE, "build" if lib == default else "build_" + os.path.basename(lib).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -58,10 +62,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def build_ab(force: bool = False, verbose: bool = False) -> str:
+    """the A/B variant next to the product library (tests/test_gpu_reg.py ab_library, bench.py --legacy-solver / --packed48-solver)"""
+    return build(force, verbose, AB_LIB, ["-DLL_AB_PATHS"])
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--ab" in sys.argv:
+        print(build_ab(force="--force" in sys.argv, verbose=True))

@@ -149,6 +149,28 @@ def load():
     return L
 
 
+AB_LIB_PATH = os.path.join(_HERE, "libloamlivox_hip_ab.so")  # -DLL_AB_PATHS build: the product library + the round-1 / round-2 solver forms
+
+
+class use_library:
+    """Context manager for tests and A/B runs: objects created inside bind to the library at `path` (a variant build of the same
+    sources, e.g. AB_LIB_PATH) instead of the product library.  Each object keeps the library it was created with."""
+
+    def __init__(self, path: str):
+        self.path = path
+
+    def __enter__(self):
+        global _lib, LIB_PATH
+        self.saved = (_lib, LIB_PATH)
+        _lib, LIB_PATH = None, self.path
+        return load()
+
+    def __exit__(self, *exc):
+        global _lib, LIB_PATH
+        _lib, LIB_PATH = self.saved
+        return False
+
+
 def check(rc: int, what: str = "") -> int:
     if rc < 0:
         msg = load().ll_last_error()

@@ -754,6 +754,11 @@ extern "C" int ll_reg_set_debug(ll_reg *r, int32_t enable)
 {
     if (!r) return set_err("ll_reg_set_debug", "null handle");
     HC(hipSetDevice(r->device));
+#ifndef LL_AB_PATHS
+    if (enable & (16 | 64))
+        return set_err("ll_reg_set_debug", "the round-1 / round-2 solver forms (bits 4 and 6) are A/B references compiled only into a -DLL_AB_PATHS build "
+                                           "(LL_LIB_OUT=... LL_EXTRA_HIPCC_FLAGS=-DLL_AB_PATHS python -m loam_livox_amd.build)");
+#endif
     r->debug = enable;
     if ((enable & 1) && !r->dev.dbg_idx) {
         DM(r->dev.dbg_idx, (size_t)r->max_scans * r->dev.cap * 5);
@@ -771,6 +776,9 @@ extern "C" int ll_reg_set_profiling(ll_reg *r, int32_t enable)
 
 static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
 {
+#ifndef LL_AB_PATHS
+    debug &= ~(16 | 64);  // (LL_DEBUG_OR cannot ask for forms this build does not carry either)
+#endif
     memset(c, 0, sizeof(*c));
     c->if_motion_deblur = p->if_motion_deblur;
     c->icp_max_iterations = p->icp_max_iterations;
@@ -792,6 +800,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
+    c->no_line_cache = (debug & 4096) ? 1 : 0;  // bit 12: no LDS copy of the line blocks in the solver (A/B)
     c->knn_tile = (debug & 512) ? 0 : ((debug & 1024) ? 1 : 2);  // bit 9: no tile search of the surface queries (A/B, ll_knn_tile.h); bit 10: tile
                                                                  // search only where all queries are searched, the reuse machinery for the rest
     c->max_d2_line_d = p->maximum_dis_line_for_match;

@@ -443,6 +443,7 @@ struct SolveShared {
     int n_active, n_corner_avail, n_surf_avail, n_unique;
     int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
     int pt_T, pt_Tl, pt_kc, pt_priv;  // plane-table path: distinct triples, table entries in LDS, record rounds cached in LDS, private entries
+    int pt_nl;                        // ... line blocks of this workgroup's first rounds kept at the top of s_raw (solver_eval3)
     double thr;
     int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
     int xch_seq, xch_epoch;                // ... exchanges of partial sums made in this launch, and the launch's number in its registration (granule tags)
@@ -1444,6 +1445,7 @@ __device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const doub
     av_load(av, rd.cap, slot, slot < rd.cap_c, r.a0, r.a1, r.a2, r.v0, r.v1, r.v2);
 }
 
+#ifdef LL_AB_PATHS  // round-1 form: an A/B reference for tests and bench.py --legacy-solver, not in the product library
 template <int DEBLUR>
 __device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a, int deblur,
                                  const unsigned char *s_flag, SolveShared &sh)
@@ -1655,6 +1657,7 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
         for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
 #endif
 }
+#endif  // LL_AB_PATHS
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1676,6 +1679,7 @@ __device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState
 //   * the LM controller is inlined (ll_reg_core.h LL_LM_FN): no calling-convention spills on the lane everyone waits for.
 // The arithmetic per block, the reduction order inside a thread (planes, then lines), the wave / workgroup reduction and
 // everything after the L1 pass are those of solve_fast.
+#ifdef LL_AB_PATHS  // round-2 form: an A/B reference for tests and bench.py --packed48-solver, not in the product library
 #define PC_RECS 2560  // plane records cached in LDS (3 x 16 B each, 120 KB of s_table); a multiple of RS_THREADS
 
 struct PRec {
@@ -2083,6 +2087,7 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
         for (int i = 0; i < 16; i++) st->dbg_cycles[i] += sh.tcyc[i];
 #endif
 }
+#endif  // LL_AB_PATHS
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2109,6 +2114,7 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
 #define PT_MAX_PROBE 192
 #define PT_LDS_BYTES 155648           // s_raw of reg_solve_kernel: 152 KB
 #define PT_TCAP (PT_LDS_BYTES / 32)   // table entries that fit LDS
+#define LL_LINE_CACHE_MAX 1024        // line blocks of a scan kept in LDS (one workgroup per scan; a group member keeps its first round)
 #define PT_EMPTY_A 0xffffffffffffffffull
 #define PT_EMPTY_B 0xffffffffu
 #define PT_PRIVATE 0xffffu   // rd.blk_id between the two passes: no slot found, the block gets a private table entry
@@ -2432,10 +2438,23 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
     }
     if (tid == 0) {
         // (T beyond the LDS part, or private entries: the evaluation takes its slower form, solver_eval3)
-        const int kc = ((PT_TCAP - Tl) * 2) / RS_THREADS;
+        // Line blocks (64 B each: sensor point + a', v' in fp64) are few in a Q-full scan and half of a voxel-filtered one; they are
+        // not pipelined -- every evaluation that reads them from HBM waits a full memory latency at its end.  The first
+        // LL_LINE_CACHE_MAX of them (this group member's first round) stay in LDS above the record cache, written by the
+        // FILL evaluation like the plane records.
+        int nl = 0;
+        if (!rc.no_line_cache && T <= PT_TCAP && sh.pt_priv == 0) {
+            int mine = GROUPED ? nC - g * RS_THREADS : nC;
+            const int cap = GROUPED ? RS_THREADS : LL_LINE_CACHE_MAX;
+            mine = mine < 0 ? 0 : (mine > cap ? cap : mine);
+            const int room = (PT_LDS_BYTES / 16 - 2 * Tl) / 4;
+            nl = mine < room ? mine : room;
+        }
+        const int kc = (PT_LDS_BYTES / 16 - 2 * Tl - 4 * nl) / RS_THREADS;
         sh.pt_T = sh.pt_priv > 0 ? PT_TCAP + 1 : T;
         sh.pt_Tl = Tl;
         sh.pt_kc = kc < kp ? kc : kp;
+        sh.pt_nl = nl;
     }
     __syncthreads();
     LL_TACC(15, t_p2);
@@ -2600,11 +2619,31 @@ __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int n
         const size_t sb = (size_t)b * rd.cap;
         const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
         const int kpl = (nS + RS_THREADS - 1) / RS_THREADS;  // the lines' first round in the activity mask
+        const int nl = sh.pt_nl;
+        int4 *lc = (int4 *)s_raw + (PT_LDS_BYTES / 16 - 4 * nl);  // four planes of nl entries: {f}, {a0, v0}, {v1, v2}, {a1, a2}
         int k = 0;
         for (int l = p0; l < nC; l += GS, k++) {
             if (!((act >> (kpl + g + G * k)) & 1ull)) continue;
             BlkRegs br;
-            load_blk(rd, sb, av, l, br);
+            const int j = GROUPED ? (k == 0 ? tid : nl) : l;  // its place in the LDS copy (>= nl: none)
+            if (!FILL && j < nl) {
+                const int4 c0 = lds_load_i4(lc + j), c1 = lds_load_i4(lc + nl + j), c2 = lds_load_i4(lc + 2 * nl + j), c3 = lds_load_i4(lc + 3 * nl + j);
+                br.f = make_float4(__int_as_float(c0.x), __int_as_float(c0.y), __int_as_float(c0.z), __int_as_float(c0.w));
+                br.a0 = __hiloint2double(c1.y, c1.x);
+                br.v0 = __hiloint2double(c1.w, c1.z);
+                br.v1 = __hiloint2double(c2.y, c2.x);
+                br.v2 = __hiloint2double(c2.w, c2.z);
+                br.a1 = __hiloint2double(c3.y, c3.x);
+                br.a2 = __hiloint2double(c3.w, c3.z);
+            } else {
+                load_blk(rd, sb, av, l, br);
+                if (FILL && j < nl) {
+                    lds_store_i4(lc + j, make_int4(__float_as_int(br.f.x), __float_as_int(br.f.y), __float_as_int(br.f.z), __float_as_int(br.f.w)));
+                    lds_store_i4(lc + nl + j, make_int4(__double2loint(br.a0), __double2hiint(br.a0), __double2loint(br.v0), __double2hiint(br.v0)));
+                    lds_store_i4(lc + 2 * nl + j, make_int4(__double2loint(br.v1), __double2hiint(br.v1), __double2loint(br.v2), __double2hiint(br.v2)));
+                    lds_store_i4(lc + 3 * nl + j, make_int4(__double2loint(br.a1), __double2hiint(br.a1), __double2loint(br.a2), __double2hiint(br.a2)));
+                }
+            }
             const double a[3] = {br.a0, br.a1, br.a2};
             const double v[3] = {br.v0, br.v1, br.v2};
             LL_CTX_ACCUM(BLK_LINE, br.f, a, v, huber_a, acc);
@@ -2868,16 +2907,21 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     }
     __syncthreads();
     const int total = rd.n_corner[b] + rd.n_surf[b];
-    if (compact && !rc.solver_packed48 && G > 1)
+    // The product library carries two forms: the plane-table path for compact scans (every Mid-40 configuration) and the general
+    // path (motion de-blurring, scans beyond FAST_MAX_BLOCKS).  The round-1 / round-2 forms exist only in a -DLL_AB_PATHS build
+    // (ll_reg_set_debug bits 4 and 6 are refused otherwise, ll_api.hip).
+#ifdef LL_AB_PATHS
+    if (compact && rc.solver_packed48 && G > 1) return solve_fast2<true>(rd, rc, b, st, sh, s_table, s_flag);
+    if (compact && rc.solver_packed48) return solve_fast2<false>(rd, rc, b, st, sh, s_table, s_flag);
+    if (!compact && rc.solver_legacy && total <= FAST_MAX_BLOCKS && !rc.force_general) return solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
+#else
+    (void)s_flag;
+    (void)total;
+#endif
+    if (compact && G > 1)
         solve_fast3<true>(rd, rc, map_surf, b, st, sh, s_raw);
-    else if (compact && !rc.solver_packed48)
-        solve_fast3<false>(rd, rc, map_surf, b, st, sh, s_raw);
-    else if (compact && G > 1)
-        solve_fast2<true>(rd, rc, b, st, sh, s_table, s_flag);
     else if (compact)
-        solve_fast2<false>(rd, rc, b, st, sh, s_table, s_flag);
-    else if (total <= FAST_MAX_BLOCKS && !rc.force_general)
-        solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
+        solve_fast3<false>(rd, rc, map_surf, b, st, sh, s_raw);
     else
         solve_general<DEBLUR>(rd, rc, b, st, sh, s_table);
 }

@@ -22,6 +22,25 @@ def dev_map(gpu_lib, small_world):
     m.close()
 
 
+def ab_library():
+    """the -DLL_AB_PATHS build of the library: the product code + the round-1 / round-2 solver forms kept as A/B references"""
+    import os
+    from loam_livox_amd import capi
+    if not os.path.exists(capi.AB_LIB_PATH):
+        pytest.skip("libloamlivox_hip_ab.so not built (LL_LIB_OUT=.../libloamlivox_hip_ab.so LL_EXTRA_HIPCC_FLAGS=-DLL_AB_PATHS python -m loam_livox_amd.build)")
+    return capi.use_library(capi.AB_LIB_PATH)
+
+
+@pytest.fixture(scope="module")
+def ab_map(gpu_lib, small_world):
+    with ab_library():
+        m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, small_world["corner"])
+    m.setInputCloud(Map_buffer.SURF, small_world["surf"])
+    yield m
+    m.close()
+
+
 def set_params(reg, icp=10, ceres=20, force=1):
     p = reg.params
     p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = icp, ceres, force
@@ -83,17 +102,23 @@ def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 @pytest.mark.parametrize("force", [0, 1])
 @pytest.mark.parametrize("general", [False, "single", True, "legacy", "packed48", "packed48_single"])
-def test_registration_matches_oracle(dev_map, small_world, scans, k, force, general):
+def test_registration_matches_oracle(request, dev_map, small_world, scans, k, force, general):
     """general=False: round-3 compact path (plane table: {n', c} once per distinct neighbour triple, 18-byte block records) in
     the form a batch of one takes: the scan spread over a group of 8 workgroups; "single": the same path with one workgroup
     per scan, as batches of more than 16 scans run it; True: the HBM-resident path used by scans with more than 24576
     residual blocks (forced here on a normal scan); "legacy": the round-1 fast path (blocks re-read on every evaluation) and
-    "packed48[_single]": the round-2 compact path (48-byte packed plane records), both kept as A/B switches."""
+    "packed48[_single]": the round-2 compact path (48-byte packed plane records), both kept as A/B references in the
+    -DLL_AB_PATHS build of the library only (the product library refuses the switches)."""
+    import contextlib
+    ab = general in ("legacy", "packed48", "packed48_single")
+    if ab:
+        dev_map = request.getfixturevalue("ab_map")
     sc = scans[k]
     _, _, _, _, fc, fs = oracle_features(sc)
     prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
-    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    with (ab_library() if ab else contextlib.nullcontext()):
+        reg = Point_cloud_registration(max_scans=1, max_features=24000)
     reg.set_debug(True, force_general_solver=(general is True), legacy_solver=(general == "legacy"),
                   no_solver_groups=(general in ("single", "packed48_single")), packed48_solver=str(general).startswith("packed48"))
     set_params(reg, 10, 20, force)
@@ -124,7 +149,7 @@ def test_registration_matches_oracle(dev_map, small_world, scans, k, force, gene
 
 
 @pytest.mark.parametrize("packed48", [False, True])
-def test_group_barrier_abort_rejects_the_scan(dev_map, scans, packed48):
+def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans, packed48):
     """A group barrier of the small-batch solver that does not complete (bounded spin; forced here) must not hand back a NaN
     pose as an accepted result: the scan is rejected with its pose restored and ll_reg_collect reports the failure."""
     import ctypes as C
@@ -133,7 +158,11 @@ def test_group_barrier_abort_rejects_the_scan(dev_map, scans, packed48):
     sc = scans[0]
     _, _, _, _, fc, fs = oracle_features(sc)
     assert len(fc) + len(fs) >= 6000  # large enough for the grouped form
-    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    import contextlib
+    if packed48:
+        dev_map = request.getfixturevalue("ab_map")
+    with (ab_library() if packed48 else contextlib.nullcontext()):
+        reg = Point_cloud_registration(max_scans=1, max_features=24000)
     reg.set_debug(False, test_group_abort=True, packed48_solver=packed48)
     set_params(reg, 4, 20, 1)
     reg.upload_features([fc], [fs])
@@ -154,7 +183,7 @@ def test_group_barrier_abort_rejects_the_scan(dev_map, scans, packed48):
 
 @pytest.mark.parametrize("groups", [False, True])
 @pytest.mark.parametrize("world", ["rooms", "random_cloud"])
-def test_plane_table_agrees_with_packed_records(dev_map, scans, groups, world):
+def test_plane_table_agrees_with_packed_records(ab_map, scans, groups, world):
     """The plane-table solver path evaluates, block for block and in the same order, the numbers of the round-2 path that
     stores {n', c} with every block (the compiler contracts the two instantiations' multiply-adds differently, so they agree to
     rounding, not to the bit) -- on the synthetic rooms (a few thousand distinct neighbour triples: the whole table in LDS) and
@@ -163,16 +192,18 @@ def test_plane_table_agrees_with_packed_records(dev_map, scans, groups, world):
     sc = scans[1]
     _, _, _, _, fc, fs = oracle_features(sc)
     if world == "rooms":
-        m = dev_map
+        m = ab_map
     else:
         rng = np.random.default_rng(5)
         lo, hi = synth.transform_points(sc.pose_init, fs[:, :3]).min(0) - 1.0, synth.transform_points(sc.pose_init, fs[:, :3]).max(0) + 1.0
-        m = Map_buffer()
+        with ab_library():
+            m = Map_buffer()
         m.setInputCloud(Map_buffer.CORNER, rng.uniform(lo, hi, (60000, 3)).astype(np.float32))
         m.setInputCloud(Map_buffer.SURF, rng.uniform(lo, hi, (400000, 3)).astype(np.float32))
     out = []
-    for packed in (False, True):
-        reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    for packed in (False, True):   # (both forms from the A/B build: the same compiler run)
+        with ab_library():
+            reg = Point_cloud_registration(max_scans=1, max_features=24000)
         reg.set_debug(False, packed48_solver=packed, no_solver_groups=not groups)
         set_params(reg, 2 if world != "rooms" else 4, 20, 1)
         reg.m_pose_w_last = sc.pose_init.copy()
@@ -678,3 +709,14 @@ def test_map_refresh_while_registering_uses_immutable_snapshots(gpu_lib, small_w
         assert match, "a registration mixed two map snapshots"
         seen.add(match[0])
     assert seen == {0, 1}  # the refresher really did swap maps under the registrars
+
+
+def test_product_library_refuses_the_ab_solver_forms(gpu_lib):
+    """ll_reg_set_debug bits 4 / 6 (round-1 / round-2 solver forms) exist only in a -DLL_AB_PATHS build"""
+    from loam_livox_amd.capi import LoamLivoxError
+    reg = Point_cloud_registration(max_scans=1, max_features=1000)
+    for kw in ({"legacy_solver": True}, {"packed48_solver": True}):
+        with pytest.raises(LoamLivoxError, match="LL_AB_PATHS"):
+            reg.set_debug(False, **kw)
+    reg.set_debug(False)
+    reg.close()
