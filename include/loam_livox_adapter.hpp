@@ -873,9 +873,10 @@ class Point_cloud_registration {
         now.hash = h;
         Handle_pool::Key &k = sm.key[kind];
         if (k.n == now.n && k.hash == now.hash && k.generation == ll_map_generation(sm.map, kind)) return;  // same contents, still the published structure
+        int64_t gen = -1;  // the generation of OUR publication, reported from inside the map's lock
         if (now.n == 0) {
             const float none[4] = {0, 0, 0, 0};
-            check(ll_map_upload(sm.map, kind, none, 4, 0, 0.0f), "ll_map_upload");
+            check(ll_map_upload_gen(sm.map, kind, none, 4, 0, 0.0f, &gen), "ll_map_upload");
         } else {
             // ll_map_upload takes x, y, z at any float stride: a point type whose coordinates are three consecutive floats
             // (pcl::PointXYZI: 8 floats per point) goes as it lies, without a staging copy
@@ -883,13 +884,13 @@ class Point_cloud_registration {
             const bool strided = sizeof(p0) % sizeof(float) == 0 && (const void *)(&p0.x + 1) == (const void *)&p0.y &&
                                  (const void *)(&p0.x + 2) == (const void *)&p0.z;
             if (strided) {
-                check(ll_map_upload(sm.map, kind, &p0.x, (int32_t)(sizeof(p0) / sizeof(float)), (int64_t)now.n, 0.0f), "ll_map_upload");
+                check(ll_map_upload_gen(sm.map, kind, &p0.x, (int32_t)(sizeof(p0) / sizeof(float)), (int64_t)now.n, 0.0f, &gen), "ll_map_upload");
             } else {
                 const std::vector<float> v = cloud_to_xyzi(c);
-                check(ll_map_upload(sm.map, kind, v.data(), 4, (int64_t)now.n, 0.0f), "ll_map_upload");
+                check(ll_map_upload_gen(sm.map, kind, v.data(), 4, (int64_t)now.n, 0.0f, &gen), "ll_map_upload");
             }
         }
-        now.generation = ll_map_generation(sm.map, kind);
+        now.generation = gen;  // (not ll_map_generation() now: a refresh may have published in between, and the key would then vouch for it)
         k = now;
     }
     ll_reg *reg_ = nullptr;

@@ -129,6 +129,10 @@ int64_t ll_map_size(const ll_map *m, int32_t kind);
  * point_cloud_registration.hpp:163-168, by their contents) stays valid only while this number is the one it saw after its own
  * upload; -1 for a bad argument. */
 int64_t ll_map_generation(const ll_map *m, int32_t kind);
+/* ll_map_upload that also reports the generation number ITS publication got (taken under the map's lock): a cache keyed by
+ * "generation after my upload" must use this one -- reading ll_map_generation after ll_map_upload returns would pick up a
+ * publication another thread (ll_history_refresh*) made in between and later skip a required re-upload. */
+int ll_map_upload_gen(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size, int64_t *generation);
 /* BASELINE config C5 ("fp16 points / fp32 accumulate k-NN"): replaces the 16-byte fp32 records of an uploaded map kind by
  * 8-byte records -- the point's position inside its grid cell in binary16 (<= 2^-11 cell sizes off) + the cell index
  * bits -- and ll_map_knn5 then returns the exact 5-NN of that dequantised cloud, distances accumulated in fp32.  The
@@ -193,6 +197,8 @@ typedef struct {
     int32_t lm_iterations_total;
     int32_t accepted;                 /* return value of find_out_incremental_transfrom */
     int32_t gated;                    /* :199 gate skipped the optimisation */
+    int32_t aborted;                  /* the small-batch solver gave up on this scan (a barrier between its workgroups timed out):
+                                         the scan is rejected (accepted 0) and its pose restored */
 } ll_reg_report;
 
 int ll_reg_create(int32_t device, int32_t max_scans, int32_t max_features_per_scan, ll_reg **out);
@@ -240,6 +246,9 @@ int ll_reg_enqueue_fe_merged(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_
                              const double *poses_last, const double *poses_curr, const double *poses_incre);
 int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, const ll_reg_params *prm,
                       const double *poses_last, const double *poses_curr, const double *poses_incre);
+/* Returns 0; a negative value on an error of the call; or the number (> 0) of scans whose registration was aborted on the device
+ * (ll_reg_report.aborted) -- not an error: all outputs are filled in, the aborted scans are rejected with their pose restored, the
+ * results of the other scans of the batch are valid, and ll_last_error() carries the reason. */
 int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, double *poses_incre, ll_reg_report *reports,
                    int32_t *results);
 

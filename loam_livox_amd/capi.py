@@ -42,7 +42,7 @@ class RegReport(C.Structure):
     _fields_ = [("final_cost", C.c_double), ("initial_cost", C.c_double), ("inlier_threshold", C.c_double),
                 ("angular_diff_deg", C.c_double), ("t_diff", C.c_double), ("icp_iterations", C.c_int32),
                 ("n_blocks_last", C.c_int32), ("corner_avail", C.c_int32), ("surf_avail", C.c_int32),
-                ("lm_iterations_total", C.c_int32), ("accepted", C.c_int32), ("gated", C.c_int32)]
+                ("lm_iterations_total", C.c_int32), ("accepted", C.c_int32), ("gated", C.c_int32), ("aborted", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/loam_livox_hip.h declares
@@ -65,6 +65,7 @@ SYMBOLS = {
     "ll_map_create": (_i32, [_i32, C.POINTER(_vp)]),
     "ll_map_destroy": (None, [_vp]),
     "ll_map_upload": (_i32, [_vp, _i32, _vp, _i32, _i64, _f]),
+    "ll_map_upload_gen": (_i32, [_vp, _i32, _vp, _i32, _i64, _f, _vp]),
     "ll_map_size": (_i64, [_vp, _i32]),
     "ll_map_generation": (_i64, [_vp, _i32]),
     "ll_map_to_f16": (_i32, [_vp, _i32]),

@@ -65,6 +65,8 @@ struct ll_fe {
     FeDev dev;
     hipStream_t stream = nullptr;
     hipEvent_t ev_done = nullptr;
+    hipEvent_t ev_staged = nullptr;  // behind the last copies out of hp_npts / hp_time0 (the next upload may rewrite the slots after it)
+    bool staged_pending = false;
     int max_n_uploaded = 0;
     // sequential time base of Livox_laser (LFE:150-152)
     double first_receive_time = -1.0, last_maximum_time_stamp = 0.0;
@@ -127,6 +129,7 @@ static int fe_create_impl(const ll_fe_params *p, ll_fe *h)
     d.ambig_cap = (int)((BN / 16 > 4096 ? BN / 16 : 4096) < 0x7fffffffull ? (BN / 16 > 4096 ? BN / 16 : 4096) : 0x7fffffffull);
     HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HC(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&h->ev_staged, hipEventDisableTiming));
     DM(h->d_xyzi, BN);
     DM(h->d_npts, B);
     DM(h->d_time0, B);
@@ -200,6 +203,7 @@ extern "C" void ll_fe_destroy(ll_fe *h)
     if (h->hp_npts) (void)hipHostFree(h->hp_npts);
     if (h->hp_time0) (void)hipHostFree(h->hp_time0);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->ev_staged) (void)hipEventDestroy(h->ev_staged);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -233,8 +237,12 @@ static int fe_upload_impl(ll_fe *h, int32_t first_scan, int32_t n_scans, const f
     if (n_points < 0 || n_points > h->prm.max_points) return set_err("ll_fe_upload", "n_points exceeds max_points");
     HC(hipSetDevice(h->prm.device));
     const size_t N = h->prm.max_points;
-    // (the staging slots of an upload still in flight are not rewritten: a second upload on a busy handle waits for it first)
-    if (hipStreamQuery(h->stream) != hipSuccess) HC(hipStreamSynchronize(h->stream));
+    // The page-locked staging slots of an upload still in flight are not rewritten: wait for the earlier upload's two small
+    // copies (an event right behind them) -- not for the stream, which may hold a whole batch of extraction kernels.
+    if (h->staged_pending) {
+        HC(hipEventSynchronize(h->ev_staged));
+        h->staged_pending = false;
+    }
     for (int i = 0; i < n_scans; i++) {
         h->h_npts[first_scan + i] = n_points;
         h->hp_npts[first_scan + i] = n_points;
@@ -242,6 +250,8 @@ static int fe_upload_impl(ll_fe *h, int32_t first_scan, int32_t n_scans, const f
     }
     HC(hipMemcpyAsync(h->d_npts + first_scan, h->hp_npts + first_scan, n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HC(hipMemcpyAsync(h->d_time0 + first_scan, h->hp_time0 + first_scan, n_scans * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HC(hipEventRecord(h->ev_staged, h->stream));
+    h->staged_pending = true;
     if (n_points > 0 && (size_t)n_points == N)  // full slots: one linear copy (a pitched copy of the same bytes does not run at link speed)
         HC(hipMemcpyAsync(h->d_xyzi + (size_t)first_scan * N, xyzi, (size_t)n_scans * N * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     else if (n_points > 0)
@@ -465,18 +475,21 @@ static std::shared_ptr<MapSnap> map_build_target(ll_map *m, int kind)
     m->pool[kind].push_back(s);
     return s;
 }
-static void map_publish(ll_map *m, int kind, const std::shared_ptr<MapSnap> &s)
+// returns the generation number this publication got (read under the mutex: a concurrent publisher cannot slip in between)
+static int64_t map_publish(ll_map *m, int kind, const std::shared_ptr<MapSnap> &s)
 {
     std::lock_guard<std::mutex> lk(m->mu);
     m->cur[kind] = s;
-    m->generation[kind]++;
+    return ++m->generation[kind];
 }
 // builds the grid of `n` device-resident points into a fresh snapshot and publishes it
-static int map_rebuild(ll_map *m, int kind, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err)
+static int map_rebuild(ll_map *m, int kind, const float *d_raw, int stride, int64_t n, float cell, hipStream_t s, const char **err,
+                       int64_t *generation = nullptr)
 {
     std::shared_ptr<MapSnap> t = map_build_target(m, kind);
     if (map_build(t->mk, d_raw, stride, n, cell, s, err)) return -1;  // returns with the stream drained
-    map_publish(m, kind, t);
+    const int64_t g = map_publish(m, kind, t);
+    if (generation) *generation = g;
     return 0;
 }
 
@@ -505,6 +518,11 @@ extern "C" void ll_map_destroy(ll_map *m)
 
 extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size)
 {
+    return ll_map_upload_gen(m, kind, xyz, stride_floats, n, cell_size, nullptr);
+}
+
+extern "C" int ll_map_upload_gen(ll_map *m, int32_t kind, const float *xyz, int32_t stride_floats, int64_t n, float cell_size, int64_t *generation)
+{
     if (!m || (!xyz && n > 0)) return set_err("ll_map_upload", "null argument");
     if (kind != LL_MAP_CORNER && kind != LL_MAP_SURF) return set_err("ll_map_upload", "bad kind");
     if (stride_floats < 3) return set_err("ll_map_upload", "stride_floats must be >= 3");
@@ -519,7 +537,7 @@ extern "C" int ll_map_upload(ll_map *m, int32_t kind, const float *xyz, int32_t 
         return set_err("ll_map_upload", "host to device copy failed");
     }
     const char *err = nullptr;
-    const int rc = map_rebuild(m, kind, d_raw, stride_floats, n, cell_size, m->stream, &err);
+    const int rc = map_rebuild(m, kind, d_raw, stride_floats, n, cell_size, m->stream, &err, generation);
     (void)hipFree(d_raw);
     if (rc != 0) return set_err("map_build", err ? err : "failed");
     return 0;
@@ -678,9 +696,11 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.state, B);
     DM(d.blk_f, B * d.cap);
     DM(d.blk_av, B * 6 * d.cap);
+#ifdef LL_AB_PATHS  // the 48-byte packed plane records exist for the round-2 solver form only (48 B x max_scans x max_features)
     DM(d.blk_pa, B * d.cap_s);
     DM(d.blk_pb, B * d.cap_s);
     DM(d.blk_pc, B * d.cap_s);
+#endif
     DM(d.blk_id, B * d.cap_s);
     {
         const int lim = d.cap_s < 24576 ? d.cap_s : 24576;  // FAST_MAX_BLOCKS: larger scans never take the plane-table path
@@ -866,6 +886,9 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
         ~PinGuard()
         {
             if (!keep) {
+                // kernels of this enqueue may already be in flight on the snapshots (a failure inside the ICP loop): they must
+                // have drained before the pins go and ll_map_upload / a refresh may recycle the buffers
+                (void)hipStreamSynchronize(r->stream);
                 r->pinned[0].reset();
                 r->pinned[1].reset();
             }
@@ -983,10 +1006,9 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
             rp.lm_iterations_total = s.lm_total;
             rp.accepted = s.accepted;
             rp.gated = s.gated;
+            rp.aborted = s.aborted ? 1 : 0;
         }
     }
-    if (n_aborted)  // (outputs are filled in: the aborted scans come back rejected, pose restored)
-        return set_err("ll_reg_collect", "a group barrier of the small-batch solver timed out (device oversubscribed?): the affected scans were rejected");
     if (r->profiling) {
         for (int k = 0; k < 3; k++) {
             r->prof_ms[k] = 0.f;
@@ -999,6 +1021,13 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
                 r->prof_launches[r->ev_class[i]]++;
             }
         }
+    }
+    if (n_aborted) {
+        // Not an error of the call: every output is filled in, the affected scans come back rejected (result 0, report.aborted 1,
+        // pose restored) like any registration the reference rejects, the others are valid.  The count is the return value and
+        // ll_last_error() says what happened.
+        (void)set_err("ll_reg_collect", "a group barrier of the small-batch solver timed out (device oversubscribed?): the affected scans were rejected");
+        return n_aborted;
     }
     return 0;
 }

@@ -766,6 +766,13 @@ LL_HD double lm_cubic_min_step(double f0, double g0, double x1, double f1, doubl
 // sign changes of the derivative on a fixed grid of the interval and bisected, operation for operation as
 // oracle/ll_oracle_reg.c quintic_min_step.  Out of line: this runs only when a bound on t_inc is active and the first
 // interpolated step still fails the Armijo test.
+// AN APPROXIMATION OF CERES HERE, not a restatement: Ceres' MinimizePolynomial takes the roots of the derivative as the eigenvalues of
+// its companion matrix (Eigen, third party) and so sees every real root; 32 cells + bisection miss a pair of roots that falls
+// inside one cell (a minimum narrower than 1/32 of [lo, hi] = [0.001, 0.6] x the step), in which case the better end point or
+// another root is returned -- still a valid contraction for the Armijo search, but not the step Ceres would take.  Near-coincident
+// samples (|x2 - x1| tiny but non-zero) are only guarded against exact zero.  The oracle and the compiled stand-in share this
+// algorithm, so the parity tests cannot see such a divergence from Ceres itself; DESIGN.md section 5 lists it with the other
+// third-party restatements.
 LL_HD_NOINLINE double lm_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo,
                                           double hi)
 {

@@ -171,13 +171,13 @@ def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans, packed48)
     pc, pi = np.zeros((1, 7)), np.zeros((1, 7))
     reps, res = (RegReport * 1)(), np.ones(1, np.int32)
     rc = reg.L.ll_reg_collect(reg.h, 1, ptr(pc), ptr(pi), reps, ptr(res))
-    assert rc < 0 and b"timed out" in reg.L.ll_last_error()
-    assert res[0] == 0 and reps[0].accepted == 0 and np.array_equal(pc[0], sc.pose_init) and np.all(np.isfinite(pc))
+    assert rc == 1 and b"timed out" in reg.L.ll_last_error()   # one aborted scan: reported, not an error of the call
+    assert res[0] == 0 and reps[0].accepted == 0 and reps[0].aborted == 1 and np.array_equal(pc[0], sc.pose_init) and np.all(np.isfinite(pc))
     # the handle is usable afterwards
     reg.set_debug(False, packed48_solver=packed48)
     reg.enqueue_uploaded(dev_map, 1, pl, pl)
-    res2, pc2, _, _ = reg.collect(1)
-    assert res2[0] == 1 and np.all(np.isfinite(pc2)) and not np.array_equal(pc2[0], sc.pose_init)
+    res2, pc2, _, reps2 = reg.collect(1)
+    assert res2[0] == 1 and np.all(np.isfinite(pc2)) and not np.array_equal(pc2[0], sc.pose_init) and reps2[0].aborted == 0
     reg.close()
 
 
