@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive figure")
+    ap.add_argument("--no-pipeline", action="store_true", help="value = one batch at a time (no overlap of consecutive batches)")
+    ap.add_argument("--q-pipe-in-flight", type=int, default=4, help="batches in flight for the secondary Q-pipe figure")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (extractor handle + registrar each)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed single-thread oracle runs (after 3 warm-ups); their median is cpu_baseline_1thread")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = os.cpu_count())")
     return ap.parse_args()
@@ -243,28 +246,54 @@ def main():
     fe = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
     times = np.full(B, 1.0)
     fe.upload(scans, times)
-    reg = Point_cloud_registration(max_scans=B, max_features=N, device=dev)
+    def make_registrar():
+        r_ = Point_cloud_registration(max_scans=B, max_features=N, device=dev)
+        q_ = r_.params
+        q_.icp_max_iterations, q_.ceres_max_iterations, q_.force_all_iterations = args.icp_iters, 20, 1
+        q_.para_max_angular_rate, q_.para_max_speed, q_.max_final_cost = 20.0, 0.3, 1000.0
+        q_.current_frame_index, q_.mapping_init_accumulate_frames = 100, 50
+        q_.maximum_allow_residual_block = N
+        r_.set_profiling(True)
+        if args.force_general or args.legacy_solver or args.packed48_solver or args.no_knn_coop or args.no_knn_tile or args.knn_tile_with_reuse:
+            r_.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver, packed48_solver=args.packed48_solver,
+                         no_knn_coop=args.no_knn_coop, no_knn_tile=args.no_knn_tile, knn_tile_with_reuse=args.knn_tile_with_reuse)
+        return r_
+
+    reg = make_registrar()
     p = reg.params
-    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = args.icp_iters, 20, 1
-    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
-    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
-    p.maximum_allow_residual_block = N
-    reg.set_profiling(True)
-    if args.force_general or args.legacy_solver or args.packed48_solver or args.no_knn_coop or args.no_knn_tile or args.knn_tile_with_reuse:
-        reg.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver, packed48_solver=args.packed48_solver,
-                      no_knn_coop=args.no_knn_coop, no_knn_tile=args.no_knn_tile, knn_tile_with_reuse=args.knn_tile_with_reuse)
+    make_vox = lambda: (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
+    vox = make_vox()
 
-    vox = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
-
-    def run_on(fe_):
+    def fe_stage(fe_):
         fe_.extract_batch(B)
         fe_.resolve()
         fe_.select_batch(B, -1, 0.0, 1.0)
-        if vox:
-            reg.enqueue_fe_downsampled(mp, fe_, vox[0], vox[1], 0.1, 0.4, B, init, init)
+
+    def enqueue(reg_, fe_, vox_):
+        if vox_:
+            reg_.enqueue_fe_downsampled(mp, fe_, vox_[0], vox_[1], 0.1, 0.4, B, init, init)
         else:
-            reg.enqueue_fe(mp, fe_, B, init, init)
+            reg_.enqueue_fe(mp, fe_, B, init, init)
+
+    def run_on(fe_):
+        fe_stage(fe_)
+        enqueue(reg, fe_, vox)
         return reg.collect(B)
+
+    def pipelined(k_steps, slots_):
+        """k_steps batches through len(slots_) (extractor, registrar, voxel filters) slots: batch i + D - 1 is extracted and enqueued
+        before batch i is collected"""
+        D_, o = len(slots_), None
+        for j in range(min(D_ - 1, k_steps)):   # prologue: the first D - 1 batches
+            fe_stage(slots_[j][0])
+            enqueue(slots_[j][1], slots_[j][0], slots_[j][2])
+        for i in range(k_steps):
+            if i + D_ - 1 < k_steps:
+                f_, r_, v_ = slots_[(i + D_ - 1) % D_]   # (the slot's previous batch, i - 1, was collected in the last iteration)
+                fe_stage(f_)
+                enqueue(r_, f_, v_)
+            o = slots_[i % D_][1].collect(B)
+        return o
 
     def step():
         return run_on(fe)
@@ -306,11 +335,53 @@ def main():
     total_scans = B * args.steps * world
     value = total_scans / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+    sequential, pipeline_note = None, None
+    seq_ms_per_step = ms_per_step
+
+    # ---- the same K steps, consecutive batches overlapped: two extractor handles (both hold the resident scans) and two registrars
+    #      on their own streams; batch i+1 is extracted and its registration enqueued while batch i's kernels run, so the device
+    #      does not idle during the host's round trips (label fix-up after extraction, result download) and the tail of one
+    #      batch's launches (a few slow scans on a few CUs) is filled by the other's.  Nothing is skipped: every batch's
+    #      extraction, selection, 10 ICP iterations and result download happen inside the timed region, the first batch's
+    #      extraction included.  The sequential figure above stays in the line as `sequential`; kernel times / roofline are
+    #      taken from it (launches of two batches sharing the device stretch each other's event intervals).
+    fe_b, slots = None, None
+    if not args.no_pipeline:
+        fe_b = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
+        fe_b.upload(scans, times)
+        D = max(2, args.in_flight, args.q_pipe_in_flight if args.q_pipe else 0)
+        slots = [(fe, reg, vox), (fe_b, make_registrar(), make_vox())]
+        for _ in range(D - 2):
+            f_ = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
+            f_.upload(scans, times)
+            slots.append((f_, make_registrar(), make_vox()))
+
+        pipelined(max(D, args.warmup), slots)
+        barrier()
+        tp = time.perf_counter()
+        out_p = pipelined(args.steps, slots)
+        barrier()
+        el_p = time.perf_counter() - tp
+        per_rank_p = [round(B * args.steps / el_p, 2)]
+        if dist is not None:
+            mine = torch.tensor([B * args.steps / el_p], device="cuda", dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank_p = [round(float(x.item()), 2) for x in allr]
+            t = torch.tensor([el_p], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_p = float(t.item())
+        same = bool(np.array_equal(out_p[0], res) and np.array_equal(out_p[1], pc) and np.array_equal(out_p[2], pi))
+        sequential = {"value": round(value, 2), "unit": "scans/s", "ms_per_step": round(ms_per_step, 3), "per_rank_scans_per_s": per_rank,
+                      "note": "one batch at a time: extract, fix up labels, select, register, download, then the next batch"}
+        value, ms_per_step, per_rank = total_scans / el_p, 1e3 * el_p / args.steps, per_rank_p
+        pipeline_note = {"batches_in_flight": D, "results_equal_sequential_bitwise": same,
+                         "what": "two extractor handles + two registrars on their own streams; batch i+1 is extracted and enqueued while batch i runs"}
 
     # ---- the same steps with the scans crossing PCIe inside the timed region (SURVEY 8d "end-to-end ... of one scan") ----
     streamed = None
     if not args.no_streamed:
-        fe2 = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
+        fe2 = fe_b if fe_b is not None else Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
         pair = (fe, fe2)
         for f_ in pair:  # warm-up of both handles' paths
             f_.upload(scans, times, wait=False)
@@ -390,6 +461,24 @@ def main():
         q_pipe_extra = {"scans_per_s_this_rank": round(B / tq, 1), "ms_per_step": round(1e3 * tq, 3),
                         "features_per_scan": {"corner": float(ncq.mean()), "surface": float(nsq.mean())},
                         "note": "device VoxelGrid (leaf 0.1 / 0.4 m, laser_mapping.hpp:1367-1373) between extraction and registration"}
+        if slots is not None:
+            # A voxel-filtered batch is a latency chain: its step lasts as long as its slowest scan's LM iterations on ONE workgroup while
+            # the other CUs idle.  Batches are independent: with several in flight the idle CUs run the other batches' scans.
+            Dq = max(2, args.q_pipe_in_flight)
+            slots_q = [(f_, r_, (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev))) for f_, r_, _ in slots[:Dq]]
+            while len(slots_q) < Dq:
+                f_ = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
+                f_.upload(scans, times)
+                slots_q.append((f_, make_registrar(), (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev))))
+            pipelined(Dq, slots_q)
+            barrier()
+            tq = time.perf_counter()
+            out_q = pipelined(3 * Dq, slots_q)
+            barrier()
+            tq = (time.perf_counter() - tq) / (3 * Dq)
+            q_pipe_extra = {"scans_per_s_this_rank": round(B / tq, 1), "ms_per_step": round(1e3 * tq, 3), "batches_in_flight": Dq,
+                            "one_batch_at_a_time": {k_: q_pipe_extra[k_] for k_ in ("scans_per_s_this_rank", "ms_per_step")},
+                            "accepted_frac": float(np.mean(out_q[0])), "features_per_scan": q_pipe_extra["features_per_scan"], "note": q_pipe_extra["note"]}
         reg.enqueue_fe(mp, fe, B, init, init)  # leave the registrar in the state of the timed configuration
         reg.collect(B)
 
@@ -469,11 +558,14 @@ def main():
                    "scan_points": N, "map_points": int(len(corner) + len(surf)), "map_corner": int(len(corner)),
                    "map_surf": int(len(surf)), "icp_iters": args.icp_iters, "batch_scans_per_step_per_gpu": B,
                    "distinct_scans_in_batch": n_distinct,
-                   "parallelism": f"replicas x{world} (independent scans, no data-path collective)"},
+                   "parallelism": f"replicas x{world} (independent scans, no data-path collective)"
+                                  + ("" if pipeline_note is None else f"; {pipeline_note['batches_in_flight']} batches in flight per GPU (extraction / registration of batch i+1 overlaps registration of batch i)")},
         "per_rank_scans_per_s": per_rank,
         # a device-side clock beside the wall clock: HIP events on the registrar's stream around every launch class, summed (the
         # extraction kernels run on the extractor's stream and are not in it: ~0.3 ms per step)
-        "device_ms_per_step_hip_events": {"registrar_kernels": round(float(k_ms.sum() / args.steps), 3), "wall": round(ms_per_step, 3)},
+        "device_ms_per_step_hip_events": {"registrar_kernels": round(float(k_ms.sum() / args.steps), 3), "wall_one_batch_at_a_time": round(seq_ms_per_step, 3)},
+        "sequential": sequential,
+        "pipeline": pipeline_note,
         "roofline": roofline,
         "roofline_path": roofline_path,
         "roofline_knn": pmc_knn_issue(B),  # the other half of the step: instruction-bound (committed counters, labelled)

@@ -42,6 +42,7 @@ def main():
                     "sub-sampling of the features on the library's reproducible stream; 0 = every feature is a residual block")
     ap.add_argument("--distinct-frames", type=int, default=0, help="generate only this many distinct scans (a multiple of 50, the period of the "
                     "out-and-back trajectory) and replay them: frame k uses scan k mod D, whose pose is frame k's; 0 = every frame its own scan")
+    ap.add_argument("--no-prefetch", action="store_true", help="A/B: extract frame k + 1 only after frame k has been registered")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of rank 0's sequence also run through the CPU oracle (0 = skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: start the ranks ourselves (bench.py's helper), one per GPU
@@ -96,7 +97,8 @@ def main():
     t0 = time.perf_counter()
     accepted, errs = 0, []
     for k in range(F):
-        accepted += lm.process_new_scan(scans[k])
+        # (the feature node runs beside the mapping node in the reference: frame k + 1 is extracted while frame k registers)
+        accepted += lm.process_new_scan(scans[k], next_xyzi=(scans[k + 1] if k + 1 < F and not args.no_prefetch else None))
         errs.append(synth.pose_error(lm.pose, truth[k]))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -124,6 +126,7 @@ def main():
         "match_buffer": {"corner": lm.map_sizes[0], "surface": lm.map_sizes[1]},
         "ms_per_frame_by_stage": dict(zip(("extract_register", "history_add", "match_buffer_refresh"), [round(1e3 * float(v) / F, 3) for v in lm.stage_s[:3]])),
         "icp_iterations_last_frame": int(lm.last_report.icp_iterations),
+        "next_frame_extracted_during_registration": not args.no_prefetch,
     }
     cyc = [int(v) for v in lm.reg.debug_cycles(0)]
     if any(cyc):  # only the -DLL_SOLVE_TIMING build (LOAM_LIVOX_LIB=...timing.so) fills these

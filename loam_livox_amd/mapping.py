@@ -27,6 +27,12 @@ class Laser_mapping:
                  maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1, cell_map_max_points: int = 1 << 21,
                  loop_closure_if_enable: int = 0, loop_closure: dict | None = None):
         self.fe = Livox_laser(max_points=scan_points, max_scans=1, device=device, piecewise_number=1)
+        # The feature node and the mapping node are separate processes in the reference: scan k + 1 is extracted while scan k is
+        # registered.  process_new_scan( scan, next_xyzi = ... ) does the same with a second extractor handle (own stream): the next
+        # scan's upload, extraction and selection are issued between this scan's enqueue and its collect.
+        self._fe_pair = [self.fe, None]
+        self._prefetched = None  # (the array object that was prefetched, its time stamp, handle)
+        self._scan_points, self._device = scan_points, device
         self.reg = Point_cloud_registration(max_scans=1, max_features=scan_points, device=device)
         self.map = Map_buffer(device=device)
         self.vox = (VoxelGrid(scan_points, 1, device=device), VoxelGrid(scan_points, 1, device=device))
@@ -66,7 +72,7 @@ class Laser_mapping:
                                                **(loop_closure or {}))
 
     def close(self):
-        for h in (self.fe, self.reg, self.map, self.vox[0], self.vox[1], self.history):
+        for h in tuple(f for f in self._fe_pair if f is not None) + (self.reg, self.map, self.vox[0], self.vox[1], self.history):
             h.close()
         if self.keyframes is not None:
             self.keyframes.close()
@@ -80,15 +86,25 @@ class Laser_mapping:
         self.keyframes.add_scan(cloud, self.pose, self.m_current_frame_index)
         self.loops += self.keyframes.process_waiting()
 
-    def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0) -> int:
-        """One frame (laser_mapping.hpp:1311-1520).  Returns the registration result (1 accepted, 0 rejected)."""
-        import time
-        t0 = time.perf_counter()
-        fe, reg = self.fe, self.reg
+    def _extract(self, fe, xyzi, time_stamp):
         fe.upload(xyzi[None], np.full(1, time_stamp))
         fe.extract_batch(1)
         fe.resolve()
         fe.select_batch(1, -1, 0.0, 1.0)
+
+    def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0, next_xyzi: np.ndarray | None = None, next_time_stamp: float = 1.0) -> int:
+        """One frame (laser_mapping.hpp:1311-1520).  Returns the registration result (1 accepted, 0 rejected).
+        next_xyzi: the scan that will be passed next (the same array object), extracted on the second handle while this one registers."""
+        import time
+        t0 = time.perf_counter()
+        reg = self.reg
+        if self._prefetched is not None and self._prefetched[0] is xyzi and self._prefetched[1] == time_stamp:
+            fe = self._prefetched[2]
+        else:
+            fe = self._fe_pair[0]
+            self._extract(fe, xyzi, time_stamp)
+        self._prefetched = None
+        self.fe = fe  # the handle that holds this frame's features (history add, key frames)
         reg.params.current_frame_index = self.m_current_frame_index  # init_pointcloud_registration runs before the increment
         self.m_current_frame_index += 1
         pose = self.pose[None]
@@ -96,6 +112,12 @@ class Laser_mapping:
             reg.enqueue_fe_downsampled(self.map, fe, self.vox[0], self.vox[1], self.line_res, self.plane_res, 1, pose, pose)
         else:
             reg.enqueue_fe(self.map, fe, 1, pose, pose)
+        if next_xyzi is not None:  # the next frame's extraction runs beside this frame's ICP kernels
+            other = 1 if fe is self._fe_pair[0] else 0
+            if self._fe_pair[other] is None:
+                self._fe_pair[other] = Livox_laser(max_points=self._scan_points, max_scans=1, device=self._device, piecewise_number=1)
+            self._extract(self._fe_pair[other], next_xyzi, next_time_stamp)
+            self._prefetched = (next_xyzi, next_time_stamp, self._fe_pair[other])
         res, pc, _, reps = reg.collect(1)
         self.last_report = reps[0]
         t1 = time.perf_counter()
