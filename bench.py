@@ -11,10 +11,19 @@ prerun solve + inlier prune + final solve (K8/K9)} -> accept/reject.  Scans are 
 reference's maximum_parallel_thread model, laser_mapping.hpp:1737-1742), so N GPUs run N independent shards
 with no data-path collective ("weak" scaling); value = scans processed by all ranks / max-over-ranks time.
 
+The K timed steps keep two batches in flight (--in-flight): batch i+1 is extracted and its registration enqueued, on a second
+extractor handle / registrar with their own streams, while batch i's kernels run -- all of every batch's work (extraction,
+selection, the ICP iterations, the result download) lies inside the timed region, the results are bit-identical to processing
+one batch at a time (the line says so: pipeline.results_equal_sequential_bitwise), and the one-at-a-time figure is reported
+beside it (`sequential`; --no-pipeline makes it the value).
+
 What the JSON line carries beyond the contract fields:
   value / ms_per_step     scans resident in HBM when the timed region starts (the contract's figure)
-  streamed                the same steps with every batch crossing PCIe inside the timed region: page-locked host
-                          buffers, asynchronous copies, two extractor handles so that batch i+1 uploads while batch i runs
+  sequential              the same K steps one batch at a time; kernel_ms_per_step and roofline are measured in THIS loop
+                          (launches of two batches sharing the device stretch each other's event intervals)
+  streamed                the same pipelined steps with every batch crossing PCIe inside the timed region: page-locked host
+                          buffers, asynchronous copies on the extractor handle's stream
+  q_pipe                  secondary figure: voxel-filtered queries (the node's input_downsample_mode), 4 batches in flight
   roofline                dominant kernel: algorithmic bytes per launch / average launch duration (HIP events), HBM peak
   roofline_path           SURVEY 8(d)'s whole-path figure  B_scan x scans/s / 8e12  with U, C counted per scan
                           (oracle/orc_roofline.py)
@@ -94,7 +103,7 @@ def pmc_traffic_bytes(kernel: str, batch: int):
     hdr, rows = rows[0], rows[1:]
     for r in rows:
         d = dict(zip(hdr, r))
-        if d["kernel"].split("<")[0] == "ll::" + kernel.replace("reg_knn_build_kernel", "reg_knn_kernel"):
+        if d["kernel"].split("<")[0] == "ll::" + kernel.replace("reg_knn_build_kernel", "reg_knn_tile_kernel"):
             g = int(d["grid_threads"])
             if best is None or g > best[0]:
                 best = (g, (2.0 * float(d["fetch_kib_avg"]) + float(d["write_kib_avg"])) * 1024.0)
@@ -138,18 +147,19 @@ def pmc_knn_issue(batch: int):
         best = None
         with open(path) as f:
             for d in csv.DictReader(l for l in f if not l.startswith("#")):
-                if d["kernel"] == kernel and (best is None or int(d["grid_threads"]) > int(best["grid_threads"])):
+                if d["kernel"].split("<")[0] == kernel and (best is None or int(d["grid_threads"]) > int(best["grid_threads"])):
                     best = d
         return best
-    c, t = biggest(pv, "ll::reg_knn_kernel"), biggest(pt, "ll::reg_knn_kernel")
+    # round 4: the surface queries' search + the corner searches + the block build are ONE kernel (ll_knn_kernels.hip)
+    c, t = biggest(pv, "ll::reg_knn_tile_kernel"), biggest(pt, "ll::reg_knn_tile_kernel")
     if not c or not t or not c.get("SQ_INSTS_VALU_avg") or not c.get("SQ_THREAD_CYCLES_VALU_avg") or not c.get("SQ_ACTIVE_INST_VALU_avg"):
         return None
     insts, us = float(c["SQ_INSTS_VALU_avg"]), float(t["avg_us"])
-    return {"bound": "valu-issue", "kernel": "reg_knn_kernel", "valu_wave_instructions_per_launch": int(insts),
+    return {"bound": "valu-issue", "kernel": "reg_knn_tile_kernel", "valu_wave_instructions_per_launch": int(insts),
             # one wave instruction occupies a SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
             "valu_issue_frac_at_2p4GHz": round(insts * 4.0 / 1024.0 / (us * 1e-6 * 2.4e9), 3),
             "lane_utilisation": round(float(c["SQ_THREAD_CYCLES_VALU_avg"]) / (64.0 * float(c["SQ_ACTIVE_INST_VALU_avg"])), 3),
-            "avg_launch_us": us, "queries_per_launch": int(t["grid_threads"]),
+            "avg_launch_us": us, "threads_per_launch": int(t["grid_threads"]),
             "sources": [os.path.relpath(pv, ROOT), os.path.relpath(pt, ROOT)]}
 
 
@@ -264,7 +274,9 @@ def main():
     make_vox = lambda: (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev)) if args.q_pipe else None
     vox = make_vox()
 
-    def fe_stage(fe_):
+    def fe_stage(fe_, upload=False):
+        if upload:
+            fe_.upload(scans, times, wait=False)  # asynchronous copy from page-locked memory on the handle's stream, ahead of its kernels
         fe_.extract_batch(B)
         fe_.resolve()
         fe_.select_batch(B, -1, 0.0, 1.0)
@@ -280,17 +292,17 @@ def main():
         enqueue(reg, fe_, vox)
         return reg.collect(B)
 
-    def pipelined(k_steps, slots_):
+    def pipelined(k_steps, slots_, upload=False):
         """k_steps batches through len(slots_) (extractor, registrar, voxel filters) slots: batch i + D - 1 is extracted and enqueued
         before batch i is collected"""
         D_, o = len(slots_), None
         for j in range(min(D_ - 1, k_steps)):   # prologue: the first D - 1 batches
-            fe_stage(slots_[j][0])
+            fe_stage(slots_[j][0], upload)
             enqueue(slots_[j][1], slots_[j][0], slots_[j][2])
         for i in range(k_steps):
             if i + D_ - 1 < k_steps:
                 f_, r_, v_ = slots_[(i + D_ - 1) % D_]   # (the slot's previous batch, i - 1, was collected in the last iteration)
-                fe_stage(f_)
+                fe_stage(f_, upload)
                 enqueue(r_, f_, v_)
             o = slots_[i % D_][1].collect(B)
         return o
@@ -376,44 +388,57 @@ def main():
                       "note": "one batch at a time: extract, fix up labels, select, register, download, then the next batch"}
         value, ms_per_step, per_rank = total_scans / el_p, 1e3 * el_p / args.steps, per_rank_p
         pipeline_note = {"batches_in_flight": D, "results_equal_sequential_bitwise": same,
-                         "what": "two extractor handles + two registrars on their own streams; batch i+1 is extracted and enqueued while batch i runs"}
+                         "what": f"{D} extractor handles + {D} registrars on their own streams; batch i+1 is extracted and enqueued while batch i runs"}
 
     # ---- the same steps with the scans crossing PCIe inside the timed region (SURVEY 8d "end-to-end ... of one scan") ----
     streamed = None
     if not args.no_streamed:
-        fe2 = fe_b if fe_b is not None else Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
-        pair = (fe, fe2)
-        for f_ in pair:  # warm-up of both handles' paths
-            f_.upload(scans, times, wait=False)
-            f_.sync()
-            run_on(f_)
-        barrier()
-        ts = time.perf_counter()
-        pair[0].upload(scans, times, wait=False)  # the first batch's copy is inside the timed region too
-        t_sync = t_up = 0.0
-        for i in range(args.steps):
-            cur, nxt = pair[i % 2], pair[(i + 1) % 2]
-            ta = time.perf_counter()
-            cur.sync()                                # batch i has arrived
-            tb = time.perf_counter()
-            if i + 1 < args.steps:
-                nxt.upload(scans, times, wait=False)  # batch i+1 crosses PCIe while batch i is processed
-            tc = time.perf_counter()
-            t_sync += tb - ta
-            t_up += tc - tb
-            run_on(cur)
-        barrier()
-        el_s = time.perf_counter() - ts
+        if slots is not None:
+            # the same loop as the resident figure, every batch's 98 MB copied from page-locked host memory inside the timed region
+            pipelined(len(slots), slots, upload=True)
+            barrier()
+            ts = time.perf_counter()
+            pipelined(args.steps, slots, upload=True)
+            barrier()
+            el_s = time.perf_counter() - ts
+            note_s = (f"every batch uploaded from page-locked host memory inside the timed region (asynchronous copy on the extractor handle's stream), "
+                      f"{len(slots)} batches in flight: batch i+1 crosses PCIe and is extracted while batch i registers")
+            t_sync = t_up = float("nan")
+        else:
+            fe2 = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
+            pair = (fe, fe2)
+            for f_ in pair:  # warm-up of both handles' paths
+                f_.upload(scans, times, wait=False)
+                f_.sync()
+                run_on(f_)
+            barrier()
+            ts = time.perf_counter()
+            pair[0].upload(scans, times, wait=False)  # the first batch's copy is inside the timed region too
+            t_sync = t_up = 0.0
+            for i in range(args.steps):
+                cur, nxt = pair[i % 2], pair[(i + 1) % 2]
+                ta = time.perf_counter()
+                cur.sync()                                # batch i has arrived
+                tb = time.perf_counter()
+                if i + 1 < args.steps:
+                    nxt.upload(scans, times, wait=False)  # batch i+1 crosses PCIe while batch i is processed
+                tc = time.perf_counter()
+                t_sync += tb - ta
+                t_up += tc - tb
+                run_on(cur)
+            barrier()
+            el_s = time.perf_counter() - ts
+            note_s = ("every batch uploaded from page-locked host memory inside the timed region (asynchronous copies, two extractor "
+                      "handles: batch i+1 crosses PCIe while batch i runs; one registration at a time)")
         if dist is not None:
             t = torch.tensor([el_s], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_s = float(t.item())
         streamed = {"value": round(total_scans / el_s, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el_s / args.steps, 3),
-                    "h2d_bytes_per_step": int(B * N * 16),
-                    "host_ms_per_step_waiting_for_the_upload": round(1e3 * t_sync / args.steps, 3),
-                    "host_ms_per_step_in_the_upload_call": round(1e3 * t_up / args.steps, 3),
-                    "note": "every batch uploaded from page-locked host memory inside the timed region (asynchronous copies, two extractor "
-                            "handles: batch i+1 crosses PCIe while batch i runs)"}
+                    "h2d_bytes_per_step": int(B * N * 16), "note": note_s}
+        if t_sync == t_sync:
+            streamed.update(host_ms_per_step_waiting_for_the_upload=round(1e3 * t_sync / args.steps, 3),
+                            host_ms_per_step_in_the_upload_call=round(1e3 * t_up / args.steps, 3))
         fe.upload(scans, times)  # leave the first handle as the resident configuration left it
 
     # single-scan latency (batch of 1 through the same code path)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--cpu-scans", type=int, default=1)
     ap.add_argument("--features-resident", action="store_true", help="time the registration only, merged feature clouds uploaded once (round-1 mode)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (1 = one at a time)")
     ap.add_argument("--no-deblur", action="store_true", help="A/B: register the same scans without the motion-deblur residuals")
     args = ap.parse_args()
     from loam_livox_amd import synth
@@ -65,31 +66,37 @@ def main():
     t0 = time.time()
     mp.setInputCloud(Map_buffer.CORNER, corner); mp.setInputCloud(Map_buffer.SURF, surf)
     t_map = time.time() - t0
-    reg = Point_cloud_registration(max_scans=B, max_features=nfeat)
-    p = reg.params
-    p.if_motion_deblur, p.minimum_pt_time_stamp, p.maximum_pt_time_stamp = (0 if args.no_deblur else 1), 0.0, float((N - 1) * np.float32(1e-5))
-    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = args.icp_iters, 20, 1
-    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
-    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
-    p.maximum_allow_residual_block = 3 * N
-    reg.set_profiling(True)
+    def make_slot():
+        """a registrar and the step that feeds it (its own extractor handle, or its own copy of the merged feature clouds)"""
+        r_ = Point_cloud_registration(max_scans=B, max_features=nfeat)
+        q_ = r_.params
+        q_.if_motion_deblur, q_.minimum_pt_time_stamp, q_.maximum_pt_time_stamp = (0 if args.no_deblur else 1), 0.0, float((N - 1) * np.float32(1e-5))
+        q_.icp_max_iterations, q_.ceres_max_iterations, q_.force_all_iterations = args.icp_iters, 20, 1
+        q_.para_max_angular_rate, q_.para_max_speed, q_.max_final_cost = 20.0, 0.3, 1000.0
+        q_.current_frame_index, q_.mapping_init_accumulate_frames = 100, 50
+        q_.maximum_allow_residual_block = 3 * N
+        r_.set_profiling(True)
+        if args.features_resident:
+            # the merged feature clouds are uploaded once: the timed region starts with them resident in HBM
+            r_.upload_features(corners, surfs)
+
+            def step_():
+                r_.enqueue_uploaded(mp, B, pose_last, pose_last)
+        else:
+            # the raw head scans are uploaded once; every step extracts, merges the heads on the device and registers
+            f_ = Livox_laser(max_points=N, max_scans=3 * B, piecewise_number=1)
+            f_.upload(np.stack([raw[3 * (b % args.distinct) + h] for b in range(B) for h in range(3)]), np.zeros(3 * B))
+            f_.sync()
+
+            def step_():
+                f_.extract_batch(3 * B)
+                f_.resolve()
+                f_.select_batch(3 * B, -1, 0.0, 1.0)
+                r_.enqueue_fe_merged(mp, f_, B, 3, pose_last, pose_last)
+        return r_, step_
+
     t0 = time.perf_counter()
-    if args.features_resident:
-        # the merged feature clouds are uploaded once: the timed region starts with them resident in HBM
-        reg.upload_features(corners, surfs)
-        def step():
-            reg.enqueue_uploaded(mp, B, pose_last, pose_last)
-    else:
-        # the raw head scans are uploaded once; every step extracts, merges the heads on the device and registers
-        feb = Livox_laser(max_points=N, max_scans=3 * B, piecewise_number=1)
-        feb.upload(np.stack([raw[3 * (b % args.distinct) + h] for b in range(B) for h in range(3)]), np.zeros(3 * B))
-        def step():
-            feb.extract_batch(3 * B)
-            feb.resolve()
-            feb.select_batch(3 * B, -1, 0.0, 1.0)
-            reg.enqueue_fe_merged(mp, feb, B, 3, pose_last, pose_last)
-    if not args.features_resident:
-        feb.sync()
+    reg, step = make_slot()
     t_upload = time.perf_counter() - t0
     for _ in range(args.warmup):
         step()
@@ -101,12 +108,36 @@ def main():
         res, pc, pi, reps = reg.collect(B)
         kms += reg.kernel_times()[0]
     el = time.perf_counter() - t0
+    sequential = None
+    if args.in_flight > 1:
+        # the same steps with consecutive batches overlapped (bench.py does the same): batch i+1 is extracted / enqueued on its own
+        # handles and streams while batch i's kernels run; same work inside the timed region, same results
+        slots = [(reg, step)] + [make_slot() for _ in range(args.in_flight - 1)]
+        D = len(slots)
+
+        def pipelined(k_steps):
+            o = None
+            for j in range(min(D - 1, k_steps)):
+                slots[j][1]()
+            for i in range(k_steps):
+                if i + D - 1 < k_steps:
+                    slots[(i + D - 1) % D][1]()
+                o = slots[i % D][0].collect(B)
+            return o
+
+        pipelined(D)
+        t0 = time.perf_counter()
+        out_p = pipelined(args.steps)
+        el_p = time.perf_counter() - t0
+        sequential = {"value": round(B * args.steps / el, 2), "ms_per_step": round(1e3 * el / args.steps, 2),
+                      "results_equal_bitwise": bool(np.array_equal(out_p[1], pc) and np.array_equal(out_p[0], res))}
+        el = el_p
     err = [synth.pose_error(pc[b], pose_true[b]) for b in range(B)]
     out = {"metric": "scans_per_s", "value": round(B * args.steps / el, 2), "unit": ("Mid-100 scans/s (registration with deblur; merged feature clouds resident in HBM, their one-off upload is reported as feature_upload_s)"
                     if args.features_resident else "Mid-100 scans/s (extract 3 heads + merge on the device + register with deblur; raw scans resident in HBM)"),
            "config": {"workload": "C3: 3x24k-pt Mid-100 scan from a moving sensor vs 20M-pt map, if_motion_deblur=1, 10 ICP iters (fixed)",
                       "map_points": int(len(corner) + len(surf)), "batch": B, "features_per_scan": {"corner": float(np.mean([len(c) for c in corners])), "surface": float(np.mean([len(s) for s in surfs]))}},
-           "ms_per_step": round(1e3 * el / args.steps, 2), "kernel_ms_per_step": {"knn+build": round(float(kms[0] / args.steps), 2), "solver": round(float(kms[1] / args.steps), 2)},
+           "ms_per_step": round(1e3 * el / args.steps, 2), "batches_in_flight": max(1, args.in_flight), "one_batch_at_a_time": sequential, "kernel_ms_per_step": {"knn+build": round(float(kms[0] / args.steps), 2), "solver": round(float(kms[1] / args.steps), 2)},
            "accepted_frac": float(np.mean(res)), "median_err_vs_truth_m": float(np.median([e[0] for e in err])), "median_err_vs_truth_rad": float(np.median([e[1] for e in err])),
            "blocks_last": float(np.mean([r.n_blocks_last for r in reps])), "map_upload_grid_build_s": round(t_map, 2), "feature_upload_s" if args.features_resident else "scan_upload_s": round(t_upload, 3)}
     if args.cpu_scans > 0:

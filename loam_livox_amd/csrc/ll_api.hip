@@ -820,6 +820,7 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
+    c->knn_tile_last_sort = (debug & 8192) ? 0 : ((debug & 16384) ? 2 : 1);  // bits 13 / 14: A/B of the re-sort schedule (sort at iteration 0 only / at 0, 1, 2)
     c->no_line_cache = (debug & 4096) ? 1 : 0;  // bit 12: no LDS copy of the line blocks in the solver (A/B)
     c->knn_tile = (debug & 512) ? 0 : ((debug & 1024) ? 1 : 2);  // bit 9: no tile search of the surface queries (A/B, ll_knn_tile.h); bit 10: tile
                                                                  // search only where all queries are searched, the reuse machinery for the rest

@@ -121,6 +121,7 @@ struct RegConst {
     int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
+    int knn_tile_last_sort;  // the tile search re-sorts a scan's queries by map cell in ICP iterations 0 .. this one (1: after the first pose update too)
     int no_line_cache;   // A/B switch: the solver reads line blocks from HBM in every evaluation (no LDS copy)
     int knn_tile;        // surface searches by the tile kernel (ll_knn_tile.h): 0 = off (A/B), 1 = wherever the per-lane search of ALL surface
                          // queries would run (ICP iterations before knn_reuse_from, or every iteration without reuse), 2 = every ICP iteration
