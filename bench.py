@@ -11,7 +11,7 @@ prerun solve + inlier prune + final solve (K8/K9)} -> accept/reject.  Scans are 
 reference's maximum_parallel_thread model, laser_mapping.hpp:1737-1742), so N GPUs run N independent shards
 with no data-path collective ("weak" scaling); value = scans processed by all ranks / max-over-ranks time.
 
-The K timed steps keep two batches in flight (--in-flight): batch i+1 is extracted and its registration enqueued, on a second
+The K timed steps keep three batches in flight (--in-flight): batch i+1 is extracted and its registration enqueued, on a second
 extractor handle / registrar with their own streams, while batch i's kernels run -- all of every batch's work (extraction,
 selection, the ICP iterations, the result download) lies inside the timed region, the results are bit-identical to processing
 one batch at a time (the line says so: pipeline.results_equal_sequential_bitwise), and the one-at-a-time figure is reported
@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive figure")
     ap.add_argument("--no-pipeline", action="store_true", help="value = one batch at a time (no overlap of consecutive batches)")
     ap.add_argument("--q-pipe-in-flight", type=int, default=4, help="batches in flight for the secondary Q-pipe figure")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed loop (extractor handle + registrar each)")
+    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight in the timed loop (extractor handle + registrar each)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed single-thread oracle runs (after 3 warm-ups); their median is cpu_baseline_1thread")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = os.cpu_count())")
     return ap.parse_args()
@@ -613,6 +613,11 @@ def main():
     if any(cyc1) or any(cycB):  # only the -DLL_SOLVE_TIMING build (LOAM_LIVOX_LIB=...timing.so) fills these
         result["single_scan_solver_phase_cycles"] = cyc1
         result["solver_phase_cycles_scan0"] = cycB
+        tot = np.array([int(reg.debug_cycles(b)[5]) for b in range(B)], np.float64)  # slot 5: the whole solver call, summed over the launches of a registration
+        ctl = np.array([int(reg.debug_cycles(b)[1]) for b in range(B)], np.float64)
+        qs = [0, 10, 25, 50, 75, 90, 99, 100]
+        result["solver_cycles_per_registration_quantiles"] = {"q": qs, "total": [int(v) for v in np.percentile(tot, qs)], "mean_total": int(tot.mean()),
+                                                              "lm_controller": [int(v) for v in np.percentile(ctl, qs)], "mean_lm_controller": int(ctl.mean())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg belongs to the N = 1 line only
         result.update(cpu_legs(args, synth, corner, surf, scans, init, B, vox, pc, res, reps, nc, ns, nc_fe, ns_fe))
     if rank == 0:

@@ -252,6 +252,11 @@ int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, 
 int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, double *poses_incre, ll_reg_report *reports,
                    int32_t *results);
 
+/* Test tap: the three-sample line-search fit (ll_reg_core.h lm_quintic_min_step: Ceres' InterpolatingPolynomialMinimizingStepSize with
+ * three samples, restated) in its sequential form and in the wavefront form the solver kernel runs, on n argument sets
+ * {f0, g0, x1, f1, g1, x2, f2, g2, lo, hi}: the two must agree to the bit. */
+int ll_debug_quintic(int32_t device, const double *args10, int32_t n, double *out_sequential, double *out_wavefront);
+
 /* Debug/parity taps of the first ICP iteration of scan slot `scan` after a solve: 5-NN indices/sq-distances
  * per corner / surface query (row = query, -1/inf when not found within the match radius). NULL to skip. */
 int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corner_d25, int32_t *surf_idx5,

@@ -120,6 +120,7 @@ SYMBOLS = {
     "ll_history_enable_cell_map": (_i32, [_vp, _i64, C.c_float, _i32]),
     "ll_history_cell_map": (_vp, [_vp, _i32]),
     "ll_history_refresh_cells": (_i32, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),
+    "ll_debug_quintic": (_i32, [_i32, _vp, _i32, _vp, _vp]),
     "ll_reg_stream": (_vp, [_vp]),
     "ll_fe_stream": (_vp, [_vp]),
     "ll_last_error": (C.c_char_p, []),

@@ -1033,6 +1033,29 @@ extern "C" int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, do
     return 0;
 }
 
+extern "C" int ll_debug_quintic(int32_t device, const double *args10, int32_t n, double *out_sequential, double *out_wavefront)
+{
+    if (!args10 || !out_sequential || !out_wavefront || n < 0) return set_err("ll_debug_quintic", "bad argument");
+    if (check_device(device)) return -1;
+    double *d_a = nullptr, *d_s = nullptr, *d_w = nullptr;
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    HC(hipMalloc((void **)&d_a, m * 10 * sizeof(double)));
+    HC(hipMalloc((void **)&d_s, m * sizeof(double)));
+    HC(hipMalloc((void **)&d_w, m * sizeof(double)));
+    int rc = 0;
+    if (hipMemcpy(d_a, args10, (size_t)n * 10 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+    if (!rc) {
+        launch_debug_quintic(d_a, n, d_s, d_w, nullptr);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_sequential, d_s, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_wavefront, d_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = -1;
+    }
+    (void)hipFree(d_a);
+    (void)hipFree(d_s);
+    (void)hipFree(d_w);
+    return rc ? set_err("ll_debug_quintic", "device error") : 0;
+}
+
 extern "C" int ll_reg_debug_cycles(ll_reg *r, int32_t scan, long long out[16])
 {
     if (!r || scan < 0 || scan >= r->max_scans) return set_err("ll_reg_debug_cycles", "bad argument");

@@ -183,6 +183,7 @@ struct RegDev {
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
                           int max_nc, int max_ns, hipStream_t s);
 void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s);
+void launch_debug_quintic(const double *args, int n, double *out_seq, double *out_wave, hipStream_t s);
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
                          bool fused, hipStream_t s);
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s);

@@ -773,78 +773,104 @@ LL_HD double lm_cubic_min_step(double f0, double g0, double x1, double f1, doubl
 // samples (|x2 - x1| tiny but non-zero) are only guarded against exact zero.  The oracle and the compiled stand-in share this
 // algorithm, so the parity tests cannot see such a divergence from Ceres itself; DESIGN.md section 5 lists it with the other
 // third-party restatements.
-LL_HD_NOINLINE double lm_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo,
-                                          double hi)
+// the interpolant in Newton form: p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0))))
+struct Quintic {
+    double x1, x2, f0, e01, a0, b0, c0, d0;
+};
+// false: coincident samples (the caller bisects like an invalid sample)
+LL_HD bool quintic_fit(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, Quintic &q)
 {
     /* Newton form on the nodes z = {0, 0, x1, x1, x2} (the sixth, x2 again, closes the table): divided differences with the
      * derivative in place of the quotient at a repeated node */
     const double h1 = x1, h2 = x2, h21 = x2 - x1;
-    if (!(h1 != 0.0) || !(h2 != 0.0) || !(h21 != 0.0)) return fmin(fmax(0.5 * x1, lo), hi); /* coincident samples: bisect like an invalid sample */
+    if (!(h1 != 0.0) || !(h2 != 0.0) || !(h21 != 0.0)) return false;
     const double e01 = g0, e12 = (f1 - f0) / h1, e23 = g1, e34 = (f2 - f1) / h21, e45 = g2;
     const double a0 = (e12 - e01) / h1, a1 = (e23 - e12) / h1, a2 = (e34 - e23) / h21, a3 = (e45 - e34) / h21;
     const double b0 = (a1 - a0) / h1, b1 = (a2 - a1) / h2, b2 = (a3 - a2) / h21;
     const double c0 = (b1 - b0) / h2, c1 = (b2 - b1) / h2;
-    const double d0 = (c1 - c0) / h2;
-    /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep of
-     * explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and on the device; half the dependent
-     * chain of a multiply and an add per step, and the sweep runs ~100 times per fit on the controller lane) */
-#define LL_Q_EVAL(X, PV, DV)                         \
-    do {                                             \
-        const double x_ = (X);                       \
-        const double u1_ = x_ - x1, u2_ = x_ - x2;   \
-        double b_ = d0, db_ = 0.0;                   \
-        db_ = fma(u2_, db_, b_);                     \
-        b_ = fma(u2_, b_, c0);                       \
-        db_ = fma(u1_, db_, b_);                     \
-        b_ = fma(u1_, b_, b0);                       \
-        db_ = fma(u1_, db_, b_);                     \
-        b_ = fma(u1_, b_, a0);                       \
-        db_ = fma(x_, db_, b_);                      \
-        b_ = fma(x_, b_, e01);                       \
-        db_ = fma(x_, db_, b_);                      \
-        b_ = fma(x_, b_, f0);                        \
-        (PV) = b_;                                   \
-        (DV) = db_;                                  \
-    } while (0)
+    q.x1 = x1;
+    q.x2 = x2;
+    q.f0 = f0;
+    q.e01 = e01;
+    q.a0 = a0;
+    q.b0 = b0;
+    q.c0 = c0;
+    q.d0 = (c1 - c0) / h2;
+    return true;
+}
+/* value and derivative by one nested sweep of explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and
+ * on the device; half the dependent chain of a multiply and an add per step, and the sweep runs ~100 times per fit) */
+LL_HD void quintic_eval(const Quintic &q, double x, double &pv, double &dv)
+{
+    const double u1 = x - q.x1, u2 = x - q.x2;
+    double b = q.d0, db = 0.0;
+    db = fma(u2, db, b);
+    b = fma(u2, b, q.c0);
+    db = fma(u1, db, b);
+    b = fma(u1, b, q.b0);
+    db = fma(u1, db, b);
+    b = fma(u1, b, q.a0);
+    db = fma(x, db, b);
+    b = fma(x, b, q.e01);
+    db = fma(x, db, b);
+    b = fma(x, b, q.f0);
+    pv = b;
+    dv = db;
+}
+// k-th grid point of [lo, hi] cut into ng cells
+LL_HD double quintic_grid(double lo, double hi, int k, int ng) { return (k == ng) ? hi : lo + (hi - lo) * ((double)k / (double)ng); }
+// does the derivative change sign over a cell with end derivatives da, db (or vanish at its right end)?
+LL_HD bool quintic_cell_has_root(double da, double db) { return (da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0; }
+// the root of the derivative inside such a cell [xa, xb]: 40 bisections
+LL_HD double quintic_cell_root(const Quintic &q, double xa, double xb, double da, double db)
+{
+    double l = xa, r = xb, dl = da;
+    if (db != 0.0) {
+        for (int it = 0; it < 40; it++) {
+            const double m = 0.5 * (l + r);
+            double pm, dm;
+            quintic_eval(q, m, pm, dm);
+            (void)pm;
+            if (dm == 0.0) {
+                l = r = m;
+                break;
+            }
+            if ((dl < 0.0) == (dm < 0.0)) {
+                l = m;
+                dl = dm;
+            } else {
+                r = m;
+            }
+        }
+    } else {
+        l = r = xb;
+    }
+    return 0.5 * (l + r);
+}
+#define LL_QUINTIC_CELLS 32 /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
+
+LL_HD_NOINLINE double lm_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo,
+                                          double hi)
+{
+    Quintic q;
+    if (!quintic_fit(f0, g0, x1, f1, g1, x2, f2, g2, q)) return fmin(fmax(0.5 * x1, lo), hi); /* coincident samples: bisect like an invalid sample */
     double best_x = lo, best_v, vh, da, dh;
-    LL_Q_EVAL(lo, best_v, da);
-    LL_Q_EVAL(hi, vh, dh);
+    quintic_eval(q, lo, best_v, da);
+    quintic_eval(q, hi, vh, dh);
     (void)dh;
     if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
         best_v = vh;
         best_x = hi;
     }
-    const int NG = 32; /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
     double xa = lo;
-    for (int k = 1; k <= NG; k++) {
-        const double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
+    for (int k = 1; k <= LL_QUINTIC_CELLS; k++) {
+        const double xb = quintic_grid(lo, hi, k, LL_QUINTIC_CELLS);
         double pb, db;
-        LL_Q_EVAL(xb, pb, db);
-        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
-            double l = xa, r = xb, dl = da;
-            if (db != 0.0) {
-                for (int it = 0; it < 40; it++) {
-                    const double m = 0.5 * (l + r);
-                    double pm, dm;
-                    LL_Q_EVAL(m, pm, dm);
-                    (void)pm;
-                    if (dm == 0.0) {
-                        l = r = m;
-                        break;
-                    }
-                    if ((dl < 0.0) == (dm < 0.0)) {
-                        l = m;
-                        dl = dm;
-                    } else {
-                        r = m;
-                    }
-                }
-            } else {
-                l = r = xb;
-            }
-            const double root = 0.5 * (l + r);
+        quintic_eval(q, xb, pb, db);
+        if (quintic_cell_has_root(da, db)) {
+            const double root = quintic_cell_root(q, xa, xb, da, db);
             double v, dv;
-            LL_Q_EVAL(root, v, dv);
+            quintic_eval(q, root, v, dv);
             (void)dv;
             if (v < best_v) {
                 best_v = v;
@@ -855,7 +881,6 @@ LL_HD_NOINLINE double lm_quintic_min_step(double f0, double g0, double x1, doubl
         xa = xb;
         da = db;
     }
-#undef LL_Q_EVAL
     return best_x;
 }
 
@@ -976,59 +1001,13 @@ LL_LM_FN int lm_init(LmCtl &c, const double e[LL_NACC], int n_active)
     return lm_propose(c);
 }
 
-// Evaluation e at c.cand is available.  Returns 1 if another evaluation (at the new c.cand) is needed.
-LL_LM_FN int lm_update(LmCtl &c, const double e_in[LL_NACC])
+// ---- lm_update, in the pieces the device needs: the three-sample fit of a line search (lm_quintic_min_step) is the one part of
+// the controller with parallel work in it, and the solver runs it on the controller's whole wavefront (ll_reg_kernels.hip
+// lm_quintic_min_step_wave) between lm_update_pre and lm_update_post.  lm_update below is the same code in one call.
+
+// the part of lm_update behind the line search: e is the evaluation that stands (at c.cand)
+LL_LM_FN int lm_update_finish(LmCtl &c, const double *e, int from_first_eval)
 {
-    double e[LL_NACC];
-    for (int i = 0; i < LL_NACC; i++) e[i] = e_in[i];
-    c.last_accept = 0;
-    int from_first_eval = 0;
-    if (c.bound >= 0) {
-        // projected ARMIJO line search (TrustRegionMinimizer::DoLineSearch)
-        if (!c.ls_active) {
-            for (int i = 0; i < LL_NACC; i++) c.first_eval[i] = e[i];
-            for (int i = 0; i < 7; i++) c.first_cand[i] = c.cand[i];
-            c.ls_active = 1;
-        }
-        const double cur_cost = e[27];
-        const bool finite_cost = (cur_cost - cur_cost) == 0.0;
-        if (!finite_cost || cur_cost > c.cost + 1e-4 * c.gd * c.ls_step) {
-            int failed = 0;
-            double new_step = 0.0, cg = 0.0;
-            if (++c.ls_iter >= 20) {
-                failed = 1;
-            } else {
-                if (!finite_cost) {
-                    new_step = fmin(fmax(c.ls_step * 0.5, 1e-3 * c.ls_step), 0.6 * c.ls_step);
-                } else {
-                    for (int j = 0; j < 6; j++) cg += e[21 + j] * c.delta[j];
-                    if (c.ls_prev_valid)  // three samples: the quintic (second and later contractions)
-                        new_step = lm_quintic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, c.ls_prev_x, c.ls_prev_f, c.ls_prev_g, 1e-3 * c.ls_step,
-                                                       0.6 * c.ls_step);
-                    else
-                        new_step = lm_cubic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, 1e-3 * c.ls_step, 0.6 * c.ls_step);
-                }
-                if (new_step * c.dmax < 1e-9) failed = 1;
-            }
-            if (!failed) {
-                c.ls_prev_valid = finite_cost ? 1 : 0;
-                c.ls_prev_x = c.ls_step;
-                c.ls_prev_f = cur_cost;
-                c.ls_prev_g = cg;
-                c.ls_step = new_step;
-                double sd[6];
-                for (int j = 0; j < 6; j++) sd[j] = c.delta[j] * c.ls_step;
-                state_plus(c.x, sd, c.bound, c.cand);
-                return 1;
-            }
-            // failed search: Ceres keeps the full step
-            from_first_eval = c.ls_iter > 1 ? 1 : 0;  // the point just evaluated is the first one only when no retry ran
-            for (int i = 0; i < LL_NACC; i++) e[i] = c.first_eval[i];
-            for (int i = 0; i < 7; i++) c.cand[i] = c.first_cand[i];
-        } else if (c.ls_step != 1.0) {
-            for (int j = 0; j < 6; j++) c.delta[j] *= c.ls_step;
-        }
-    }
     double cand_cost = e[27];
     if (!((cand_cost - cand_cost) == 0.0)) cand_cost = DBL_MAX;
 
@@ -1069,6 +1048,105 @@ LL_LM_FN int lm_update(LmCtl &c, const double e_in[LL_NACC])
         c.reuse_diagonal = 1;
     }
     return lm_propose(c);
+}
+
+// lm_update_pre / _post return one of these; LM_FINISH_* -> lm_update_finish is still to be called (once, by the caller: the
+// controller is inlined into the solver loop, and two copies of lm_propose's factorisation cost the loop registers and code)
+#define LM_DONE 0         /* (only from lm_update_finish) */
+#define LM_EVAL 1         /* evaluate at c.cand and call lm_update again */
+#define LM_FIT 2          /* evaluate the three-sample fit and call lm_update_post */
+#define LM_FINISH_E 3     /* lm_update_finish( c, e_in, 0 ): the evaluation just made stands */
+#define LM_FINISH_FIRST 4 /* lm_update_finish( c, c.first_eval, c.ls_iter > 1 ): a failed search keeps the full step */
+
+// a contraction of the line search has its new step (or has failed): take it, or fall back to the full step (Ceres keeps it)
+LL_LM_FN int lm_update_contract(LmCtl &c, int failed, double new_step, int finite_cost, double cur_cost, double cg)
+{
+    if (!failed) {
+        c.ls_prev_valid = finite_cost ? 1 : 0;
+        c.ls_prev_x = c.ls_step;
+        c.ls_prev_f = cur_cost;
+        c.ls_prev_g = cg;
+        c.ls_step = new_step;
+        double sd[6];
+        for (int j = 0; j < 6; j++) sd[j] = c.delta[j] * c.ls_step;
+        state_plus(c.x, sd, c.bound, c.cand);
+        return LM_EVAL;
+    }
+    for (int i = 0; i < 7; i++) c.cand[i] = c.first_cand[i];
+    return LM_FINISH_FIRST;
+}
+
+// Evaluation e at c.cand is available: the line search's part of lm_update.  LM_FIT: the caller has to evaluate
+// lm_quintic_min_step( c.cost, c.gd, c.ls_step, *cur_cost, *cg, c.ls_prev_x, c.ls_prev_f, c.ls_prev_g, 1e-3 * c.ls_step, 0.6 * c.ls_step )
+// and hand the step to lm_update_post.
+// e_in: the caller's copy of the evaluation (registers on the device: one batch of loads from the LDS sums, which may alias c as
+// far as the compiler can tell); lm_update_close gets the same array.
+LL_LM_FN int lm_update_pre(LmCtl &c, const double e_in[LL_NACC], double *cur_cost_out, double *cg_out)
+{
+    c.last_accept = 0;
+    if (c.bound >= 0) {
+        // projected ARMIJO line search (TrustRegionMinimizer::DoLineSearch)
+        if (!c.ls_active) {
+            for (int i = 0; i < LL_NACC; i++) c.first_eval[i] = e_in[i];
+            for (int i = 0; i < 7; i++) c.first_cand[i] = c.cand[i];
+            c.ls_active = 1;
+        }
+        const double cur_cost = e_in[27];
+        const bool finite_cost = (cur_cost - cur_cost) == 0.0;
+        if (!finite_cost || cur_cost > c.cost + 1e-4 * c.gd * c.ls_step) {
+            int failed = 0;
+            double new_step = 0.0, cg = 0.0;
+            if (++c.ls_iter >= 20) {
+                failed = 1;
+            } else {
+                if (!finite_cost) {
+                    new_step = fmin(fmax(c.ls_step * 0.5, 1e-3 * c.ls_step), 0.6 * c.ls_step);
+                } else {
+                    for (int j = 0; j < 6; j++) cg += e_in[21 + j] * c.delta[j];
+                    if (c.ls_prev_valid) {  // three samples: the quintic (second and later contractions)
+                        *cur_cost_out = cur_cost;
+                        *cg_out = cg;
+                        return LM_FIT;
+                    }
+                    new_step = lm_cubic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, 1e-3 * c.ls_step, 0.6 * c.ls_step);
+                }
+                if (new_step * c.dmax < 1e-9) failed = 1;
+            }
+            return lm_update_contract(c, failed, new_step, finite_cost ? 1 : 0, cur_cost, cg);
+        } else if (c.ls_step != 1.0) {
+            for (int j = 0; j < 6; j++) c.delta[j] *= c.ls_step;
+        }
+    }
+    return LM_FINISH_E;
+}
+
+LL_LM_FN int lm_update_post(LmCtl &c, double cur_cost, double cg, double new_step)
+{
+    return lm_update_contract(c, (new_step * c.dmax < 1e-9) ? 1 : 0, new_step, 1, cur_cost, cg);
+}
+
+// what is left after lm_update_pre / _post answered `code` (e: the array lm_update_pre had; overwritten when the full step comes back)
+LL_LM_FN int lm_update_close(LmCtl &c, double e[LL_NACC], int code)
+{
+    if (code == LM_EVAL) return 1;
+    if (code == LM_FINISH_FIRST)
+        for (int i = 0; i < LL_NACC; i++) e[i] = c.first_eval[i];
+    // (from_first_eval: the point just evaluated is the first one only when no retry ran)
+    return lm_update_finish(c, e, (code == LM_FINISH_FIRST && c.ls_iter > 1) ? 1 : 0);
+}
+
+// Evaluation e at c.cand is available.  Returns 1 if another evaluation (at the new c.cand) is needed.
+LL_LM_FN int lm_update(LmCtl &c, const double e_p[LL_NACC])
+{
+    double e_in[LL_NACC];
+    for (int i = 0; i < LL_NACC; i++) e_in[i] = e_p[i];
+    double cur_cost = 0.0, cg = 0.0;
+    int code = lm_update_pre(c, e_in, &cur_cost, &cg);
+    if (code == LM_FIT)
+        code = lm_update_post(c, cur_cost, cg,
+                              lm_quintic_min_step(c.cost, c.gd, c.ls_step, cur_cost, cg, c.ls_prev_x, c.ls_prev_f, c.ls_prev_g, 1e-3 * c.ls_step,
+                                                  0.6 * c.ls_step));
+    return lm_update_close(c, e_in, code);
 }
 
 }  // namespace ll

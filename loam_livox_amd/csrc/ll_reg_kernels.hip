@@ -443,6 +443,7 @@ struct SolveShared {
     int n_active, n_corner_avail, n_surf_avail, n_unique;
     int l1_valid;  // compact path: blk_l1 holds the L1 values at the prerun result (written by its last evaluation)
     int pt_T, pt_Tl, pt_kc, pt_priv;  // plane-table path: distinct triples, table entries in LDS, record rounds cached in LDS, private entries
+    double fit[10];                   // arguments of a line search's three-sample fit, from the controller lane to its wavefront
     int pt_nl;                        // ... line blocks of this workgroup's first rounds kept at the top of s_raw (solver_eval3)
     double thr;
     int grp_g, grp_G, grp_seq, grp_abort;  // grouped solver: this workgroup's rank in its scan's group, the group size, barriers passed
@@ -2680,6 +2681,107 @@ __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int n
 #undef LL3_USE
 #undef LL3_PIPE
 
+// lm_quintic_min_step (ll_reg_core.h) on the controller's whole wavefront.  The sequential form evaluates the interpolant at 33 grid
+// points one after the other and bisects every cell with a sign change of the derivative 40 times in turn: ~75 dependent
+// ten-step sweeps for one root, ~12 k cycles on one lane while the workgroup -- and the launch, whose length is its slowest
+// scan's -- waits.  Here lane k takes grid point k, the cells with a root are bisected side by side (each lane runs the very
+// loop of quintic_cell_root on its own cell), and the sequential "strictly smaller wins" scan over the roots becomes a
+// (value, cell) minimum: the same operations on the same operands for every number that is kept, so the same bits (compared
+// on random fits by tests/test_gpu_reg.py through ll_debug_quintic).  All 64 lanes must call it.
+__device__ __forceinline__ double lm_quintic_min_step_wave(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2,
+                                                           double lo, double hi, int lane)
+{
+    Quintic q;
+    if (!quintic_fit(f0, g0, x1, f1, g1, x2, f2, g2, q)) return fmin(fmax(0.5 * x1, lo), hi);  // (uniform: every lane has the same arguments)
+    const int k = lane <= LL_QUINTIC_CELLS ? lane : LL_QUINTIC_CELLS;  // the lanes above the grid repeat its last point; nothing of theirs is kept
+    const double xk = (k == 0) ? lo : quintic_grid(lo, hi, k, LL_QUINTIC_CELLS);
+    double pk, dk;
+    quintic_eval(q, xk, pk, dk);
+    const double v_lo = __shfl(pk, 0), v_hi = __shfl(pk, LL_QUINTIC_CELLS);
+    double best_x = lo, best_v = v_lo;
+    if (!(best_v < v_hi)) {
+        best_v = v_hi;
+        best_x = hi;
+    }
+    const double xa = __shfl_up(xk, 1), da = __shfl_up(dk, 1);  // cell k = [x_(k-1), x_k]
+    const bool mine = lane >= 1 && lane <= LL_QUINTIC_CELLS && quintic_cell_has_root(da, dk);
+    double root = 0.0, v = 0.0;
+    if (mine) {
+        root = quintic_cell_root(q, xa, xk, da, dk);
+        double dv;
+        quintic_eval(q, root, v, dv);
+        (void)dv;
+    }
+    // the scan  `if (v < best_v) take it`  over the cells in order ends on the smallest value below the end points' best, the first
+    // cell among equal values
+    const bool cand = mine && (v < best_v);
+    double bv = cand ? v : INFINITY;
+    int bl = cand ? lane : 64;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int ol = __shfl_xor(bl, off);
+        if (ol < 64 && (bl >= 64 || ov < bv || (ov == bv && ol < bl))) {
+            bv = ov;
+            bl = ol;
+        }
+    }
+    const double r = __shfl(root, bl & 63);
+    return bl < 64 ? r : best_x;
+}
+
+// the fit with its ten arguments in LDS (written by lane 0).  (Out of line -- a real call inside the solver kernel -- it cost the WHOLE
+// kernel half of its speed: 4.6 ms of solver per step against 3.0; the kernel then carries the calling convention's scratch set-up
+// and the allocator's call-clobber constraints through every phase.  Inlined, as everything else in this kernel.)
+__device__ __forceinline__ double lm_quintic_min_step_wave_call(const double *a, int lane)
+{
+    return lm_quintic_min_step_wave(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], lane);
+}
+
+// lm_update with the three-sample fit on the wavefront: called by every lane of the controller's wavefront (lane 0 holds the controller)
+__device__ __forceinline__ int lm_update_wave(LmCtl &c, const double *sum, double *fit, int lane)
+{
+    int code = 0;
+    double e[LL_NACC];  // lane 0's register copy of the evaluation
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < LL_NACC; i++) e[i] = sum[i];
+        double cur_cost = 0.0, cg = 0.0;
+        code = lm_update_pre(c, e, &cur_cost, &cg);
+        if (code == LM_FIT) {
+            fit[0] = c.cost, fit[1] = c.gd, fit[2] = c.ls_step, fit[3] = cur_cost, fit[4] = cg, fit[5] = c.ls_prev_x, fit[6] = c.ls_prev_f, fit[7] = c.ls_prev_g;
+            fit[8] = 1e-3 * c.ls_step, fit[9] = 0.6 * c.ls_step;
+        }
+    }
+    if (__shfl(code, 0) == LM_FIT) {  // (uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 0's LDS stores before the wavefront's loads (same wavefront: in order)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double step = lm_quintic_min_step_wave_call(fit, lane);
+        if (lane == 0) code = lm_update_post(c, fit[3], fit[4], step);
+    }
+    int r = 0;
+    if (lane == 0) r = lm_update_close(c, e, code);
+    return r;  // (lane 0's is the answer)
+}
+
+// test tap (ll_debug_quintic): the sequential and the wavefront form of the fit on n argument sets, one wavefront each
+__global__ __launch_bounds__(64) void debug_quintic_kernel(const double *args, int n, double *out_seq, double *out_wave)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const double *a = args + 10 * (size_t)i;
+    const double w = lm_quintic_min_step_wave(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], lane);
+    if (lane == 0) {
+        out_wave[i] = w;
+        out_seq[i] = lm_quintic_min_step(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+    }
+}
+void launch_debug_quintic(const double *args, int n, double *out_seq, double *out_wave, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(debug_quintic_kernel, dim3(n), dim3(64), 0, s, args, n, out_seq, out_wave);
+}
+
 // one ceres::Solve on the plane-table layout: starts at x0, leaves the result in sh.ctl
 template <bool WANT_L1, bool GROUPED>
 __device__ __forceinline__ void solver_lm3(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
@@ -2711,9 +2813,12 @@ __device__ __forceinline__ void solver_lm3(const RegDev &rd, const RegConst &rc,
             solver_eval3<false, false, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, act, s_raw, q_last, sh);
         LL_TACC(0, t0);
         LL_T0(t1);
-        if (tid == 0) {
-            sh.need = lm_update(sh.ctl, sh.sum);
-            sh.l1_valid = (spec && !sh.need && sh.ctl.last_accept == 1) ? 1 : 0;
+        if (tid < 64) {  // the controller's wavefront: lane 0 steps the controller, all of it fits a line search's interpolant
+            const int need = lm_update_wave(sh.ctl, sh.sum, sh.fit, tid);
+            if (tid == 0) {
+                sh.need = need;
+                sh.l1_valid = (spec && !need && sh.ctl.last_accept == 1) ? 1 : 0;
+            }
         }
         __syncthreads();
         LL_TACC(1, t1);

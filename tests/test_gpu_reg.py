@@ -720,3 +720,42 @@ def test_product_library_refuses_the_ab_solver_forms(gpu_lib):
             reg.set_debug(False, **kw)
     reg.set_debug(False)
     reg.close()
+
+
+def test_wavefront_line_search_fit_equals_the_sequential_one(gpu_lib):
+    """The solver fits a line search's three-sample interpolant on the controller's whole wavefront (grid points side by side, the cells
+    with a root bisected side by side): to the bit the step of the sequential form on the device, and of the same code compiled for
+    the host (which tests/test_hostcheck.py / test_ref_pin.py hold to the oracle and to the Ceres stand-in)."""
+    import ctypes as C
+    from loam_livox_amd.capi import ptr
+    from tests.hostcheck import hc
+    rng = np.random.default_rng(31)
+    args = []
+    for i in range(4000):
+        x1 = float(10.0 ** rng.uniform(-4, 0))
+        x2 = x1 * float(rng.uniform(1.2, 8.0))
+        if i % 5 == 0:   # samples of a wiggly function: several roots of the derivative inside [lo, hi]
+            w, ph, a0, s = rng.uniform(5, 60) / x1, rng.uniform(0, 6.28), rng.uniform(0.1, 3.0), rng.uniform(-2, 0.5)
+            f = lambda x: a0 * np.sin(w * x + ph) + s * x / x1
+            g = lambda x: a0 * w * np.cos(w * x + ph) + s / x1
+        else:            # samples of a random quintic (descent at 0)
+            c = rng.normal(size=6) * np.array([1, 1, 1 / x1, 1 / x1 ** 2, 1 / x1 ** 3, 1 / x1 ** 4])
+            c[1] = -abs(c[1]) - 1e-3
+            f = lambda x: float(np.polyval(c[::-1], x))
+            g = lambda x: float(np.polyval(np.polyder(c[::-1]), x))
+        row = [f(0.0), g(0.0), x1, f(x1), g(x1), x2, f(x2), g(x2), 1e-3 * x1, 0.6 * x1]
+        if i % 97 == 0:
+            row[5] = row[2]      # coincident samples
+        if i % 101 == 0:
+            row[3] = np.inf      # a non-finite sample value
+        if i % 103 == 0:
+            row[1] = row[4] = row[7] = 0.0   # flat derivative samples
+        args.append(row)
+    a = np.ascontiguousarray(args, np.float64)
+    seq, wav = np.zeros(len(a)), np.zeros(len(a))
+    assert gpu_lib.ll_debug_quintic(0, ptr(a), len(a), ptr(seq), ptr(wav)) == 0
+    host = np.array([hc.quintic_min_step(*r) for r in a])
+    same = lambda x, y: np.array_equal(x.view(np.uint64), y.view(np.uint64))
+    assert same(wav, seq) and same(seq, host)
+    inner = (seq != a[:, 8]) & (seq != a[:, 9])
+    assert inner.sum() > 500     # a root of the derivative won, not an end point, in a good share of the cases
