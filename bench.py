@@ -52,8 +52,8 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="independent scans per step and per GPU")
     ap.add_argument("--map-points", type=int, default=5_000_000)
     ap.add_argument("--scan-points", type=int, default=24000)
