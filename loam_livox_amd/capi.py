@@ -165,7 +165,11 @@ class use_library:
         global _lib, LIB_PATH
         self.saved = (_lib, LIB_PATH)
         _lib, LIB_PATH = None, self.path
-        return load()
+        try:
+            return load()
+        except Exception:
+            _lib, LIB_PATH = self.saved  # (a variant that does not load leaves the product library in place)
+            raise
 
     def __exit__(self, *exc):
         global _lib, LIB_PATH

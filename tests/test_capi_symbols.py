@@ -3,6 +3,8 @@ No compute calls here (there is no CPU path to call)."""
 import os
 import re
 
+import pytest
+
 from loam_livox_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -53,3 +55,14 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), f"{f} uses oracle/"
+
+
+def test_use_library_restores_the_product_library_when_the_variant_is_missing(tmp_path):
+    """capi.use_library (how the tests reach the -DLL_AB_PATHS build): a variant that cannot be loaded raises and leaves the module
+    bound to the library it had"""
+    from loam_livox_amd import capi
+    before = (capi._lib, capi.LIB_PATH)
+    with pytest.raises(capi.LoamLivoxError):
+        with capi.use_library(str(tmp_path / "no_such_variant.so")):
+            pass
+    assert (capi._lib, capi.LIB_PATH) == before
