@@ -12,12 +12,14 @@
 //
 // See INTEGRATION.md for the two-line change in laser_feature_extractor.hpp / laser_mapping.hpp.
 #pragma once
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -492,6 +494,24 @@ class Points_cloud_map {
     {
         const std::vector<float> v = cloud_to_xyzi(cloud);
         check(ll_cellmap_append(h_, v.data(), (int32_t)(v.size() / 4)), "ll_cellmap_append");
+    }
+    // append_cloud( pts, &cell_vec ) (:619-672, what the mapping node calls when loop closure is on, laser_mapping.hpp:1442): the
+    // reference's cell_vec is a set of cell POINTERS; the cells live on the device here, so the set holds their integer cell
+    // indices {ix, iy, iz} (centre = index * box + box / 2, :559-568) -- every cell of the first cloud, afterwards the cells that
+    // received at least three points of this cloud (:640-662).  Set arithmetic of Maps_keyframe::add_cells (:1243-1261) works on
+    // these as it does on the pointers.
+    typedef std::array<int32_t, 3> Cell_index;
+    template <class Cloud>
+    void append_cloud(const Cloud &cloud, std::set<Cell_index> *cell_vec)
+    {
+        if (!cell_vec) return append_cloud(cloud);
+        const std::vector<float> v = cloud_to_xyzi(cloud);
+        const int32_t n = (int32_t)(v.size() / 4);
+        std::vector<int32_t> ijk((size_t)(n > 0 ? n : 1) * 3);  // a cloud of n points touches at most n cells
+        int64_t n_touched = 0;
+        check(ll_cellmap_append_touched(h_, v.data(), n, 3, ijk.data(), (int64_t)(ijk.size() / 3), &n_touched), "ll_cellmap_append_touched");
+        cell_vec->clear();
+        for (int64_t i = 0; i < n_touched; i++) cell_vec->insert(Cell_index{ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2]});
     }
     int64_t get_cells_size() const  // :551-554
     {

@@ -129,9 +129,12 @@ int main(int argc, char **argv)
         int64_t n_map_cells = 0;
         int n_line_cells = 0, n_plane_cells = 0;
         float self_sim = 0.f, ratio_nz[4] = {0, 0, 0, 0};
+        size_t n_cell_vec_first = 0, n_cell_vec_second = 0;
         {
             loam_livox_hip::Points_cloud_map cell_map(1 << 16, 1.0f);
-            cell_map.append_cloud(full);
+            std::set<loam_livox_hip::Points_cloud_map::Cell_index> cell_vec;
+            cell_map.append_cloud(full, &cell_vec);  // append_cloud( pts, &cell_vec ): every cell of the first cloud ...
+            n_cell_vec_first = cell_vec.size();
             n_map_cells = cell_map.get_cells_size();
             std::vector<int32_t> ftype;
             std::vector<float> fvec;
@@ -143,6 +146,8 @@ int main(int argc, char **argv)
             std::vector<float> images;
             cell_map.analyze(images, ratio_nz);
             self_sim = loam_livox_hip::Points_cloud_map::max_similiarity_of_two_image(images.data() + 3600, images.data() + 3600);
+            cell_map.append_cloud(full, &cell_vec);  // ... afterwards the cells that received at least three points
+            n_cell_vec_second = cell_vec.size();
         }
 
         FILE *o = fopen(argv[5], "w");
@@ -151,7 +156,8 @@ int main(int argc, char **argv)
         fprintf(o, "\n%.9g %.9g\n", piece_start, piece_end);
         fprintf(o, "%zu %zu\n", n_hist_corner, n_hist_surf);
         fprintf(o, "%lld %lld %lld %lld\n", (long long)n_cell_corner, (long long)n_cell_surf, (long long)n_cells, (long long)n_cell_pts);
-        fprintf(o, "%lld %d %d %.9g %.9g %.9g\n", (long long)n_map_cells, n_line_cells, n_plane_cells, self_sim, ratio_nz[0], ratio_nz[1]);
+        fprintf(o, "%lld %d %d %.9g %.9g %.9g %zu %zu\n", (long long)n_map_cells, n_line_cells, n_plane_cells, self_sim, ratio_nz[0], ratio_nz[1],
+                n_cell_vec_first, n_cell_vec_second);
         fclose(o);
     } catch (const std::exception &e) {
         fprintf(stderr, "adapter_demo: %s\n", e.what());

@@ -74,9 +74,13 @@ def test_adapter_demo_matches_oracle(tmp_path, small_world, scans, downsample):
     # ... and Points_cloud_map: cells, labels, key-frame image of the scan's full cloud
     from oracle.orc_cellmap import CellMap
     km = CellMap(1.0)
-    km.append(orc.feature_cloud(o, fi))
+    touched_first = km.append(orc.feature_cloud(o, fi))
     f = km.features()
-    n_cells, n_line, n_plane, self_sim, rz_line, rz_plane = [float(v) for v in lines[5].split()]
+    n_cells, n_line, n_plane, self_sim, rz_line, rz_plane, n_vec_first, n_vec_second = [float(v) for v in lines[5].split()]
+    # append_cloud( pts, &cell_vec ) through the adapter: every cell of the first cloud, then the cells with >= 3 points of the cloud
+    km2 = CellMap(1.0)
+    km2.append(orc.feature_cloud(o, fi))
+    assert n_vec_first == len(touched_first) == len(km.cells) and n_vec_second == len(km2.append(orc.feature_cloud(o, fi))) > 20
     loose = int(np.sum(f["margin"] <= 1e-3))                  # cells on a decision boundary may fall either way
     assert n_cells == len(km.cells) > 100
     assert abs(n_line - np.sum(f["type"] == 1)) <= loose and abs(n_plane - np.sum(f["type"] == 2)) <= loose and n_plane > 20
