@@ -32,7 +32,12 @@ def keyframe_clouds(km: Cell_map):
 
 class Scene_alignment:
     def __init__(self, line_res: float = 0.4, plane_res: float = 0.4, maximum_icp_iteration: int = 10, accepted_threshold: float = 0.2,
-                 maximum_residual_block: int = 5000, max_points: int = 1 << 18, device: int = 0, subsample_seed: int = 1):
+                 maximum_residual_block: int = 5000, max_points: int = 1 << 18, device: int = 0, subsample_seed: int = 1,
+                 registrar_init: bool = True):
+        # registrar_init: apply the registrar settings of Scene_alignment::init (SA:233-243: ICP_LINE = 0, m_max_final_cost 20000,
+        # m_para_max_speed 1000, m_para_max_angular_rate 360 * 57.3, m_inliner_dis 0.2) as the loop detector does before its first
+        # alignment (laser_mapping.hpp:896); False = a default-constructed Scene_alignment (class defaults of the registrar)
+        self.registrar_init = registrar_init
         self.m_line_res, self.m_plane_res = np.float32(line_res), np.float32(plane_res)         # SA:27-28
         self.m_maximum_icp_iteration, self.m_accepted_threshold = maximum_icp_iteration, accepted_threshold   # SA:35-36
         self.m_para_scene_alignments_maximum_residual_block = maximum_residual_block                # SA:34
@@ -48,6 +53,12 @@ class Scene_alignment:
         mp = Map_buffer(device=self.device)
         vox = VoxelGrid(max(1, len(src_line), len(src_plane), len(tgt_line), len(tgt_plane)), 1, device=self.device)
         p = reg.params
+        if self.registrar_init:                                           # Scene_alignment::init, SA:233-243 (the detector calls it, laser_mapping.hpp:896)
+            p.icp_line = 0
+            p.max_final_cost = 20000.0
+            p.para_max_speed = 1000.0
+            p.para_max_angular_rate = 360 * 57.3
+            p.inliner_dis = 0.2
         p.current_frame_index = 10000000                                  # SA:296
         p.icp_max_iterations = self.m_maximum_icp_iteration               # SA:300
         p.ceres_max_iterations, p.ceres_prerun_times = 50, 2              # SA:301-302

@@ -28,7 +28,11 @@ def keyframe_clouds(km):
 
 class SceneAlignment:
     def __init__(self, line_res=0.4, plane_res=0.4, maximum_icp_iteration=10, accepted_threshold=0.2, maximum_residual_block=5000,
-                 subsample_seed=1):
+                 subsample_seed=1, registrar_init=True):
+        # registrar_init: the registrar settings of Scene_alignment::init (SA:233-243: plane blocks only, the bounds and the cost
+        # gate wide open, m_inliner_dis 0.2) -- the loop detector calls init() before it aligns anything (laser_mapping.hpp:896);
+        # False = a default-constructed Scene_alignment, whose m_pc_reg keeps the class defaults of point_cloud_registration.hpp
+        self.registrar_init = registrar_init
         self.line_res, self.plane_res = F(line_res), F(plane_res)
         self.max_icp, self.accepted, self.max_blocks, self.seed = maximum_icp_iteration, accepted_threshold, maximum_residual_block, subsample_seed
         self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
@@ -38,6 +42,12 @@ class SceneAlignment:
         src_line, src_plane, ca = keyframe_clouds(keyframe_a)
         tgt_line, tgt_plane, cb = keyframe_clouds(keyframe_b)
         prm = orc.RegParams.code_defaults()                                          # m_pc_reg, SA:32
+        if self.registrar_init:                                                      # init(), SA:233-243 (laser_mapping.hpp:896 calls it)
+            prm.icp_line = 0
+            prm.max_final_cost = 20000.0
+            prm.para_max_speed = 1000.0
+            prm.para_max_angular_rate = 360 * 57.3
+            prm.inliner_dis = 0.2
         prm.current_frame_index = 10000000                                           # SA:296
         prm.icp_max_iterations, prm.ceres_max_iterations, prm.ceres_prerun_times = self.max_icp, 50, 2   # SA:300-302
         prm.maximum_allow_residual_block, prm.subsample_seed = self.max_blocks, self.seed               # SA:303

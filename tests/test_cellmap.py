@@ -281,6 +281,49 @@ def test_oracle_scene_alignment_recovers_the_motion():
     assert sa.reports[0].n_blocks_last < sa.reports[2].n_blocks_last
 
 
+@pytest.mark.parametrize("seed,res,max_icp,accepted", [(3, 0.4, 10, 0.2), (4, 0.2, 2, 0.35), (5, 0.4, 3, 0.01)])
+def test_oracle_scene_alignment_equals_the_reference_driver(tmp_path, seed, res, max_icp, accepted):
+    """Scene_alignment::find_tranfrom_of_two_mappings as the loop detector runs it (init() + the driver, scene_alignment.hpp:233-243,
+    269-391) compiled VERBATIM on the reference's own Maps_keyframe / Points_cloud_map / Point_cloud_registration
+    (tests/verbatim_build.py build_scene_alignment; stand-in third-party headers) against oracle/orc_scene_alignment.py on the same
+    two clouds.  (0.2 m / 2 iterations / 0.35 are the loop detector's values, laser_mapping.hpp:700-706; accepted = 0.01 makes the
+    coarse-to-fine loop stop early, SA:350.)  The reference concatenates a key frame's cells in the order of their heap addresses,
+    so the voxel centroids differ in their last bits: poses to 1e-5, not to the bit."""
+    import subprocess
+    from oracle.orc_scene_alignment import SceneAlignment
+    from tests import verbatim_build
+    exe = verbatim_build.build_scene_alignment()
+    if not exe:
+        pytest.skip("verbatim scene-alignment harness not built (no /root/reference here and none travelled)")
+    a, b, _ = keyframe_pair(seed)
+
+    def by_cell(c):
+        # The reference walks a key frame's cells in the order of their heap addresses (a std::set of shared_ptr), i.e. -- with a
+        # bump allocator and nothing freed in between -- in the order the cells were created = first touched by the cloud.  Clouds
+        # sorted by cell (stable: the order inside a cell stays) make that order the oracle's ascending cell order.
+        k, ok = CellMap(1.0).cell_index(c[:, :3])
+        assert ok.all()
+        return c[np.lexsort((np.arange(len(c)), k[:, 2], k[:, 1], k[:, 0]))]
+    a, b = by_cell(a), by_cell(b)
+    fa, fb, out = str(tmp_path / "a.bin"), str(tmp_path / "b.bin"), str(tmp_path / "out.txt")
+    a[:, :3].astype(np.float32).tofile(fa)
+    b[:, :3].astype(np.float32).tofile(fb)
+    subprocess.check_call([exe, fa, fb, repr(res), repr(res), str(max_icp), repr(accepted), "100000000", out], timeout=600, stdout=subprocess.DEVNULL)
+    l0, l1 = open(out).read().strip().split("\n")
+    _, icp_final, thr_ref = l0.split()
+    pose_ref = np.array([float(v) for v in l1.split()])
+    ka, kb = CellMap(1.0), CellMap(1.0)
+    ka.append(a); kb.append(b)
+    so = SceneAlignment(res, res, max_icp, accepted, 100000000)   # (no random sub-sampling: the reference seeds it from random_device)
+    thr = so.find_tranfrom_of_two_mappings(ka, kb)
+    dt, dr = synth.pose_error(so.pose, pose_ref)
+    assert dt < 1e-5 and dr < 1e-6 and abs(thr - float(thr_ref)) < 1e-5 * max(1.0, abs(thr))
+    rounds = len(so.reports)
+    assert int(icp_final) == (2 * max_icp if rounds == 3 else max_icp)   # SA:327: doubled once the finest resolution is reached
+    if accepted == 0.01:
+        assert rounds < 3                                                 # SA:350-351: stopped after a coarse round
+
+
 # ------------------------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_device_scene_alignment_matches_oracle(gpu_lib):

@@ -774,3 +774,117 @@ def build_keyframes(force=False):
             f.write(tu)
         subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-o", EXE_KF, src])
     return EXE_KF
+
+
+# ---- Scene_alignment::find_tranfrom_of_two_mappings, the WHOLE driver (source/scene_alignment.hpp:269-391), on the reference's own
+# classes: Maps_keyframe / Points_cloud_map (cell_map_keyframe.hpp, compiled verbatim -- no override stub here) and
+# Point_cloud_registration (point_cloud_registration.hpp, verbatim), against the stand-in third-party headers of oracle/ref_stubs
+# (pcl::VoxelGrid, KdTreeFLANN, ceres::Solve, Eigen, the OpenCV calls).  scene_alignment.hpp itself is not included as a whole: its
+# other includes (pcl/registration/ndt.h, icp.h, ceres_pose_graph_3d.hpp, g2o dump) are off the path.  The excerpted lines are the
+# members the driver uses (:27-36), set_downsample_resolution (:214-222), the registrar set-up of init() (:233-243) and the driver
+# (:269-391).  CPU only: pins oracle/orc_scene_alignment.py (tests/test_cellmap.py).
+EXE_SA = os.path.join(OUT, "verbatim_scene_alignment")
+SA_HARNESS = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <set>
+#include <vector>
+#include "cell_map_keyframe.hpp"
+#include "point_cloud_registration.hpp"
+#include <pcl/filters/voxel_grid.h>
+
+template < typename PT_DATA_TYPE >
+class Scene_alignment
+{
+  public:
+    Common_tools::File_logger file_logger_commond, file_logger_timer;
+    Common_tools::Timer       timer;
+// ---- verbatim: scene_alignment.hpp:27-36
+@SA_MEMBERS@
+    ADD_SCREEN_PRINTF_OUT_METHOD;
+    Scene_alignment()
+    {
+        m_if_verbose_screen_printf = 0;
+// ---- verbatim: scene_alignment.hpp:233-243 (the registrar set-up of init(); the loggers are never opened: their streams
+//      swallow what the registrar writes, as in oracle/ref_shim.cpp)
+@SA_INIT@
+        m_pc_reg.m_logger_pcd = &file_logger_pcd;
+    }
+    Common_tools::File_logger file_logger_pcd;
+// ---- verbatim: scene_alignment.hpp:214-222
+@SA_RES@
+// ---- verbatim: scene_alignment.hpp:269-391
+@SA_DRIVER@
+};
+
+typedef Points_cloud_map< float >                   Map_t;
+typedef Maps_keyframe< float >                      Kf_t;
+typedef Eigen::Matrix< float, 3, 1 >                Pt_t;
+
+static std::vector< Pt_t > read_cloud( const char *path )
+{
+    std::vector< Pt_t > v;
+    FILE *              f = fopen( path, "rb" );
+    if ( !f ) exit( 3 );
+    float p[ 3 ];
+    while ( fread( p, sizeof( float ), 3, f ) == 3 ) v.push_back( Pt_t( p[ 0 ], p[ 1 ], p[ 2 ] ) );
+    fclose( f );
+    return v;
+}
+
+// usage: exe a.bin b.bin line_res plane_res max_icp accepted max_blocks out.txt   (clouds: float32 x y z)
+int main( int argc, char **argv )
+{
+    if ( argc < 9 ) return 2;
+    std::streambuf *old = std::cout.rdbuf( nullptr );  // the reference chats on std::cout
+    Map_t map_a, map_b;
+    Kf_t  kf_a, kf_b;
+    Map_t *maps[ 2 ] = { &map_a, &map_b };
+    Kf_t * kfs[ 2 ] = { &kf_a, &kf_b };
+    for ( int i = 0; i < 2; i++ )
+    {
+        maps[ i ]->set_resolution( 1.0 );                                   // laser_mapping.hpp:616
+        std::set< Map_t::Mapping_cell_ptr > cell_vec;
+        maps[ i ]->append_cloud( read_cloud( argv[ 1 + i ] ), &cell_vec );  // every cell of the (first) cloud
+        kfs[ i ]->add_cells( cell_vec );
+        kfs[ i ]->update_features_of_each_cells( 1 );                       // as the detector does before it aligns (:927-934)
+        kfs[ i ]->analyze( 1 );
+    }
+    Scene_alignment< float > sa;
+    sa.set_downsample_resolution( atof( argv[ 3 ] ), atof( argv[ 4 ] ) );
+    sa.m_maximum_icp_iteration = atoi( argv[ 5 ] );
+    sa.m_accepted_threshold = atof( argv[ 6 ] );
+    sa.m_para_scene_alignments_maximum_residual_block = atoi( argv[ 7 ] );
+    const double thr = sa.find_tranfrom_of_two_mappings( &kf_a, &kf_b, 0 );
+    std::cout.rdbuf( old );
+    FILE *out = fopen( argv[ 8 ], "w" );
+    fprintf( out, "%.17g %d %.17g\n", thr, sa.m_pc_reg.m_para_icp_max_iterations, ( double ) sa.m_pc_reg.m_inlier_threshold );
+    fprintf( out, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", sa.m_pc_reg.m_q_w_curr.x(), sa.m_pc_reg.m_q_w_curr.y(), sa.m_pc_reg.m_q_w_curr.z(),
+             sa.m_pc_reg.m_q_w_curr.w(), sa.m_pc_reg.m_t_w_curr( 0 ), sa.m_pc_reg.m_t_w_curr( 1 ), sa.m_pc_reg.m_t_w_curr( 2 ) );
+    fclose( out );
+    return 0;
+}
+'''
+
+
+def build_scene_alignment(force=False):
+    """-> exe of the scene-alignment harness (None where neither /root/reference nor a travelled binary exists)"""
+    if not have_reference():
+        return EXE_SA if os.path.exists(EXE_SA) else None
+    stubs = os.path.join(ROOT, "oracle", "ref_stubs")
+    deps = [os.path.abspath(__file__)] + [os.path.join(dp, f) for dp, _, fs in os.walk(stubs) for f in fs]
+    if not force and os.path.exists(EXE_SA) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_SA) for d in deps):
+        return EXE_SA
+    os.makedirs(OUT, exist_ok=True)
+    tu = (SA_HARNESS.replace("@SA_MEMBERS@", _lines("source/scene_alignment.hpp", 27, 36))
+                    .replace("@SA_INIT@", _lines("source/scene_alignment.hpp", 233, 243))
+                    .replace("@SA_RES@", _lines("source/scene_alignment.hpp", 214, 222))
+                    .replace("@SA_DRIVER@", _lines("source/scene_alignment.hpp", 269, 391)))
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_scene_alignment.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", stubs, "-I", os.path.join(REF, "source"),
+                               "-I", os.path.join(REF, "include"), "-I", os.path.join(REF, "include", "tools"), "-o", EXE_SA, src])
+    return EXE_SA
