@@ -162,12 +162,15 @@ static int fe_create_impl(const ll_fe_params *p, ll_fe *h)
     DM(d.n_full, B);
     DM(d.n_ambig, 1);
     DM(d.ambig_list, d.ambig_cap);
-    HC(hipMemset(d.n_ambig, 0, sizeof(int)));
-    HC(hipMemset(h->d_npts, 0, B * sizeof(int)));
-    HC(hipMemset(d.n_corner, 0, B * sizeof(int)));
-    HC(hipMemset(d.n_surf, 0, B * sizeof(int)));
-    HC(hipMemset(d.n_full, 0, B * sizeof(int)));
-    HC(hipMemset(d.info, 0, B * sizeof(FeScanInfo)));
+    // On the handle's own stream, ahead of everything it will ever run.  (A hipMemset on the null stream is asynchronous to the host
+    // and NOT ordered with a non-blocking stream: issued behind a busy null stream -- a 5 M-point map upload just before -- the
+    // zeroing of d_npts landed after the first upload's copy into it, and the first extraction of a fresh handle saw zero points.)
+    HC(hipMemsetAsync(d.n_ambig, 0, sizeof(int), h->stream));
+    HC(hipMemsetAsync(h->d_npts, 0, B * sizeof(int), h->stream));
+    HC(hipMemsetAsync(d.n_corner, 0, B * sizeof(int), h->stream));
+    HC(hipMemsetAsync(d.n_surf, 0, B * sizeof(int), h->stream));
+    HC(hipMemsetAsync(d.n_full, 0, B * sizeof(int), h->stream));
+    HC(hipMemsetAsync(d.info, 0, B * sizeof(FeScanInfo), h->stream));
     h->h_npts.assign(B, 0);
     HC(hipHostMalloc((void **)&h->hp_npts, B * sizeof(int), hipHostMallocDefault));
     HC(hipHostMalloc((void **)&h->hp_time0, B * sizeof(double), hipHostMallocDefault));
@@ -730,7 +733,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(r->d_nc, B);
     DM(r->d_ns, B);
     DM(r->d_pose_tmp, 8);
-    HC(hipMemset(d.blk_flag, 0, B * d.cap));
+    HC(hipMemsetAsync(d.blk_flag, 0, B * d.cap, r->stream));  // (on the registrar's stream: a null-stream memset is not ordered with it)
     r->h_state.resize(B);
     r->h_nc.assign(B, 0);
     r->h_ns.assign(B, 0);

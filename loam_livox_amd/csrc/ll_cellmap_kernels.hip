@@ -560,6 +560,7 @@ int cellmap_alloc(CellMapDev &m, int cap, float resolution, int revisit_threshol
     CMCHK(hipMalloc(&m.filt_key, (size_t)cap * sizeof(u64)));
     CMCHK(hipMalloc(&m.counts, 8 * sizeof(int)));
     CMCHK(hipMemset(m.counts, 0, 8 * sizeof(int)));
+    CMCHK(hipStreamSynchronize(nullptr));  // (a null-stream memset is not ordered with the non-blocking streams the map is used on)
     size_t t1 = 0, t2 = 0;
     CMCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, m.pkey, m.pkey2, m.val, m.val2, (int)n2, 0, 64));
     CMCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, m.flag, m.rank, (int)n2));

@@ -24,6 +24,7 @@
 namespace ll {
 
 #define QS_THREADS 1024
+#define QS_BINS 32768  // cells of a scan's box the counting sort takes (128 KB of LDS bins); larger boxes take the radix sort
 // the query position the sort and the tile kernel agree on: FUSED = transformed here from the extractor's feature cloud with the
 // scan's current pose (no motion deblur), else read from rd.qw (reg_transform_kernel has run)
 // transform_query without motion deblur (the only case the fused kernels serve): pointAssociateToMap's plain branch, PCR:629
@@ -49,7 +50,13 @@ template <int ITEMS, bool FUSED>
 __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegConst rc, Grid gs)
 {
     typedef hipcub::BlockRadixSort<unsigned int, QS_THREADS, ITEMS, unsigned short> Sort;
-    __shared__ typename Sort::TempStorage sort;
+    typedef hipcub::BlockScan<int, QS_THREADS> Scan;
+    // the radix sort's exchange buffers and the counting sort's bins share the same LDS
+    constexpr size_t RAW = sizeof(typename Sort::TempStorage) > (QS_BINS + 1) * sizeof(int) ? sizeof(typename Sort::TempStorage) : (QS_BINS + 1) * sizeof(int);
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW];
+    typename Sort::TempStorage &sort = *reinterpret_cast<typename Sort::TempStorage *>(s_raw);
+    int *s_hist = reinterpret_cast<int *>(s_raw);
+    __shared__ typename Scan::TempStorage scan;
     __shared__ int s_lo[3][QS_THREADS / 64], s_hi[3][QS_THREADS / 64];
     __shared__ int s_box[6];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,14 +65,20 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
     const int nS = rd.n_surf[b];
     // ---- box of the cells the scan's queries fall into (striped reads: coalesced; any initial order is as good as another)
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+    // the cell of every query, kept from this pass when the grid's dimensions fit 10 bits each (every map of a few hundred metres):
+    // the pose transform (fp64) and the cell lookup then run once per query instead of once per pass
+    const bool packable = gs.nx <= 1024 && gs.ny <= 1024 && gs.nz <= 1024;
+    unsigned int key[ITEMS];
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const int i = u * QS_THREADS + tid;
+        key[u] = 0u;
         if (i < nS) {
             const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);
             TileQ tq;
             tile_query(gs, p.x, p.y, p.z, tq);
             if (tq.ingrid) {
+                key[u] = 0x80000000u | ((unsigned int)tq.cz << 20) | ((unsigned int)tq.cy << 10) | (unsigned int)tq.cx;
                 lo[0] = min(lo[0], tq.cx);
                 lo[1] = min(lo[1], tq.cy);
                 lo[2] = min(lo[2], tq.cz);
@@ -107,26 +120,68 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
     // row); a box too large for 30 bits (a scan scattered over kilometres) degrades to one key: correct, just not grouped
     const bool wide = !any || ex * ey * ez > (1ll << 30);
     const unsigned int kmax = wide ? 0u : (unsigned int)(ex * ey * ez - 1);
-    unsigned int key[ITEMS];
     unsigned short val[ITEMS];
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const int i = u * QS_THREADS + tid;
         unsigned int k = kmax + 2u;  // padding: behind everything
         if (i < nS) {
-            const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);  // (again: ITEMS points held in registers would spill)
-            TileQ tq;
-            tile_query(gs, p.x, p.y, p.z, tq);
+            bool ingrid;
+            int cx, cy, cz;
+            if (packable) {  // (uniform)
+                ingrid = (key[u] >> 31) != 0u;
+                cx = (int)(key[u] & 1023u);
+                cy = (int)((key[u] >> 10) & 1023u);
+                cz = (int)((key[u] >> 20) & 1023u);
+            } else {
+                const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);  // (again: ITEMS points held in registers would spill)
+                TileQ tq;
+                tile_query(gs, p.x, p.y, p.z, tq);
+                ingrid = tq.ingrid;
+                cx = tq.cx, cy = tq.cy, cz = tq.cz;
+            }
             k = kmax + 1u;  // not in the grid / not finite: behind the grouped ones (they take the per-lane search anyway)
-            if (tq.ingrid) k = wide ? 0u : (unsigned int)(((long long)(tq.cz - bz0) * ey + (tq.cy - by0)) * ex + (tq.cx - bx0));
+            if (ingrid) k = wide ? 0u : (unsigned int)(((long long)(cz - bz0) * ey + (cy - by0)) * ex + (cx - bx0));
         }
         key[u] = k;
         val[u] = (unsigned short)i;
     }
+    unsigned short *perm = rd.qperm + (size_t)b * rd.cap_s;
+    if (kmax + 2u <= (unsigned int)QS_BINS) {
+        // ---- counting sort (uniform branch: the scan's cell box has at most QS_BINS cells -- every C2 scan): one LDS histogram over
+        //      the box, the atomic's return value is the query's rank inside its cell, one scan over the bins, one scatter.  The
+        //      order INSIDE a cell is the order the atomics were served in -- it differs from run to run and nothing depends on it
+        //      (the order is a grouping; every result goes to its query's own slot and is exact whatever the grouping).
+        const int nbins = (int)kmax + 2;  // cells of the box + one bin for the queries outside the grid
+        for (int e = tid; e < nbins; e += QS_THREADS) s_hist[e] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ITEMS; u++) {
+            const int i = u * QS_THREADS + tid;
+            if (i < nS) val[u] = (unsigned short)atomicAdd(&s_hist[key[u]], 1);
+        }
+        __syncthreads();
+        const int per = (nbins + QS_THREADS - 1) / QS_THREADS, e0 = tid * per;
+        int sum = 0;
+        for (int e = e0; e < e0 + per && e < nbins; e++) sum += s_hist[e];
+        int base;
+        Scan(scan).ExclusiveSum(sum, base);
+        for (int e = e0; e < e0 + per && e < nbins; e++) {
+            const int c = s_hist[e];
+            s_hist[e] = base;
+            base += c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ITEMS; u++) {
+            const int i = u * QS_THREADS + tid;
+            if (i < nS) perm[s_hist[key[u]] + (int)val[u]] = (unsigned short)i;
+        }
+        return;
+    }
     int bits = 1;
     while (bits < 32 && ((kmax + 2u) >> bits)) bits++;
     Sort(sort).Sort(key, val, 0, bits);
-    unsigned short *perm = rd.qperm + (size_t)b * rd.cap_s;
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const int pos = tid * ITEMS + u;  // (blocked arrangement after the sort)
