@@ -783,7 +783,7 @@ def build_keyframes(force=False):
 # other includes (pcl/registration/ndt.h, icp.h, ceres_pose_graph_3d.hpp, g2o dump) are off the path.  The excerpted lines are the
 # members the driver uses (:27-36), set_downsample_resolution (:214-222), the registrar set-up of init() (:233-243) and the driver
 # (:269-391).  CPU only: pins oracle/orc_scene_alignment.py (tests/test_cellmap.py).
-EXE_SA = os.path.join(OUT, "verbatim_scene_alignment")
+EXE_SCENE = os.path.join(OUT, "verbatim_scene_alignment")
 SA_HARNESS = r'''
 #include <cstdio>
 #include <cstdlib>
@@ -871,11 +871,11 @@ int main( int argc, char **argv )
 def build_scene_alignment(force=False):
     """-> exe of the scene-alignment harness (None where neither /root/reference nor a travelled binary exists)"""
     if not have_reference():
-        return EXE_SA if os.path.exists(EXE_SA) else None
+        return EXE_SCENE if os.path.exists(EXE_SCENE) else None
     stubs = os.path.join(ROOT, "oracle", "ref_stubs")
     deps = [os.path.abspath(__file__)] + [os.path.join(dp, f) for dp, _, fs in os.walk(stubs) for f in fs]
-    if not force and os.path.exists(EXE_SA) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_SA) for d in deps):
-        return EXE_SA
+    if not force and os.path.exists(EXE_SCENE) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_SCENE) for d in deps):
+        return EXE_SCENE
     os.makedirs(OUT, exist_ok=True)
     tu = (SA_HARNESS.replace("@SA_MEMBERS@", _lines("source/scene_alignment.hpp", 27, 36))
                     .replace("@SA_INIT@", _lines("source/scene_alignment.hpp", 233, 243))
@@ -886,5 +886,5 @@ def build_scene_alignment(force=False):
         with open(src, "w") as f:
             f.write(tu)
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", stubs, "-I", os.path.join(REF, "source"),
-                               "-I", os.path.join(REF, "include"), "-I", os.path.join(REF, "include", "tools"), "-o", EXE_SA, src])
-    return EXE_SA
+                               "-I", os.path.join(REF, "include"), "-I", os.path.join(REF, "include", "tools"), "-o", EXE_SCENE, src])
+    return EXE_SCENE
