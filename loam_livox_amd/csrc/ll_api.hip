@@ -308,8 +308,11 @@ static int fe_resolve_ambiguous(ll_fe *h)
             d[k] = o.depth_sq2;
         }
         const LabelOut lo = point_label(p, t, d, h->fc);  // host build: glibc acosf
-        HC(hipMemcpy(h->dev.label + (size_t)b * N + i, &lo.label, sizeof(int), hipMemcpyHostToDevice));
-        HC(hipMemcpy(h->dev.view + (size_t)b * N + i, &lo.view_angle, sizeof(float), hipMemcpyHostToDevice));
+        // on the handle's stream and waited for: the selection kernel that reads these runs on that stream, and a null-stream copy
+        // from pageable memory is not ordered with it
+        HC(hipMemcpyAsync(h->dev.label + (size_t)b * N + i, &lo.label, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HC(hipMemcpyAsync(h->dev.view + (size_t)b * N + i, &lo.view_angle, sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HC(hipStreamSynchronize(h->stream));
     }
     return n_amb;
 }
