@@ -139,3 +139,86 @@ def test_out_and_back_sequence_closes_a_loop(gpu_lib):
     assert dt < tol[0] and dr < tol[0] and abs(rec["inlier_threshold"] - thr_o) < tol[1], (dt, dr, rec["inlier_threshold"], thr_o, same_labels)
     assert thr_o < 0.35 and loops[0]["inlier_threshold"] == rec["inlier_threshold"]
     ka.close()
+
+
+@pytest.mark.parametrize("seed,min_diff", [(1, 3), (2, 1), (3, 6), (4, 2), (5, 4), (6, 2)])
+def test_loop_detector_walk_equals_the_reference_text(tmp_path, monkeypatch, seed, min_diff):
+    """service_loop_detection's loop over the earlier key frames (laser_mapping.hpp:988-1057, 1110-1127, compiled verbatim into a harness
+    with scripted key frames, similarities and alignment results) against Keyframe_assembly.process_waiting with the same script:
+    which pairs get their images compared, which are handed to the scene alignment, where `his` jumps (continue, += 10, += 5 inside
+    the for), the cell-count gate's unsigned arithmetic, and the loop that ends the search."""
+    from loam_livox_amd import keyframes as kfm
+    exe = verbatim_build.build_loop_detector()
+    if not exe:
+        pytest.skip("verbatim loop-detector harness not built (no /root/reference here and none travelled)")
+    rng = np.random.default_rng(seed)
+    K = 40
+    avail_p, avail_l, sim_lin, sim_plan, inlier = 0.05, 0.03, 0.65, 0.95, 0.35
+    ratio_p, ratio_l = rng.uniform(0.0, 0.12, K).astype(np.float32), rng.uniform(0.0, 0.07, K).astype(np.float32)
+    roi = rng.uniform(4.0, 13.0, K).astype(np.float32)
+    n_cells = rng.integers(900, 1100, K)
+    sim_p = rng.uniform(0.85, 1.0, (K, K)).astype(np.float32)
+    sim_l = rng.uniform(0.4, 0.9, (K, K)).astype(np.float32)
+    thr = rng.uniform(0.36 if seed % 2 else 0.2, 1.0, (K, K)).astype(np.float32)   # odd seeds: no loop is ever accepted, the walk covers all K frames
+    if seed % 2 == 0:                                                               # even seeds: key frame K - 5 closes a loop
+        thr[thr < 0.35] += 0.2
+        thr[K - 5, :] = 0.1
+        sim_p[K - 5, :] = 0.99
+        roi[K - 5] = roi[: K - 5].mean()
+        n_cells[K - 5] = 1200
+    script, out = str(tmp_path / "script.txt"), str(tmp_path / "walk.txt")
+    with open(script, "w") as f:
+        f.write(f"{K} {min_diff} {avail_p!r} {avail_l!r} {sim_lin!r} {sim_plan!r} {inlier!r}\n")
+        for k in range(K):
+            f.write(f"{float(ratio_p[k])!r} {float(ratio_l[k])!r} {float(roi[k])!r} {int(n_cells[k])}\n")
+        for m in (sim_p, sim_l, thr):
+            f.write(" ".join(repr(float(v)) for v in m.ravel()) + "\n")
+    subprocess.check_call([exe, script, out], timeout=120, stdout=subprocess.DEVNULL)
+    want = [l for l in open(out).read().strip().split("\n") if not l.startswith("K ")]
+
+    got = []
+
+    class StubMap:
+        def __init__(self, k):
+            self.k = k
+
+        def keyframe_images(self):
+            img = np.zeros((4, 1, 1), np.float32)
+            img[:, 0, 0] = self.k
+            return dict(images=img, ratio_nonzero=np.array([ratio_l[self.k], ratio_p[self.k], 0, 0], np.float32), roi_range=float(roi[self.k]))
+
+        def close(self):
+            pass
+
+    def similarity(a, b, device=0):
+        ka, kb = int(a[0, 0]), int(b[0, 0])
+        plane = similarity.calls % 2 == 0      # process_waiting asks for the plane image first, then the line image (:1009-1010)
+        similarity.calls += 1
+        if plane:
+            got.append(f"S {ka} {kb}")
+        return float((sim_p if plane else sim_l)[ka, kb])
+    similarity.calls = 0
+
+    class StubAlignment:
+        def __init__(self, *a, **kw):
+            self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+
+        def find_tranfrom_of_two_mappings(self, a, b):
+            got.append(f"A {a.k} {b.k}")
+            return float(thr[a.k, b.k])
+
+    monkeypatch.setattr(kfm, "keyframe_similarity", similarity)
+    monkeypatch.setattr(kfm, "Scene_alignment", StubAlignment)
+    ka = kfm.Keyframe_assembly(full_cell_map=ScriptedMap([]), minimum_keyframe_differen=min_diff, minimum_similarity_linear=sim_lin,
+                               minimum_similarity_planar=sim_plan, map_alignment_inlier_threshold=inlier, avail_ratio_plane=avail_p,
+                               avail_ratio_line=avail_l)
+    monkeypatch.setattr(ka, "materialize", lambda kf: StubMap(kf.k))
+    for k in range(K):
+        kf = kfm.Maps_keyframe()
+        kf.k = k
+        kf.m_set_cell = set((c, 0, 0) for c in range(int(n_cells[k])))
+        ka.m_keyframe_need_precession_list.append(kf)
+        for loop in ka.process_waiting():
+            got.append(f"L {loop['last']} {loop['his']}")
+    assert got == want
+    assert sum(l.startswith("A ") for l in want) > 3 and (seed % 2 == 1 or any(l.startswith("L ") for l in want))

@@ -888,3 +888,130 @@ def build_scene_alignment(force=False):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", stubs, "-I", os.path.join(REF, "source"),
                                "-I", os.path.join(REF, "include"), "-I", os.path.join(REF, "include", "tools"), "-o", EXE_SCENE, src])
     return EXE_SCENE
+
+
+# ---- service_loop_detection's loop over the earlier key frames (source/laser_mapping.hpp:988-1057 + 1110-1127): which pairs are
+# compared, which are handed to the scene alignment, how `his` advances (continue / += 10 / += 5 inside a for), when a loop is
+# declared.  Key frames, image similarity and the alignment are scripted stand-ins; the lines in between (:1058-1109: the pose
+# graph, g2o dump, map refinement -- out of scope) are replaced by a record of the loop.  CPU only: pins
+# loam_livox_amd/keyframes.py Keyframe_assembly.process_waiting (tests/test_keyframes.py).
+EXE_LOOP = os.path.join(OUT, "verbatim_loop_detector")
+LOOP_HARNESS = r'''
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace std;  // include/tools/tools_logger.hpp:86 does this for every translation unit of the reference: the unqualified
+                      // abs( float ) of laser_mapping.hpp:1004 is std::abs( float ), not ::abs( int )
+static int                              g_K;
+static std::vector< float >             g_sim[ 2 ], g_thr;  // [kind][a * K + b], thr[a * K + b]
+static FILE *                           g_out;
+struct Img { int kf, kind; };
+struct Maps_keyframe_stub
+{
+    float           m_ratio_nonzero_plane, m_ratio_nonzero_line, m_roi_range;
+    Img             m_feature_img_plane, m_feature_img_line, m_feature_img_plane_roi, m_feature_img_line_roi;
+    std::set< int > m_set_cell;
+    float max_similiarity_of_two_image( const Img &a, const Img &b )
+    {
+        if ( a.kind == 0 ) fprintf( g_out, "S %d %d\n", a.kf, b.kf );
+        return g_sim[ a.kind ][ a.kf * g_K + b.kf ];
+    }
+};
+struct Logger_stub { void printf( const char *, ... ) {} };
+struct Summary_stub { std::string BriefReport() { return ""; } };
+struct Reg_stub { double m_inlier_threshold = 0; Summary_stub m_final_opt_summary; };
+struct Scene_alignment_stub
+{
+    Reg_stub m_pc_reg;
+    int      m_para_scene_alignments_maximum_residual_block = 0;
+    void set_downsample_resolution( float, float ) {}
+    int find_tranfrom_of_two_mappings( std::shared_ptr< Maps_keyframe_stub > a, std::shared_ptr< Maps_keyframe_stub > b, int )
+    {
+        m_pc_reg.m_inlier_threshold = g_thr[ a->m_feature_img_plane.kf * g_K + b->m_feature_img_plane.kf ];
+        fprintf( g_out, "A %d %d\n", a->m_feature_img_plane.kf, b->m_feature_img_plane.kf );
+        return ( int ) m_pc_reg.m_inlier_threshold;
+    }
+};
+#define screen_printf( ... ) do { } while ( 0 )
+
+// usage: exe script.txt out.txt
+int main( int argc, char **argv )
+{
+    if ( argc < 3 ) return 2;
+    FILE *in = fopen( argv[ 1 ], "r" );
+    g_out = fopen( argv[ 2 ], "w" );
+    if ( !in || !g_out ) return 3;
+    int   m_loop_closure_minimum_keyframe_differen;
+    float avail_ratio_plane, avail_ratio_line, m_loop_closure_minimum_similarity_linear, m_loop_closure_minimum_similarity_planar;
+    float m_loop_closure_map_alignment_inlier_threshold;
+    if ( fscanf( in, "%d %d %f %f %f %f %f", &g_K, &m_loop_closure_minimum_keyframe_differen, &avail_ratio_plane, &avail_ratio_line,
+                 &m_loop_closure_minimum_similarity_linear, &m_loop_closure_minimum_similarity_planar, &m_loop_closure_map_alignment_inlier_threshold ) != 7 )
+        return 4;
+    std::vector< std::shared_ptr< Maps_keyframe_stub > > all( g_K );
+    for ( int k = 0; k < g_K; k++ )
+    {
+        all[ k ] = std::make_shared< Maps_keyframe_stub >();
+        int n_cells;
+        if ( fscanf( in, "%f %f %f %d", &all[ k ]->m_ratio_nonzero_plane, &all[ k ]->m_ratio_nonzero_line, &all[ k ]->m_roi_range, &n_cells ) != 4 ) return 4;
+        for ( int c = 0; c < n_cells; c++ ) all[ k ]->m_set_cell.insert( c );
+        all[ k ]->m_feature_img_plane = all[ k ]->m_feature_img_plane_roi = Img{ k, 0 };
+        all[ k ]->m_feature_img_line = all[ k ]->m_feature_img_line_roi = Img{ k, 1 };
+    }
+    for ( int t = 0; t < 3; t++ )
+    {
+        std::vector< float > &v = t < 2 ? g_sim[ t ] : g_thr;
+        v.resize( ( size_t ) g_K * g_K );
+        for ( float &x : v )
+            if ( fscanf( in, "%f", &x ) != 1 ) return 4;
+    }
+    std::vector< std::shared_ptr< Maps_keyframe_stub > > keyframe_vec;
+    std::vector< std::string >                           m_filename_vec;
+    Logger_stub          m_logger_loop_closure;
+    Scene_alignment_stub m_scene_align;
+    float                m_loop_closure_map_alignment_resolution = 0.2;
+    int                  m_para_scene_alignments_maximum_residual_block = 5000, m_loop_closure_map_alignment_if_dump_matching_result = 0;
+    int                  if_end = 0;
+    for ( int k = 0; k < g_K && !if_end; k++ )  // `while ( 1 )` of the service thread: one pass per key frame that arrives
+    {
+        keyframe_vec.push_back( all[ k ] );
+        m_filename_vec.push_back( std::to_string( k ) );
+        std::shared_ptr< Maps_keyframe_stub > last_keyframe = keyframe_vec.back();
+        float sim_plane_res_cv = 0, sim_plane_res = 0;
+        float sim_line_res_cv = 0, sim_line_res = 0;
+        float sim_plane_res_roi = 0, sim_line_res_roi = 0;
+        fprintf( g_out, "K %d\n", k );
+// ---- verbatim: laser_mapping.hpp:988-1057
+@LOOP_HEAD@
+                        fprintf( g_out, "L %d %d\n", ( int ) keyframe_vec.size() - 1, ( int ) his );  // (:1058-1109: pose graph, refinement)
+// ---- verbatim: laser_mapping.hpp:1110-1127
+@LOOP_TAIL@
+    }
+    fclose( g_out );
+    return 0;
+}
+'''
+
+
+def build_loop_detector(force=False):
+    """-> exe of the loop-detector harness (None where neither /root/reference nor a travelled binary exists)"""
+    if not have_reference():
+        return EXE_LOOP if os.path.exists(EXE_LOOP) else None
+    deps = [os.path.abspath(__file__)]
+    if not force and os.path.exists(EXE_LOOP) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_LOOP) for d in deps):
+        return EXE_LOOP
+    os.makedirs(OUT, exist_ok=True)
+    tu = (LOOP_HARNESS.replace("@LOOP_HEAD@", _lines("source/laser_mapping.hpp", 988, 1057))
+                      .replace("@LOOP_TAIL@", _lines("source/laser_mapping.hpp", 1110, 1127)))
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_loop_detector.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-o", EXE_LOOP, src, "-lpthread"])
+    return EXE_LOOP
