@@ -324,6 +324,59 @@ def test_oracle_scene_alignment_equals_the_reference_driver(tmp_path, seed, res,
         assert rounds < 3                                                 # SA:350-351: stopped after a coarse round
 
 
+@pytest.mark.parametrize("revisit,replace,fov", [(3, 1, 50.0), (2**31 - 1, 0, 30.0), (2, 1, 80.0)])
+def test_oracle_cell_refresh_equals_the_reference_branch(tmp_path, revisit, replace, fov):
+    """update_buff_for_matching with m_matching_mode = 1 (laser_mapping.hpp:465-537 as ONE verbatim range, with if_pt_in_fov :309-324 and
+    the cell-map appends :1492-1493) on the reference's own Points_cloud_map (tests/verbatim_build.py build_cell_refresh; stand-in
+    pcl::VoxelGrid / octree) against History.refresh_cells over five frames: cells in range and field of view, per-cell filter, the
+    replace of a cell's points by its filtered cloud, concatenation, final filters.  Same voxels every frame; coordinates to an ulp (the
+    reference concatenates the cells in octree order, the oracle in cell order: the float sums inside a final voxel differ in order)."""
+    import struct
+    import subprocess
+    from oracle.orc_mapping import History
+    from tests import verbatim_build
+    exe = verbatim_build.build_cell_refresh()
+    if not exe:
+        pytest.skip("verbatim cell-refresh harness not built (no /root/reference here and none travelled)")
+    rng = np.random.default_rng(3)
+    frames = []
+    for k in range(5):
+        c = structured_cloud(5 + (k % 3))                      # (the third and fourth frame revisit the first two places)
+        corner, surf = c[rng.uniform(size=len(c)) < 0.15].astype(np.float32), c[rng.uniform(size=len(c)) < 0.6].astype(np.float32)
+        corner[:, 3] = 0
+        surf[:, 3] = 0
+        pose = np.r_[synth.quat_from_axis_angle(np.array([0.1, 0.2, 1.0]), np.deg2rad(20.0 * k)), [25.0 + 0.5 * k, -22.0, 4.0]]
+        frames.append((pose, corner, surf))
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("i", len(frames)))
+        for pose, c, s in frames:
+            f.write(np.asarray(pose, np.float64).tobytes() + struct.pack("ii", len(c), len(s)) + c.tobytes() + s.tobytes())
+    line_res, plane_res, ranges = 0.1, 0.4, (12.0, 15.0)
+    subprocess.check_call([exe, fin, fout, "1.0", str(revisit), repr(line_res), repr(plane_res), repr(ranges[0]), repr(ranges[1]), repr(fov), str(replace)],
+                          timeout=600, stdout=subprocess.DEVNULL)
+    raw, off = open(fout, "rb").read(), 0
+    h = History(100, line_res, plane_res)
+    h.enable_cell_map(1.0, revisit)
+    n_exact = n_all = 0
+    for k, (pose, c, s) in enumerate(frames):
+        h.cells[0].append(c)
+        h.cells[1].append(s)
+        got = h.refresh_cells(pose, ranges, fov, replace)
+        for kind, leaf in ((0, line_res), (1, plane_res)):
+            n = struct.unpack_from("i", raw, off)[0]
+            ref = np.frombuffer(raw, np.float32, 4 * n, off + 4).reshape(n, 4)
+            off += 4 + 16 * n
+            a = got[kind]
+            assert len(a) == n > 200, (k, kind)
+            ka, kb = np.floor(a[:, :3].astype(np.float64) / leaf).astype(np.int64), np.floor(ref[:, :3].astype(np.float64) / leaf).astype(np.int64)
+            ia, ib = np.lexsort((ka[:, 2], ka[:, 1], ka[:, 0])), np.lexsort((kb[:, 2], kb[:, 1], kb[:, 0]))
+            assert np.array_equal(ka[ia], kb[ib]) and np.abs(a[ia, :3] - ref[ib, :3]).max() < 2e-5, (k, kind)
+            n_exact += int(np.sum(np.all(bits(a[ia, :3]) == bits(ref[ib, :3]), axis=1)))
+            n_all += n
+    assert off == len(raw) and n_exact > 0.9 * n_all   # (most voxels lie inside one cell: same points, same order, same bits)
+
+
 # ------------------------------------------------------------------------------------------------------ GPU tier
 @pytest.mark.gpu
 def test_device_scene_alignment_matches_oracle(gpu_lib):

@@ -1015,3 +1015,140 @@ def build_loop_detector(force=False):
             f.write(tu)
         subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-o", EXE_LOOP, src, "-lpthread"])
     return EXE_LOOP
+
+
+# ---- update_buff_for_matching, BOTH branches in one verbatim range (source/laser_mapping.hpp:465-537), with if_pt_in_fov (:309-324) and
+# the cell-map appends of process_new_scan (:1492-1493), on the reference's own Points_cloud_map (cell_map_keyframe.hpp verbatim) and
+# the stand-in pcl::VoxelGrid.  Pins the cell ("cube") branch of the match-buffer refresh: oracle/orc_mapping.py History.refresh_cells
+# (tests/test_cellmap.py).  CPU only.
+EXE_CELLREFRESH = os.path.join(OUT, "verbatim_cell_refresh")
+CELLREFRESH_HARNESS = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <list>
+#include <mutex>
+#include <vector>
+#include "cell_map_keyframe.hpp"
+#include "tools_eigen_math.hpp"
+#include <pcl/filters/voxel_grid.h>
+
+typedef pcl::PointXYZI PointType;
+
+struct Mapping_excerpt
+{
+    Points_cloud_map< float >               m_pt_cell_map_corners, m_pt_cell_map_planes;
+    Eigen::Quaterniond                      m_q_w_curr = Eigen::Quaterniond( 1, 0, 0, 0 );
+    Eigen::Vector3d                         m_t_w_curr = Eigen::Vector3d( 0, 0, 0 );
+    float                                   m_maximum_in_fov_angle = 30, m_maximum_search_range_corner = 100, m_maximum_search_range_surface = 100;
+    float                                   m_line_resolution = 0.1, m_plane_resolution = 0.4;
+    int                                     m_matching_mode = 1, m_down_sample_replace = 1;
+    pcl::VoxelGrid< PointType >             m_down_sample_filter_corner, m_down_sample_filter_surface;
+    std::list< pcl::PointCloud< PointType > > m_laser_cloud_corner_history, m_laser_cloud_surface_history;
+    std::mutex                              m_mutex_mapping;
+    pcl::PointCloud< PointType >            out_corner, out_surf;
+
+// ---- verbatim: laser_mapping.hpp:309-324
+@FOV@
+
+    void append( pcl::PointCloud< PointType >::Ptr pc_new_feature_corners, pcl::PointCloud< PointType >::Ptr pc_new_feature_surface )
+    {
+// ---- verbatim: laser_mapping.hpp:1492-1493
+@APPEND@
+    }
+
+    void refresh()
+    {
+// ---- verbatim: laser_mapping.hpp:465-537
+@REFRESH@
+        out_corner = *laser_cloud_corner_from_map;
+        out_surf = *laser_cloud_surf_from_map;
+    }
+};
+
+static pcl::PointCloud< PointType >::Ptr read_cloud( FILE *f, int n )
+{
+    pcl::PointCloud< PointType >::Ptr c( new pcl::PointCloud< PointType >() );
+    for ( int i = 0; i < n; i++ )
+    {
+        float v[ 4 ];
+        if ( fread( v, sizeof( float ), 4, f ) != 4 ) exit( 3 );
+        PointType p;
+        p.x = v[ 0 ], p.y = v[ 1 ], p.z = v[ 2 ], p.intensity = v[ 3 ];
+        c->points.push_back( p );
+    }
+    return c;
+}
+static void write_cloud( FILE *f, const pcl::PointCloud< PointType > &c )
+{
+    int n = ( int ) c.points.size();
+    fwrite( &n, sizeof( int ), 1, f );
+    for ( auto &p : c.points )
+    {
+        float v[ 4 ] = { p.x, p.y, p.z, p.intensity };
+        fwrite( v, sizeof( float ), 4, f );
+    }
+}
+
+// usage: exe in.bin out.bin cell_res revisit line_res plane_res range_c range_s fov replace
+// in.bin: int n_frames; per frame: double pose[7] {qx qy qz qw tx ty tz}, int n_corner, int n_surf, corner xyzi, surf xyzi (map frame)
+// out.bin: per frame the two match-buffer clouds after the refresh at that frame's pose
+int main( int argc, char **argv )
+{
+    if ( argc < 11 ) return 2;
+    std::streambuf *old = std::cout.rdbuf( nullptr );
+    FILE *in = fopen( argv[ 1 ], "rb" ), *out = fopen( argv[ 2 ], "wb" );
+    if ( !in || !out ) return 3;
+    Mapping_excerpt m;
+    m.m_pt_cell_map_corners.set_resolution( atof( argv[ 3 ] ) );   // laser_mapping.hpp:620-624
+    m.m_pt_cell_map_planes.set_resolution( atof( argv[ 3 ] ) );
+    m.m_pt_cell_map_corners.m_minimum_revisit_threshold = atoi( argv[ 4 ] );
+    m.m_pt_cell_map_planes.m_minimum_revisit_threshold = atoi( argv[ 4 ] );
+    m.m_line_resolution = atof( argv[ 5 ] );
+    m.m_plane_resolution = atof( argv[ 6 ] );
+    m.m_down_sample_filter_corner.setLeafSize( m.m_line_resolution, m.m_line_resolution, m.m_line_resolution );      // :742-743
+    m.m_down_sample_filter_surface.setLeafSize( m.m_plane_resolution, m.m_plane_resolution, m.m_plane_resolution );
+    m.m_maximum_search_range_corner = atof( argv[ 7 ] );
+    m.m_maximum_search_range_surface = atof( argv[ 8 ] );
+    m.m_maximum_in_fov_angle = atof( argv[ 9 ] );
+    m.m_down_sample_replace = atoi( argv[ 10 ] );
+    int n_frames = 0;
+    if ( fread( &n_frames, sizeof( int ), 1, in ) != 1 ) return 4;
+    for ( int k = 0; k < n_frames; k++ )
+    {
+        double pose[ 7 ];
+        int    nc, ns;
+        if ( fread( pose, sizeof( double ), 7, in ) != 7 || fread( &nc, sizeof( int ), 1, in ) != 1 || fread( &ns, sizeof( int ), 1, in ) != 1 ) return 4;
+        auto c = read_cloud( in, nc ), s = read_cloud( in, ns );
+        m.append( c, s );
+        m.m_q_w_curr = Eigen::Quaterniond( pose[ 3 ], pose[ 0 ], pose[ 1 ], pose[ 2 ] );
+        m.m_t_w_curr = Eigen::Vector3d( pose[ 4 ], pose[ 5 ], pose[ 6 ] );
+        m.refresh();
+        write_cloud( out, m.out_corner );
+        write_cloud( out, m.out_surf );
+    }
+    std::cout.rdbuf( old );
+    fclose( out );
+    return 0;
+}
+'''
+
+
+def build_cell_refresh(force=False):
+    """-> exe of the cell-branch refresh harness (None where neither /root/reference nor a travelled binary exists)"""
+    if not have_reference():
+        return EXE_CELLREFRESH if os.path.exists(EXE_CELLREFRESH) else None
+    stubs = os.path.join(ROOT, "oracle", "ref_stubs")
+    deps = [os.path.abspath(__file__)] + [os.path.join(dp, f) for dp, _, fs in os.walk(stubs) for f in fs]
+    if not force and os.path.exists(EXE_CELLREFRESH) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_CELLREFRESH) for d in deps):
+        return EXE_CELLREFRESH
+    os.makedirs(OUT, exist_ok=True)
+    tu = (CELLREFRESH_HARNESS.replace("@FOV@", _lines("source/laser_mapping.hpp", 309, 324))
+                             .replace("@APPEND@", _lines("source/laser_mapping.hpp", 1492, 1493))
+                             .replace("@REFRESH@", _lines("source/laser_mapping.hpp", 465, 537)))
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_cell_refresh.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", stubs, "-I", os.path.join(REF, "source"),
+                               "-I", os.path.join(REF, "include"), "-I", os.path.join(REF, "include", "tools"), "-o", EXE_CELLREFRESH, src])
+    return EXE_CELLREFRESH
