@@ -2,7 +2,9 @@
 
 CPU tier: the bookkeeping -- which key frames are open, which cells they hold, when one is closed / opened / dropped from the waiting
 list -- against the REFERENCE'S OWN TEXT: laser_mapping.hpp:1524-1564 and Maps_keyframe::add_cells (cell_map_keyframe.hpp:1243-1261)
-compiled verbatim into a small harness (tests/verbatim_build.py, build_keyframes) and driven with scripted touched-cell sets.
+compiled verbatim into a small harness (tests/verbatim_build.py, build_keyframes) and driven with scripted touched-cell sets; and the
+detector's walk over the earlier key frames (laser_mapping.hpp:988-1057, 1110-1127; build_loop_detector) with scripted key frames,
+similarities and alignment results.
 GPU tier: the whole chain on the device -- cells touched per scan (ll_cellmap_append_touched) against the oracle cell map, and an
 out-and-back sequence whose revisit is detected and aligned."""
 import os
