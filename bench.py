@@ -163,6 +163,21 @@ def pmc_knn_issue(batch: int):
             "sources": [os.path.relpath(pv, ROOT), os.path.relpath(pt, ROOT)]}
 
 
+def pipeline_schedule(k_steps, n_slots, start, collect):
+    """k_steps batches through n_slots slots (slot = extractor handle + registrar + voxel filters, each with its own streams):
+    batch i + D - 1 is started (start(slot): extract, select, enqueue the registration) before batch i is collected (collect(slot):
+    wait for it and download the results).  A slot is started again only after its previous batch has been collected; every batch
+    is started once and collected once, in order.  Returns the last collect's value.  (tests/test_bench_helpers.py replays it.)"""
+    D_, o = n_slots, None
+    for j in range(min(D_ - 1, k_steps)):   # prologue: the first D - 1 batches
+        start(j)
+    for i in range(k_steps):
+        if i + D_ - 1 < k_steps:
+            start((i + D_ - 1) % D_)        # (the slot's previous batch, i - 1, was collected in the last iteration)
+        o = collect(i % D_)
+    return o
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -293,19 +308,8 @@ def main():
         return reg.collect(B)
 
     def pipelined(k_steps, slots_, upload=False):
-        """k_steps batches through len(slots_) (extractor, registrar, voxel filters) slots: batch i + D - 1 is extracted and enqueued
-        before batch i is collected"""
-        D_, o = len(slots_), None
-        for j in range(min(D_ - 1, k_steps)):   # prologue: the first D - 1 batches
-            fe_stage(slots_[j][0], upload)
-            enqueue(slots_[j][1], slots_[j][0], slots_[j][2])
-        for i in range(k_steps):
-            if i + D_ - 1 < k_steps:
-                f_, r_, v_ = slots_[(i + D_ - 1) % D_]   # (the slot's previous batch, i - 1, was collected in the last iteration)
-                fe_stage(f_, upload)
-                enqueue(r_, f_, v_)
-            o = slots_[i % D_][1].collect(B)
-        return o
+        return pipeline_schedule(k_steps, len(slots_), lambda j: (fe_stage(slots_[j][0], upload), enqueue(slots_[j][1], slots_[j][0], slots_[j][2])),
+                                 lambda j: slots_[j][1].collect(B))
 
     def step():
         return run_on(fe)

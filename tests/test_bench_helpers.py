@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -86,3 +88,30 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["requested_gpus"] == 2 and len(d["per_rank_scans_per_s"]) == 2
     assert d["value"] == 2 * 4 * 2 / 0.020  # all ranks' scans over the slowest rank's time
+
+
+@pytest.mark.parametrize("n_slots", [1, 2, 3, 4])
+@pytest.mark.parametrize("k_steps", [1, 2, 5, 20])
+def test_pipeline_schedule_starts_and_collects_every_batch_once_and_never_reuses_a_busy_slot(n_slots, k_steps):
+    """bench.py's batches-in-flight loop: all K batches are started and collected inside the call (nothing hoisted out of the timed
+    region, nothing skipped), in order, at most n_slots in flight, and a slot is not started again before its batch was collected."""
+    import bench
+    events, busy, started, collected = [], {}, [], []
+
+    def start(slot):
+        assert slot not in busy, "slot started again while its batch is in flight"
+        busy[slot] = len(started)
+        started.append(len(started))
+        events.append(("s", slot))
+        assert len(busy) <= max(1, n_slots)
+
+    def collect(slot):
+        assert slot in busy, "collect of a slot with nothing in flight"
+        collected.append(busy.pop(slot))
+        events.append(("c", slot))
+        return collected[-1]
+
+    last = bench.pipeline_schedule(k_steps, n_slots, start, collect)
+    assert started == list(range(k_steps)) and collected == list(range(k_steps)) and last == k_steps - 1 and not busy
+    if n_slots > 1 and k_steps >= n_slots:
+        assert max(sum(1 for e in events[:i + 1] if e[0] == "s") - sum(1 for e in events[:i + 1] if e[0] == "c") for i in range(len(events))) == n_slots
