@@ -96,6 +96,10 @@ int ll_fe_upload_async(ll_fe *h, int32_t first_scan, int32_t n_scans, const floa
 int ll_fe_extract_batch(ll_fe *h, int32_t n_scans); /* asynchronous on the handle's stream */
 /* piece >= 0: use the device-computed piece-wise window `piece`; piece < 0: explicit [minimum,maximum]_blur */
 int ll_fe_select_batch(ll_fe *h, int32_t n_scans, int32_t piece, float minimum_blur, float maximum_blur);
+/* The selection ll_fe_select_batch left in slot `scan`: what ll_fe_select returns for slot 0 (get_features' outputs,
+ * livox_feature_extractor.hpp:219-272), for any slot of a batch.  Output buffers sized max_points; NULL to skip.  Synchronises. */
+int ll_fe_selection(ll_fe *h, int32_t scan, int32_t *corner_idx, int32_t *n_corner, int32_t *surf_idx, int32_t *n_surf,
+                    int32_t *full_idx, int32_t *n_full, float *corner_xyzi, float *surf_xyzi);
 int ll_fe_counts(ll_fe *h, int32_t n_scans, int32_t *n_corner, int32_t *n_surf, int32_t *n_full,
                  int32_t *n_ambiguous); /* synchronises */
 int ll_fe_sync(ll_fe *h);
@@ -271,6 +275,9 @@ int ll_reg_debug_knn(ll_reg *r, int32_t scan, int32_t *corner_idx5, float *corne
  * each cover an eighth of the blocks, resident in LDS; the sums are then grouped differently, so results agree with the
  * one-workgroup form to rounding, not bit for bit). */
 int ll_reg_set_debug(ll_reg *r, int32_t enable);
+/* Test tap: the ICP iteration (0-based, point_cloud_registration.hpp:211 `iterCount`) whose 5-NN lists ll_reg_debug_knn returns;
+ * default 0.  A scan that has converged before that iteration keeps the lists of an earlier registration (or zeros). */
+int ll_reg_set_debug_knn_iteration(ll_reg *r, int32_t icp_iteration);
 /* Further A/B switches of ll_reg_set_debug (measurement and tests only): bit 8 = searches one per lane everywhere (no
  * wavefront-per-query search where the work is small).  Environment switches read by the library, same purpose:
  * LL_LIST_NO_LOCAL_OFFSETS (small batches launch the work-list offsets kernel like large ones), LL_VOXEL_GENERAL_PATH (read

@@ -60,14 +60,19 @@ class Livox_laser:
         self._n[0] = n
         return npc.value
 
-    def get_features(self, minimum_blur: float = 0.0, maximum_blur: float = 0.3):
-        """Returns dict(corner_idx, surf_idx, full_idx, pc_corners, pc_surface) for scan slot 0."""
+    def get_features(self, minimum_blur: float = 0.0, maximum_blur: float = 0.3, scan: int | None = None):
+        """Returns dict(corner_idx, surf_idx, full_idx, pc_corners, pc_surface) for scan slot 0; with `scan` given: the selection
+        select_batch() left in that slot (the blur window is then the one select_batch was called with)."""
         n = self.params.max_points
         ci, si, fi = (np.zeros(n, np.int32) for _ in range(3))
         cc, sc = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
         nc, ns, nf = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        check(self.L.ll_fe_select(self.h, minimum_blur, maximum_blur, ptr(ci), C.byref(nc), ptr(si), C.byref(ns), ptr(fi),
-                                  C.byref(nf), ptr(cc), ptr(sc)), "ll_fe_select")
+        if scan is None:
+            check(self.L.ll_fe_select(self.h, minimum_blur, maximum_blur, ptr(ci), C.byref(nc), ptr(si), C.byref(ns), ptr(fi),
+                                      C.byref(nf), ptr(cc), ptr(sc)), "ll_fe_select")
+        else:
+            check(self.L.ll_fe_selection(self.h, int(scan), ptr(ci), C.byref(nc), ptr(si), C.byref(ns), ptr(fi), C.byref(nf), ptr(cc), ptr(sc)),
+                  "ll_fe_selection")
         return dict(corner_idx=ci[:nc.value].copy(), surf_idx=si[:ns.value].copy(), full_idx=fi[:nf.value].copy(),
                     pc_corners=cc[:nc.value].copy(), pc_surface=sc[:ns.value].copy())
 
@@ -563,6 +568,10 @@ class Point_cloud_registration:
                  | (128 if test_group_abort else 0) | (256 if no_knn_coop else 0) | (512 if no_knn_tile else 0)
                  | (1024 if knn_tile_with_reuse else 0) | (2048 if knn_tile_small_batches else 0) | (4096 if no_line_cache else 0))
         check(self.L.ll_reg_set_debug(self.h, flags), "ll_reg_set_debug")
+
+    def set_debug_knn_iteration(self, icp_iteration: int):
+        """the ICP iteration whose neighbour lists debug_knn() returns (default 0)"""
+        check(self.L.ll_reg_set_debug_knn_iteration(self.h, int(icp_iteration)), "ll_reg_set_debug_knn_iteration")
 
     def debug_knn(self, scan: int, n_corner: int, n_surf: int):
         ci, cd = np.zeros((n_corner, 5), np.int32), np.zeros((n_corner, 5), np.float32)

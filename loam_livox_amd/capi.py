@@ -55,6 +55,7 @@ SYMBOLS = {
     "ll_fe_labels": (_i32, [_vp, _i32] + [_vp] * 8),
     "ll_fe_splits": (_i32, [_vp, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp, _vp]),
     "ll_fe_select": (_i32, [_vp, _f, _f, _vp, C.POINTER(_i32), _vp, C.POINTER(_i32), _vp, C.POINTER(_i32), _vp, _vp]),
+    "ll_fe_selection": (_i32, [_vp, _i32, _vp, C.POINTER(_i32), _vp, C.POINTER(_i32), _vp, C.POINTER(_i32), _vp, _vp]),
     "ll_fe_upload": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),
     "ll_fe_upload_async": (_i32, [_vp, _i32, _i32, _vp, _i32, _vp]),
     "ll_fe_extract_batch": (_i32, [_vp, _i32]),
@@ -85,6 +86,7 @@ SYMBOLS = {
     "ll_reg_collect": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ll_reg_debug_knn": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ll_reg_set_debug": (_i32, [_vp, _i32]),
+    "ll_reg_set_debug_knn_iteration": (_i32, [_vp, _i32]),
     "ll_cloud_transform": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "ll_cloud_transform_fe_device": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "ll_reg_set_profiling": (_i32, [_vp, _i32]),

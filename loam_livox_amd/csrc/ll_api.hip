@@ -440,6 +440,30 @@ extern "C" int ll_fe_select(ll_fe *h, float minimum_blur, float maximum_blur, in
     return 0;
 }
 
+// the selection ll_fe_select_batch left in slot `scan` (the batched counterpart of ll_fe_select's downloads)
+extern "C" int ll_fe_selection(ll_fe *h, int32_t scan, int32_t *corner_idx, int32_t *n_corner, int32_t *surf_idx, int32_t *n_surf,
+                               int32_t *full_idx, int32_t *n_full, float *corner_xyzi, float *surf_xyzi)
+{
+    if (!h) return set_err("ll_fe_selection", "null handle");
+    if (scan < 0 || scan >= h->prm.max_scans) return set_err("ll_fe_selection", "scan out of range");
+    HC(hipSetDevice(h->prm.device));
+    HC(hipStreamSynchronize(h->stream));
+    int nc = 0, ns = 0, nf = 0;
+    HC(hipMemcpy(&nc, h->dev.n_corner + scan, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&ns, h->dev.n_surf + scan, sizeof(int), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&nf, h->dev.n_full + scan, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_corner) *n_corner = nc;
+    if (n_surf) *n_surf = ns;
+    if (n_full) *n_full = nf;
+    const size_t off = (size_t)scan * h->dev.stride;
+    D2H_OPT(corner_idx, h->dev.corner_idx + off, nc, int);
+    D2H_OPT(surf_idx, h->dev.surf_idx + off, ns, int);
+    D2H_OPT(full_idx, h->dev.full_idx + off, nf, int);
+    D2H_OPT(corner_xyzi, h->dev.corner_feat + off, nc, float4);
+    D2H_OPT(surf_xyzi, h->dev.surf_feat + off, ns, float4);
+    return 0;
+}
+
 // ============================================================================================== map
 
 // A search structure is an IMMUTABLE snapshot once published (the match buffer is refreshed on one thread,
@@ -642,6 +666,7 @@ struct ll_reg {
     std::vector<int> h_nc, h_ns;
     std::shared_ptr<MapSnap> pinned[2];  // map snapshots of the solve in flight (released once it has been collected)
     int debug = 0, profiling = 0;
+    int debug_knn_iter = 0;  // ll_reg_set_debug_knn_iteration
     int last_n_scans = 0, last_gated = 0;
     // profiling
     std::vector<hipEvent_t> ev;   // pairs
@@ -793,6 +818,14 @@ extern "C" int ll_reg_set_debug(ll_reg *r, int32_t enable)
     return 0;
 }
 
+extern "C" int ll_reg_set_debug_knn_iteration(ll_reg *r, int32_t icp_iteration)
+{
+    if (!r) return set_err("ll_reg_set_debug_knn_iteration", "null handle");
+    if (icp_iteration < 0) return set_err("ll_reg_set_debug_knn_iteration", "negative ICP iteration");
+    r->debug_knn_iter = icp_iteration;
+    return 0;
+}
+
 extern "C" int ll_reg_set_profiling(ll_reg *r, int32_t enable)
 {
     if (!r) return set_err("ll_reg_set_profiling", "null handle");
@@ -880,6 +913,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     if (map->device != r->device) return set_err("ll_reg", "map lives on another device");
     static const int debug_or = getenv("LL_DEBUG_OR") ? atoi(getenv("LL_DEBUG_OR")) : 0;  // (A/B runs of unmodified drivers: bits of ll_reg_set_debug)
     make_reg_const(prm, r->debug | debug_or, &r->rc);
+    r->rc.debug_knn_iter = r->debug_knn_iter;
     // A solve enqueued earlier on this handle and never collected still reads its snapshots: let it finish before its pins are
     // replaced (the snapshots could otherwise be recycled and rebuilt under its kernels by a concurrent ll_map_upload / refresh).
     if (r->pinned[0] || r->pinned[1]) HC(hipStreamSynchronize(r->stream));

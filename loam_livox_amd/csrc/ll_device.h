@@ -111,6 +111,7 @@ struct RegState {
 struct RegConst {
     int if_motion_deblur, icp_max_iterations, ceres_max_iterations, ceres_prerun_times;
     int icp_line, icp_plane, force_all_iterations, debug_knn;
+    int debug_knn_iter;  // the ICP iteration whose neighbour lists the debug taps record (ll_reg_set_debug_knn_iteration; default 0)
     int force_general;   // test switch: run the HBM-resident solver path even for small scans
     int knn_reuse;       // exact neighbour reuse across ICP iterations (ll_knn_core.h)
     int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)

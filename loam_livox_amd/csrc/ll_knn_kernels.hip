@@ -237,7 +237,7 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
     knn5_tile_wave(gs, valid, pw.x, pw.y, pw.z, max_d2, s_tile[threadIdx.x >> 6], r, fin);
     if (!valid) return;
     if (fin) {
-        if (rc.debug_knn && iter == 0) {
+        if (rc.debug_knn && iter == rc.debug_knn_iter) {
 #pragma unroll
             for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
         }

@@ -173,7 +173,7 @@ __device__ __forceinline__ void knn_store(const RegDev &rd, const RegConst &rc, 
     nn.y = kind ? r.pos[2] : r.pos[1];  // plane: 0, k/2, k-1 (PCR:416-418); line: 0, 1 (PCR:300-301)
     nn.z = r.pos[4];
     rd.nn[sb + slot] = nn;
-    if (rc.debug_knn && iter == 0 && rd.dbg_idx) {
+    if (rc.debug_knn && iter == rc.debug_knn_iter && rd.dbg_idx) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             rd.dbg_idx[(sb + slot) * 5 + k] = (knn5_idx(r, k) == LL_KNN_EMPTY) ? -1 : knn5_idx(r, k);
