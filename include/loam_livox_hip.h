@@ -282,7 +282,11 @@ int ll_reg_set_debug_knn_iteration(ll_reg *r, int32_t icp_iteration);
  * wavefront-per-query search where the work is small).  Environment switches read by the library, same purpose:
  * LL_LIST_NO_LOCAL_OFFSETS (small batches launch the work-list offsets kernel like large ones), LL_VOXEL_GENERAL_PATH (read
  * when a voxel filter is created: every cloud through the multi-kernel pipeline instead of one workgroup per small cloud).
- * None of them changes a result bit. */
+ * None of them changes a result bit.
+ * Small scans (at most 1024 corner + surface queries in the largest scan of a batch: voxel-filtered clouds, laser_mapping.hpp:1367-1373)
+ * take a solver of their own, one wavefront per scan in batches of 512 scans or more and four below (ll_reg_small_kernels.hip):
+ * bit 15 = off (such scans on the 512-thread solver: A/B; results agree to rounding, counts exactly); bit 16 / bit 17 = one / four
+ * wavefronts per scan whatever the batch size (tests). */
 
 /* ------------------------------------------------------------------------------------------------------------
  * VoxelGrid  (SURVEY 8(f) row 1).  pcl::VoxelGrid<pcl::PointXYZI> as hku-mars/loam_livox uses it:

@@ -23,6 +23,10 @@ namespace ll {
 #define LL_KNN_TILE_MIN_SURF 1024   // batches whose largest scan has at least this many surface queries (below: the wavefront-per-query search)
 #define LL_KNN_TILE_MAX_SURF 24576  // ... and at most this many (one sorting workgroup per scan holds them: 1024 threads x 24)
 
+// Small scans (voxel-filtered feature clouds: a few hundred residual blocks) have a solver of their own (ll_reg_small_kernels.hip)
+#define LL_SMALL_MAX_BLOCKS 1024     // batches whose largest scan has at most this many corner + surface queries
+#define LL_SMALL_W1_MIN_SCANS 512    // ... one wavefront per scan from this batch size on (many scans per CU), four wavefronts below
+
 struct FeScanInfo {
     int n_split;         // entries in split_idx (incl. the closing n-1)
     int clutter_size;    // return value of projection_scan_3d_2d (LFE:606; 0 when fewer than 6 entries)
@@ -123,6 +127,8 @@ struct RegConst {
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
     int knn_tile_last_sort;  // the tile search re-sorts a scan's queries by map cell in ICP iterations 0 .. this one (1: after the first pose update too)
+    int no_small_solver; // A/B switch: small scans take the 512-thread solver too (ll_reg_set_debug bit 15)
+    int small_waves;     // test switch: wavefronts per scan of the small solver whatever the batch size (0 = by batch size; bits 16 / 17: 1 / 4)
     int no_line_cache;   // A/B switch: the solver reads line blocks from HBM in every evaluation (no LDS copy)
     int knn_tile;        // surface searches by the tile kernel (ll_knn_tile.h): 0 = off (A/B), 1 = wherever the per-lane search of ALL surface
                          // queries would run (ICP iterations before knn_reuse_from, or every iteration without reuse), 2 = every ICP iteration
@@ -187,7 +193,9 @@ void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int 
 void launch_debug_quintic(const double *args, int n, double *out_seq, double *out_wave, hipStream_t s);
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
                          bool fused, hipStream_t s);
-void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, hipStream_t s);
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, hipStream_t s);
+bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns);
+void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, hipStream_t s);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);
 void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride, int heads,
