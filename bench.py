@@ -619,6 +619,9 @@ def main():
         result["solver_phase_cycles_scan0"] = cycB
         tot = np.array([int(reg.debug_cycles(b)[5]) for b in range(B)], np.float64)  # slot 5: the whole solver call, summed over the launches of a registration
         ctl = np.array([int(reg.debug_cycles(b)[1]) for b in range(B)], np.float64)
+        allc = np.array([[int(v) for v in reg.debug_cycles(b)] for b in range(B)], np.float64)
+        result["solver_phase_cycles_mean_over_scans"] = [int(v) for v in allc.mean(0)]
+        result["solver_phase_cycles_of_the_slowest_scan"] = [int(v) for v in allc[int(np.argmax(allc[:, 5]))]]
         qs = [0, 10, 25, 50, 75, 90, 99, 100]
         result["solver_cycles_per_registration_quantiles"] = {"q": qs, "total": [int(v) for v in np.percentile(tot, qs)], "mean_total": int(tot.mean()),
                                                               "lm_controller": [int(v) for v in np.percentile(ctl, qs)], "mean_lm_controller": int(ctl.mean())}

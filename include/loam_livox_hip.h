@@ -286,7 +286,7 @@ int ll_reg_set_debug_knn_iteration(ll_reg *r, int32_t icp_iteration);
  * Small scans (at most 1024 corner + surface queries in the largest scan of a batch: voxel-filtered clouds, laser_mapping.hpp:1367-1373)
  * take a solver of their own, one wavefront per scan in batches of 512 scans or more and four below (ll_reg_small_kernels.hip):
  * bit 15 = off (such scans on the 512-thread solver: A/B; results agree to rounding, counts exactly); bit 16 / bit 17 = one / four
- * wavefronts per scan whatever the batch size (tests). */
+ * wavefronts per scan whatever the batch size, both = two (tests); bit 18 = its workgroups in scan order instead of longest first (A/B). */
 
 /* ------------------------------------------------------------------------------------------------------------
  * VoxelGrid  (SURVEY 8(f) row 1).  pcl::VoxelGrid<pcl::PointXYZI> as hku-mars/loam_livox uses it:

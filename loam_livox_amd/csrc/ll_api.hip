@@ -752,6 +752,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.work_cnt, B * 4);
     DM(d.work_off, 3 * 2049);  // 3 prefix tables x (RL_MAX_SEG + 1), ll_reg_kernels.hip
     DM(d.grp_ctl, 2 * B + 1);
+    DM(d.solve_order, B);
     DM(d.grp_part, B * 2 * LL_GRP * 28);
     DM(d.grp_xch, B * 2 * LL_GRP * 56);
     DM(d.blk_l1, B * d.cap);
@@ -789,7 +790,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.solve_order, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -860,8 +861,9 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
     c->knn_tile_last_sort = (debug & 8192) ? 0 : ((debug & 16384) ? 2 : 1);  // bits 13 / 14: A/B of the re-sort schedule (sort at iteration 0 only / at 0, 1, 2)
+    c->no_solve_order = (debug & 262144) ? 1 : 0;  // bit 18: the small solver's workgroups in scan order (A/B)
     c->no_small_solver = (debug & 32768) ? 1 : 0;  // bit 15: small scans on the 512-thread solver too (A/B)
-    c->small_waves = (debug & 65536) ? 1 : ((debug & 131072) ? 4 : 0);  // bits 16 / 17: the small solver with one / four wavefronts per scan whatever the batch size (tests)
+    c->small_waves = ((debug & 65536) && (debug & 131072)) ? 2 : ((debug & 65536) ? 1 : ((debug & 131072) ? 4 : 0));  // bits 16 / 17: the small solver with one / four wavefronts per scan whatever the batch size (tests)
     c->no_line_cache = (debug & 4096) ? 1 : 0;  // bit 12: no LDS copy of the line blocks in the solver (A/B)
     c->knn_tile = (debug & 512) ? 0 : ((debug & 1024) ? 1 : 2);  // bit 9: no tile search of the surface queries (A/B, ll_knn_tile.h); bit 10: tile
                                                                  // search only where all queries are searched, the reuse machinery for the rest
@@ -1004,7 +1006,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
             prof_end(r);
             prof_begin(r, 1);
             if (r->rc.solve_group > 1) HC(hipMemsetAsync(r->dev.grp_ctl, 0, (size_t)(2 * n_scans + 1) * sizeof(int), r->stream));
-            launch_reg_solve(r->dev, r->rc, mk1.grid, n_scans, max_nc, max_ns, r->stream);
+            launch_reg_solve(r->dev, r->rc, mk1.grid, n_scans, max_nc, max_ns, it, r->stream);
             prof_end(r);
         }
     }

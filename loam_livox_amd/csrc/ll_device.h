@@ -25,7 +25,9 @@ namespace ll {
 
 // Small scans (voxel-filtered feature clouds: a few hundred residual blocks) have a solver of their own (ll_reg_small_kernels.hip)
 #define LL_SMALL_MAX_BLOCKS 1024     // batches whose largest scan has at most this many corner + surface queries
-#define LL_SMALL_W1_MIN_SCANS 512    // ... one wavefront per scan from this batch size on (many scans per CU), four wavefronts below
+#define LL_SMALL_W1_MIN_SCANS 512    // ... one or two wavefronts per scan from this batch size on (many scans per CU), four wavefronts below
+#define LL_SMALL_ORDER_MIN_SCANS 512  // batches of this many scans or more start their longest scans first (reg_solve_order_kernel) ...
+#define LL_SMALL_ORDER_MAX_SCANS 8192 // ... up to this many (one ordering workgroup)
 
 struct FeScanInfo {
     int n_split;         // entries in split_idx (incl. the closing n-1)
@@ -106,6 +108,7 @@ struct RegState {
     double inlier_thr, final_cost, initial_cost, angular_diff, t_diff;
     int icp_iters, n_blocks_last, corner_avail, surf_avail, lm_total;
     int done, accepted, gated, result;
+    int last_work;  // small solver: cost evaluations of this scan's last solver launch (the next launch starts the longest scans first)
     int aborted;  // the grouped solver gave up on a barrier (bounded spin): the scan is rejected and ll_reg_collect reports it
     long long dbg_cycles[16];  // LL_SOLVE_TIMING builds (shader clocks): eval, LM controller, L1, dedupe, select, total, census (+ triple inserts), prune,
                                // epilogue (plane-table path: table build), [9] = exchanges / L1 shortcuts taken; plane-table path: [10] census load waits,
@@ -127,6 +130,7 @@ struct RegConst {
     int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
     int knn_tile_last_sort;  // the tile search re-sorts a scan's queries by map cell in ICP iterations 0 .. this one (1: after the first pose update too)
+    int no_solve_order;  // A/B switch: the small solver's workgroups in scan order, not longest first (ll_reg_set_debug bit 18)
     int no_small_solver; // A/B switch: small scans take the 512-thread solver too (ll_reg_set_debug bit 15)
     int small_waves;     // test switch: wavefronts per scan of the small solver whatever the batch size (0 = by batch size; bits 16 / 17: 1 / 4)
     int no_line_cache;   // A/B switch: the solver reads line blocks from HBM in every evaluation (no LDS copy)
@@ -164,6 +168,7 @@ struct RegDev {
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
     float2 *ref_s;                // [B][cap]  x = bits(neighbour 4, -1 when fewer than 5 inside the radius), y = m_set
+    int *solve_order;             // [B] small solver: the scans in the order their workgroups start (reg_solve_order_kernel)
     int *grp_ctl;                 // [1 + 2 B] grouped solver: [0] ticket counter, [1 + 2 b] arrival counter of scan b's group barrier, [2 + 2 b] its abort word (zeroed per launch)
     double *grp_part;             // [B][2][LL_GRP][28] grouped solver: the workgroups' partial sums of the evaluation that also publishes the L1 values
     unsigned long long *grp_xch;  // [B][2][LL_GRP][56] ... of every other evaluation, as self-validating 8-byte granules {32-bit half, tag}; zeroed per registration
@@ -193,9 +198,10 @@ void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int 
 void launch_debug_quintic(const double *args, int n, double *out_seq, double *out_wave, hipStream_t s);
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
                          bool fused, hipStream_t s);
-void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, hipStream_t s);
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s);
 bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns);
-void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, hipStream_t s);
+void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s);
+int reg_solve_small_waves(const RegConst &rc, int n_scans, int max_nc, int max_ns);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);
 void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride, int heads,

@@ -2931,10 +2931,10 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, 0);
     }
 }
-void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, hipStream_t s)
+void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s)
 {
     if (reg_solve_small_eligible(rc, max_nc, max_ns))  // voxel-filtered scans: one or four wavefronts per scan (ll_reg_small_kernels.hip)
-        launch_reg_solve_small(rd, rc, gs, n_scans, max_nc, max_ns, s);
+        launch_reg_solve_small(rd, rc, gs, n_scans, max_nc, max_ns, iter, s);
     else if (rc.if_motion_deblur)
         hipLaunchKernelGGL(reg_solve_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
     else

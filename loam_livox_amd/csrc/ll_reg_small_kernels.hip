@@ -46,7 +46,19 @@ namespace ll {
         t_[2] = (x)[6];                                         \
     }
 
+#ifdef LL_SOLVE_TIMING
+#define SM_T0(var) long long var = clock64()
+#define SM_TACC(slot, var)                                      \
+    do {                                                        \
+        if (threadIdx.x == 0) sh.tcyc[slot] += clock64() - var; \
+    } while (0)
+#else
+#define SM_T0(var)
+#define SM_TACC(slot, var)
+#endif
+
 struct SmallShared {
+    long long tcyc[16];  // LL_SOLVE_TIMING builds: evaluations, controller, L1 pass, sort + select, -, total, census, prune, build (RegState::dbg_cycles)
     LmCtl ctl;
     double red[4][LL_NACC];  // per-wavefront sums of an evaluation (W <= 4)
     double sum[LL_NACC];
@@ -55,16 +67,32 @@ struct SmallShared {
     double x_start[7];
     int need, n_active, n_corner_avail, n_surf_avail;
     int nL, nA;              // kept line blocks, kept blocks (lines first)
+    int n_eval;              // cost evaluations of this launch
     int cnt[16][4];          // census: active blocks per (round, wavefront)
     int isum[4];
     unsigned long long lsum[4];
+};
+
+// what the kernel reads of the registrar's buffers (ll_device.h RegDev holds ~50 pointers: passed whole, the ones a phase keeps live
+// crowd the scalar registers of a kernel that already spills them)
+struct SmallArgs {
+    RegState *state;
+    const int *n_corner, *n_surf;
+    const int *order;              // scan of workgroup i (longest first, reg_solve_order_kernel), or nullptr
+    const unsigned char *blk_flag0;
+    const float4 *blk_f;
+    const double *blk_av;
+    const int4 *nn;
+    const float4 *surf_feat;
+    const f4 *map_surf;
+    int cap_all, cap_c, feat_stride_s;  // RegDev::cap, cap_c, feat_stride_s
+    int cap, capl;                      // LDS capacity in blocks / line blocks
 };
 
 // the LDS arrays of one scan (dynamic shared memory): see the header
 struct SmallBlocks {
     LL_AS_LDS double *v0, *v1, *v2, *a0, *a1, *a2;
     LL_AS_LDS float *fx, *fy, *fz;
-    LL_AS_LDS double *l1s;  // W > 1: the L1 values of all blocks, for the sorting wavefront
 };
 
 template <int W>
@@ -86,7 +114,7 @@ __device__ __forceinline__ unsigned long long small_sum_u64(unsigned long long v
 // compare-exchange of two keys held by the same lane
 __device__ __forceinline__ void cx_local(unsigned long long &a, unsigned long long &b, bool up)
 {
-    const bool sw = up ? (b < a) : (a < b);
+    const bool sw = (b < a) == up;  // (equal keys: swapping them or not is the same)
     const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
     a = lo;
     b = hi;
@@ -113,7 +141,7 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&key)[K], 
                     const unsigned long long mine = key[r];
                     const unsigned long long other = (unsigned long long)__shfl_xor((long long)mine, lj);
                     const bool keep_min = lower == up;
-                    const bool take = keep_min ? (other < mine) : (mine < other);
+                    const bool take = (other < mine) == keep_min;  // one compare, no branch (equal keys: taking the partner's is the same)
                     key[r] = take ? other : mine;
                 }
             } else {
@@ -189,31 +217,51 @@ __device__ __forceinline__ void small_lm(const SmallBlocks &B, const RegConst &r
     const int tid = threadIdx.x;
     if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
     __syncthreads();
-    small_eval<W>(B, sh.ctl.x, rc.huber_a, act, sh.nL, sh.nA, sh);
-    if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, sh.n_active);
-    __syncthreads();
+    {
+        SM_T0(t0);
+        small_eval<W>(B, sh.ctl.x, rc.huber_a, act, sh.nL, sh.nA, sh);
+        SM_TACC(0, t0);
+    }
+    {
+        SM_T0(t1);
+        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, sh.n_active);
+        __syncthreads();
+        SM_TACC(1, t1);
+    }
     while (sh.need) {
+        SM_T0(t0);
         small_eval<W>(B, sh.ctl.cand, rc.huber_a, act, sh.nL, sh.nA, sh);
+        SM_TACC(0, t0);
+        SM_T0(t1);
         if (tid < 64) {  // the controller's wavefront: lane 0 steps the controller, all of it fits a line search's interpolant
             const int need = lm_update_wave(sh.ctl, sh.sum, sh.fit, tid);
-            if (tid == 0) sh.need = need;
+            if (tid == 0) {
+                sh.need = need;
+                sh.n_eval++;
+            }
         }
         __syncthreads();
+        SM_TACC(1, t1);
+#ifdef LL_SOLVE_TIMING
+        if (tid == 0) sh.tcyc[9] += 1;  // evaluations beyond the first of a solve
+#endif
     }
 }
 
 // W wavefronts per scan, at most M candidate blocks per thread (64 * W * M >= n_corner + n_surf of every scan of the batch)
 template <int W, int M>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W == 1 ? 2 : 1, 8)))
-void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap, int capl)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W == 4 ? 1 : 2, 8)))
+void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
 {
+    const int cap = rd.cap, capl = rd.capl;
+    const f4 *map_surf = rd.map_surf;
     constexpr int NT = 64 * W;
     constexpr int K = M * W;  // keys per lane of the sorting wavefront
     static_assert(M <= 16 && K <= 16, "census rounds / sort keys per lane");
     __shared__ SmallShared sh;
     extern __shared__ double s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = rd.order ? rd.order[blockIdx.x] : (int)blockIdx.x;
     RegState *st = rd.state + b;
     if (st->done) return;
     SmallBlocks B;
@@ -221,14 +269,19 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
         LL_AS_LDS double *p = (LL_AS_LDS double *)s_dyn;
         B.v0 = p, B.v1 = p + cap, B.v2 = p + 2 * cap, B.a0 = p + 3 * cap;
         B.a1 = p + 4 * cap, B.a2 = p + 4 * cap + capl;
-        B.l1s = p + 4 * cap + 2 * capl;  // (W > 1 only)
-        LL_AS_LDS float *q = (LL_AS_LDS float *)(p + 4 * cap + 2 * capl + (W > 1 ? cap : 0));
+        LL_AS_LDS float *q = (LL_AS_LDS float *)(p + 4 * cap + 2 * capl);
         B.fx = q, B.fy = q + cap, B.fz = q + 2 * cap;
     }
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
     const int ncand = nC + nS;  // <= NT * M (the host chose M)
-    const size_t sb = (size_t)b * rd.cap;
+    const size_t sb = (size_t)b * rd.cap_all;
     const unsigned char *flag0 = rd.blk_flag0 + sb;
+#ifdef LL_SOLVE_TIMING
+    if (tid < 16) sh.tcyc[tid] = 0;
+    __syncthreads();
+#endif
+    SM_T0(t_total);
+    SM_T0(t_census);
 
     // ---- census (PCR:325, 425) in the reference's order: candidate c < nC is corner query c, else surface query c - nC -------------
     unsigned int act = 0;  // bit r: candidate r * NT + tid is a kept block
@@ -294,6 +347,7 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
             kept_lines = (int)small_sum_u64<W>((unsigned long long)kl, sh);
         }
         if (tid == 0) {
+            sh.n_eval = 0;
             sh.n_active = base;
             sh.nA = base;
             sh.nL = kept_lines;
@@ -301,12 +355,14 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
             sh.n_surf_avail = nsa;
         }
     }
+    SM_TACC(6, t_census);
+    SM_T0(t_build);
     // ---- build: the kept blocks' constants -> LDS -------------------------------------------------------------------------------------
     {
         double pose_last[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) pose_last[i] = gload_f64(st->pose_last + i);
-        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap_all;
         const float4 *sfeat = rd.surf_feat + (size_t)b * rd.feat_stride_s;
 #pragma unroll
         for (int r = 0; r < M; r++) {
@@ -316,7 +372,7 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
             if (c < nC) {
                 const float4 f = gload_f4(rd.blk_f + sb + c);
                 double a0, a1, a2, v0, v1, v2;
-                av_load(av, rd.cap, c, true, a0, a1, a2, v0, v1, v2);
+                av_load(av, rd.cap_all, c, true, a0, a1, a2, v0, v1, v2);
                 B.fx[p] = f.x, B.fy[p] = f.y, B.fz[p] = f.z;
                 B.v0[p] = v0, B.v1[p] = v1, B.v2[p] = v2;
                 B.a0[p] = a0, B.a1[p] = a1, B.a2[p] = a2;
@@ -338,6 +394,7 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
         }
     }
     __syncthreads();
+    SM_TACC(8, t_build);
     const int nA = sh.nA, nL = sh.nL;
     // from here on a thread's blocks are the DENSE ones r * NT + tid
     unsigned int live = 0;
@@ -351,6 +408,7 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
 
     // ---- loss-corrected L1 values at the prerun result (PCR:476-485), in registers -----------------------------------------------------
     double l1[M];
+    SM_T0(t_l1);
     {
         constexpr int DEBLUR = 0;
         LL_CTX_DECL_SMALL(sh.ctl.x)
@@ -375,26 +433,32 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
             l1[r] = v1;
         }
     }
+    SM_TACC(2, t_l1);
+    SM_T0(t_sort);
     // ---- std::set de-duplication + rank select (PCR:153-161): one bitonic sort on the first wavefront --------------------------------
-    if (W > 1) {
+    unsigned long long key[K];  // (the first wavefront's: its own M values per lane, then the other wavefronts')
 #pragma unroll
-        for (int r = 0; r < M; r++)
-            if ((live >> r) & 1u) B.l1s[r * NT + tid] = l1[r];
-        __syncthreads();
+    for (int k = 0; k < K; k++) {
+        const double v = l1[k < M ? k : 0];
+        key[k] = (k < M && v >= 0.0) ? (unsigned long long)__double_as_longlong(v) : 0xffffffffffffffffull;  // inactive slot or NaN (NaN never enters the set)
+    }
+    if (W > 1) {
+        // the other wavefronts hand their keys to the first one, 64 at a time through the 512 bytes of one wavefront's partial sums
+        // (nothing is being summed now): which lane ends up with which key does not matter to a sort
+        unsigned long long *xch = (unsigned long long *)&sh.red[0][0];
+        static_assert(sizeof(sh.red) >= 64 * sizeof(unsigned long long), "exchange buffer");
+#pragma unroll
+        for (int w = 1; w < W; w++) {
+#pragma unroll
+            for (int r = 0; r < M; r++) {
+                if (wave == w) xch[lane] = key[r];
+                __syncthreads();
+                if (wave == 0) key[w * M + r] = xch[lane];
+                __syncthreads();
+            }
+        }
     }
     if (wave == 0) {
-        unsigned long long key[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            double v;
-            if (W == 1) {
-                v = l1[k < M ? k : 0];
-            } else {
-                const int idx = k * 64 + lane;
-                v = idx < nA ? B.l1s[idx] : -1.0;
-            }
-            key[k] = (v >= 0.0) ? (unsigned long long)__double_as_longlong(v) : 0xffffffffffffffffull;  // inactive slot or NaN (NaN never enters the set)
-        }
         wave_bitonic_sort<K>(key, lane);
         // element g = lane * K + k is the first of its value iff it differs from element g - 1
         const unsigned long long prev_last = (unsigned long long)__shfl_up((long long)key[K - 1], 1);
@@ -431,6 +495,8 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
         }
     }
     __syncthreads();
+    SM_TACC(3, t_sort);
+    SM_T0(t_prune);
     // ---- prune (PCR:487-499) -----------------------------------------------------------------------------------------------------------
     {
         const double thr = sh.thr;
@@ -448,25 +514,69 @@ void reg_solve_small_kernel(RegDev rd, RegConst rc, const f4 *map_surf, int cap,
         if (tid < 7) sh.x_start[tid] = sh.ctl.x[tid];
         __syncthreads();
     }
+    SM_TACC(7, t_prune);
     // ---- final solve (PCR:501-508) -------------------------------------------------------------------------------------------------------
     small_lm<W>(B, rc, sh.x_start, rc.ceres_max_iterations, live, sh);
     lm_iters += sh.ctl.iteration;
     solve_epilogue(rc, st, sh, lm_iters);
+    if (tid == 0) st->last_work = sh.n_eval;  // next launch: the scans that worked longest start first
+#ifdef LL_SOLVE_TIMING
+    SM_TACC(5, t_total);
+    if (tid == 0)
+        for (int i = 0; i < 16; i++) st->dbg_cycles[i] += sh.tcyc[i];
+#endif
+}
+
+// Longest first: the scans of a batch differ five-fold in the work of a launch (the ones whose step runs into the bound on t_inc contract a
+// line search: dozens of extra evaluations), a launch of more scans than the device holds at once ends when its last scan does, and a
+// scan's work changes little from one ICP iteration to the next.  One workgroup orders the scans by the evaluations of their previous
+// launch, descending (counting sort: the first launch of a registration runs in scan order).  Only the order of dispatch depends on it, no result does.
+#define SO_THREADS 1024
+#define SO_BINS 256
+__global__ __launch_bounds__(SO_THREADS) void reg_solve_order_kernel(const RegState *state, int n_scans, int *order)
+{
+    __shared__ int hist[SO_BINS], start[SO_BINS];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < SO_BINS; e += SO_THREADS) hist[e] = 0;
+    __syncthreads();
+    for (int b = tid; b < n_scans; b += SO_THREADS) {
+        int w = state[b].last_work;
+        w = w < 0 ? 0 : (w > SO_BINS - 1 ? SO_BINS - 1 : w);
+        atomicAdd(&hist[SO_BINS - 1 - w], 1);  // bin 0 = the most work
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int e = 0; e < SO_BINS; e++) {
+            start[e] = run;
+            run += hist[e];
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < n_scans; b += SO_THREADS) {  // (the order inside a bin is whatever the atomics hand out: it decides nothing but timing)
+        int w = state[b].last_work;
+        w = w < 0 ? 0 : (w > SO_BINS - 1 ? SO_BINS - 1 : w);
+        order[atomicAdd(&start[SO_BINS - 1 - w], 1)] = b;
+    }
 }
 
 // dynamic LDS of one scan
-static size_t small_lds_bytes(int W, int cap, int capl) { return (size_t)cap * (4 * 8 + 3 * 4) + (size_t)capl * 16 + (W > 1 ? (size_t)cap * 8 : 0); }
+static size_t small_lds_bytes(int W, int cap, int capl)
+{
+    (void)W;
+    return (size_t)cap * (4 * 8 + 3 * 4) + (size_t)capl * 16;
+}
 
 template <int W, int M>
-static void launch_small(const RegDev &rd, const RegConst &rc, const f4 *map_surf, int n_scans, int cap, int capl, hipStream_t s)
+static void launch_small(const SmallArgs &a, const RegConst &rc, int n_scans, hipStream_t s)
 {
-    const size_t lds = small_lds_bytes(W, cap, capl);
+    const size_t lds = small_lds_bytes(W, a.cap, a.capl);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)reg_solve_small_kernel<W, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((reg_solve_small_kernel<W, M>), dim3(n_scans), dim3(64 * W), lds, s, rd, rc, map_surf, cap, capl);
+    hipLaunchKernelGGL((reg_solve_small_kernel<W, M>), dim3(n_scans), dim3(64 * W), lds, s, a, rc);
 }
 
 bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns)
@@ -475,19 +585,46 @@ bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns)
            max_nc + max_ns <= LL_SMALL_MAX_BLOCKS;
 }
 
-void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, hipStream_t s)
+// wavefronts per scan: four for batches that leave CUs idle anyway (latency); for large batches as many as keep two wavefronts per SIMD
+// busy at the number of scans whose blocks fit a CU's LDS together (256 VGPRs per wavefront: eight wavefronts per CU)
+int reg_solve_small_waves(const RegConst &rc, int n_scans, int max_nc, int max_ns)
+{
+    if (rc.small_waves) return rc.small_waves;
+    if (n_scans < LL_SMALL_W1_MIN_SCANS) return 4;
+    const int total = max_nc + max_ns;
+    const int cap = (total + 63) / 64 * 64, capl = (max_nc + 63) / 64 * 64 + 64;
+    const size_t per_scan = small_lds_bytes(1, cap, capl) + sizeof(SmallShared) + 512;
+    const int per_cu = (int)((size_t)(160 * 1024) / per_scan);
+    return per_cu >= 8 ? 1 : (per_cu >= 4 ? 2 : 4);
+}
+
+void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s)
 {
     const int total = max_nc + max_ns;
-    const int cap = (total + 63) / 64 * 64, capl = (max_nc + 63) / 64 * 64 + 64;  // (+64: the clamped line index of a scan without lines stays inside)
-    const bool one = rc.small_waves ? rc.small_waves == 1 : n_scans >= LL_SMALL_W1_MIN_SCANS;
-    if (one) {
-        if (total <= 256) launch_small<1, 4>(rd, rc, gs.pts, n_scans, cap, capl, s);
-        else if (total <= 512) launch_small<1, 8>(rd, rc, gs.pts, n_scans, cap, capl, s);
-        else launch_small<1, 16>(rd, rc, gs.pts, n_scans, cap, capl, s);
+    SmallArgs a;
+    a.state = rd.state, a.n_corner = rd.n_corner, a.n_surf = rd.n_surf, a.blk_flag0 = rd.blk_flag0, a.blk_f = rd.blk_f, a.blk_av = rd.blk_av;
+    a.nn = rd.nn, a.surf_feat = rd.surf_feat, a.map_surf = gs.pts, a.cap_all = rd.cap, a.cap_c = rd.cap_c, a.feat_stride_s = rd.feat_stride_s;
+    a.cap = (total + 63) / 64 * 64, a.capl = (max_nc + 63) / 64 * 64 + 64;  // (+64: the clamped line index of a scan without lines stays inside)
+    const int W = reg_solve_small_waves(rc, n_scans, max_nc, max_ns);
+    // more scans than the device runs at once: longest first (from the second launch of a registration on)
+    a.order = nullptr;
+    if (rd.solve_order && !rc.no_solve_order && n_scans >= LL_SMALL_ORDER_MIN_SCANS && n_scans <= LL_SMALL_ORDER_MAX_SCANS && iter > 0) {
+        hipLaunchKernelGGL(reg_solve_order_kernel, dim3(1), dim3(SO_THREADS), 0, s, rd.state, n_scans, rd.solve_order);
+        a.order = rd.solve_order;
+    }
+    const int cls = total <= 256 ? 0 : (total <= 512 ? 1 : 2);  // 64 * W * M >= total
+    if (W == 1) {
+        if (cls == 0) launch_small<1, 4>(a, rc, n_scans, s);
+        else if (cls == 1) launch_small<1, 8>(a, rc, n_scans, s);
+        else launch_small<1, 16>(a, rc, n_scans, s);
+    } else if (W == 2) {
+        if (cls == 0) launch_small<2, 2>(a, rc, n_scans, s);
+        else if (cls == 1) launch_small<2, 4>(a, rc, n_scans, s);
+        else launch_small<2, 8>(a, rc, n_scans, s);
     } else {
-        if (total <= 256) launch_small<4, 1>(rd, rc, gs.pts, n_scans, cap, capl, s);
-        else if (total <= 512) launch_small<4, 2>(rd, rc, gs.pts, n_scans, cap, capl, s);
-        else launch_small<4, 4>(rd, rc, gs.pts, n_scans, cap, capl, s);
+        if (cls == 0) launch_small<4, 1>(a, rc, n_scans, s);
+        else if (cls == 1) launch_small<4, 2>(a, rc, n_scans, s);
+        else launch_small<4, 4>(a, rc, n_scans, s);
     }
 }
 

@@ -52,7 +52,7 @@ def check_against(rep, orep, pose, opose, res, ret, tol=1e-7):
     assert np.isclose(rep.final_cost, orep.final_cost, rtol=1e-7)
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 @pytest.mark.parametrize("force", [0, 1])
 def test_small_solver_matches_oracle_and_the_512_thread_solver(dev_map, small_world, scans, filtered, waves, force):
     B = len(scans)
@@ -77,7 +77,7 @@ def test_small_solver_matches_oracle_and_the_512_thread_solver(dev_map, small_wo
         assert (reps[b].n_blocks_last, reps[b].lm_iterations_total, reps[b].icp_iterations) == (reps5[b].n_blocks_last, reps5[b].lm_iterations_total, reps5[b].icp_iterations)
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 @pytest.mark.parametrize("sizes", [(40, 150), (150, 330), (230, 760), (0, 300), (200, 0)])
 def test_every_size_class(dev_map, small_world, scans, waves, sizes):
     """the three capacities of a kernel form (256 / 512 / 1024 candidate blocks), a scan without corner and one without surface features"""
@@ -95,7 +95,7 @@ def test_every_size_class(dev_map, small_world, scans, waves, sizes):
     check_against(reps[0], orep, pc[0], opc, res[0], ret)
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 def test_shipped_block_cap_200(dev_map, small_world, scans, filtered, waves):
     """a13 at the shipped setting: more than 200 candidate blocks -> the reproducible block drop of PCR:438-458"""
     prm = orc.RegParams.defaults(icp_iters=8, ceres_iters=20, force_all=1)
@@ -114,7 +114,7 @@ def test_shipped_block_cap_200(dev_map, small_world, scans, filtered, waves):
         assert reps[0].n_blocks_last < 260
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 def test_duplicate_residuals_follow_std_set_semantics(dev_map, small_world, scans, filtered, waves):
     """compute_inlier_residual_threshold (PCR:155-160) ranks the DISTINCT values: features repeated verbatim give exact duplicates, which
     the sort has to count once"""
@@ -136,7 +136,7 @@ def test_duplicate_residuals_follow_std_set_semantics(dev_map, small_world, scan
     check_against(reps[0], orep, pc[0], opc, res[0], ret)
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 def test_bounded_line_search(dev_map, small_world, scans, filtered, waves):
     """start 0.25 m outside a 0.05 m bound on t_inc: repeated contractions of the projected line search, the three-sample fit on the
     controller's wavefront"""
@@ -179,6 +179,13 @@ def test_large_batch_one_wavefront_per_scan_by_default(dev_map, small_world, sca
         check_against(reps[d], orep, pc[d], opc, res[d], ret)
     for b in range(D, B):
         assert np.array_equal(pc[b], pc[b % D]) and res[b] == res[b % D]
+    # the order the workgroups start in (longest first from the second ICP iteration on) decides nothing
+    reg = Point_cloud_registration(max_scans=B, max_features=1024)
+    reg.set_debug(False, no_solve_order=True)
+    set_params(reg, 10, 20, 1)
+    res_o, pc_o, _, _ = reg.solve_batch(dev_map, [filtered[b % S][0] for b in range(B)], [filtered[b % S][1] for b in range(B)], pl, pl)
+    reg.close()
+    assert np.array_equal(pc_o, pc) and np.array_equal(res_o, res)
     reg4 = Point_cloud_registration(max_scans=D, max_features=1024)
     set_params(reg4, 10, 20, 1)
     res4, pc4, _, reps4 = reg4.solve_batch(dev_map, [filtered[b % S][0] for b in range(D)], [filtered[b % S][1] for b in range(D)], pl[:D], pl[:D])
