@@ -76,7 +76,8 @@ def parse():
     ap.add_argument("--no-q-pipe", action="store_true", help="skip the secondary Q-pipe figure (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the PCIe-inclusive figure")
     ap.add_argument("--no-pipeline", action="store_true", help="value = one batch at a time (no overlap of consecutive batches)")
-    ap.add_argument("--q-pipe-in-flight", type=int, default=4, help="batches in flight for the secondary Q-pipe figure")
+    ap.add_argument("--q-pipe-in-flight", type=int, default=3, help="batches in flight for the secondary Q-pipe figure")
+    ap.add_argument("--q-pipe-batch", type=int, default=2048, help="scans per batch of the secondary Q-pipe figure (the small-scan solver packs several scans per CU)")
     ap.add_argument("--in-flight", type=int, default=3, help="batches in flight in the timed loop (extractor handle + registrar each)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed single-thread oracle runs (after 3 warm-ups); their median is cpu_baseline_1thread")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU baseline (0 = os.cpu_count())")
@@ -469,47 +470,75 @@ def main():
         lat.append(time.perf_counter() - t1)
     latency_ms = 1e3 * float(np.median(lat[1:]))
 
-    # secondary figure: the same workload in the other query mode (SURVEY 8d reports both), a short untimed-warm-up run
+    # secondary figure: the same workload in the other query mode (SURVEY 8d reports both) -- the reference's operating point: features
+    # voxel-filtered on the device before registration (laser_mapping.hpp:1367-1373), a few hundred residual blocks per scan.  Such scans
+    # take the small-scan solver (ll_reg_small_kernels.hip): one or two wavefronts per scan, several scans per CU -- which needs more scans
+    # than CUs to pay, so the figure is taken at --q-pipe-batch scans per batch (default 2048) as well as at the headline's batch size.
     q_pipe_extra = None
     if not vox and not args.no_q_pipe:
-        vq = (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev))
+        def q_pipe_figure(Bq, shipped_cap=False, in_flight=0):
+            rq = np.random.default_rng(777 + rank)
+            idx = np.arange(Bq) % B
+            init_q = init if Bq == B else np.stack([
+                synth.pose_compose(poses_true[i], np.r_[synth.quat_from_axis_angle(rq.normal(size=3), np.deg2rad(rq.uniform(0, 1.0))), rq.uniform(-0.1, 0.1, 3)])
+                for i in idx])
 
-        def step_q():
-            fe.extract_batch(B); fe.resolve(); fe.select_batch(B, -1, 0.0, 1.0)
-            reg.enqueue_fe_downsampled(mp, fe, vq[0], vq[1], 0.1, 0.4, B, init, init)
-            return reg.collect(B)
+            def make_slot_q():
+                f_ = Livox_laser(max_points=N, max_scans=Bq, device=dev, piecewise_number=1)
+                for b0 in range(0, Bq, B):  # (the batch's scans repeat the headline's distinct ones; every slot has its own initial guess)
+                    f_.upload(scans[:min(B, Bq - b0)], times[:min(B, Bq - b0)], first_scan=b0)
+                r_ = Point_cloud_registration(max_scans=Bq, max_features=N, device=dev)
+                for f in ("icp_max_iterations", "ceres_max_iterations", "force_all_iterations", "para_max_angular_rate", "para_max_speed",
+                          "max_final_cost", "current_frame_index", "mapping_init_accumulate_frames", "maximum_allow_residual_block"):
+                    setattr(r_.params, f, getattr(p, f))
+                if shipped_cap:  # config/performance_precision.yaml:23 -- what cpu_baseline_shipped_config[_allcores] run
+                    r_.params.maximum_allow_residual_block, r_.params.subsample_seed = 200, 7
+                return f_, r_, (VoxelGrid(N, Bq, device=dev), VoxelGrid(N, Bq, device=dev))
 
-        step_q()
-        barrier()
-        tq = time.perf_counter()
-        for _ in range(3):
-            step_q()
-        barrier()
-        tq = (time.perf_counter() - tq) / 3
-        ncq, nsq = vq[0].counts(B)[0], vq[1].counts(B)[0]
-        q_pipe_extra = {"scans_per_s_this_rank": round(B / tq, 1), "ms_per_step": round(1e3 * tq, 3),
-                        "features_per_scan": {"corner": float(ncq.mean()), "surface": float(nsq.mean())},
-                        "note": "device VoxelGrid (leaf 0.1 / 0.4 m, laser_mapping.hpp:1367-1373) between extraction and registration"}
-        if slots is not None:
-            # A voxel-filtered batch is a latency chain: its step lasts as long as its slowest scan's LM iterations on ONE workgroup while
-            # the other CUs idle.  Batches are independent: with several in flight the idle CUs run the other batches' scans.
-            Dq = max(2, args.q_pipe_in_flight)
-            slots_q = [(f_, r_, (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev))) for f_, r_, _ in slots[:Dq]]
-            while len(slots_q) < Dq:
-                f_ = Livox_laser(max_points=N, max_scans=B, device=dev, piecewise_number=1)
-                f_.upload(scans, times)
-                slots_q.append((f_, make_registrar(), (VoxelGrid(N, B, device=dev), VoxelGrid(N, B, device=dev))))
-            pipelined(Dq, slots_q)
+            def start_q(sl):
+                sl[0].extract_batch(Bq); sl[0].resolve(); sl[0].select_batch(Bq, -1, 0.0, 1.0)
+                sl[1].enqueue_fe_downsampled(mp, sl[0], sl[2][0], sl[2][1], 0.1, 0.4, Bq, init_q, init_q)
+
+            sl0 = make_slot_q()
+            start_q(sl0); sl0[1].collect(Bq)
             barrier()
             tq = time.perf_counter()
-            out_q = pipelined(3 * Dq, slots_q)
+            for _ in range(3):
+                start_q(sl0)
+                out_q = sl0[1].collect(Bq)
             barrier()
-            tq = (time.perf_counter() - tq) / (3 * Dq)
-            q_pipe_extra = {"scans_per_s_this_rank": round(B / tq, 1), "ms_per_step": round(1e3 * tq, 3), "batches_in_flight": Dq,
-                            "one_batch_at_a_time": {k_: q_pipe_extra[k_] for k_ in ("scans_per_s_this_rank", "ms_per_step")},
-                            "accepted_frac": float(np.mean(out_q[0])), "features_per_scan": q_pipe_extra["features_per_scan"], "note": q_pipe_extra["note"]}
-        reg.enqueue_fe(mp, fe, B, init, init)  # leave the registrar in the state of the timed configuration
-        reg.collect(B)
+            tq = (time.perf_counter() - tq) / 3
+            ncq, nsq = sl0[2][0].counts(Bq)[0], sl0[2][1].counts(Bq)[0]
+            fig = {"batch": Bq, "scans_per_s_this_rank": round(Bq / tq, 1), "ms_per_step": round(1e3 * tq, 3),
+                   "features_per_scan": {"corner": float(ncq.mean()), "surface": float(nsq.mean())},
+                   "blocks_per_scan_last_iteration": float(np.mean([r.n_blocks_last for r in out_q[3]])),
+                   "accepted_frac": float(np.mean(out_q[0])), "lm_iters_per_scan": float(np.mean([r.lm_iterations_total for r in out_q[3]]))}
+            if in_flight > 1:
+                # A voxel-filtered batch ends with its slowest scan's last line search; batches are independent: with several in flight the
+                # CUs of the early finishers run the other batches' scans
+                slots_q = [sl0] + [make_slot_q() for _ in range(in_flight - 1)]
+                pipeline_schedule(in_flight, in_flight, lambda j: start_q(slots_q[j]), lambda j: slots_q[j][1].collect(Bq))
+                barrier()
+                tq = time.perf_counter()
+                out_p = pipeline_schedule(3 * in_flight, in_flight, lambda j: start_q(slots_q[j]), lambda j: slots_q[j][1].collect(Bq))
+                barrier()
+                tq = (time.perf_counter() - tq) / (3 * in_flight)
+                fig = {**fig, "one_batch_at_a_time": {k_: fig[k_] for k_ in ("scans_per_s_this_rank", "ms_per_step")},
+                       "scans_per_s_this_rank": round(Bq / tq, 1), "ms_per_step": round(1e3 * tq, 3), "batches_in_flight": in_flight,
+                       "results_equal_one_at_a_time_bitwise": bool(np.array_equal(out_p[1], out_q[1]))}
+                for sl in slots_q[1:]:
+                    sl[0].close(); sl[1].close(); sl[2][0].close(); sl[2][1].close()
+            sl0[0].close(); sl0[1].close(); sl0[2][0].close(); sl0[2][1].close()
+            return fig
+
+        Bq = max(B, args.q_pipe_batch)
+        q_pipe_extra = q_pipe_figure(Bq, in_flight=(max(2, args.q_pipe_in_flight) if slots is not None else 0))
+        q_pipe_extra["note"] = ("device VoxelGrid (leaf 0.1 / 0.4 m, laser_mapping.hpp:1367-1373) between extraction and registration; small-scan solver "
+                                "(one / two wavefronts per scan in batches of >= 512 scans, four below)")
+        if Bq != B:
+            q_pipe_extra["at_the_headline_batch_size"] = q_pipe_figure(B)
+        # like-for-like with cpu_baseline_shipped_config[_allcores]: the same features capped at maximum_residual_blocks = 200
+        q_pipe_extra["shipped_config_200_blocks"] = q_pipe_figure(Bq, shipped_cap=True)
 
     # ---- roofline of the dominant kernel (HIP events on the registrar's stream, see ll_reg_set_profiling) ----
     names = ["reg_knn_build_kernel", "reg_solve_kernel", "reg_finalize_kernel"]
@@ -605,7 +634,8 @@ def main():
         "per_iter_ms_split_per_batch": {"transform_knn_build": round(float(k_ms[0] / args.steps / max(1, args.icp_iters)), 4),
                                         "solve": round(float(k_ms[1] / args.steps / max(1, args.icp_iters)), 4)},
         "single_scan_latency_ms": round(latency_ms, 3),
-        "single_scan_solver": "one workgroup per scan" if args.no_solver_groups else "group of 8 workgroups per scan (batches <= 16)",
+        "single_scan_solver": ("small-scan solver, four wavefronts (<= 1024 features)" if vox else
+                               ("one workgroup per scan" if args.no_solver_groups else "group of 8 workgroups per scan (batches <= 16)")),
         "features_per_scan": {"corner": float(nc.mean()), "surface": float(ns.mean())},
         "knn_reuse_last_iter": dict(zip(("searched", "resorted"), reg.debug_worklists(B)), queries=int(nc.sum() + ns.sum()),
                                     corner_searched_resorted=reg.debug_worklists_by_kind(B)[0], corner_queries=int(nc.sum())),

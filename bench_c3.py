@@ -102,11 +102,12 @@ def main():
         step()
         reg.collect(B)
     t0 = time.perf_counter()
-    kms = np.zeros(3)
+    kms, kn = np.zeros(3), np.zeros(3)
     for _ in range(args.steps):
         step()
         res, pc, pi, reps = reg.collect(B)
         kms += reg.kernel_times()[0]
+        kn += reg.kernel_times()[1]
     el = time.perf_counter() - t0
     sequential = None
     if args.in_flight > 1:
@@ -140,6 +141,29 @@ def main():
            "ms_per_step": round(1e3 * el / args.steps, 2), "batches_in_flight": max(1, args.in_flight), "one_batch_at_a_time": sequential, "kernel_ms_per_step": {"knn+build": round(float(kms[0] / args.steps), 2), "solver": round(float(kms[1] / args.steps), 2)},
            "accepted_frac": float(np.mean(res)), "median_err_vs_truth_m": float(np.median([e[0] for e in err])), "median_err_vs_truth_rad": float(np.median([e[1] for e in err])),
            "blocks_last": float(np.mean([r.n_blocks_last for r in reps])), "map_upload_grid_build_s": round(t_map, 2), "feature_upload_s" if args.features_resident else "scan_upload_s": round(t_upload, 3)}
+    # ---- roofline of the dominant kernel: the general-path solver (reg_solve_kernel<1>, motion-deblur residuals), one launch per ICP
+    #      iteration; algorithmic bytes = every residual block's constants once per launch (49 B per plane block: fp32 point +
+    #      blur ratio, {a0, v0}, {v1, v2}, flag; 65 B per line block) + 224 B of state out per scan; duration from the HIP events around
+    #      the solver launches on the registrar's stream (one batch at a time)
+    n_line = float(np.sum([r.corner_avail for r in reps])), float(np.sum([r.surf_avail for r in reps]))
+    alg = n_line[0] * 65.0 + n_line[1] * 49.0 + 224.0 * B
+    ms_launch = float(kms[1] / max(1.0, kn[1]))
+    traffic = src = None
+    import csv, glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_c3_pmc_hbm_bytes.csv")))
+    if hits:
+        best = None
+        for r in csv.DictReader(open(hits[-1])):
+            if "reg_solve_kernel" in r["kernel"] and (best is None or int(r["grid_threads"]) > int(best["grid_threads"])):
+                best = r
+        if best is not None and int(best["grid_threads"]) == B * 512:
+            traffic, src = int(float(best["fetch_kib_avg"]) * 2048 + float(best["write_kib_avg"]) * 1024), os.path.relpath(hits[-1], ROOT)
+    out["roofline"] = {"bound": "hbm", "kernel": "reg_solve_kernel<1>", "achieved": round(alg / (ms_launch * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(alg / (ms_launch * 1e-3) / 1e9 / 8000.0, 4), "avg_launch_ms": round(ms_launch, 4), "launches_timed": int(kn[1]),
+                       "algorithmic_bytes_per_launch": int(alg), "traffic": traffic, "traffic_source": src,
+                       "traffic_over_algorithmic": (round(traffic / alg, 2) if traffic else None),
+                       "limited_by": "fp64 VALU issue of the motion-deblur evaluations (one sincos + the interpolated rotation per block) and the HBM-resident "
+                                     "flag / L1 passes of the general path, not HBM bandwidth"}
     if args.cpu_scans > 0:
         from oracle import orc
         tb = time.perf_counter()

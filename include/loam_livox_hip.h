@@ -133,6 +133,8 @@ int64_t ll_map_size(const ll_map *m, int32_t kind);
  * point_cloud_registration.hpp:163-168, by their contents) stays valid only while this number is the one it saw after its own
  * upload; -1 for a bad argument. */
 int64_t ll_map_generation(const ll_map *m, int32_t kind);
+/* cells of the published grid of `kind` (the cell table is 4 bytes per cell): with ll_map_size() the map's footprint in HBM */
+int64_t ll_map_cells(const ll_map *m, int32_t kind);
 /* ll_map_upload that also reports the generation number ITS publication got (taken under the map's lock): a cache keyed by
  * "generation after my upload" must use this one -- reading ll_map_generation after ll_map_upload returns would pick up a
  * publication another thread (ll_history_refresh*) made in between and later skip a required re-upload. */
@@ -150,6 +152,10 @@ int ll_map_dequantized(ll_map *m, int32_t kind, float *xyz, int64_t capacity_poi
  * missing entries are idx -1 / d2 +inf.  Returns 0. */
 int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, int32_t n_queries, float max_sq_dis,
                 int32_t *idx5, float *sq_dis5);
+/* The same search with the queries and both result arrays resident on the device (hipMalloc'd / a framework tensor's pointer): nothing
+ * crosses PCIe.  *kernel_ms (may be NULL): duration of the search kernel from HIP events on the map's stream.  Synchronous. */
+int ll_map_knn5_device(ll_map *m, int32_t kind, const float *dev_queries_xyz, int64_t n_queries, float max_sq_dis, int32_t *dev_idx5,
+                       float *dev_sq_dis5, float *kernel_ms);
 
 /* ------------------------------------------------------------------------------------------------ registrar */
 

@@ -425,6 +425,9 @@ class Map_buffer:
     def size(self, kind: int) -> int:
         return int(self.L.ll_map_size(self.h, kind))
 
+    def cells(self, kind: int) -> int:
+        return int(self.L.ll_map_cells(self.h, kind))
+
     def to_f16(self, kind: int):
         """fp16-point records for this kind (BASELINE config C5); the registrar cannot use the map afterwards"""
         check(self.L.ll_map_to_f16(self.h, kind), "ll_map_to_f16")
@@ -441,6 +444,17 @@ class Map_buffer:
         d2 = np.zeros((q.shape[0], 5), np.float32)
         check(self.L.ll_map_knn5(self.h, kind, ptr(q), q.shape[0], max_sq_dis, ptr(idx), ptr(d2)), "ll_map_knn5")
         return idx, d2
+
+
+    def nearestKSearch_device(self, kind: int, queries, max_sq_dis: float, idx_out, d2_out) -> float:
+        """The same search on torch DEVICE tensors (queries (n, 3) float32, idx_out (n, 5) int32, d2_out (n, 5) float32, contiguous):
+        nothing crosses PCIe.  Returns the search kernel's duration in ms (HIP events on the map's stream)."""
+        n = int(queries.shape[0])
+        assert queries.is_contiguous() and idx_out.is_contiguous() and d2_out.is_contiguous() and queries.shape[1] == 3
+        ms = C.c_float(0)
+        check(self.L.ll_map_knn5_device(self.h, kind, C.c_void_p(queries.data_ptr()), n, max_sq_dis, C.c_void_p(idx_out.data_ptr()),
+                                        C.c_void_p(d2_out.data_ptr()), C.byref(ms)), "ll_map_knn5_device")
+        return float(ms.value)
 
 
 class Point_cloud_registration:

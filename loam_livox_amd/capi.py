@@ -71,7 +71,9 @@ SYMBOLS = {
     "ll_map_generation": (_i64, [_vp, _i32]),
     "ll_map_to_f16": (_i32, [_vp, _i32]),
     "ll_map_dequantized": (_i32, [_vp, _i32, _vp, _i64]),
+    "ll_map_cells": (_i64, [_vp, _i32]),
     "ll_map_knn5": (_i32, [_vp, _i32, _vp, _i32, _f, _vp, _vp]),
+    "ll_map_knn5_device": (_i32, [_vp, _i32, _vp, _i64, _f, _vp, _vp, _vp]),
     "ll_reg_default_params": (None, [C.POINTER(RegParams)]),
     "ll_reg_create": (_i32, [_i32, _i32, _i32, C.POINTER(_vp)]),
     "ll_reg_destroy": (None, [_vp]),

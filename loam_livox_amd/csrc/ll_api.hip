@@ -625,6 +625,15 @@ extern "C" int64_t ll_map_size(const ll_map *m, int32_t kind)
     return snap ? snap->mk.n : 0;
 }
 
+// cells of the published grid of `kind` (its cell table holds one 32-bit start per cell + 1): the map's footprint in HBM is
+// ll_map_size() records + this table (bench_c5.py's algorithmic bytes)
+extern "C" int64_t ll_map_cells(const ll_map *m, int32_t kind)
+{
+    if (!m || kind < 0 || kind > 1) return -1;
+    std::shared_ptr<MapSnap> snap = map_pin(m, kind);
+    return snap ? (int64_t)snap->mk.ncell : 0;
+}
+
 extern "C" int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, int32_t n_queries, float max_sq_dis, int32_t *idx5,
                            float *sq_dis5)
 {
@@ -647,6 +656,36 @@ extern "C" int ll_map_knn5(ll_map *m, int32_t kind, const float *queries_xyz, in
     (void)hipFree(d_q);
     (void)hipFree(d_d2);
     (void)hipFree(d_idx);
+    return 0;
+}
+
+// The same search with queries and results RESIDENT on the device (pointers from hipMalloc / a torch tensor's data_ptr): nothing crosses
+// PCIe, and *kernel_ms (optional) is the search kernel's duration from HIP events on the map's stream -- the figure a roofline needs
+// (bench_c5.py).  Synchronous.
+extern "C" int ll_map_knn5_device(ll_map *m, int32_t kind, const float *dev_queries_xyz, int64_t n_queries, float max_sq_dis, int32_t *dev_idx5,
+                                  float *dev_sq_dis5, float *kernel_ms)
+{
+    if (!m || !dev_queries_xyz || !dev_idx5 || !dev_sq_dis5) return set_err("ll_map_knn5_device", "null argument");
+    if (n_queries < 0 || n_queries > 0x7fffffffLL / 5) return set_err("ll_map_knn5_device", "n_queries out of range");
+    std::shared_ptr<MapSnap> snap = (kind < 0 || kind > 1) ? nullptr : map_pin(m, kind);
+    if (!snap || (!snap->mk.pts && !snap->mk.pts16)) return set_err("ll_map_knn5_device", "map kind not uploaded");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_queries == 0) return 0;
+    HC(hipSetDevice(m->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HC(hipEventCreate(&e0));
+    HC(hipEventCreate(&e1));
+    HC(hipDeviceSynchronize());  // (the caller's buffers may have been written on another stream)
+    HC(hipEventRecord(e0, m->stream));
+    launch_knn5(snap->mk.grid, dev_queries_xyz, (int)n_queries, max_sq_dis, dev_idx5, dev_sq_dis5, m->stream);
+    HC(hipEventRecord(e1, m->stream));
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(m->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
 }
 

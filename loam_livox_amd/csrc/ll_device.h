@@ -24,7 +24,7 @@ namespace ll {
 #define LL_KNN_TILE_MAX_SURF 24576  // ... and at most this many (one sorting workgroup per scan holds them: 1024 threads x 24)
 
 // Small scans (voxel-filtered feature clouds: a few hundred residual blocks) have a solver of their own (ll_reg_small_kernels.hip)
-#define LL_SMALL_MAX_BLOCKS 1024     // batches whose largest scan has at most this many corner + surface queries
+#define LL_SMALL_MAX_BLOCKS 2048     // batches whose largest scan has at most this many corner + surface queries (more than 1024: eight wavefronts per scan)
 #define LL_SMALL_W1_MIN_SCANS 512    // ... one or two wavefronts per scan from this batch size on (many scans per CU), four wavefronts below
 #define LL_SMALL_ORDER_MIN_SCANS 512  // batches of this many scans or more start their longest scans first (reg_solve_order_kernel) ...
 #define LL_SMALL_ORDER_MAX_SCANS 8192 // ... up to this many (one ordering workgroup)

@@ -60,7 +60,7 @@ namespace ll {
 struct SmallShared {
     long long tcyc[16];  // LL_SOLVE_TIMING builds: evaluations, controller, L1 pass, sort + select, -, total, census, prune, build (RegState::dbg_cycles)
     LmCtl ctl;
-    double red[4][LL_NACC];  // per-wavefront sums of an evaluation (W <= 4)
+    double red[8][LL_NACC];  // per-wavefront sums of an evaluation (W <= 8)
     double sum[LL_NACC];
     double fit[10];
     double thr;
@@ -68,9 +68,10 @@ struct SmallShared {
     int need, n_active, n_corner_avail, n_surf_avail;
     int nL, nA;              // kept line blocks, kept blocks (lines first)
     int n_eval;              // cost evaluations of this launch
-    int cnt[16][4];          // census: active blocks per (round, wavefront)
-    int isum[4];
-    unsigned long long lsum[4];
+    int cnt[16][8];          // census: active blocks per (round, wavefront)
+    int isum[8];
+    unsigned long long lsum[8];
+    int sel_nu;              // W >= 4: distinct L1 values
 };
 
 // what the kernel reads of the registrar's buffers (ll_device.h RegDev holds ~50 pointers: passed whole, the ones a phase keeps live
@@ -256,8 +257,9 @@ void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
     const int cap = rd.cap, capl = rd.capl;
     const f4 *map_surf = rd.map_surf;
     constexpr int NT = 64 * W;
-    constexpr int K = M * W;  // keys per lane of the sorting wavefront
-    static_assert(M <= 16 && K <= 16, "census rounds / sort keys per lane");
+    constexpr int K = W <= 2 ? M * W : 1;  // W <= 2: keys per lane of the sorting wavefront (register sort); W >= 4: the sort runs in LDS
+    constexpr int NS = W <= 2 ? 1 : (M * NT <= 256 ? 256 : (M * NT <= 512 ? 512 : (M * NT <= 1024 ? 1024 : 2048)));  // ... over this many keys
+    static_assert(M <= 16 && K <= 16 && M * NT <= 2048, "census rounds / sort keys per lane / LDS sort size");
     __shared__ SmallShared sh;
     extern __shared__ double s_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,11 +271,19 @@ void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
         LL_AS_LDS double *p = (LL_AS_LDS double *)s_dyn;
         B.v0 = p, B.v1 = p + cap, B.v2 = p + 2 * cap, B.a0 = p + 3 * cap;
         B.a1 = p + 4 * cap, B.a2 = p + 4 * cap + capl;
-        LL_AS_LDS float *q = (LL_AS_LDS float *)(p + 4 * cap + 2 * capl);
+        LL_AS_LDS float *q = (LL_AS_LDS float *)(p + 4 * cap + 2 * capl + (W >= 4 ? NS : 0));
         B.fx = q, B.fy = q + cap, B.fz = q + 2 * cap;
     }
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
     const int ncand = nC + nS;  // <= NT * M (the host chose M)
+    if (ncand > NT * M) {       // (a launch that does not hold the scan must not answer for it: rejected and reported, ll_reg_collect)
+        if (tid == 0) {
+            st->aborted = 1;
+            st->done = 1;
+            st->icp_iters += 1;
+        }
+        return;
+    }
     const size_t sb = (size_t)b * rd.cap_all;
     const unsigned char *flag0 = rd.blk_flag0 + sb;
 #ifdef LL_SOLVE_TIMING
@@ -436,38 +446,97 @@ void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
     SM_TACC(2, t_l1);
     SM_T0(t_sort);
     // ---- std::set de-duplication + rank select (PCR:153-161): one bitonic sort on the first wavefront --------------------------------
-    unsigned long long key[K];  // (the first wavefront's: its own M values per lane, then the other wavefronts')
+    if (W <= 2) {
+        unsigned long long key[K];  // (the first wavefront's: its own M values per lane, then the other wavefront's)
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const double v = l1[k < M ? k : 0];
-        key[k] = (k < M && v >= 0.0) ? (unsigned long long)__double_as_longlong(v) : 0xffffffffffffffffull;  // inactive slot or NaN (NaN never enters the set)
-    }
-    if (W > 1) {
-        // the other wavefronts hand their keys to the first one, 64 at a time through the 512 bytes of one wavefront's partial sums
-        // (nothing is being summed now): which lane ends up with which key does not matter to a sort
-        unsigned long long *xch = (unsigned long long *)&sh.red[0][0];
-        static_assert(sizeof(sh.red) >= 64 * sizeof(unsigned long long), "exchange buffer");
+        for (int k = 0; k < K; k++) {
+            const double v = l1[k < M ? k : 0];
+            key[k] = (k < M && v >= 0.0) ? (unsigned long long)__double_as_longlong(v) : 0xffffffffffffffffull;  // inactive slot or NaN (NaN never enters the set)
+        }
+        if (W > 1) {
+            // the other wavefront hands its keys to the first one, 64 at a time through the 512 bytes of one wavefront's partial sums
+            // (nothing is being summed now): which lane ends up with which key does not matter to a sort
+            unsigned long long *xch = (unsigned long long *)&sh.red[0][0];
+            static_assert(sizeof(sh.red) >= 64 * sizeof(unsigned long long), "exchange buffer");
 #pragma unroll
-        for (int w = 1; w < W; w++) {
+            for (int w = 1; w < (W <= 2 ? W : 1); w++) {
 #pragma unroll
-            for (int r = 0; r < M; r++) {
-                if (wave == w) xch[lane] = key[r];
-                __syncthreads();
-                if (wave == 0) key[w * M + r] = xch[lane];
+                for (int r = 0; r < M; r++) {
+                    if (wave == w) xch[lane] = key[r];
+                    __syncthreads();
+                    if (wave == 0) key[(w * M + r) < K ? (w * M + r) : 0] = xch[lane];
+                    __syncthreads();
+                }
+            }
+        }
+        if (wave == 0) {
+            wave_bitonic_sort<K>(key, lane);
+            // element g = lane * K + k is the first of its value iff it differs from element g - 1
+            const unsigned long long prev_last = (unsigned long long)__shfl_up((long long)key[K - 1], 1);
+            unsigned int first = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const unsigned long long pv = k == 0 ? prev_last : key[k - 1];
+                const bool valid = key[k] != 0xffffffffffffffffull;
+                if (valid && ((k == 0 && lane == 0) || key[k] != pv)) first |= 1u << k;
+            }
+            const int cnt = __popc(first);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off) incl += y;
+            }
+            const int nu = __shfl(incl, 63);
+            int target = (int)(rc.inlier_ratio * (double)nu);  // PCR:160
+            if (target > nu - 1) target = nu - 1;
+            if (nu == 0) {
+                if (lane == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
+            } else if (target >= incl - cnt && target < incl) {
+                int rk = incl - cnt;
+                unsigned long long sel = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if ((first >> k) & 1u) {
+                        if (rk == target) sel = key[k];
+                        rk++;
+                    }
+                }
+                sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sel));  // PCR:485
+            }
+        }
+    } else {
+        // four / eight wavefronts: the same sort in LDS, every thread a pair per step (NS / 2 pairs, NT threads)
+        LL_AS_LDS unsigned long long *sk = (LL_AS_LDS unsigned long long *)(B.a2 + capl);  // [NS], behind the line arrays
+#pragma unroll
+        for (int r = 0; r < M; r++) {
+            const double v = l1[r];
+            sk[r * NT + tid] = (v >= 0.0) ? (unsigned long long)__double_as_longlong(v) : 0xffffffffffffffffull;
+        }
+        for (int e = M * NT + tid; e < NS; e += NT) sk[e] = 0xffffffffffffffffull;
+        __syncthreads();
+        for (int k = 2; k <= NS; k <<= 1) {
+            for (int j = k >> 1; j >= 1; j >>= 1) {
+                for (int pidx = tid; pidx < NS / 2; pidx += NT) {
+                    const int i = ((pidx & ~(j - 1)) << 1) | (pidx & (j - 1));  // the pair's lower element (bit j clear)
+                    const unsigned long long a = sk[i], bb = sk[i | j];
+                    const bool up = (i & k) == 0;
+                    if ((bb < a) == up && a != bb) {
+                        sk[i] = bb;
+                        sk[i | j] = a;
+                    }
+                }
                 __syncthreads();
             }
         }
-    }
-    if (wave == 0) {
-        wave_bitonic_sort<K>(key, lane);
-        // element g = lane * K + k is the first of its value iff it differs from element g - 1
-        const unsigned long long prev_last = (unsigned long long)__shfl_up((long long)key[K - 1], 1);
+        // distinct values: every thread looks at NS / NT consecutive elements
+        constexpr int C = NS / NT;
         unsigned int first = 0;
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const unsigned long long pv = k == 0 ? prev_last : key[k - 1];
-            const bool valid = key[k] != 0xffffffffffffffffull;
-            if (valid && ((k == 0 && lane == 0) || key[k] != pv)) first |= 1u << k;
+        for (int c = 0; c < C; c++) {
+            const int g = tid * C + c;
+            const unsigned long long kv = sk[g];
+            if (kv != 0xffffffffffffffffull && (g == 0 || kv != sk[g - 1])) first |= 1u << c;
         }
         const int cnt = __popc(first);
         int incl = cnt;
@@ -476,18 +545,25 @@ void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
             const int y = __shfl_up(incl, off);
             if (lane >= off) incl += y;
         }
-        const int nu = __shfl(incl, 63);
+        if (lane == 63) sh.isum[wave] = incl;
+        __syncthreads();
+        int below = incl - cnt, nu = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            if (w < wave) below += sh.isum[w];
+            nu += sh.isum[w];
+        }
         int target = (int)(rc.inlier_ratio * (double)nu);  // PCR:160
         if (target > nu - 1) target = nu - 1;
         if (nu == 0) {
-            if (lane == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
-        } else if (target >= incl - cnt && target < incl) {
-            int rk = incl - cnt;
+            if (tid == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
+        } else if (target >= below && target < below + cnt) {
+            int rk = below;
             unsigned long long sel = 0;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                if ((first >> k) & 1u) {
-                    if (rk == target) sel = key[k];
+            for (int c = 0; c < C; c++) {
+                if ((first >> c) & 1u) {
+                    if (rk == target) sel = sk[tid * C + c];
                     rk++;
                 }
             }
@@ -561,19 +637,20 @@ __global__ __launch_bounds__(SO_THREADS) void reg_solve_order_kernel(const RegSt
 }
 
 // dynamic LDS of one scan
-static size_t small_lds_bytes(int W, int cap, int capl)
+static size_t small_lds_bytes(int W, int M, int cap, int capl)
 {
-    (void)W;
-    return (size_t)cap * (4 * 8 + 3 * 4) + (size_t)capl * 16;
+    const int keys = M * 64 * W;
+    const int ns = W <= 2 ? 0 : (keys <= 256 ? 256 : (keys <= 512 ? 512 : (keys <= 1024 ? 1024 : 2048)));  // (NS of the kernel)
+    return (size_t)cap * (4 * 8 + 3 * 4) + (size_t)capl * 16 + (size_t)ns * 8;
 }
 
 template <int W, int M>
 static void launch_small(const SmallArgs &a, const RegConst &rc, int n_scans, hipStream_t s)
 {
-    const size_t lds = small_lds_bytes(W, a.cap, a.capl);
+    const size_t lds = small_lds_bytes(W, M, a.cap, a.capl);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)reg_solve_small_kernel<W, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void *)reg_solve_small_kernel<W, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL((reg_solve_small_kernel<W, M>), dim3(n_scans), dim3(64 * W), lds, s, a, rc);
@@ -589,11 +666,12 @@ bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns)
 // busy at the number of scans whose blocks fit a CU's LDS together (256 VGPRs per wavefront: eight wavefronts per CU)
 int reg_solve_small_waves(const RegConst &rc, int n_scans, int max_nc, int max_ns)
 {
+    const int total = max_nc + max_ns;
+    if (total > 1024) return 8;  // (the only form that holds them)
     if (rc.small_waves) return rc.small_waves;
     if (n_scans < LL_SMALL_W1_MIN_SCANS) return 4;
-    const int total = max_nc + max_ns;
     const int cap = (total + 63) / 64 * 64, capl = (max_nc + 63) / 64 * 64 + 64;
-    const size_t per_scan = small_lds_bytes(1, cap, capl) + sizeof(SmallShared) + 512;
+    const size_t per_scan = small_lds_bytes(1, 1, cap, capl) + sizeof(SmallShared) + 512;
     const int per_cu = (int)((size_t)(160 * 1024) / per_scan);
     return per_cu >= 8 ? 1 : (per_cu >= 4 ? 2 : 4);
 }
@@ -612,7 +690,7 @@ void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs
         hipLaunchKernelGGL(reg_solve_order_kernel, dim3(1), dim3(SO_THREADS), 0, s, rd.state, n_scans, rd.solve_order);
         a.order = rd.solve_order;
     }
-    const int cls = total <= 256 ? 0 : (total <= 512 ? 1 : 2);  // 64 * W * M >= total
+    const int cls = total <= 256 ? 0 : (total <= 512 ? 1 : 2);  // 64 * W * M >= total (more than 1024: eight wavefronts, M = 4)
     if (W == 1) {
         if (cls == 0) launch_small<1, 4>(a, rc, n_scans, s);
         else if (cls == 1) launch_small<1, 8>(a, rc, n_scans, s);
@@ -621,10 +699,12 @@ void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs
         if (cls == 0) launch_small<2, 2>(a, rc, n_scans, s);
         else if (cls == 1) launch_small<2, 4>(a, rc, n_scans, s);
         else launch_small<2, 8>(a, rc, n_scans, s);
-    } else {
+    } else if (W == 4) {
         if (cls == 0) launch_small<4, 1>(a, rc, n_scans, s);
         else if (cls == 1) launch_small<4, 2>(a, rc, n_scans, s);
         else launch_small<4, 4>(a, rc, n_scans, s);
+    } else {
+        launch_small<8, 4>(a, rc, n_scans, s);
     }
 }
 

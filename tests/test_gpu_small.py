@@ -95,6 +95,29 @@ def test_every_size_class(dev_map, small_world, scans, waves, sizes):
     check_against(reps[0], orep, pc[0], opc, res[0], ret)
 
 
+@pytest.mark.parametrize("sizes", [(340, 1600), (100, 1948), (0, 1025)])
+@pytest.mark.parametrize("force", [0, 1])
+def test_eight_wavefronts_for_up_to_2048_blocks(dev_map, small_world, scans, sizes, force):
+    """the sequential mapping loop's scans (VoxelGrid 0.1 / 0.15 m: 1 000 - 2 000 features): eight wavefronts per scan, the sort in LDS"""
+    sc = scans[3]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    fc, fs = fc[:sizes[0]], fs[::max(1, len(fs) // sizes[1])][:sizes[1]]
+    assert len(fc) == sizes[0] and len(fs) == sizes[1]
+    prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
+    ret, opc, _, orep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
+    outs = []
+    for kw in ({}, {"no_small_solver": True}):
+        reg = Point_cloud_registration(max_scans=1, max_features=2048)
+        reg.set_debug(False, **kw)
+        set_params(reg, 10, 20, force)
+        outs.append(reg.solve_batch(dev_map, [fc], [fs], sc.pose_init[None], sc.pose_init[None]))
+        reg.close()
+    res, pc, _, reps = outs[0]
+    check_against(reps[0], orep, pc[0], opc, res[0], ret)
+    dt, dr = synth.pose_error(pc[0], outs[1][1][0])
+    assert dt < 1e-9 and dr < 1e-9
+
+
 @pytest.mark.parametrize("waves", [1, 2, 4])
 def test_shipped_block_cap_200(dev_map, small_world, scans, filtered, waves):
     """a13 at the shipped setting: more than 200 candidate blocks -> the reproducible block drop of PCR:438-458"""
