@@ -382,6 +382,9 @@ int ll_history_map_cloud_device(ll_history *h, int32_t kind, const float **dev_x
 typedef struct ll_cellmap ll_cellmap;
 int ll_cellmap_create(int32_t device, int64_t max_points, float resolution, int32_t minimum_revisit_threshold, ll_cellmap **out);
 void ll_cellmap_destroy(ll_cellmap *c);
+/* raises the capacity to max_points (no-op when not larger); stored points, cells, revisit stamps and the frame counter are kept.  The
+ * reference's Points_cloud_map grows on the heap without bound (cell_map_keyframe.hpp:619-672). */
+int ll_cellmap_reserve(ll_cellmap *c, int64_t max_points);
 int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n);
 /* append_cloud( pts, &cell_vec ) (cell_map_keyframe.hpp:619-672, the form the mapping node calls when loop closure is on,
  * laser_mapping.hpp:1527): the append, plus the cells that received at least min_points of this cloud's points (3 in the
@@ -398,6 +401,10 @@ int ll_cellmap_stats(const ll_cellmap *c, int64_t *n_cells, int64_t *n_points, i
  * each cell [n_cells + 1], m_last_update_frame_idx [n_cells]; any output may be NULL */
 int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_points, int32_t *cell_ijk, int32_t *cell_start,
                     int32_t *cell_last_update, int64_t capacity_cells);
+/* The map where it lies: device pointers to the stored points ({x, y, z, 0} float4, ordered by (cell key, insertion order)) and to the
+ * 64-bit cell key of every point.  Valid until the next call that changes this map.  Input of the multi-GPU gather of cell maps
+ * (BASELINE config C4; laser_mapping.hpp:274-275, 1492-1493). */
+int ll_cellmap_device_view(ll_cellmap *c, const float **dev_xyz0, const uint64_t **dev_point_keys, int64_t *n_points, int64_t *n_cells);
 
 /* Points_cloud_cell::determine_feature( if_recompute = 1 ) for every cell (cell_map_keyframe.hpp:436-473 with get_mean
  * :225-237, get_covmat :280-315, covmat_eig_decompose :239-249; SURVEY 8(f) row 4, first half): float sums and second
@@ -440,6 +447,13 @@ int ll_keyframe_similarity(int32_t device, const float *img_a, const float *img_
  * the two search structures of `map`.  ll_history_cell_map returns a borrowed handle (stats / dump). */
 int ll_history_enable_cell_map(ll_history *h, int64_t max_points, float cell_resolution, int32_t threshold_cell_revisit);
 ll_cellmap *ll_history_cell_map(ll_history *h, int32_t kind);
+/* enable != 0: frames handed to ll_history_add* reach the two cell maps through a service thread of the handle, in order, beside the
+ * caller -- in matching mode 0 nothing reads them between frames (laser_mapping.hpp:1492-1493 only appends; the reference runs its map
+ * services on threads as well, :568-594), and an append re-sorts the stored map.  Every entry point that reads the cell maps
+ * (ll_history_cell_map, ll_history_refresh_cells) waits for the frames handed over so far, as does ll_history_sync_cell_maps; a failure
+ * of the thread is reported by the next of those calls.  The history-owned cell maps double their capacity when a frame would not fit. */
+int ll_history_set_cell_map_async(ll_history *h, int32_t enable);
+int ll_history_sync_cell_maps(ll_history *h);
 int ll_history_refresh_cells(ll_history *h, ll_map *map, const double pose[7], float maximum_search_range_corner,
                              float maximum_search_range_surface, float maximum_in_fov_angle, int32_t down_sample_replace,
                              int64_t *n_map_corner, int64_t *n_map_surf);

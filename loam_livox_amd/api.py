@@ -250,6 +250,13 @@ class History_buffer:
         check(self.L.ll_history_enable_cell_map(self.h, max_points, cell_resolution, threshold_cell_revisit), "ll_history_enable_cell_map")
         self._cell_resolution = cell_resolution
 
+    def set_cell_map_async(self, enable: bool = True) -> None:
+        """feed the cell maps through the handle's service thread, beside the caller (matching mode 0: nothing reads them per frame)"""
+        check(self.L.ll_history_set_cell_map_async(self.h, int(bool(enable))), "ll_history_set_cell_map_async")
+
+    def sync_cell_maps(self) -> None:
+        check(self.L.ll_history_sync_cell_maps(self.h), "ll_history_sync_cell_maps")
+
     def cell_map(self, kind: int) -> "Cell_map":
         h = self.L.ll_history_cell_map(self.h, kind)
         if not h:
@@ -297,6 +304,13 @@ class _DeviceView:
         self.__cuda_array_interface__ = {"shape": (int(n), 4), "typestr": "<f4", "data": (int(address), False), "version": 2}
 
 
+class _DeviceView64:
+    """(n,) int64 at a raw device address"""
+
+    def __init__(self, address: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(address), False), "version": 2}
+
+
 class Cell_map:
     """Points_cloud_map<float> (cell_map_keyframe.hpp:477-790) as used by the "cube" matching mode, resident on the
     device (include/loam_livox_hip.h, ll_cellmap_*): append_cloud, find_cells_in_radius + if_pt_in_fov + per-cell
@@ -307,6 +321,7 @@ class Cell_map:
         self.L = capi.load()
         self.owned = _borrowed is None
         self.resolution = resolution
+        self.max_points = int(max_points)
         if self.owned:
             self.h = C.c_void_p()
             check(self.L.ll_cellmap_create(device, max_points, resolution, minimum_revisit_threshold, C.byref(self.h)), "ll_cellmap_create")
@@ -323,6 +338,23 @@ class Cell_map:
             self.close()
         except Exception:
             pass
+
+    def device_view(self, device: int = 0):
+        """(points (n, 4) float32, cell keys (n,) int64) as torch DEVICE tensors, copied device-to-device out of the handle's arrays
+        (which the next append rewrites): the input of multigpu.gather_cell_maps, no host hop"""
+        import torch
+        p, k, n, nc = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        check(self.L.ll_cellmap_device_view(self.h, C.byref(p), C.byref(k), C.byref(n), C.byref(nc)), "ll_cellmap_device_view")
+        if n.value == 0:
+            return torch.zeros((0, 4), dtype=torch.float32, device=f"cuda:{device}"), torch.zeros(0, dtype=torch.int64, device=f"cuda:{device}")
+        pts = torch.as_tensor(_DeviceView(p.value, n.value), device=f"cuda:{device}").clone()
+        keys = torch.as_tensor(_DeviceView64(k.value, n.value), device=f"cuda:{device}").clone()
+        return pts, keys
+
+    def reserve(self, max_points: int) -> None:
+        """room for max_points points (no-op when not larger); content, revisit stamps and frame counter are kept"""
+        check(self.L.ll_cellmap_reserve(self.h, int(max_points)), "ll_cellmap_reserve")
+        self.max_points = max(self.max_points, int(max_points))
 
     def append_cloud(self, cloud) -> None:
         cloud = capi.as_f32(cloud, 4)

@@ -112,6 +112,8 @@ SYMBOLS = {
     "ll_history_map_cloud_device": (_i32, [_vp, _i32, _vp, _vp]),
     "ll_cellmap_create": (_i32, [_i32, _i64, C.c_float, _i32, _vp]),
     "ll_cellmap_destroy": (None, [_vp]),
+    "ll_cellmap_reserve": (_i32, [_vp, _i64]),
+    "ll_cellmap_device_view": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "ll_cellmap_append": (_i32, [_vp, _vp, _i32]),
     "ll_cellmap_append_touched": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, C.POINTER(_i64)]),
     "ll_cellmap_query_filter": (_i32, [_vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),
@@ -122,6 +124,8 @@ SYMBOLS = {
     "ll_cellmap_keyframe_images": (_i32, [_vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "ll_keyframe_similarity": (_i32, [_i32, _vp, _vp, _vp]),
     "ll_history_enable_cell_map": (_i32, [_vp, _i64, C.c_float, _i32]),
+    "ll_history_set_cell_map_async": (_i32, [_vp, _i32]),
+    "ll_history_sync_cell_maps": (_i32, [_vp]),
     "ll_history_cell_map": (_vp, [_vp, _i32]),
     "ll_history_refresh_cells": (_i32, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp]),
     "ll_debug_quintic": (_i32, [_i32, _vp, _i32, _vp, _vp]),

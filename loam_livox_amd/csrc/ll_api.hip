@@ -8,8 +8,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -1023,6 +1026,10 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     // (small batches are latency chains, not issue-bound: the wavefront-per-query searches and the short work lists serve them better --
     //  single scan 2.24 ms against 2.49 with a tile launch per iteration; debug bit 11 forces the tile search for tests)
     if (max_ns < LL_KNN_TILE_MIN_SURF || max_ns > LL_KNN_TILE_MAX_SURF || (n_scans <= LL_KNN_COOP_MAX_SCANS && !((r->debug | debug_or) & 2048))) r->rc.knn_tile = 0;
+    // Scans sorted in segments (more than LL_KNN_TILE_SEG surface queries: Mid-100) keep the reuse machinery behind the tile search of ICP
+    // iterations 0 / 1: measured on C3 (bench_c3.py, k-NN class per step) 6.7 ms against 10.3 ms with a tile search in every iteration and
+    // 7.2 ms without the tile search
+    if (r->rc.knn_tile == 2 && max_ns > LL_KNN_TILE_SEG) r->rc.knn_tile = 1;
     if (r->rc.knn_tile == 2) r->rc.knn_reuse = 0;
     // Small batches leave most of the chip idle with one workgroup per scan: spread each scan's cost evaluations over a
     // group of LL_GRP workgroups (ll_reg_kernels.hip, group_*).  Compact scans only; the others run on the group's first.
@@ -1339,6 +1346,26 @@ extern "C" int ll_cellmap_create(int32_t device, int64_t max_points, float resol
 
 extern "C" void ll_cellmap_destroy(ll_cellmap *c) { cellmap_release(c); }
 
+// Points_cloud_map grows on the heap without bound (CMK:619-672); the device map has a capacity: raise it, content kept.
+extern "C" int ll_cellmap_reserve(ll_cellmap *c, int64_t max_points)
+{
+    if (!c) return set_err("ll_cellmap_reserve", "null argument");
+    if (max_points < 1 || max_points >= 0x3fffffffLL) return set_err("ll_cellmap_reserve", "max_points out of range");
+    if (max_points <= c->dev.cap) return 0;
+    HC(hipSetDevice(c->device));
+    const char *err = nullptr;
+    if (cellmap_grow(c->dev, (int)max_points, c->stream, &err)) return set_err("ll_cellmap_reserve", err ? err : "allocation failed");
+    float4 *d_new = nullptr;
+    HC(hipMalloc((void **)&d_new, (size_t)max_points * sizeof(float4)));
+    if (c->d_in) (void)hipFree(c->d_in);
+    c->d_in = d_new;
+    if (c->d_stats) {  // (sized by the capacity: allocated again by the next ll_cellmap_features / ll_cellmap_keyframe_images)
+        (void)hipFree(c->d_stats);
+        c->d_stats = nullptr;
+    }
+    return 0;
+}
+
 extern "C" int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n)
 {
     if (!c || (n > 0 && !xyzi)) return set_err("ll_cellmap_append", "null argument");
@@ -1516,6 +1543,21 @@ extern "C" int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_poin
     return 0;
 }
 
+// The map where it lies: device pointers to the stored points ({x, y, z, 0}, ordered by (cell key, insertion order)) and to the 64-bit
+// cell key of every point (21 bits per axis of the cell index + 2^20: ll_cellmap_core.h cell_pack).  Valid until the next call that
+// changes this map; the handle's stream has been drained.  The input of the multi-GPU cell-map gather (multigpu.gather_cell_maps).
+extern "C" int ll_cellmap_device_view(ll_cellmap *c, const float **dev_xyz0, const uint64_t **dev_point_keys, int64_t *n_points, int64_t *n_cells)
+{
+    if (!c || !dev_xyz0 || !dev_point_keys || !n_points) return set_err("ll_cellmap_device_view", "null argument");
+    HC(hipSetDevice(c->device));
+    HC(hipStreamSynchronize(c->stream));
+    *dev_xyz0 = (const float *)c->dev.pts;
+    *dev_point_keys = (const uint64_t *)c->dev.pkey;
+    *n_points = c->dev.n_pts;
+    if (n_cells) *n_cells = c->dev.n_cells;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------- history
 struct ll_history {
     int device = 0;
@@ -1539,7 +1581,105 @@ struct ll_history {
     VoxelDev vox_cells{};
     float4 *d_cmap[2] = {nullptr, nullptr};  // match buffer of the last ll_history_refresh_cells
     const float4 *map_src[2] = {nullptr, nullptr};
+    // The cell maps fed BESIDE the mapping loop (ll_history_set_cell_map_async): in matching mode 0 nothing reads them between frames
+    // (laser_mapping.hpp:1492-1493 only appends), and an append re-sorts the whole stored map -- 0.4 ms per frame once the map holds a
+    // couple of million points.  A service thread (the reference runs its map services on threads too, laser_mapping.hpp:568-594) takes the
+    // filtered frames from a ring of staging buffers and appends them in order on the cell maps' own streams; every reader drains it first.
+    bool cells_async = false;
+    std::thread feeder;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_idle;
+    struct FeedJob {
+        int kind, slot, n;
+        hipEvent_t ready;  // recorded on h->stream behind the copy into the staging slot
+    };
+    std::deque<FeedJob> jobs;
+    int in_flight = 0;        // jobs queued or being appended
+    bool stop = false;
+    std::string feed_error;   // first failure of the thread (reported by the next drain)
+    static constexpr int kStage = 16;
+    float4 *stage[2][16] = {};
+    int stage_next[2] = {0, 0};
 };
+
+// history-owned cell maps grow with the sequence (the reference's cells live on the heap, CMK:619-672): twice the capacity when the
+// next cloud would not fit
+static int history_cells_append(ll_history *h, int kind, const float4 *d_src, int n, std::string *why)
+{
+    ll_cellmap *c = h->cells[kind];
+    const char *err = nullptr;
+    if ((long long)c->dev.n_pts + n > c->dev.cap) {
+        long long want = 2LL * c->dev.cap;
+        while (want < (long long)c->dev.n_pts + n) want *= 2;
+        if (want >= 0x3fffffffLL || cellmap_grow(c->dev, (int)want, c->stream, &err)) {
+            *why = err ? err : "cell map cannot grow further";
+            return -1;
+        }
+        if (c->d_in) (void)hipFree(c->d_in);
+        c->d_in = nullptr;
+        if (hipMalloc((void **)&c->d_in, (size_t)want * sizeof(float4)) != hipSuccess) {
+            *why = "allocation failed";
+            return -1;
+        }
+        if (c->d_stats) {
+            (void)hipFree(c->d_stats);
+            c->d_stats = nullptr;
+        }
+    }
+    if (cellmap_append(c->dev, d_src, n, c->stream, &err)) {
+        *why = err ? err : "append failed";
+        return -1;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        *why = "stream error";
+        return -1;
+    }
+    return 0;
+}
+
+static void history_feeder_main(ll_history *h)
+{
+    (void)hipSetDevice(h->device);
+    for (;;) {
+        ll_history::FeedJob job;
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv_job.wait(lk, [h] { return h->stop || !h->jobs.empty(); });
+            if (h->jobs.empty()) return;  // (stop, and nothing left)
+            job = h->jobs.front();
+            h->jobs.pop_front();
+        }
+        std::string why;
+        bool failed = false;
+        if (hipEventSynchronize(job.ready) != hipSuccess) {
+            failed = true;
+            why = "staging copy failed";
+        } else if (history_cells_append(h, job.kind, h->stage[job.kind][job.slot], job.n, &why)) {
+            failed = true;
+        }
+        (void)hipEventDestroy(job.ready);
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            if (failed && h->feed_error.empty()) h->feed_error = why;
+            h->in_flight--;
+        }
+        h->cv_idle.notify_all();
+    }
+}
+
+// every frame handed to the feeder has been appended; 0, or -1 with the feeder's first error
+static int history_cells_drain(ll_history *h)
+{
+    if (!h->cells_async) return 0;
+    std::unique_lock<std::mutex> lk(h->mu);
+    h->cv_idle.wait(lk, [h] { return h->in_flight == 0; });
+    if (!h->feed_error.empty()) {
+        const std::string e = h->feed_error;
+        h->feed_error.clear();
+        return set_err("ll_history (cell-map feeder)", e.c_str());
+    }
+    return 0;
+}
 
 extern "C" void ll_history_destroy(ll_history *h);
 static int history_create_impl(int32_t device, int32_t maximum_history_size, int32_t max_points_per_frame, float line_res, float plane_res,
@@ -1594,6 +1734,17 @@ extern "C" void ll_history_destroy(ll_history *h)
     voxel_free(h->vox_frame);
     voxel_free(h->vox_map);
     voxel_free(h->vox_cells);
+    if (h->feeder.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->stop = true;
+        }
+        h->cv_job.notify_all();
+        h->feeder.join();
+    }
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < ll_history::kStage; i++)
+            if (h->stage[k][i]) (void)hipFree(h->stage[k][i]);
     for (int k = 0; k < 2; k++) cellmap_release(h->cells[k]);
     void *ptrs[] = {h->frames[0], h->frames[1], h->d_map[0], h->d_map[1], h->d_in, h->d_xf, h->d_concat, h->d_n, h->d_pose, h->d_cmap[0], h->d_cmap[1]};
     for (void *p : ptrs)
@@ -1631,11 +1782,33 @@ static int history_push_kind(ll_history *h, int kind, const float4 *d_src, int n
                               hipMemcpyDeviceToDevice, h->stream));
         h->count[kind][slot] = n_out;
     }
-    if (h->cells[kind]) {
-        ll_cellmap *c = h->cells[kind];
-        const char *err = nullptr;
-        if (cellmap_append(c->dev, h->vox_frame.out, n_out, c->stream, &err)) return set_err("ll_history_add (cell map)", err);
-        HC(hipStreamSynchronize(c->stream));
+    if (h->cells[kind] && h->cells_async) {
+        // hand the filtered frame to the feeder: copy into the next staging slot (free again: at most kStage frames are in flight)
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv_idle.wait(lk, [h] { return h->in_flight < ll_history::kStage; });
+            if (!h->feed_error.empty()) {
+                const std::string e = h->feed_error;
+                h->feed_error.clear();
+                return set_err("ll_history_add (cell-map feeder)", e.c_str());
+            }
+        }
+        const int slot = h->stage_next[kind];
+        h->stage_next[kind] = (slot + 1) % ll_history::kStage;
+        if (n_out > 0)
+            HC(hipMemcpyAsync(h->stage[kind][slot], h->vox_frame.out, (size_t)n_out * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        ll_history::FeedJob job{kind, slot, n_out, nullptr};
+        HC(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
+        HC(hipEventRecord(job.ready, h->stream));
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->jobs.push_back(job);
+            h->in_flight++;
+        }
+        h->cv_job.notify_one();
+    } else if (h->cells[kind]) {
+        std::string why;
+        if (history_cells_append(h, kind, h->vox_frame.out, n_out, &why)) return set_err("ll_history_add (cell map)", why.c_str());
     }
     HC(hipStreamSynchronize(h->stream));
     return 0;
@@ -1833,7 +2006,37 @@ extern "C" ll_cellmap *ll_history_cell_map(ll_history *h, int32_t kind)
         set_err("ll_history_cell_map", "bad argument");
         return nullptr;
     }
+    if (history_cells_drain(h)) return nullptr;  // (the caller is about to read the map)
     return h->cells[kind];
+}
+
+// enable != 0: the frames ll_history_add* receives from now on reach the cell maps through a service thread, in order, beside the caller
+// (matching mode 0: nothing reads the cell maps between frames); every entry point that reads them -- ll_history_cell_map,
+// ll_history_refresh_cells, ll_history_sync_cell_maps -- waits for the frames handed over so far.  enable == 0: drain and append inline
+// again (the default).
+extern "C" int ll_history_set_cell_map_async(ll_history *h, int32_t enable)
+{
+    if (!h) return set_err("ll_history_set_cell_map_async", "null argument");
+    if (!h->cells[0]) return set_err("ll_history_set_cell_map_async", "cell maps are not enabled (ll_history_enable_cell_map)");
+    HC(hipSetDevice(h->device));
+    if (!enable) {
+        const int rc = history_cells_drain(h);
+        h->cells_async = false;
+        return rc;
+    }
+    if (h->cells_async) return 0;
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < ll_history::kStage; i++)
+            if (!h->stage[k][i]) DM(h->stage[k][i], (size_t)h->max_pts);
+    if (!h->feeder.joinable()) h->feeder = std::thread(history_feeder_main, h);
+    h->cells_async = true;
+    return 0;
+}
+
+extern "C" int ll_history_sync_cell_maps(ll_history *h)
+{
+    if (!h) return set_err("ll_history_sync_cell_maps", "null argument");
+    return history_cells_drain(h);
 }
 
 // update_buff_for_matching with m_matching_mode == 1 (laser_mapping.hpp:471-546)
@@ -1844,6 +2047,7 @@ extern "C" int ll_history_refresh_cells(ll_history *h, ll_map *map, const double
     if (!h || !map || !pose) return set_err("ll_history_refresh_cells", "null argument");
     if (!h->cells[0]) return set_err("ll_history_refresh_cells", "cell maps are not enabled (ll_history_enable_cell_map)");
     if (map->device != h->device) return set_err("ll_history_refresh_cells", "map lives on another device");
+    if (history_cells_drain(h)) return -1;
     HC(hipSetDevice(h->device));
     const float range[2] = {maximum_search_range_corner, maximum_search_range_surface};
     for (int kind = 0; kind < 2; kind++) {

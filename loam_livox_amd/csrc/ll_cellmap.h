@@ -34,6 +34,8 @@ struct CellMapDev {
 
 int cellmap_alloc(CellMapDev &m, int cap, float resolution, int revisit_threshold, const char **err);
 void cellmap_free(CellMapDev &m);
+// capacity -> new_cap (no-op when not larger), content kept
+int cellmap_grow(CellMapDev &m, int new_cap, hipStream_t s, const char **err);
 // append_cloud (CMK:619-672): n points at d_src (device)
 int cellmap_append(CellMapDev &m, const float4 *d_src, int n, hipStream_t s, const char **err);
 // after cellmap_append of n_appended points onto n_before stored ones: points received per cell of the new table -> m.csel

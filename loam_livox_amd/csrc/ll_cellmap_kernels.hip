@@ -569,6 +569,34 @@ int cellmap_alloc(CellMapDev &m, int cap, float resolution, int revisit_threshol
     return 0;
 }
 
+// more room, same content: the stored points, their keys, the cell table and the frame counter move to arrays of the new capacity
+int cellmap_grow(CellMapDev &m, int new_cap, hipStream_t s, const char **err)
+{
+    if (new_cap <= m.cap) return 0;
+    CMCHK(hipStreamSynchronize(s));
+    CellMapDev n;
+    if (cellmap_alloc(n, new_cap, m.resolution, m.revisit_threshold, err)) {
+        cellmap_free(n);
+        return -1;
+    }
+    if (m.n_pts > 0) {
+        CMCHK(hipMemcpyAsync(n.pts, m.pts, (size_t)m.n_pts * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        CMCHK(hipMemcpyAsync(n.pkey, m.pkey, (size_t)m.n_pts * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    }
+    if (m.n_cells > 0) {
+        CMCHK(hipMemcpyAsync(n.ckey, m.ckey, (size_t)m.n_cells * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        CMCHK(hipMemcpyAsync(n.cstart, m.cstart, (size_t)(m.n_cells + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+        CMCHK(hipMemcpyAsync(n.clast, m.clast, (size_t)m.n_cells * sizeof(int), hipMemcpyDeviceToDevice, s));
+    }
+    CMCHK(hipStreamSynchronize(s));
+    n.frame = m.frame;
+    n.n_pts = m.n_pts;
+    n.n_cells = m.n_cells;
+    cellmap_free(m);
+    m = n;
+    return 0;
+}
+
 void cellmap_free(CellMapDev &m)
 {
     void *ptrs[] = {m.pts,  m.pts2, m.pkey,  m.pkey2,     m.val,  m.val2,  m.ckey,     m.ckey2, m.cstart,   m.cstart2, m.clast, m.clast2,

@@ -21,7 +21,8 @@ namespace ll {
 // Tile search of the surface queries (ll_knn_tile.h, ll_knn_kernels.hip): queries sorted by map cell once per registration, one
 // wavefront per 64 of them against the LDS-staged points of their cells' common neighbourhood
 #define LL_KNN_TILE_MIN_SURF 1024   // batches whose largest scan has at least this many surface queries (below: the wavefront-per-query search)
-#define LL_KNN_TILE_MAX_SURF 24576  // ... and at most this many (one sorting workgroup per scan holds them: 1024 threads x 24)
+#define LL_KNN_TILE_SEG 24576       // queries one sorting workgroup orders (1024 threads x 24); a multiple of the tile kernel's workgroup
+#define LL_KNN_TILE_MAX_SURF (4 * LL_KNN_TILE_SEG)  // ... and at most this many: larger scans are sorted in segments (Mid-100: three heads)
 
 // Small scans (voxel-filtered feature clouds: a few hundred residual blocks) have a solver of their own (ll_reg_small_kernels.hip)
 #define LL_SMALL_MAX_BLOCKS 2048     // batches whose largest scan has at most this many corner + surface queries (more than 1024: eight wavefronts per scan)

@@ -62,7 +62,13 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RegState *st = rd.state + b;
     if (st->done) return;
-    const int nS = rd.n_surf[b];
+    // Scans of more than LL_KNN_TILE_SEG surface queries (Mid-100: three heads, ~50 k) are sorted in SEGMENTS of that many consecutive
+    // queries, one workgroup each (blockIdx.y): the order only has to put the 64 queries of a wavefront into neighbouring cells, and a
+    // segment of a sweep is as compact as the sweep.  perm holds segment-relative indices (16 bits); the tile kernel adds the base.
+    const int q0 = (int)blockIdx.y * LL_KNN_TILE_SEG;
+    const int nS_all = rd.n_surf[b];
+    const int nS = nS_all - q0 < LL_KNN_TILE_SEG ? nS_all - q0 : LL_KNN_TILE_SEG;  // queries of this segment
+    if (nS <= 0) return;
     // ---- box of the cells the scan's queries fall into (striped reads: coalesced; any initial order is as good as another)
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
     // the cell of every query, kept from this pass when the grid's dimensions fit 10 bits each (every map of a few hundred metres):
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
         const int i = u * QS_THREADS + tid;
         key[u] = 0u;
         if (i < nS) {
-            const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);
+            const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, q0 + i, nS_all);
             TileQ tq;
             tile_query(gs, p.x, p.y, p.z, tq);
             if (tq.ingrid) {
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
                 cy = (int)((key[u] >> 10) & 1023u);
                 cz = (int)((key[u] >> 20) & 1023u);
             } else {
-                const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, i, nS);  // (again: ITEMS points held in registers would spill)
+                const float4 p = tile_query_pos<FUSED>(rd, rc, st, b, q0 + i, nS_all);  // (again: ITEMS points held in registers would spill)
                 TileQ tq;
                 tile_query(gs, p.x, p.y, p.z, tq);
                 ingrid = tq.ingrid;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
         key[u] = k;
         val[u] = (unsigned short)i;
     }
-    unsigned short *perm = rd.qperm + (size_t)b * rd.cap_s;
+    unsigned short *perm = rd.qperm + (size_t)b * rd.cap_s + q0;
     if (kmax + 2u <= (unsigned int)QS_BINS) {
         // ---- counting sort (uniform branch: the scan's cell box has at most QS_BINS cells -- every C2 scan): one LDS histogram over
         //      the box, the atomic's return value is the query's rank inside its cell, one scan over the bins, one scatter.  The
@@ -228,7 +234,7 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
     const int i = sblk * KT_THREADS + threadIdx.x;  // position in the scan's cell order
     if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
     const bool valid = i < nS;
-    const int q = valid ? (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
+    const int q = valid ? (i / LL_KNN_TILE_SEG) * LL_KNN_TILE_SEG + (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;  // (segment base + index in the segment)
     const int slot = rd.cap_c + q;
     const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
     const float max_d2 = rc.max_d2_plane;
@@ -261,12 +267,13 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
 
 void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s)
 {
+    const int nseg = (max_ns + LL_KNN_TILE_SEG - 1) / LL_KNN_TILE_SEG;
 #define LL_QSORT(ITEMS)                                                                                                        \
     do {                                                                                                                       \
         if (fused)                                                                                                             \
-            hipLaunchKernelGGL((reg_qsort_kernel<ITEMS, true>), dim3(n_scans), dim3(QS_THREADS), 0, s, rd, rc, gs);           \
+            hipLaunchKernelGGL((reg_qsort_kernel<ITEMS, true>), dim3(n_scans, nseg), dim3(QS_THREADS), 0, s, rd, rc, gs);     \
         else                                                                                                                   \
-            hipLaunchKernelGGL((reg_qsort_kernel<ITEMS, false>), dim3(n_scans), dim3(QS_THREADS), 0, s, rd, rc, gs);          \
+            hipLaunchKernelGGL((reg_qsort_kernel<ITEMS, false>), dim3(n_scans, nseg), dim3(QS_THREADS), 0, s, rd, rc, gs);    \
     } while (0)
     if (max_ns <= QS_THREADS * 4)
         LL_QSORT(4);

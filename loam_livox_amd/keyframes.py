@@ -18,6 +18,12 @@ what a key frame is analysed with is whatever those cells contain when it is pro
 frame keeps the cell indices; `materialize` reads those cells out of the device-resident full map into a cell map of its own, in the
 map's (cell, insertion) order, which is the order determine_feature's float sums run in.
 
+Memory (the shipped loop_closure settings keep a few hundred key frames before any pair is old enough to be compared,
+minimum_keyframe_differen = 200): a processed key frame keeps its direction images, its cell set and the compacted points it was analysed
+with (12 bytes per point, host memory) -- NOT a device cell map; `cell_map_of` builds one again from those points (same order, so the same
+cells, features and clouds) for the pairs that pass the similarity gates, and it is closed after the alignment.  The full map starts at
+max_points and doubles (ll_cellmap_reserve) when a scan would not fit, as the reference's heap-allocated cells grow.
+
 Differences from the node, by design: everything runs synchronously (the node's service thread polls every millisecond);
 m_accumulated_point_cloud (only consumed by the map refinement) is not kept."""
 from __future__ import annotations
@@ -39,12 +45,11 @@ class Maps_keyframe:
         self.m_ending_frame_idx = 0
         self.m_pose_q = np.array([0, 0, 0, 1], np.float64)
         self.m_pose_t = np.zeros(3, np.float64)
-        self.cell_map = None             # set by Keyframe_assembly.materialize
-        self.analysis = None             # Cell_map.keyframe_images() of it
+        self.points = None               # xyz of its cells as they were when it was processed, in the full map's (cell, insertion) order
+        self.analysis = None             # Cell_map.keyframe_images() of those cells
 
     def add_cells(self, cell_ijk: np.ndarray) -> None:   # :1243-1261
-        for c in np.asarray(cell_ijk, np.int64).reshape(-1, 3):
-            self.m_set_cell.add((int(c[0]), int(c[1]), int(c[2])))
+        self.m_set_cell.update(_pack_cells(cell_ijk).tolist())
         self.m_accumulate_frames += 1
 
     # what service_loop_detection reads
@@ -111,10 +116,6 @@ class Keyframe_assembly:
         return ("U " + u).rstrip() + " W" + (" " + w if w else "")
 
     def close(self):
-        for kf in list(self.m_keyframe_need_precession_list) + self.keyframe_vec:
-            if kf.cell_map is not None:
-                kf.cell_map.close()
-                kf.cell_map = None
         if self.m_pt_cell_map_full is not None:
             self.m_pt_cell_map_full.close()
             self.m_pt_cell_map_full = None
@@ -123,7 +124,12 @@ class Keyframe_assembly:
     def add_scan(self, full_cloud_map_frame: np.ndarray, pose: np.ndarray, current_frame_index: int) -> np.ndarray:
         """One accepted scan.  full_cloud_map_frame: current_laser_cloud_full after pointcloudAssociateToMap; pose: m_q_w_curr /
         m_t_w_curr as {qx, qy, qz, qw, tx, ty, tz}.  Returns the touched cells (cell_vec)."""
-        cell_vec = self.m_pt_cell_map_full.append_cloud_touched(full_cloud_map_frame, 3)
+        full = self.m_pt_cell_map_full
+        if hasattr(full, "reserve"):  # the reference's map grows on the heap: double the device map's capacity when this scan would not fit
+            need = full.stats()[1] + len(full_cloud_map_frame)
+            if need > full.max_points:
+                full.reserve(max(2 * full.max_points, need))
+        cell_vec = full.append_cloud_touched(full_cloud_map_frame, 3)
         for kf in self.m_keyframe_of_updating_list:
             kf.add_cells(cell_vec)
         front = self.m_keyframe_of_updating_list[0]
@@ -146,16 +152,25 @@ class Keyframe_assembly:
     # ---- the key frame's view of the shared cells ------------------------------------------------------------------------------------
     def materialize(self, kf: Maps_keyframe) -> Cell_map:
         xyz, ijk, start, _ = self.m_pt_cell_map_full.dump()
-        keep = np.array([(int(c[0]), int(c[1]), int(c[2])) in kf.m_set_cell for c in ijk], bool)
-        sel = np.flatnonzero(keep)
-        if len(sel):
-            idx = np.concatenate([np.arange(start[c], start[c + 1]) for c in sel])
-        else:
-            idx = np.zeros(0, np.int64)
-        km = Cell_map(max(self.keyframe_max_points, len(idx) + 1), self.m_pt_cell_resolution, device=self.device)
-        if len(idx):
-            km.append_cloud(np.c_[xyz[idx], np.zeros(len(idx), np.float32)].astype(np.float32))
+        want = np.fromiter(kf.m_set_cell, np.int64, len(kf.m_set_cell))
+        sel = np.flatnonzero(np.isin(_pack_cells(ijk), want))
+        start = np.asarray(start, np.int64)
+        lens = start[sel + 1] - start[sel]
+        # the points of the selected cells, cell after cell: position p of the output lies in selected cell c(p) at offset p - first(c)
+        first = np.cumsum(lens) - lens
+        idx = np.repeat(start[sel] - first, lens) + np.arange(int(lens.sum()), dtype=np.int64)
+        return self._cell_map_from_points(xyz[idx])
+
+    def _cell_map_from_points(self, xyz: np.ndarray) -> Cell_map:
+        km = Cell_map(max(1024, len(xyz) + 1), self.m_pt_cell_resolution, device=self.device)
+        if len(xyz):
+            km.append_cloud(np.c_[xyz, np.zeros(len(xyz), np.float32)].astype(np.float32))
         return km
+
+    def cell_map_of(self, kf: Maps_keyframe):
+        """a device cell map of a processed key frame, rebuilt from the points it was analysed with (the caller closes it); a key frame
+        that kept no points (test stubs) is read out of the full map again"""
+        return self._cell_map_from_points(kf.points) if kf.points is not None else self.materialize(kf)
 
     # ---- laser_mapping.hpp:919-1060 --------------------------------------------------------------------------------------------------
     def process_waiting(self):
@@ -164,8 +179,10 @@ class Keyframe_assembly:
         avail_ratio_plane, avail_ratio_line = self.avail_ratio_plane, self.avail_ratio_line   # :887-888
         while self.m_keyframe_need_precession_list and not self.if_end:
             last = self.m_keyframe_need_precession_list.popleft()
-            last.cell_map = self.materialize(last)          # update_features_of_each_cells + analyze read the cells as they are now
-            last.analysis = last.cell_map.keyframe_images()
+            cm = self.materialize(last)                     # update_features_of_each_cells + analyze read the cells as they are now
+            last.analysis = cm.keyframe_images()
+            last.points = cm.dump()[0] if hasattr(cm, "dump") else None
+            _close(cm)
             self.keyframe_vec.append(last)
             self.pose3d_vec.append((last.m_pose_q.copy(), last.m_pose_t.copy()))
             n_kf = len(self.keyframe_vec)
@@ -197,7 +214,10 @@ class Keyframe_assembly:
                     sa = Scene_alignment(self.m_loop_closure_map_alignment_resolution, self.m_loop_closure_map_alignment_resolution,   # :1034
                                          self.m_loop_closure_map_alignment_maximum_icp_iteration, self.m_loop_closure_map_alignment_inlier_threshold,
                                          self.m_para_scene_alignments_maximum_residual_block, device=self.device)   # :897-898, 1035
-                    thr = sa.find_tranfrom_of_two_mappings(last.cell_map, old.cell_map)   # :1036
+                    cm_last, cm_old = self.cell_map_of(last), self.cell_map_of(old)
+                    thr = sa.find_tranfrom_of_two_mappings(cm_last, cm_old)   # :1036
+                    _close(cm_last)
+                    _close(cm_old)
                     rec.update(inlier_threshold=thr, pose=sa.pose.copy())
                     if thr > self.m_loop_closure_map_alignment_inlier_threshold * 2:   # :1048-1052
                         his += 10 + 1
@@ -215,6 +235,17 @@ class Keyframe_assembly:
                     continue
                 his += 1
         return found
+
+
+def _pack_cells(cell_ijk) -> np.ndarray:
+    """(i, j, k) cell indices -> one int64 per cell (21 bits per axis, like the device's cell key)"""
+    c = np.asarray(cell_ijk, np.int64).reshape(-1, 3) + (1 << 20)
+    return c[:, 0] | (c[:, 1] << 21) | (c[:, 2] << 42)
+
+
+def _close(cm) -> None:
+    if hasattr(cm, "close"):
+        cm.close()
 
 
 def _quat_rot(q, v):

@@ -25,7 +25,7 @@ class Laser_mapping:
                  subsample_seed: int = 1, matching_mode: int = 0, cell_resolution: float = 1.0, threshold_cell_revisit: int = 5000,
                  maximum_search_range_corner: float = 100.0, maximum_search_range_surface: float = 100.0,
                  maximum_in_fov_angle: float = 30.0, down_sample_replace: int = 1, cell_map_max_points: int = 1 << 21,
-                 loop_closure_if_enable: int = 0, loop_closure: dict | None = None):
+                 loop_closure_if_enable: int = 0, loop_closure: dict | None = None, keep_cell_maps: bool = False):
         self.fe = Livox_laser(max_points=scan_points, max_scans=1, device=device, piecewise_number=1)
         # The feature node and the mapping node are separate processes in the reference: scan k + 1 is extracted while scan k is
         # registered.  process_new_scan( scan, next_xyzi = ... ) does the same with a second extractor handle (own stream): the next
@@ -43,8 +43,14 @@ class Laser_mapping:
         self.m_maximum_search_range = (maximum_search_range_corner, maximum_search_range_surface)  # :694-695
         self.m_maximum_in_fov_angle = maximum_in_fov_angle                                           # :691
         self.m_down_sample_replace = down_sample_replace                                             # :277
-        if matching_mode:
+        # m_pt_cell_map_corners / m_pt_cell_map_planes receive every registered frame in BOTH match modes (:1492-1493); only mode 1 reads
+        # them per frame.  keep_cell_maps: maintain them in mode 0 too -- the sub-map a batched map-building job hands over at its end
+        # (BASELINE config C4, bench_c4.py); they grow with the sequence (ll_cellmap_reserve)
+        self.keep_cell_maps = bool(matching_mode or keep_cell_maps)
+        if self.keep_cell_maps:
             self.history.enable_cell_map(cell_map_max_points, cell_resolution, threshold_cell_revisit)  # :620-624
+            if not matching_mode:  # nothing reads them between frames: fed by the handle's service thread, beside the loop
+                self.history.set_cell_map_async(True)
         self.m_if_input_downsample_mode = input_downsample_mode
         self.history_add_t_step, self.history_add_angle_step = history_add_t_step, history_add_angle_step
         p = self.reg.params
@@ -85,6 +91,11 @@ class Laser_mapping:
         cloud = self.reg.pointcloudAssociateToMap(full, self.pose) if len(full) else full
         self.keyframes.add_scan(cloud, self.pose, self.m_current_frame_index)
         self.loops += self.keyframes.process_waiting()
+
+    def sync(self) -> None:
+        """every frame handed to the cell maps' service thread has been appended (keep_cell_maps in matching mode 0)"""
+        if self.keep_cell_maps:
+            self.history.sync_cell_maps()
 
     def _extract(self, fe, xyzi, time_stamp):
         fe.upload(xyzi[None], np.full(1, time_stamp))

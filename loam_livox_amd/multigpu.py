@@ -53,6 +53,40 @@ def gather_submaps(local_pts, dist=None):
     return out, counts
 
 
+def cell_keys(cell_ijk) -> np.ndarray:
+    """the device's 64-bit cell key of (i, j, k) cell indices (ll_cellmap_core.h cell_pack: 21 bits per axis, i most significant, so key
+    order is the lexicographic order of the indices), as int64"""
+    c = np.asarray(cell_ijk, np.int64).reshape(-1, 3) + (1 << 20)
+    return (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+
+
+def gather_cell_maps(points, keys, dist=None):
+    """The exchange step of batched offline map building as BASELINE config C4 words it: a gather of the ranks' CELL MAPS
+    (m_pt_cell_map_corners / m_pt_cell_map_planes, laser_mapping.hpp:274-275, fed by every registered frame at :1492-1493;
+    cell_map_keyframe.hpp:477-672).  A rank's map is what the device holds: `points` (n, 4) float32 in (cell, insertion) order and
+    `keys` (n,) int64, the cell key of every point (api.Cell_map.device_view).  One exchange: points and keys travel together as
+    24-byte rows through gather_submaps (counts all-gather + grouped point-to-point sends), then the union is put back into cell-map
+    layout -- a stable sort by cell key, so a cell that several ranks saw holds rank 0's points first, each rank's in insertion order.
+    Returns (merged points (N, 4), merged keys (N,), first point of each distinct cell (C + 1,), per-rank point counts)."""
+    import torch
+    n = int(points.shape[0])
+    assert points.shape[1] == 4 and keys.shape[0] == n
+    rows = torch.cat([points.contiguous().view(torch.float32), keys.contiguous().view(torch.float32).reshape(n, 2)], 1) if n else \
+        torch.zeros((0, 6), dtype=torch.float32, device=points.device)
+    allrows, counts = gather_submaps(rows, dist)
+    pts = allrows[:, :4].contiguous()
+    k64 = allrows[:, 4:6].contiguous().view(torch.int64).reshape(-1)
+    order = torch.sort(k64, stable=True).indices
+    pts, k64 = pts[order], k64[order]
+    if len(k64):
+        head = torch.ones(len(k64), dtype=torch.bool, device=k64.device)
+        head[1:] = k64[1:] != k64[:-1]
+        cell_start = torch.cat([torch.nonzero(head).reshape(-1), torch.tensor([len(k64)], device=k64.device)])
+    else:
+        cell_start = torch.zeros(1, dtype=torch.int64, device=k64.device)
+    return pts, k64, cell_start, counts
+
+
 class DeviceHandles:
     """The three device handles a rank's share runs on (one GPU): resident map, batched extractor, batched registrar."""
 

@@ -139,3 +139,66 @@ def test_sequence_runner_sharding_world2_gloo(tmp_path):
                           "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("runner ok") == 2
+
+
+CELLMAP_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from loam_livox_amd.multigpu import cell_keys, gather_cell_maps
+from oracle.orc_cellmap import CellMap   # the checker: real cell maps of different sizes, one per rank
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+
+
+def rank_map(r):
+    # what rank r's sequence left in its cell map: five clouds over an area that overlaps the other rank's
+    rng = np.random.default_rng(40 + r)
+    m = CellMap(1.0)
+    for k in range(5):
+        n = 300 + 450 * r + 40 * k
+        m.append(np.c_[rng.uniform(-4 + 3 * r, 5 + 3 * r, (n, 3)), np.zeros(n)].astype(np.float32))
+    return m
+
+
+def as_rows(m):
+    xyz, ijk, start, _ = m.dump()
+    pts = np.c_[xyz, np.zeros(len(xyz), np.float32)].astype(np.float32)
+    keys = np.repeat(cell_keys(ijk), np.diff(start))
+    return pts, keys
+
+
+pts, keys = as_rows(rank_map(rank))
+mp, mk, cell_start, counts = gather_cell_maps(torch.from_numpy(pts), torch.from_numpy(keys))
+sizes = [len(as_rows(rank_map(r))[1]) for r in range(world)]
+assert counts == sizes and sizes[0] != sizes[1], (counts, sizes)
+# the union in cell-map layout = the cell map that received rank 0's stored points, then rank 1's (a cell's points in insertion order)
+union = CellMap(1.0)
+for r in range(world):
+    union.append(as_rows(rank_map(r))[0])
+uxyz, uijk, ustart, _ = union.dump()
+assert np.array_equal(mp.numpy()[:, :3], uxyz) and np.array_equal(mk.numpy(), np.repeat(cell_keys(uijk), np.diff(ustart)))
+assert np.array_equal(cell_start.numpy(), ustart.astype(np.int64))
+shared = np.intersect1d(as_rows(rank_map(0))[1], as_rows(rank_map(1))[1])
+assert len(shared) > 10   # the two maps really overlap: cells with points of both ranks
+# a rank whose map is empty
+e_pts, e_keys = (torch.zeros((0, 4)), torch.zeros(0, dtype=torch.int64)) if rank == 0 else (torch.from_numpy(pts), torch.from_numpy(keys))
+mp2, mk2, cs2, counts2 = gather_cell_maps(e_pts, e_keys)
+assert counts2[0] == 0 and len(mk2) == counts2[1] and bool(torch.all(mk2[1:] >= mk2[:-1]))
+print("rank", rank, "cell maps ok", counts)
+dist.destroy_process_group()
+"""
+
+
+def test_gather_cell_maps_world2_gloo(tmp_path):
+    """the exchange step of C4 as BASELINE words it (a gather of cell maps): two ranks with real cell maps of different sizes over
+    overlapping areas; the union comes back in cell-map layout, equal to the map that appended both ranks' points"""
+    script = tmp_path / "cellmap_worker.py"
+    script.write_text(CELLMAP_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("cell maps ok") == 2

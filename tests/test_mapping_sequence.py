@@ -151,3 +151,28 @@ def test_device_mapping_loop_matches_oracle(gpu_lib, sequence, oracle_run, downs
     dt, dr = synth.pose_error(lm.pose, truth[len(ref) - 1])
     assert dt < 0.03 and dr < 0.006
     lm.close()
+
+
+@pytest.mark.gpu
+def test_cell_maps_fed_by_the_service_thread_equal_the_inline_ones(gpu_lib, sequence):
+    """matching mode 0 with keep_cell_maps: the frames reach m_pt_cell_map_corners / _planes (laser_mapping.hpp:1492-1493) through the
+    history handle's service thread, beside the loop; the maps -- which also outgrow their first allocation on the way -- are bit for bit
+    the ones the inline path builds, and the poses do not notice"""
+    from loam_livox_amd.mapping import Laser_mapping
+    scans, _ = sequence
+    dumps, poses = [], []
+    for async_ in (True, False):
+        lm = Laser_mapping(scan_points=N_PTS, keep_cell_maps=True, cell_map_max_points=N_PTS, **MAP_ARGS)
+        if not async_:
+            lm.history.set_cell_map_async(False)
+        for xyzi in scans:
+            lm.process_new_scan(xyzi)
+        lm.sync()
+        dumps.append([lm.history.cell_map(k).dump() for k in (0, 1)])
+        poses.append(lm.pose.copy())
+        assert lm.history.cell_map(1).stats()[1] > N_PTS // 4
+        lm.close()
+    assert np.array_equal(poses[0], poses[1])
+    for k in (0, 1):
+        assert all(np.array_equal(a, b) for a, b in zip(dumps[0][k], dumps[1][k]))
+    assert len(dumps[0][1][0]) > 1000
