@@ -22,7 +22,7 @@
 //   solve     cost evaluations read the blocks from LDS (one round ahead), 28 accumulators per lane -> the butterfly reduction of
 //             ll_reg_solve_common.h -> the controller lane (the same lm_* code as every other path, the line-search fit on its
 //             wavefront);
-//   inliers   loss-corrected L1 values in registers; std::set de-duplication (PCR:155-160) and the rank select by ONE bitonic sort of
+//   inliers   loss-corrected L1 values in registers; std::set de-duplication (PCR:155-160) and the rank select by a bitonic sort of
 //             the 64-bit keys across the registers of a wavefront (no table, no LDS): equal keys end up adjacent, the distinct values are
 //             counted and the wanted rank picked by a prefix sum;
 //   epilogue  pose composition and the convergence test (solve_epilogue).
@@ -71,7 +71,8 @@ struct SmallShared {
     int cnt[16][8];          // census: active blocks per (round, wavefront)
     int isum[8];
     unsigned long long lsum[8];
-    int sel_nu;              // W >= 4: distinct L1 values
+    int hist[256];           // W >= 4: digit histogram of the radix select
+    int sel_digit, sel_rank;
 };
 
 // what the kernel reads of the registrar's buffers (ll_device.h RegDev holds ~50 pointers: passed whole, the ones a phase keeps live
@@ -271,7 +272,7 @@ void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
         LL_AS_LDS double *p = (LL_AS_LDS double *)s_dyn;
         B.v0 = p, B.v1 = p + cap, B.v2 = p + 2 * cap, B.a0 = p + 3 * cap;
         B.a1 = p + 4 * cap, B.a2 = p + 4 * cap + capl;
-        LL_AS_LDS float *q = (LL_AS_LDS float *)(p + 4 * cap + 2 * capl + (W >= 4 ? NS : 0));
+        LL_AS_LDS float *q = (LL_AS_LDS float *)(p + 4 * cap + 2 * capl + (W >= 4 ? 2 * NS : 0));
         B.fx = q, B.fy = q + cap, B.fz = q + 2 * cap;
     }
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
@@ -506,68 +507,88 @@ void reg_solve_small_kernel(SmallArgs rd, RegConst rc)
             }
         }
     } else {
-        // four / eight wavefronts: the same sort in LDS, every thread a pair per step (NS / 2 pairs, NT threads)
-        LL_AS_LDS unsigned long long *sk = (LL_AS_LDS unsigned long long *)(B.a2 + capl);  // [NS], behind the line arrays
+        // four / eight wavefronts: no sort.  (A bitonic sort of the keys in LDS -- 66 barrier steps for 2 048 keys -- was a third of a
+        // launch of the mapping loop's scans: 44 k of 149 k cycles.)  std::set semantics by an exact LDS hash table -- a key is inserted
+        // with one 64-bit compare-and-swap; whoever finds its own key already there is a duplicate, exactly one lane per distinct value is
+        // not, whatever the order of the atomics -- then a most-significant-digit-first radix select over the distinct keys, 8 bits per
+        // pass: a 256-bin LDS histogram, one wavefront finds the digit that holds the wanted rank.
+        LL_AS_LDS unsigned long long *tab = (LL_AS_LDS unsigned long long *)(B.a2 + capl);  // [2 * NS] slots, behind the line arrays
+        constexpr unsigned int TS = 2u * NS;
+        for (int e = tid; e < (int)TS; e += NT) tab[e] = 0xffffffffffffffffull;
+        __syncthreads();
+        unsigned int uniq = 0;  // bit r: l1[r] is the first of its value
 #pragma unroll
         for (int r = 0; r < M; r++) {
             const double v = l1[r];
-            sk[r * NT + tid] = (v >= 0.0) ? (unsigned long long)__double_as_longlong(v) : 0xffffffffffffffffull;
-        }
-        for (int e = M * NT + tid; e < NS; e += NT) sk[e] = 0xffffffffffffffffull;
-        __syncthreads();
-        for (int k = 2; k <= NS; k <<= 1) {
-            for (int j = k >> 1; j >= 1; j >>= 1) {
-                for (int pidx = tid; pidx < NS / 2; pidx += NT) {
-                    const int i = ((pidx & ~(j - 1)) << 1) | (pidx & (j - 1));  // the pair's lower element (bit j clear)
-                    const unsigned long long a = sk[i], bb = sk[i | j];
-                    const bool up = (i & k) == 0;
-                    if ((bb < a) == up && a != bb) {
-                        sk[i] = bb;
-                        sk[i | j] = a;
-                    }
+            if (!(v >= 0.0)) continue;  // inactive slot or NaN (NaN never enters the set)
+            const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+            unsigned int hsh = (unsigned int)key * 0x9E3779B1u;
+            hsh ^= hsh >> 15;
+            hsh += (unsigned int)(key >> 32) * 0x85EBCA77u;
+            hsh ^= hsh >> 13;
+            unsigned int slot = hsh & (TS - 1u);
+            for (;;) {  // (at most half of the slots are ever taken: the probe ends)
+                const unsigned long long old = atomicCAS((unsigned long long *)&tab[slot], 0xffffffffffffffffull, key);
+                if (old == 0xffffffffffffffffull) {
+                    uniq |= 1u << r;
+                    break;
                 }
-                __syncthreads();
+                if (old == key) break;
+                slot = (slot + 1u) & (TS - 1u);
             }
         }
-        // distinct values: every thread looks at NS / NT consecutive elements
-        constexpr int C = NS / NT;
-        unsigned int first = 0;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const int g = tid * C + c;
-            const unsigned long long kv = sk[g];
-            if (kv != 0xffffffffffffffffull && (g == 0 || kv != sk[g - 1])) first |= 1u << c;
-        }
-        const int cnt = __popc(first);
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
-        }
-        if (lane == 63) sh.isum[wave] = incl;
-        __syncthreads();
-        int below = incl - cnt, nu = 0;
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            if (w < wave) below += sh.isum[w];
-            nu += sh.isum[w];
-        }
+        const int nu = (int)small_sum_u64<W>((unsigned long long)__popc(uniq), sh);  // (its barriers: every insert has landed)
         int target = (int)(rc.inlier_ratio * (double)nu);  // PCR:160
         if (target > nu - 1) target = nu - 1;
         if (nu == 0) {
             if (tid == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
-        } else if (target >= below && target < below + cnt) {
-            int rk = below;
-            unsigned long long sel = 0;
+        } else {
+            unsigned long long prefix = 0ull;
+            int rank = target;
+            for (int pass = 0; pass < 8; pass++) {
+                const int shift = 56 - 8 * pass;
+                if (tid < 256) sh.hist[tid] = 0;
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                if ((first >> c) & 1u) {
-                    if (rk == target) sel = sk[tid * C + c];
-                    rk++;
+                for (int r = 0; r < M; r++) {
+                    if (!((uniq >> r) & 1u)) continue;
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(l1[r]);
+                    if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
                 }
+                __syncthreads();
+                if (wave == 0) {  // lane l sums bins 4 l .. 4 l + 3; the lane whose range holds the rank walks its four bins
+                    const int b0 = sh.hist[4 * lane], b1 = sh.hist[4 * lane + 1], b2 = sh.hist[4 * lane + 2], b3 = sh.hist[4 * lane + 3];
+                    const int part = b0 + b1 + b2 + b3;
+                    int incl = part;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int y = __shfl_up(incl, off);
+                        if (lane >= off) incl += y;
+                    }
+                    const int below = incl - part;
+                    if (rank >= below && rank < incl) {
+                        int d = 4 * lane, cum = below;
+                        if (cum + b0 <= rank) {
+                            cum += b0;
+                            d++;
+                            if (cum + b1 <= rank) {
+                                cum += b1;
+                                d++;
+                                if (cum + b2 <= rank) {
+                                    cum += b2;
+                                    d++;
+                                }
+                            }
+                        }
+                        sh.sel_digit = d;
+                        sh.sel_rank = rank - cum;
+                    }
+                }
+                __syncthreads();
+                prefix = (prefix << 8) | (unsigned long long)sh.sel_digit;
+                rank = sh.sel_rank;
             }
-            sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sel));  // PCR:485
+            if (tid == 0) sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)prefix));  // PCR:485
         }
     }
     __syncthreads();
@@ -641,7 +662,7 @@ static size_t small_lds_bytes(int W, int M, int cap, int capl)
 {
     const int keys = M * 64 * W;
     const int ns = W <= 2 ? 0 : (keys <= 256 ? 256 : (keys <= 512 ? 512 : (keys <= 1024 ? 1024 : 2048)));  // (NS of the kernel)
-    return (size_t)cap * (4 * 8 + 3 * 4) + (size_t)capl * 16 + (size_t)ns * 8;
+    return (size_t)cap * (4 * 8 + 3 * 4) + (size_t)capl * 16 + (size_t)ns * 16;  // (W >= 4: a hash table of 2 NS slots)
 }
 
 template <int W, int M>
@@ -649,8 +670,12 @@ static void launch_small(const SmallArgs &a, const RegConst &rc, int n_scans, hi
 {
     const size_t lds = small_lds_bytes(W, M, a.cap, a.capl);
     static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)reg_solve_small_kernel<W, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (!attr_set) {  // dynamic LDS beyond the default 64 KB: everything the CU has left beside the kernel's static block
+        hipFuncAttributes fa;
+        int room = 160 * 1024 - 8 * 1024;
+        if (hipFuncGetAttributes(&fa, (const void *)reg_solve_small_kernel<W, M>) == hipSuccess) room = 160 * 1024 - (int)fa.sharedSizeBytes;
+        if (hipFuncSetAttribute((const void *)reg_solve_small_kernel<W, M>, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess)
+            (void)hipGetLastError();  // (not sticky: a launch that needs more than the default then fails on its own)
         attr_set = true;
     }
     hipLaunchKernelGGL((reg_solve_small_kernel<W, M>), dim3(n_scans), dim3(64 * W), lds, s, a, rc);
@@ -659,7 +684,7 @@ static void launch_small(const SmallArgs &a, const RegConst &rc, int n_scans, hi
 bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns)
 {
     return !rc.if_motion_deblur && !rc.force_general && !rc.solver_legacy && !rc.solver_packed48 && !rc.no_small_solver && max_nc + max_ns > 0 &&
-           max_nc + max_ns <= LL_SMALL_MAX_BLOCKS;
+           max_nc + max_ns <= LL_SMALL_MAX_BLOCKS && max_nc <= 1024;  // (line blocks take 16 B more of LDS each)
 }
 
 // wavefronts per scan: four for batches that leave CUs idle anyway (latency); for large batches as many as keep two wavefronts per SIMD

@@ -118,6 +118,26 @@ def test_eight_wavefronts_for_up_to_2048_blocks(dev_map, small_world, scans, siz
     assert dt < 1e-9 and dr < 1e-9
 
 
+def test_eight_wavefronts_duplicate_residuals(dev_map, small_world, scans):
+    """the hash de-duplication + radix select of the four / eight-wavefront forms on a scan with many exact duplicates"""
+    sc = scans[1]
+    _, _, _, _, fc, fs = oracle_features(sc)
+    fs = fs[::14][:1100]
+    rng = np.random.default_rng(8)
+    rep = rng.choice(len(fs), 500, replace=False)
+    fs2 = np.concatenate([fs, fs[rep], fs[rep[:200]]])  # 1 800 surface features: 500 of them twice, 200 three times
+    fc2 = np.concatenate([fc[:120], fc[:60]])
+    prm = orc.RegParams.defaults(icp_iters=6, ceres_iters=20, force_all=1)
+    ret, opc, _, orep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc2, fs2, prm, sc.pose_init, sc.pose_init)
+    _, _, _, orep_plain = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc[:120], fs, prm, sc.pose_init, sc.pose_init)
+    assert orep.inlier_threshold != orep_plain.inlier_threshold
+    reg = Point_cloud_registration(max_scans=1, max_features=2048)
+    set_params(reg, 6, 20, 1)
+    res, pc, _, reps = reg.solve_batch(dev_map, [fc2], [fs2], sc.pose_init[None], sc.pose_init[None])
+    reg.close()
+    check_against(reps[0], orep, pc[0], opc, res[0], ret)
+
+
 @pytest.mark.parametrize("waves", [1, 2, 4])
 def test_shipped_block_cap_200(dev_map, small_world, scans, filtered, waves):
     """a13 at the shipped setting: more than 200 candidate blocks -> the reproducible block drop of PCR:438-458"""
