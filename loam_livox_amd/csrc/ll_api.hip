@@ -1570,6 +1570,7 @@ struct ll_history {
     float4 *d_in = nullptr, *d_xf = nullptr, *d_concat = nullptr;
     int *d_n = nullptr;
     double *d_pose = nullptr;
+    int2 *hp_table = nullptr, *d_table = nullptr;  // [2 kinds][LL_HIST_CONCAT_MAX + 1] segment tables of the concatenation (pinned host / device)
     VoxelDev vox_frame{}, vox_map{};
     double last_q[4] = {0, 0, 0, 1}, last_t[3] = {0, 0, 0};  // m_last_his_add_q / m_last_his_add_t
     double gate[7] = {0, 0, 0, 1, 0, 0, 0};                   // ll_history_set_gate_pose: the node's pose BEFORE the registration
@@ -1721,6 +1722,8 @@ static int history_create_impl(int32_t device, int32_t maximum_history_size, int
     DM(h->d_concat, cap);
     DM(h->d_n, 1);
     DM(h->d_pose, 8);
+    DM(h->d_table, 2 * (LL_HIST_CONCAT_MAX + 1));
+    HC(hipHostMalloc((void **)&h->hp_table, 2 * (LL_HIST_CONCAT_MAX + 1) * sizeof(int2), hipHostMallocDefault));
     const char *err = nullptr;
     if (voxel_alloc(h->vox_frame, 1, max_points_per_frame, &err) || voxel_alloc(h->vox_map, 1, (int)cap, &err))
         return set_err("ll_history_create", err);
@@ -1746,7 +1749,8 @@ extern "C" void ll_history_destroy(ll_history *h)
         for (int i = 0; i < ll_history::kStage; i++)
             if (h->stage[k][i]) (void)hipFree(h->stage[k][i]);
     for (int k = 0; k < 2; k++) cellmap_release(h->cells[k]);
-    void *ptrs[] = {h->frames[0], h->frames[1], h->d_map[0], h->d_map[1], h->d_in, h->d_xf, h->d_concat, h->d_n, h->d_pose, h->d_cmap[0], h->d_cmap[1]};
+    if (h->hp_table) (void)hipHostFree(h->hp_table);
+    void *ptrs[] = {h->frames[0], h->frames[1], h->d_map[0], h->d_map[1], h->d_in, h->d_xf, h->d_concat, h->d_n, h->d_pose, h->d_cmap[0], h->d_cmap[1], h->d_table};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1910,13 +1914,30 @@ extern "C" int ll_history_refresh(ll_history *h, ll_map *map, int64_t *n_map_cor
     for (int kind = 0; kind < 2; kind++) {
         // laser_mapping.hpp:519-530: concatenate the history, oldest frame first
         int total = 0;
-        for (int i = 0; i < h->size; i++) {
-            const int slot = (h->head + i) % slots;
-            const int c = h->count[kind][slot];
-            if (c > 0)
-                HC(hipMemcpyAsync(h->d_concat + total, h->frames[kind] + (size_t)slot * h->max_pts, (size_t)c * sizeof(float4),
-                                  hipMemcpyDeviceToDevice, h->stream));
-            total += c;
+        if (h->size <= LL_HIST_CONCAT_MAX && h->hp_table) {  // one gather launch (the table travels as one small pinned copy)
+            int2 *tab = h->hp_table + (size_t)kind * (LL_HIST_CONCAT_MAX + 1);
+            int n_seg = 0;
+            for (int i = 0; i < h->size; i++) {
+                const int slot = (h->head + i) % slots;
+                const int c = h->count[kind][slot];
+                if (c > 0) tab[n_seg++] = make_int2((int)((size_t)slot * h->max_pts), total);  // (ring size x max_pts < 2^31: ll_history_create)
+                total += c;
+            }
+            tab[n_seg] = make_int2(0, total);
+            if (total > 0) {
+                int2 *d_tab = h->d_table + (size_t)kind * (LL_HIST_CONCAT_MAX + 1);
+                HC(hipMemcpyAsync(d_tab, tab, (size_t)(n_seg + 1) * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+                launch_history_concat(h->frames[kind], d_tab, n_seg, total, h->d_concat, h->stream);
+            }
+        } else {
+            for (int i = 0; i < h->size; i++) {
+                const int slot = (h->head + i) % slots;
+                const int c = h->count[kind][slot];
+                if (c > 0)
+                    HC(hipMemcpyAsync(h->d_concat + total, h->frames[kind] + (size_t)slot * h->max_pts, (size_t)c * sizeof(float4),
+                                      hipMemcpyDeviceToDevice, h->stream));
+                total += c;
+            }
         }
         int n_out = 0;
         if (total > 0) {

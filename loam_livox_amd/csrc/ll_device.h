@@ -205,6 +205,8 @@ void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs
 int reg_solve_small_waves(const RegConst &rc, int n_scans, int max_nc, int max_ns);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s);
+#define LL_HIST_CONCAT_MAX 1023  // frames one history_concat_kernel launch gathers (longer histories: the per-frame copies)
+void launch_history_concat(const float4 *frames, const int2 *d_table, int n_seg, int total, float4 *out, hipStream_t s);
 void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, const int *fe_nc, const int *fe_ns, int fe_stride, int heads,
                             float4 *dst_corner, float4 *dst_surf, int *dst_nc, int *dst_ns, int dst_stride, int n_scans, hipStream_t s);
 

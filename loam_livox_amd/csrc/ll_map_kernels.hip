@@ -120,7 +120,8 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
     float *d_mm = mk.b_mm;
     const float init[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, s));
-    if (n > 0) hipLaunchKernelGGL(aabb_kernel, dim3(1024), dim3(256), 0, s, d_raw, stride, n, d_mm, d_mm + 3);
+    if (n > 0)  // (a match buffer of a few thousand points: 1024 mostly idle workgroups contending on six atomics cost 12 us per rebuild)
+        hipLaunchKernelGGL(aabb_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s, d_raw, stride, n, d_mm, d_mm + 3);
     float mm[6];
     HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

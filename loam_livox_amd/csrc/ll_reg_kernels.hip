@@ -2971,6 +2971,34 @@ void launch_reg_merge_heads(const float4 *fe_corner, const float4 *fe_surf, cons
     hipLaunchKernelGGL(reg_merge_heads_kernel, dim3((fe_stride + 255) / 256, n_scans * heads, 2), dim3(256), 0, s, fe_corner, fe_surf, fe_nc,
                        fe_ns, fe_stride, heads, dst_corner, dst_surf, dst_nc, dst_ns, dst_stride);
 }
+// The history's frames, oldest first, into one cloud (laser_mapping.hpp:519-530): segment g of the table is {first point of the frame in
+// `frames`, its first position in `out`}, the table ends with {-, total}.  One launch instead of one device-to-device copy per frame
+// (20 frames x 2 kinds per refresh of the match buffer: the copies' launch overhead was a third of the refresh).
+__global__ __launch_bounds__(256) void history_concat_kernel(const float4 *frames, const int2 *table, int n_seg, float4 *out)
+{
+    __shared__ int2 s_tab[LL_HIST_CONCAT_MAX + 1];
+    for (int e = threadIdx.x; e <= n_seg; e += 256) s_tab[e] = table[e];
+    __syncthreads();
+    const int total = s_tab[n_seg].y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int lo = 0, hi = n_seg - 1;  // the last segment whose first output position is <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_tab[mid].y <= i)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        out[i] = frames[(size_t)s_tab[lo].x + (size_t)(i - s_tab[lo].y)];
+    }
+}
+void launch_history_concat(const float4 *frames, const int2 *d_table, int n_seg, int total, float4 *out, hipStream_t s)
+{
+    if (n_seg <= 0 || total <= 0) return;
+    const int blocks = (total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024;
+    hipLaunchKernelGGL(history_concat_kernel, dim3(blocks), dim3(256), 0, s, frames, d_table, n_seg, out);
+}
+
 void launch_cloud_transform(const float4 *in, float4 *out, int n, const double *d_pose, hipStream_t s)
 {
     if (n <= 0) return;
