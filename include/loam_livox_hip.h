@@ -259,6 +259,11 @@ int ll_reg_enqueue_fe(ll_reg *r, const ll_map *map, ll_fe *fe, int32_t n_scans, 
 /* Returns 0; a negative value on an error of the call; or the number (> 0) of scans whose registration was aborted on the device
  * (ll_reg_report.aborted) -- not an error: all outputs are filled in, the aborted scans are rejected with their pose restored, the
  * results of the other scans of the batch are valid, and ll_last_error() carries the reason. */
+/* RETURN VALUE of ll_reg_collect and of the calls that end in it (ll_reg_solve, ll_reg_solve_batch, ll_reg_solve_fe ...; the adapter's
+ * find_out_incremental_transfrom): < 0 an error; 0 every scan solved; > 0 the NUMBER OF SCANS whose solve was abandoned (a bounded
+ * wait of the small-batch grouped solver ran out, or a launch that could not hold the scan): those scans come back rejected -- result 0,
+ * report.aborted 1, pose restored -- the others are valid, and ll_last_error() says why.  Callers that treat any non-zero status as
+ * failure should test `< 0`. */
 int ll_reg_collect(ll_reg *r, int32_t n_scans, double *poses_curr, double *poses_incre, ll_reg_report *reports,
                    int32_t *results);
 
@@ -390,6 +395,8 @@ int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n);
  * laser_mapping.hpp:1527): the append, plus the cells that received at least min_points of this cloud's points (3 in the
  * reference, :646; on an empty map every cell that received a point, set_point_cloud :596-607), as cell indices [n][3] in
  * ascending cell order.  cell_ijk == NULL only counts. */
+/* (ll_cellmap_append_touched never fails after the cloud has been stored: *n_touched is always the full number of touched cells; when it
+ * exceeds capacity_cells the list was cut to capacity_cells entries -- call again with nothing to append is NOT a retry, the cloud is in.) */
 int ll_cellmap_append_touched(ll_cellmap *c, const float *xyzi, int32_t n, int32_t min_points, int32_t *cell_ijk, int64_t capacity_cells,
                               int64_t *n_touched);
 int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], float radius, float maximum_in_fov_angle, float leaf,

@@ -295,6 +295,12 @@ static int fe_resolve_ambiguous(ll_fe *h)
     std::vector<int2> list(n_list);
     HC(hipMemcpy(list.data(), h->dev.ambig_list, n_list * sizeof(int2), hipMemcpyDeviceToHost));
     const size_t N = h->prm.max_points;
+    // the re-derived labels are applied behind the loop: copies queued on the handle's stream from staging that outlives them, one wait
+    // (a pair of copies and a stream drain per point made a batch with a few thousand flagged points thousands of round trips)
+    std::vector<int> fix_label(n_list);
+    std::vector<float> fix_view(n_list);
+    std::vector<size_t> fix_at;
+    fix_at.reserve(n_list);
     for (const int2 &e : list) {
         const int b = e.x, i = e.y, n = h->h_npts[b];
         if (i < 2 || i >= n - 2) continue;
@@ -311,12 +317,17 @@ static int fe_resolve_ambiguous(ll_fe *h)
             d[k] = o.depth_sq2;
         }
         const LabelOut lo = point_label(p, t, d, h->fc);  // host build: glibc acosf
-        // on the handle's stream and waited for: the selection kernel that reads these runs on that stream, and a null-stream copy
-        // from pageable memory is not ordered with it
-        HC(hipMemcpyAsync(h->dev.label + (size_t)b * N + i, &lo.label, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HC(hipMemcpyAsync(h->dev.view + (size_t)b * N + i, &lo.view_angle, sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HC(hipStreamSynchronize(h->stream));
+        fix_label[fix_at.size()] = lo.label;
+        fix_view[fix_at.size()] = lo.view_angle;
+        fix_at.push_back((size_t)b * N + i);
     }
+    // on the handle's stream and waited for: the selection kernel that reads these runs on that stream, and a null-stream copy from
+    // pageable memory is not ordered with it
+    for (size_t k = 0; k < fix_at.size(); k++) {
+        HC(hipMemcpyAsync(h->dev.label + fix_at[k], &fix_label[k], sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HC(hipMemcpyAsync(h->dev.view + fix_at[k], &fix_view[k], sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    if (!fix_at.empty()) HC(hipStreamSynchronize(h->stream));
     return n_amb;
 }
 
@@ -1402,10 +1413,9 @@ extern "C" int ll_cellmap_append_touched(ll_cellmap *c, const float *xyzi, int32
     int64_t k = 0;
     for (int i = 0; i < nc; i++) {
         if (cnt[i] < need) continue;
-        if (cell_ijk) {
-            if (k >= capacity_cells) return set_err("ll_cellmap_append_touched", "buffer too small");
-            cell_unpack(keys[i], cell_ijk + 3 * (size_t)k);
-        }
+        // (the append is committed by now: a short buffer truncates the list, it does not fail the call -- a retry would append the
+        //  cloud a second time.  *n_touched is always the full count; more than capacity_cells means the list was cut.)
+        if (cell_ijk && k < capacity_cells) cell_unpack(keys[i], cell_ijk + 3 * (size_t)k);
         k++;
     }
     *n_touched = k;

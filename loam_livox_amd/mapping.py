@@ -65,6 +65,7 @@ class Laser_mapping:
         self.pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)  # m_q_w_curr / m_t_w_curr
         self.map_sizes = (0, 0)
         self.last_report = None
+        self.aborted_solves = 0     # registrations abandoned by the grouped solver and repeated on one workgroup (ll_reg_report.aborted)
         self.stage_s = np.zeros(4)  # cumulative wall time: extract+register, history add, match-buffer refresh, frames
         self.m_last_time_stamp = 0.0
         self._host_vox = None
@@ -103,18 +104,32 @@ class Laser_mapping:
         fe.resolve()
         fe.select_batch(1, -1, 0.0, 1.0)
 
-    def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0, next_xyzi: np.ndarray | None = None, next_time_stamp: float = 1.0) -> int:
+    def process_new_scan(self, xyzi: np.ndarray, time_stamp: float = 1.0, next_xyzi: np.ndarray | None = None, next_time_stamp: float = 1.0,
+                         scan_id=None, next_scan_id=None) -> int:
         """One frame (laser_mapping.hpp:1311-1520).  Returns the registration result (1 accepted, 0 rejected).
-        next_xyzi: the scan that will be passed next (the same array object), extracted on the second handle while this one registers."""
+        next_xyzi: the scan that will be passed next, extracted on the second handle while this one registers.  The prefetched extraction
+        is used by the next call only if it is recognisably the same scan: the caller's token (scan_id of that call == next_scan_id of
+        this one) when tokens are given -- the contract for callers that refill one buffer in place, e.g. a ring filled by a driver thread
+        -- otherwise the same array OBJECT with the same time stamp, which the caller must then not have rewritten in between."""
+        try:
+            return self._process_new_scan(xyzi, time_stamp, next_xyzi, next_time_stamp, scan_id, next_scan_id)
+        except Exception:
+            self._prefetched = None  # (a failure between the prefetch and its use must not leave a stale extraction behind)
+            raise
+
+    def _process_new_scan(self, xyzi, time_stamp, next_xyzi, next_time_stamp, scan_id, next_scan_id) -> int:
         import time
         t0 = time.perf_counter()
         reg = self.reg
-        if self._prefetched is not None and self._prefetched[0] is xyzi and self._prefetched[1] == time_stamp:
-            fe = self._prefetched[2]
+        pf = self._prefetched
+        self._prefetched = None
+        hit = pf is not None and pf[1] == time_stamp and ((scan_id is not None and pf[3] is not None and pf[3] == scan_id) or
+                                                           (scan_id is None and pf[3] is None and pf[0] is xyzi))
+        if hit:
+            fe = pf[2]
         else:
             fe = self._fe_pair[0]
             self._extract(fe, xyzi, time_stamp)
-        self._prefetched = None
         self.fe = fe  # the handle that holds this frame's features (history add, key frames)
         reg.params.current_frame_index = self.m_current_frame_index  # init_pointcloud_registration runs before the increment
         self.m_current_frame_index += 1
@@ -128,8 +143,19 @@ class Laser_mapping:
             if self._fe_pair[other] is None:
                 self._fe_pair[other] = Livox_laser(max_points=self._scan_points, max_scans=1, device=self._device, piecewise_number=1)
             self._extract(self._fe_pair[other], next_xyzi, next_time_stamp)
-            self._prefetched = (next_xyzi, next_time_stamp, self._fe_pair[other])
+            self._prefetched = (next_xyzi, next_time_stamp, self._fe_pair[other], next_scan_id)
         res, pc, _, reps = reg.collect(1)
+        if reps[0].aborted:
+            # not a rejection the reference would have made: a bounded wait of the grouped solver ran out (the device was oversubscribed,
+            # e.g. by the prefetched extraction beside it).  Counted apart, and the scan is registered once more on one workgroup.
+            self.aborted_solves += 1
+            reg.set_debug(False, no_solver_groups=True)
+            if self.m_if_input_downsample_mode:
+                reg.enqueue_fe_downsampled(self.map, fe, self.vox[0], self.vox[1], self.line_res, self.plane_res, 1, pose, pose)
+            else:
+                reg.enqueue_fe(self.map, fe, 1, pose, pose)
+            res, pc, _, reps = reg.collect(1)
+            reg.set_debug(False)
         self.last_report = reps[0]
         t1 = time.perf_counter()
         self.stage_s[0] += t1 - t0

@@ -557,3 +557,24 @@ def test_device_mapping_loop_cell_mode_matches_oracle(gpu_lib, small_world):
     dt, dr = synth.pose_error(lm.pose, truth[len(scans) - 1])
     assert dt < 0.03 and dr < 0.006 and lm.map_sizes[1] > 300
     lm.close()
+
+
+@pytest.mark.gpu
+def test_append_touched_with_a_short_buffer_truncates_and_does_not_fail(gpu_lib):
+    """ll_cellmap_append_touched stores the cloud before it lists the touched cells: a list buffer that is too short must not turn
+    the call into an error -- a caller that retried would append the cloud twice.  The full count comes back, the list is cut."""
+    import ctypes as C
+    from loam_livox_amd import capi
+    from loam_livox_amd.api import Cell_map
+    rng = np.random.default_rng(12)
+    cloud = np.c_[rng.uniform(-5, 5, (3000, 3)), np.zeros(3000)].astype(np.float32)
+    full, short = Cell_map(1 << 14, 1.0), Cell_map(1 << 14, 1.0)
+    want = full.append_cloud_touched(cloud, 3)
+    assert len(want) > 40
+    ijk = np.full((8, 3), -777, np.int32)
+    n = C.c_int64(0)
+    rc = short.L.ll_cellmap_append_touched(short.h, cloud.ctypes.data_as(C.c_void_p), len(cloud), 3, ijk.ctypes.data_as(C.c_void_p), 8, C.byref(n))
+    assert rc == 0 and n.value == len(want)            # the full count, no error
+    assert np.array_equal(ijk, want[:8])               # the first capacity_cells entries
+    assert short.stats() == full.stats()               # the cloud is in exactly once
+    full.close(); short.close()
