@@ -493,6 +493,7 @@ def main():
                     setattr(r_.params, f, getattr(p, f))
                 if shipped_cap:  # config/performance_precision.yaml:23 -- what cpu_baseline_shipped_config[_allcores] run
                     r_.params.maximum_allow_residual_block, r_.params.subsample_seed = 200, 7
+                r_.set_profiling(True)
                 return f_, r_, (VoxelGrid(N, Bq, device=dev), VoxelGrid(N, Bq, device=dev))
 
             def start_q(sl):
@@ -503,16 +504,29 @@ def main():
             start_q(sl0); sl0[1].collect(Bq)
             barrier()
             tq = time.perf_counter()
+            kq_ms, kq_n = np.zeros(3), np.zeros(3)
             for _ in range(3):
                 start_q(sl0)
                 out_q = sl0[1].collect(Bq)
+                kq_ms += sl0[1].kernel_times()[0]
+                kq_n += sl0[1].kernel_times()[1]
             barrier()
             tq = (time.perf_counter() - tq) / 3
             ncq, nsq = sl0[2][0].counts(Bq)[0], sl0[2][1].counts(Bq)[0]
+            # the small-scan solver against the HBM roofline, SURVEY 8(d)'s accounting: every residual block's constants once per launch
+            # (65 B per line block, 48 B per plane block) + 224 B of state out per scan; duration = HIP events around the solver launches
+            solver_ms = float(kq_ms[1] / max(1.0, kq_n[1]))
+            alg_q = float(np.sum([65.0 * r.corner_avail + 48.0 * r.surf_avail + 224.0 for r in out_q[3]]))
             fig = {"batch": Bq, "scans_per_s_this_rank": round(Bq / tq, 1), "ms_per_step": round(1e3 * tq, 3),
                    "features_per_scan": {"corner": float(ncq.mean()), "surface": float(nsq.mean())},
                    "blocks_per_scan_last_iteration": float(np.mean([r.n_blocks_last for r in out_q[3]])),
-                   "accepted_frac": float(np.mean(out_q[0])), "lm_iters_per_scan": float(np.mean([r.lm_iterations_total for r in out_q[3]]))}
+                   "accepted_frac": float(np.mean(out_q[0])), "lm_iters_per_scan": float(np.mean([r.lm_iterations_total for r in out_q[3]])),
+                   "kernel_ms_per_step": {"knn+build": round(float(kq_ms[0] / 3), 3), "solver": round(float(kq_ms[1] / 3), 3)},
+                   "solver_roofline": {"bound": "hbm", "kernel": "reg_solve_small_kernel", "avg_launch_ms": round(solver_ms, 4),
+                                       "algorithmic_bytes_per_launch": int(alg_q), "achieved": round(alg_q / (solver_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                       "peak": 8000.0, "frac": round(alg_q / (solver_ms * 1e-3) / 1e9 / 8000.0, 5),
+                                       "limited_by": "dependent fp64 issue of the per-scan Levenberg-Marquardt controller and the evaluations of "
+                                                     "a few hundred blocks per wavefront (latency chains), not HBM bandwidth"}}
             if in_flight > 1:
                 # A voxel-filtered batch ends with its slowest scan's last line search; batches are independent: with several in flight the
                 # CUs of the early finishers run the other batches' scans

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output into the per-(kernel, grid) summaries kept under profiles/.
 
-  summarize_rocprof.py trace   <*_kernel_trace.csv>                          -> kernel,grid_threads,workgroup,vgpr,lds_bytes,scratch_bytes,calls,total_ms,avg_us,min_us,max_us
+  summarize_rocprof.py trace   <*_kernel_trace.csv> [lib] [--all]             -> kernel,grid_threads,workgroup,vgpr,lds_bytes,scratch_bytes,calls,total_ms,avg_us,min_us,max_us
+                                                                                (--all: the library kernels of hipcub / rocprim too, names cut to 70 characters;
+                                                                                 kernel names that contain a comma -- template arguments -- are quoted)
   summarize_rocprof.py pmc     <fetch *_counter_collection.csv> <write ...>  -> kernel,grid_threads,dispatches,fetch_kib_avg,fetch_mib_corrected_x2,write_kib_avg
 
   summarize_rocprof.py generic <*_counter_collection.csv> [...]              -> kernel,grid_threads,dispatches,<counter>_avg ... (any counters, per-dispatch averages)
@@ -79,7 +81,7 @@ def codeobj(lib):
         c = co[n]
         if not n.startswith("ll::"):
             continue
-        print(f"{n},{c.get('vgpr_count', 0)},{c.get('agpr_count', 0)},{c.get('sgpr_count', 0)},{c.get('vgpr_spill_count', 0)},"
+        print(f"{q(n)},{c.get('vgpr_count', 0)},{c.get('agpr_count', 0)},{c.get('sgpr_count', 0)},{c.get('vgpr_spill_count', 0)},"
               f"{c.get('sgpr_spill_count', 0)},{c.get('private_segment_fixed_size', 0)},{c.get('group_segment_fixed_size', 0)},"
               f"{waves_per_simd(c.get('vgpr_count', 0), c.get('agpr_count', 0))}")
 
@@ -89,14 +91,21 @@ def short(name):
     return n[5:] if n.startswith("void ") else n
 
 
-def trace(path, lib=None):
+def q(name):
+    """CSV field: quoted when it holds a comma (reg_solve_small_kernel<1, 16>)"""
+    return '"' + name + '"' if "," in name else name
+
+
+def trace(path, lib=None, include_all=False):
     agg = defaultdict(list)
     meta = {}
     co = code_objects(lib) if lib else {}
     for r in csv.DictReader(open(path)):
         n = short(r["Kernel_Name"])
         if not n.startswith("ll::"):
-            continue
+            if not include_all:
+                continue
+            n = n[:70]
         grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
         key = (n, grid)
         agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -113,7 +122,7 @@ def trace(path, lib=None):
                     f"{waves_per_simd(c['vgpr_count'], c.get('agpr_count', 0)) if 'vgpr_count' in c else ''}")
         else:
             regs = f"{m[1]}"
-        print(f"{key[0]},{key[1]},{m[0]},{regs},{m[2]},{m[3]},{len(v)},{sum(v) / 1e3:.3f},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}")
+        print(f"{q(key[0])},{key[1]},{m[0]},{regs},{m[2]},{m[3]},{len(v)},{sum(v) / 1e3:.3f},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}")
 
 
 def counters(path, name):
@@ -133,7 +142,7 @@ def pmc(fetch_path, write_path):
     for key, v in sorted(f.items(), key=lambda kv: -sum(kv[1])):
         fa = sum(v) / len(v)
         wv = w.get(key, [0.0])
-        print(f"{key[0]},{key[1]},{len(v)},{fa:.1f},{2 * fa / 1024:.2f},{sum(wv) / len(wv):.1f}")
+        print(f"{q(key[0])},{key[1]},{len(v)},{fa:.1f},{2 * fa / 1024:.2f},{sum(wv) / len(wv):.1f}")
 
 
 def generic(paths):
@@ -150,12 +159,13 @@ def generic(paths):
     print("kernel,grid_threads,dispatches," + ",".join(c + "_avg" for c in names))
     for key, d in sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
         nd = max(len(v) for v in d.values())
-        print(f"{key[0]},{key[1]},{nd}," + ",".join(f"{sum(d[c]) / len(d[c]):.1f}" if d.get(c) else "" for c in names))
+        print(f"{q(key[0])},{key[1]},{nd}," + ",".join(f"{sum(d[c]) / len(d[c]):.1f}" if d.get(c) else "" for c in names))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
-        trace(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+        rest = [a for a in sys.argv[2:] if a != "--all"]
+        trace(rest[0], rest[1] if len(rest) > 1 else None, "--all" in sys.argv)
     elif sys.argv[1] == "codeobj":
         codeobj(sys.argv[2])
     elif sys.argv[1] == "generic":
