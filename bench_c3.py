@@ -162,8 +162,10 @@ def main():
                        "frac": round(alg / (ms_launch * 1e-3) / 1e9 / 8000.0, 4), "avg_launch_ms": round(ms_launch, 4), "launches_timed": int(kn[1]),
                        "algorithmic_bytes_per_launch": int(alg), "traffic": traffic, "traffic_source": src,
                        "traffic_over_algorithmic": (round(traffic / alg, 2) if traffic else None),
-                       "limited_by": "fp64 VALU issue of the motion-deblur evaluations (one sincos + the interpolated rotation per block) and the HBM-resident "
-                                     "flag / L1 passes of the general path, not HBM bandwidth"}
+                       "hbm_gb_per_s_from_counters": (round(traffic / (ms_launch * 1e-3) / 1e9, 1) if traffic else None),
+                       "limited_by": "HBM traffic of the general path -- every block's 49 / 65 B is streamed again by each of the ~9 cost evaluations and the "
+                                     "flag / L1 passes of a launch (counters: ~10 x the algorithmic bytes, a third of the HBM peak) -- together with the "
+                                     "fp64 issue of the motion-deblur evaluations (one sincos + the interpolated rotation per block)"}
     if args.cpu_scans > 0:
         from oracle import orc
         tb = time.perf_counter()

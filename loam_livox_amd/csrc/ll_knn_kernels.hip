@@ -234,7 +234,9 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
     const int i = sblk * KT_THREADS + threadIdx.x;  // position in the scan's cell order
     if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
     const bool valid = i < nS;
-    const int q = valid ? (i / LL_KNN_TILE_SEG) * LL_KNN_TILE_SEG + (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;  // (segment base + index in the segment)
+    // segment base + index in the segment; the segment is the same for the whole wavefront (LL_KNN_TILE_SEG is a multiple of 64): scalar
+    const int seg_base = (__builtin_amdgcn_readfirstlane(i) / LL_KNN_TILE_SEG) * LL_KNN_TILE_SEG;
+    const int q = valid ? seg_base + (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
     const int slot = rd.cap_c + q;
     const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
     const float max_d2 = rc.max_d2_plane;
