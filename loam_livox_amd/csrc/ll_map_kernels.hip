@@ -81,10 +81,12 @@ __global__ void cellkey_kernel(const float *raw, int stride, int64_t n, Grid g, 
     vals[i] = (int)i;
 }
 
-__global__ void gather_kernel(const float *raw, int stride, int64_t n_valid, const int *vals_sorted, f4 *pts)
+// (n_valid is read on the device -- cell_start[ncell], the scan's total -- so the host does not have to wait for it between the sort and
+//  this launch: one stream drain less per build, and the match buffer is rebuilt twice per frame of the mapping loop)
+__global__ void gather_kernel(const float *raw, int stride, const int *d_n_valid, const int *vals_sorted, f4 *pts)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_valid) return;
+    if (j >= (int64_t)*d_n_valid) return;
     const int i = vals_sorted[j];
     f4 p;
     p.x = raw[(int64_t)i * stride];
@@ -198,13 +200,11 @@ int map_build(MapKind &mk, const float *d_raw, int stride, int64_t n, float cell
     if (n > 0) HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)n, 0, end_bit, s));
     int n_valid = 0;
     HIPCHK(hipMemcpyAsync(&n_valid, mk.cell_start + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (grow(&mk.pts, &mk.cap_pts, nn, err)) return -1;  // (room for every point given: n_valid <= n is known only after the drain below)
+    if (n > 0)
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_raw, stride, mk.cell_start + ncell, d_vals2, mk.pts);
     HIPCHK(hipStreamSynchronize(s));
     mk.n_valid = n_valid;
-    if (grow(&mk.pts, &mk.cap_pts, (size_t)(n_valid > 0 ? n_valid : 1), err)) return -1;
-    if (n_valid > 0)
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, s, d_raw, stride,
-                           (int64_t)n_valid, d_vals2, mk.pts);
-    HIPCHK(hipStreamSynchronize(s));
     g.pts = mk.pts;
     g.cell_start = mk.cell_start;
     mk.grid = g;
