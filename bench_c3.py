@@ -21,6 +21,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# The ROCm runtime multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Batches in flight live on their
+# own handles = their own streams; with 4 queues two of them regularly share one and their kernels serialise (measured, profiles/README.md round 5:
+# 44.0 k scans/s with 4 queues, 46.5 k with 12 - 32; Q-pipe with three 2 048-scan batches in flight 122 k -> 169 k).  Must be set before the
+# first HIP call of the process; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)

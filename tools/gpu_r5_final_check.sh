@@ -12,5 +12,9 @@ print({k:d.get(k) for k in ("value","steps","warmup","ms_per_step","sequential",
 print("q_pipe", d.get("q_pipe"))
 PY
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+# the pipelined default loop's timeline (kernel trace only)
+export TMPDIR=/tmp; rm -rf /tmp/ptrace_$TAG; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/ptrace_$TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-streamed --no-q-pipe > /tmp/ptrace_$TAG.log 2>&1 )
+python tools/trace_overlap.py "$(find /tmp/ptrace_$TAG -name '*kernel_trace.csv' | head -1)" 50 > gpurun_out/${TAG}_pipelined_timeline.txt
+tail -1 /tmp/ptrace_$TAG.log | cut -c1-300 >> gpurun_out/${TAG}_pipelined_timeline.txt; head -4 gpurun_out/${TAG}_pipelined_timeline.txt
 ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > gpurun_out/${TAG}_tests.log 2>&1
 tail -6 gpurun_out/${TAG}_tests.log
