@@ -88,5 +88,52 @@ def test_gather_over_rccl_world_of_one(small):
         res, poses, merged, counts = run_sharded(runner, xyzi, inits)
         r1, p1, m1 = runner.run(xyzi, inits)
         assert np.array_equal(res, r1) and np.array_equal(poses, p1) and torch.equal(merged, m1) and counts == [len(m1)]
+        # the cell-map gather (BASELINE config C4's exchange step) on a device cell map: a world of one returns the map unchanged
+        from loam_livox_amd.api import Cell_map
+        from loam_livox_amd.multigpu import gather_cell_maps
+        rng = np.random.default_rng(3)
+        cm = Cell_map(1 << 14, 1.0)
+        cm.append_cloud(np.c_[rng.uniform(-5, 5, (2500, 3)), np.zeros(2500)].astype(np.float32))
+        p_dev, k_dev = cm.device_view(0)
+        mp, mk, cell_start, counts = gather_cell_maps(p_dev, k_dev)
+        assert counts == [2500] and torch.equal(mp, p_dev) and torch.equal(mk, k_dev) and mp.is_cuda
+        assert np.array_equal(cell_start.cpu().numpy(), cm.dump()[2].astype(np.int64))
+        cm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_cell_map_device_view_equals_the_dump(gpu_lib):
+    """ll_cellmap_device_view (the input of multigpu.gather_cell_maps on a GPU): the points and per-point cell keys read where they lie equal
+    ll_cellmap_dump's host copies (gather_cell_maps over an RCCL world of one: test_gather_over_rccl_world_of_one)"""
+    import torch
+    from loam_livox_amd.api import Cell_map
+    from loam_livox_amd.multigpu import cell_keys
+    rng = np.random.default_rng(21)
+    cm = Cell_map(1 << 14, 1.0)
+    for k in range(3):
+        cm.append_cloud(np.c_[rng.uniform(-6, 6, (1500 + 300 * k, 3)), np.zeros(1500 + 300 * k)].astype(np.float32))
+    xyz, ijk, start, _ = cm.dump()
+    pts, keys = cm.device_view(0)
+    assert pts.is_cuda and keys.is_cuda and pts.shape == (len(xyz), 4) and keys.dtype == torch.int64
+    assert np.array_equal(pts.cpu().numpy()[:, :3], xyz)
+    assert np.array_equal(keys.cpu().numpy(), np.repeat(cell_keys(ijk), np.diff(start)))
+    cm.close()
+
+
+def test_knn5_on_device_resident_queries_equals_the_host_call(gpu_lib, small_world):
+    """ll_map_knn5_device: the same lists as ll_map_knn5, nothing crossing PCIe, a positive kernel time"""
+    import torch
+    from loam_livox_amd.api import Map_buffer
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.SURF, small_world["surf"])
+    rng = np.random.default_rng(6)
+    q = (small_world["surf"][rng.choice(len(small_world["surf"]), 20000, replace=False), :3] + rng.normal(0, 0.05, (20000, 3))).astype(np.float32)
+    hi, hd = m.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    dq = torch.from_numpy(q).cuda()
+    di = torch.empty((len(q), 5), dtype=torch.int32, device="cuda")
+    dd = torch.empty((len(q), 5), dtype=torch.float32, device="cuda")
+    ms = m.nearestKSearch_device(Map_buffer.SURF, dq, 50.0, di, dd)
+    assert ms > 0.0 and np.array_equal(di.cpu().numpy(), hi) and np.array_equal(dd.cpu().numpy(), hd)
+    assert m.cells(Map_buffer.SURF) > 1000
+    m.close()
