@@ -450,6 +450,19 @@ class History_buffer {
     {
         check(ll_history_enable_cell_map(h_, max_points, m_pt_cell_resolution, m_para_threshold_cell_revisit), "ll_history_enable_cell_map");
     }
+    // m_matching_mode == 0 never reads the cell maps between frames (laser_mapping.hpp:1492-1493 only appends): feed them beside the mapping
+    // loop, on a service thread of the handle, as the reference runs its own map services on threads (:568-594).  Every reader
+    // (refresh_cells, cell_map_size, cell_map) waits for the frames handed over so far; sync_cell_maps() does only that.
+    void set_cell_map_async(bool enable = true) { check(ll_history_set_cell_map_async(h_, enable ? 1 : 0), "ll_history_set_cell_map_async"); }
+    void sync_cell_maps() { check(ll_history_sync_cell_maps(h_), "ll_history_sync_cell_maps"); }
+    // the cell map of one feature kind (borrowed: valid as long as this object), e.g. for ll_cellmap_device_view -- the input of a multi-GPU
+    // gather of cell maps
+    ll_cellmap *cell_map(int kind)
+    {
+        ll_cellmap *c = ll_history_cell_map(h_, kind);
+        if (!c) check(-1, "ll_history_cell_map");
+        return c;
+    }
     // update_buff_for_matching(), cell branch (laser_mapping.hpp:471-546): pose = m_q_w_curr / m_t_w_curr
     void refresh_cells(ll_map *map, const double pose[7], float m_maximum_search_range_corner = 100.0f,
                        float m_maximum_search_range_surface = 100.0f, float m_maximum_in_fov_angle = 30.0f, int m_down_sample_replace = 1,
@@ -511,7 +524,17 @@ class Points_cloud_map {
         int64_t n_touched = 0;
         check(ll_cellmap_append_touched(h_, v.data(), n, 3, ijk.data(), (int64_t)(ijk.size() / 3), &n_touched), "ll_cellmap_append_touched");
         cell_vec->clear();
-        for (int64_t i = 0; i < n_touched; i++) cell_vec->insert(Cell_index{ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2]});
+        const int64_t n_listed = n_touched < (int64_t)(ijk.size() / 3) ? n_touched : (int64_t)(ijk.size() / 3);  // (a short buffer truncates; this one never is)
+        for (int64_t i = 0; i < n_listed; i++) cell_vec->insert(Cell_index{ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2]});
+    }
+    // The reference's cells live on the heap and the map grows without bound (:619-672); the device map has a capacity: raise it, content,
+    // revisit stamps and frame counter kept (no-op when not larger).
+    void reserve(int64_t max_points) { check(ll_cellmap_reserve(h_, max_points), "ll_cellmap_reserve"); }
+    // the stored points ({x, y, z, 0}, ordered by (cell, insertion)) and the 64-bit cell key of every point where they lie on the device;
+    // valid until the next call that changes the map
+    void device_view(const float **dev_xyz0, const uint64_t **dev_point_keys, int64_t *n_points, int64_t *n_cells = nullptr)
+    {
+        check(ll_cellmap_device_view(h_, dev_xyz0, dev_point_keys, n_points, n_cells), "ll_cellmap_device_view");
     }
     int64_t get_cells_size() const  // :551-554
     {
