@@ -557,7 +557,8 @@ def main():
         q_pipe_extra["note"] = ("device VoxelGrid (leaf 0.1 / 0.4 m, laser_mapping.hpp:1367-1373) between extraction and registration; small-scan solver "
                                 "(one / two wavefronts per scan in batches of >= 512 scans, four below)")
         if Bq != B:
-            q_pipe_extra["at_the_headline_batch_size"] = q_pipe_figure(B)
+            # (a batch of 256 small scans is one scan per CU and ends with its slowest scan: only batches in flight fill the device)
+            q_pipe_extra["at_the_headline_batch_size"] = q_pipe_figure(B, in_flight=(8 if slots is not None else 0))
         # like-for-like with cpu_baseline_shipped_config[_allcores]: the same features capped at maximum_residual_blocks = 200
         q_pipe_extra["shipped_config_200_blocks"] = q_pipe_figure(Bq, shipped_cap=True)
 
