@@ -71,8 +71,6 @@ def parse():
     ap.add_argument("--q-pipe", action="store_true", help="Q-pipe query mode (SURVEY 8d): device VoxelGrid (leaf 0.1 corner / 0.4 surface, "
                     "laser_mapping.hpp:742-743,1367-1373) between extraction and registration; default is Q-full")
     ap.add_argument("--force-general", action="store_true", help="A/B: run the HBM-resident solver path that large scans use")
-    ap.add_argument("--legacy-solver", action="store_true", help="A/B: round-1 solver fast path (49-byte fp64 plane blocks, no LDS block cache)")
-    ap.add_argument("--packed48-solver", action="store_true", help="A/B: round-2 compact solver path (48-byte packed plane records) instead of the plane table")
     ap.add_argument("--no-knn-coop", action="store_true", help="A/B: corner searches one per lane everywhere (no wavefront-cooperative search)")
     ap.add_argument("--no-knn-tile", action="store_true", help="A/B: per-lane search of the surface queries + neighbour reuse (round 3) instead of the tile search")
     ap.add_argument("--knn-tile-with-reuse", action="store_true", help="A/B: tile search at ICP iterations 0 / 1, neighbour reuse + work lists afterwards")
@@ -247,9 +245,6 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
     torch.cuda.set_device(dev)
 
-    if (args.legacy_solver or args.packed48_solver) and "LOAM_LIVOX_LIB" not in os.environ:
-        # the older solver forms live in the A/B build of the library only (python -m loam_livox_amd.build --ab)
-        os.environ["LOAM_LIVOX_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loam_livox_amd", "libloamlivox_hip_ab.so")
     from loam_livox_amd import synth
     from loam_livox_amd.api import Livox_laser, Map_buffer, Point_cloud_registration, VoxelGrid
 
@@ -287,8 +282,8 @@ def main():
         q_.current_frame_index, q_.mapping_init_accumulate_frames = 100, 50
         q_.maximum_allow_residual_block = N
         r_.set_profiling(True)
-        if args.force_general or args.legacy_solver or args.packed48_solver or args.no_knn_coop or args.no_knn_tile or args.knn_tile_with_reuse:
-            r_.set_debug(False, force_general_solver=args.force_general, legacy_solver=args.legacy_solver, packed48_solver=args.packed48_solver,
+        if args.force_general or args.no_knn_coop or args.no_knn_tile or args.knn_tile_with_reuse:
+            r_.set_debug(False, force_general_solver=args.force_general,
                          no_knn_coop=args.no_knn_coop, no_knn_tile=args.no_knn_tile, knn_tile_with_reuse=args.knn_tile_with_reuse)
         return r_
 
@@ -571,7 +566,7 @@ def main():
     line_blocks = float(sum(r.corner_avail for r in reps))
     plane_blocks = float(sum(r.surf_avail for r in reps))
     queries = float(nc.sum() + ns.sum())
-    compact = not (args.force_general or args.legacy_solver)
+    compact = not args.force_general
     # residual-block constants as stored (data layout): plane blocks 48 B packed (fp32 point, fp64 normal and
     # offset; round-1 layout: the same 48 B in three planes + 1 B flag), line blocks 65 B (16 B point + 1 B flag + 48 B a', u')
     plane_bytes = 48.0 if compact else 49.0

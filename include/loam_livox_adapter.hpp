@@ -134,6 +134,19 @@ inline void check(int rc, const char *what)
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + ll_last_error());
 }
 
+// Runtime hints of the process, applied once before the adapter's first *_create (= before its first HIP call): 16 hardware queues
+// instead of the runtime's default of 4, so that registrations in flight on different handles do not share a queue
+// (ll_runtime_hint_hw_queues in loam_livox_hip.h).  The caller's environment always wins; a host that
+// initialises HIP before constructing any adapter object must export GPU_MAX_HW_QUEUES itself.  -DLOAM_LIVOX_HIP_NO_RUNTIME_HINTS
+// leaves the process environment alone.
+inline void runtime_hints()
+{
+#ifndef LOAM_LIVOX_HIP_NO_RUNTIME_HINTS
+    static std::once_flag once;
+    std::call_once(once, [] { (void)ll_runtime_hint_hw_queues(16); });
+#endif
+}
+
 template <class Cloud>
 inline std::vector<float> cloud_to_xyzi(const Cloud &c)
 {
@@ -300,6 +313,7 @@ class Livox_laser {
         p.max_points = max_points;
         p.max_scans = 1;
         p.piecewise_number = piecewise_number;
+        runtime_hints();
         check(ll_fe_create(&p, &h_), "ll_fe_create");
     }
     static size_t hash_xyz(float x, float y, float z)
@@ -378,6 +392,7 @@ class VoxelGrid {
             if (h_) ll_voxel_destroy(h_);
             h_ = nullptr;
             cap_ = n > max_points ? n : max_points;
+            runtime_hints();
             check(ll_voxel_create(device, 1, cap_, &h_), "ll_voxel_create");
         }
         std::vector<float> out(in_.size());
@@ -403,6 +418,7 @@ class History_buffer {
    public:
     History_buffer(int maximum_history_size, int max_points_per_frame, float line_res, float plane_res, int device = 0)
     {
+        runtime_hints();
         check(ll_history_create(device, maximum_history_size, max_points_per_frame, line_res, plane_res, &h_), "ll_history_create");
     }
     ~History_buffer()
@@ -493,6 +509,7 @@ class Points_cloud_map {
 
     explicit Points_cloud_map(int64_t max_points, float resolution = 1.0f, int m_minimum_revisit_threshold = 2147483647, int device = 0)
     {
+        runtime_hints();
         check(ll_cellmap_create(device, max_points, resolution, m_minimum_revisit_threshold, &h_), "ll_cellmap_create");
     }
     ~Points_cloud_map()
@@ -594,6 +611,7 @@ class Handle_pool {
                 }
         }
         ll_reg *r = nullptr;
+        runtime_hints();
         check(ll_reg_create(device, 1, max_features, &r), "ll_reg_create");
         std::lock_guard<std::mutex> lk(mu_);
         feat_.push_back(std::make_pair(r, Entry{r, device, max_features}));
@@ -629,6 +647,7 @@ class Handle_pool {
         for (auto &m : maps_)
             if (m->device == device) return *m;
         ll_map *m = nullptr;
+        runtime_hints();
         check(ll_map_create(device, &m), "ll_map_create");
         maps_.push_back(std::unique_ptr<Shared_map>(new Shared_map()));
         maps_.back()->device = device;

@@ -499,6 +499,17 @@ int ll_reg_debug_worklists(ll_reg *r, int32_t n_scans, int64_t out[4]);
 void *ll_reg_stream(ll_reg *r);
 void *ll_fe_stream(ll_fe *h);
 
+/* Process-wide runtime hint.  The ROCm runtime multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4);
+ * every handle launches on its own stream, so a host that keeps several registrations in flight (the reference runs up to
+ * maximum_parallel_thread process_new_scan tasks at once, laser_mapping.hpp:1737-1742) gets two of them on one queue, where their
+ * kernels serialise (measured on MI355X: 44.0 k -> 46.5 k scans/s with three 256-scan batches in flight, profiles/README.md).
+ * ll_runtime_hint_hw_queues(n) sets GPU_MAX_HW_QUEUES=n for this process when the caller's environment does not set it.
+ * It only takes effect when called before the process's FIRST HIP call (any library's); it never overrides the environment.
+ * Returns 1 if it set the variable, 0 if the environment already had it (nothing changed), < 0 on a bad argument.
+ * The library never calls it on its own: loam_livox_adapter.hpp does (once, before its first *_create) unless
+ * LOAM_LIVOX_HIP_NO_RUNTIME_HINTS is defined; the Python package leaves it to the application (bench.py sets the variable itself). */
+int ll_runtime_hint_hw_queues(int32_t n);
+
 const char *ll_last_error(void);
 const char *ll_version(void);
 

@@ -606,12 +606,12 @@ class Point_cloud_registration:
         return self.collect(n_scans)
 
     def set_debug(self, enable: bool = True, force_general_solver: bool = False, no_knn_reuse: bool = False,
-                  reuse_from_iter1: bool = False, legacy_solver: bool = False, no_solver_groups: bool = False,
-                  packed48_solver: bool = False, test_group_abort: bool = False, no_knn_coop: bool = False, no_knn_tile: bool = False,
+                  reuse_from_iter1: bool = False, no_solver_groups: bool = False,
+                  test_group_abort: bool = False, no_knn_coop: bool = False, no_knn_tile: bool = False,
                   knn_tile_with_reuse: bool = False, knn_tile_small_batches: bool = False, no_line_cache: bool = False,
                   no_small_solver: bool = False, small_solver_waves: int = 0, no_solve_order: bool = False):
         flags = (int(bool(enable)) | (2 if force_general_solver else 0) | (4 if no_knn_reuse else 0) | (8 if reuse_from_iter1 else 0)
-                 | (16 if legacy_solver else 0) | (32 if no_solver_groups else 0) | (64 if packed48_solver else 0)
+                 | (32 if no_solver_groups else 0)
                  | (128 if test_group_abort else 0) | (256 if no_knn_coop else 0) | (512 if no_knn_tile else 0)
                  | (1024 if knn_tile_with_reuse else 0) | (2048 if knn_tile_small_batches else 0) | (4096 if no_line_cache else 0)
                  | (32768 if no_small_solver else 0) | {0: 0, 1: 65536, 4: 131072, 2: 65536 | 131072}[int(small_solver_waves)] | (262144 if no_solve_order else 0))

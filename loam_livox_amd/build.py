@@ -29,8 +29,6 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libloamlivox_hip.so)")
 
 
-AB_LIB = os.path.join(HERE, "libloamlivox_hip_ab.so")  # the product sources + the round-1 / round-2 solver forms (-DLL_AB_PATHS): A/B references of tests / bench.py
-
 
 def needs_build(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
@@ -67,12 +65,5 @@ def build(force: bool = False, verbose: bool = False, lib: str = LIB, extra_flag
     return lib
 
 
-def build_ab(force: bool = False, verbose: bool = False) -> str:
-    """the A/B variant next to the product library (tests/test_gpu_reg.py ab_library, bench.py --legacy-solver / --packed48-solver)"""
-    return build(force, verbose, AB_LIB, ["-DLL_AB_PATHS"])
-
-
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
-    if "--no-ab" not in sys.argv:  # (the tests' A/B library goes stale silently otherwise: it exports the same C ABI)
-        print(build_ab(force="--force" in sys.argv, verbose=True))

@@ -131,6 +131,7 @@ SYMBOLS = {
     "ll_debug_quintic": (_i32, [_i32, _vp, _i32, _vp, _vp]),
     "ll_reg_stream": (_vp, [_vp]),
     "ll_fe_stream": (_vp, [_vp]),
+    "ll_runtime_hint_hw_queues": (_i32, [_i32]),
     "ll_last_error": (C.c_char_p, []),
     "ll_version": (C.c_char_p, []),
 }
@@ -138,11 +139,14 @@ SYMBOLS = {
 _lib = None
 
 
-# The ROCm runtime multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Callers that keep batches in flight (bench.py, any node with several registrars) have them on their
-# own handles = their own streams; with 4 queues two of them regularly share one and their kernels serialise (measured, profiles/README.md round 5:
-# 44.0 k scans/s with 4 queues, 46.5 k with 12 - 32; Q-pipe with three 2 048-scan batches in flight 122 k -> 169 k).  Must be set before the
-# first HIP call of the process; an explicit setting of the caller wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Importing this module does NOT touch the process environment.  Applications that keep batches in flight on several handles should set
+# GPU_MAX_HW_QUEUES (bench*.py do, before their first HIP call) or call hint_hw_queues() below first thing: the ROCm runtime multiplexes a
+# process's HIP streams onto 4 hardware queues by default (measured, profiles/README.md round 5: 44.0 k scans/s with 4 queues, 46.5 k with 12 - 32).
+
+
+def hint_hw_queues(n: int = 16) -> bool:
+    """ll_runtime_hint_hw_queues: GPU_MAX_HW_QUEUES=n for this process unless the environment sets it; effective only before the first HIP call"""
+    return check(load().ll_runtime_hint_hw_queues(int(n)), "ll_runtime_hint_hw_queues") == 1
 
 
 def load():
@@ -166,12 +170,9 @@ def load():
     return L
 
 
-AB_LIB_PATH = os.path.join(_HERE, "libloamlivox_hip_ab.so")  # -DLL_AB_PATHS build: the product library + the round-1 / round-2 solver forms
-
-
 class use_library:
     """Context manager for tests and A/B runs: objects created inside bind to the library at `path` (a variant build of the same
-    sources, e.g. AB_LIB_PATH) instead of the product library.  Each object keeps the library it was created with."""
+    sources, e.g. a -DLL_SOLVE_TIMING build) instead of the product library.  Each object keeps the library it was created with."""
 
     def __init__(self, path: str):
         self.path = path

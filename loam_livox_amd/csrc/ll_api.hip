@@ -39,6 +39,16 @@ static int set_err(const char *where, const char *what)
 extern "C" const char *ll_last_error(void) { return g_err.c_str(); }
 extern "C" const char *ll_version(void) { return "loam_livox_hip 0.1 (gfx950)"; }
 
+extern "C" int ll_runtime_hint_hw_queues(int32_t n)
+{
+    if (n < 1 || n > 64) return set_err("ll_runtime_hint_hw_queues", "n must be in 1 .. 64");
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;  // the caller's environment wins
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%d", (int)n);
+    if (setenv("GPU_MAX_HW_QUEUES", buf, 0) != 0) return set_err("ll_runtime_hint_hw_queues", "setenv failed");
+    return 1;
+}
+
 template <typename T>
 static int dmalloc(T **p, size_t count)
 {
@@ -780,11 +790,6 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.state, B);
     DM(d.blk_f, B * d.cap);
     DM(d.blk_av, B * 6 * d.cap);
-#ifdef LL_AB_PATHS  // the 48-byte packed plane records exist for the round-2 solver form only (48 B x max_scans x max_features)
-    DM(d.blk_pa, B * d.cap_s);
-    DM(d.blk_pb, B * d.cap_s);
-    DM(d.blk_pc, B * d.cap_s);
-#endif
     DM(d.blk_id, B * d.cap_s);
     {
         const int lim = d.cap_s < 24576 ? d.cap_s : 24576;  // FAST_MAX_BLOCKS: larger scans never take the plane-table path
@@ -843,7 +848,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_pa, d.blk_pb, d.blk_pc, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.solve_order, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.solve_order, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -859,11 +864,9 @@ extern "C" int ll_reg_set_debug(ll_reg *r, int32_t enable)
 {
     if (!r) return set_err("ll_reg_set_debug", "null handle");
     HC(hipSetDevice(r->device));
-#ifndef LL_AB_PATHS
     if (enable & (16 | 64))
-        return set_err("ll_reg_set_debug", "the round-1 / round-2 solver forms (bits 4 and 6) are A/B references compiled only into a -DLL_AB_PATHS build "
-                                           "(LL_LIB_OUT=... LL_EXTRA_HIPCC_FLAGS=-DLL_AB_PATHS python -m loam_livox_amd.build)");
-#endif
+        return set_err("ll_reg_set_debug", "bits 4 and 6 selected the round-1 / round-2 solver forms, which were retired in round 6 (the plane-table and the "
+                                           "general path are the only solver forms)");
     r->debug = enable;
     if ((enable & 1) && !r->dev.dbg_idx) {
         DM(r->dev.dbg_idx, (size_t)r->max_scans * r->dev.cap * 5);
@@ -889,9 +892,7 @@ extern "C" int ll_reg_set_profiling(ll_reg *r, int32_t enable)
 
 static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
 {
-#ifndef LL_AB_PATHS
-    debug &= ~(16 | 64);  // (LL_DEBUG_OR cannot ask for forms this build does not carry either)
-#endif
+    debug &= ~(16 | 64);  // (retired solver forms; LL_DEBUG_OR cannot ask for them either)
     memset(c, 0, sizeof(*c));
     c->if_motion_deblur = p->if_motion_deblur;
     c->icp_max_iterations = p->icp_max_iterations;
@@ -908,10 +909,8 @@ static int make_reg_const(const ll_reg_params *p, int debug, RegConst *c)
     c->force_general = (debug & 2) ? 1 : 0;
     c->knn_reuse = (debug & 4) ? 0 : 1;
     c->knn_reuse_from = (debug & 8) ? 1 : 2;  // bit 3: also try reuse at ICP iteration 1 (test coverage)
-    c->solver_legacy = (debug & 16) ? 1 : 0;  // bit 4: round-1 solver fast path (A/B)
     c->solve_group = (debug & 32) ? 1 : 0;    // bit 5: never spread a scan over a group of workgroups (A/B); 0 = decide per batch size
     c->test_group_abort = (debug & 128) ? 1 : 0;  // bit 7: the grouped solver gives up at once (exercises the abort / reject path)
-    c->solver_packed48 = (debug & 64) ? 1 : 0;  // bit 6: round-2 compact path (48-byte packed plane records) instead of the plane table (A/B)
     c->knn_coop = (debug & 256) ? 0 : 1;  // bit 8: corner searches per lane everywhere instead of per wavefront where few (A/B, ll_knn_coop.h)
     c->knn_tile_last_sort = (debug & 8192) ? 0 : ((debug & 16384) ? 2 : 1);  // bits 13 / 14: A/B of the re-sort schedule (sort at iteration 0 only / at 0, 1, 2)
     c->no_solve_order = (debug & 262144) ? 1 : 0;  // bit 18: the small solver's workgroups in scan order (A/B)
@@ -1047,7 +1046,7 @@ static int reg_enqueue(ll_reg *r, const ll_map *map, int n_scans, const ll_reg_p
     // A scan whose records (nearly) fit one CU's LDS cache gains nothing from it and pays ~3.5 us per exchange: voxel-filtered
     // clouds of a few thousand features (the mapping loop, Q-pipe) stay on one workgroup.
     r->rc.solve_group = (r->rc.solve_group == 1 || n_scans > LL_GRP_MAX_SCANS || r->rc.if_motion_deblur || r->rc.force_general ||
-                         r->rc.solver_legacy || max_nc + max_ns < LL_GRP_MIN_BLOCKS) ? 1 : LL_GRP;
+                         max_nc + max_ns < LL_GRP_MIN_BLOCKS) ? 1 : LL_GRP;
     if (run) {
         if (!mk0.pts || !mk1.pts) return set_err("ll_reg", "map not uploaded (or converted to fp16 points: the registrar needs the fp32 records)");
         // the searches of a registration that reuses neighbours prune with a guard band (ll_knn_core.h Grid::guard): ~8 % more

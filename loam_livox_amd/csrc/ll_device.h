@@ -124,11 +124,9 @@ struct RegConst {
     int knn_reuse;       // exact neighbour reuse across ICP iterations (ll_knn_core.h)
     int knn_reuse_from;  // first ICP iteration that tries it (iteration 1 usually moves the queries too far)
     int check_line_pca, check_plane_pca;  // K7 (PCR:46,48)
-    int solver_legacy;   // A/B switch: round-1 fast path (49-byte fp64 plane blocks, no LDS block cache)
     int solve_group;     // workgroups per scan of the compact solver (1, or LL_GRP for small batches: ll_reg_kernels.hip, group_*)
     int xch_epoch;       // ... number of this solver launch within its registration, from 1 (tags of the exchange granules, group_reduce)
     int test_group_abort; // test switch: the grouped solver behaves as if its first barrier had timed out
-    int solver_packed48; // A/B switch: round-2 compact path (48-byte packed plane records) instead of the round-3 plane table
     int knn_coop;        // corner searches by whole wavefronts where a launch has few of them (ll_knn_coop.h); 0 = A/B switch off
     int knn_tile_last_sort;  // the tile search re-sorts a scan's queries by map cell in ICP iterations 0 .. this one (1: after the first pose update too)
     int no_solve_order;  // A/B switch: the small solver's workgroups in scan order, not longest first (ll_reg_set_debug bit 18)
@@ -157,9 +155,6 @@ struct RegDev {
     int cap_c, cap_s, cap;        // cap = cap_c + cap_s
     float4 *blk_f;                // [B][cap]  f.xyz (sensor frame), w = motion-blur ratio s
     double *blk_av;               // [B][6 * cap] per scan {a0, v0}[cap], {v1, v2}[cap], {a1, a2}[cap] (16-byte pairs; ll_reg_kernels.hip av_load), frame of pose_last
-    int4 *blk_pa, *blk_pb, *blk_pc;  // [B][cap_s] packed plane blocks of the round-2 fast path, 48 B in three coalesced 16-byte planes:
-                                  // pa = {bits f.x, f.y, f.z, 0} (fp32, sensor frame), pb = {n'.x, n'.y} (fp64), pc = {n'.z, c = n'.a'} (fp64);
-                                  // the same numbers as blk_f / blk_av hold, so every solver path computes bit-identical blocks
     // round-3 compact path (solve_fast3): the plane constants {n', c} are stored once per DISTINCT neighbour triple of a scan
     // (a scan's ~17 k plane blocks share 2.4 - 4.6 k triples), built by the solver itself at the start of every launch
     unsigned short *blk_id;       // [B][cap_s] plane id of every surface block (relative to its solver workgroup's table region)

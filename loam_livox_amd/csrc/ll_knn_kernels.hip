@@ -250,7 +250,7 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
             for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
         }
         knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
-        if (!rc.check_plane_pca && rc.icp_plane && !rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
+        if (!rc.check_plane_pca && rc.icp_plane && scan_is_compact(rd, rc, b)) {
             // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
             // still knows -- no second look at rd.nn
             // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)

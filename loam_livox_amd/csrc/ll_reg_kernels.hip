@@ -15,9 +15,8 @@
 //                              the final solve and the pose composition -- replacing ceres::Solve /
 //                              Problem::Evaluate by a 28-value (21 H + 6 g + 1 cost) workgroup reduction and a
 //                              Levenberg-Marquardt controller on lane 0.  No host round trip per iteration.
-//                              Three forms: solve_fast2 (packed 48-byte plane records, LDS record cache; every C2 scan),
-//                              solve_fast (round-1 layout, A/B switch), solve_general (> 24 576 blocks or motion deblur:
-//                              flags and L1 values in HBM)
+//                              Two forms: solve_fast3 (plane table in LDS, 18 B streamed per plane block; every compact scan)
+//                              and solve_general (> 24 576 blocks or motion deblur)
 //        reg_finalize_kernel : accept / reject (:559-573)
 //        reg_merge_heads_kernel : Mid-100, the feature clouds of a sweep's heads concatenated on the device
 //
@@ -1333,658 +1332,17 @@ __device__ __forceinline__ void load_blk(const RegDev &rd, size_t sb, const doub
     av_load(av, rd.cap, slot, slot < rd.cap_c, r.a0, r.a1, r.a2, r.v0, r.v1, r.v2);
 }
 
-#ifdef LL_AB_PATHS  // round-1 form: an A/B reference for tests and bench.py --legacy-solver, not in the product library
-template <int DEBLUR>
-__device__ __noinline__ void solver_eval_fast(const RegDev &rd, int b, int nC, int total, const double *x, double huber_a, int deblur,
-                                 const unsigned char *s_flag, SolveShared &sh)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t sb = (size_t)b * rd.cap;
-    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    LL_CTX_DECL(x)
-    double acc[LL_NACC];
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
-#if RS_PREFETCH >= 2
-    // Two blocks ahead: with one workgroup per CU (LDS) the sweep is bound by latency x bytes in flight.  Measured at C2
-    // (A/B in one run): 4.46 ms of solver per step against 4.66 ms one block ahead; three ahead 4.64 ms; a ring with
-    // refill-after-use 4.85 ms and worse with depth.  The register sets rotate by name, the accumulation order is unchanged.
-    int j = tid;
-    BlkRegs cur, nxt, nx2;
-    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
-    if (j + RS_THREADS < total) load_blk(rd, sb, av, slot_of(j + RS_THREADS, nC, rd.cap_c), nxt);
-    while (j < total) {
-        const int jf = j + 2 * RS_THREADS;
-        if (jf < total) load_blk(rd, sb, av, slot_of(jf, nC, rd.cap_c), nx2);
-        const unsigned char fl = s_flag[j];
-        if (fl & BLK_ACTIVE) {
-            const double a[3] = {cur.a0, cur.a1, cur.a2};
-            const double v[3] = {cur.v0, cur.v1, cur.v2};
-            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
-        }
-        cur = nxt;
-        nxt = nx2;
-        j += RS_THREADS;
-    }
-#elif RS_PREFETCH
-    int j = tid;
-    BlkRegs cur, nxt;
-    if (j < total) load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);
-    while (j < total) {
-        const int jn = j + RS_THREADS;
-        if (jn < total) load_blk(rd, sb, av, slot_of(jn, nC, rd.cap_c), nxt);  // in flight while we compute
-        const unsigned char fl = s_flag[j];
-        if (fl & BLK_ACTIVE) {
-            const double a[3] = {cur.a0, cur.a1, cur.a2};
-            const double v[3] = {cur.v0, cur.v1, cur.v2};
-            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
-        }
-        cur = nxt;
-        j = jn;
-    }
-#else
-    for (int j = tid; j < total; j += RS_THREADS) {
-        BlkRegs cur;
-        load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), cur);  // unconditional: no dependence on the flag
-        const unsigned char fl = s_flag[j];
-        if (fl & BLK_ACTIVE) {
-            const double a[3] = {cur.a0, cur.a1, cur.a2};
-            const double v[3] = {cur.v0, cur.v1, cur.v2};
-            LL_CTX_ACCUM(fl & 3, cur.f, a, v, huber_a, acc);
-        }
-    }
-#endif
-    wave_sum_acc(acc, sh.red[wave], lane);
-    __syncthreads();
-    if (tid < LL_NACC) {
-        double s = 0.0;
-        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
-        sh.sum[tid] = s;
-    }
-    __syncthreads();
-}
-
-template <int DEBLUR>
-__device__ void solver_lm_fast(const RegDev &rd, const RegConst &rc, int b, int nC, int total, const double *x0, int max_iter,
-                               int n_active, const unsigned char *s_flag, SolveShared &sh)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
-    __syncthreads();
-    {
-        LL_T0(t0);
-        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.x, rc.huber_a, DEBLUR, s_flag, sh);
-        LL_TACC(0, t0);
-    }
-    {
-        LL_T0(t1);
-        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
-        __syncthreads();
-        LL_TACC(1, t1);
-    }
-    while (sh.need) {
-        LL_T0(t0);
-        solver_eval_fast<DEBLUR>(rd, b, nC, total, sh.ctl.cand, rc.huber_a, DEBLUR, s_flag, sh);
-        LL_TACC(0, t0);
-        LL_T0(t1);
-        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
-        __syncthreads();
-        LL_TACC(1, t1);
-    }
-}
-
-template <int DEBLUR>
-__device__ void solve_fast(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
-                           unsigned long long *s_table, unsigned char *s_flag)
-{
-    const int tid = threadIdx.x;
-    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
-    const int total = nC + nS;
-    const size_t sb = (size_t)b * rd.cap;
-    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    if (tid < 6) sh.tcyc[tid] = 0;
-    __syncthreads();
-    LL_T0(t_total);
-
-    // ---- flags -> LDS, census (PCR:325,425) -------------------------------------------------------------------
-    {
-        int na = 0, nca = 0, nsa = 0;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const unsigned char fl = rd.blk_flag0[sb + slot_of(j, nC, rd.cap_c)];
-            s_flag[j] = fl;
-            na += (fl & BLK_ACTIVE) ? 1 : 0;
-            if (fl & 8) {
-                if (j < nC) nca++; else nsa++;
-            }
-        }
-        na = block_sum_int(na, sh);
-        nca = block_sum_int(nca, sh);
-        nsa = block_sum_int(nsa, sh);
-        if (rc.subsample_seed && na > rc.max_blocks) {  // a13: "Number of residual blocks too Large, drop them" (PCR:438-458)
-            int kept = 0;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const unsigned char fl = s_flag[j];
-                if (!(fl & BLK_ACTIVE)) continue;
-                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, j, na, rc.max_blocks))
-                    s_flag[j] = fl & ~BLK_ACTIVE;
-                else
-                    kept++;
-            }
-            na = block_sum_int(kept, sh);
-        }
-        if (tid == 0) {
-            sh.n_active = na;
-            sh.n_corner_avail = nca;
-            sh.n_surf_avail = nsa;
-        }
-        __syncthreads();
-    }
-
-    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, sh);
-    int lm_iters = sh.ctl.iteration;
-
-    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483), kept in registers ------------------
-    double l1r[FAST_MAXK];
-    LL_T0(t_l1);
-    {
-        LL_CTX_DECL(sh.ctl.x)
-#pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++) {
-            const int j = tid + k * RS_THREADS;
-            double l1 = -1.0;  // marker: not an active block
-            if (j < total) {
-                const unsigned char fl = s_flag[j];
-                if (fl & BLK_ACTIVE) {
-                    BlkRegs br;
-                    load_blk(rd, sb, av, slot_of(j, nC, rd.cap_c), br);
-                    const double a[3] = {br.a0, br.a1, br.a2};
-                    const double v[3] = {br.v0, br.v1, br.v2};
-                    LL_CTX_L1(l1, fl & 3, br.f, a, v, rc.huber_a, st->pose_last);
-                }
-            }
-            l1r[k] = l1;
-        }
-    }
-
-    __syncthreads();
-    LL_TACC(2, t_l1);
-    inlier_threshold_regs(l1r, total, s_table, sh, rc);
-    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
-    {
-        const double thr = sh.thr;
-        int na = 0;
-#pragma unroll
-        for (int k = 0; k < FAST_MAXK; k++) {
-            const int j = tid + k * RS_THREADS;
-            if (j >= total) continue;
-            const unsigned char fl = s_flag[j];
-            if (!(fl & BLK_ACTIVE)) continue;
-            if (l1r[k] > thr)
-                s_flag[j] = fl & ~BLK_ACTIVE;
-            else
-                na++;
-        }
-        na = block_sum_int(na, sh);
-        if (tid == 0) sh.n_active = na;
-        __syncthreads();
-    }
-
-    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
-    {
-        __shared__ double x_start_f[7];
-        if (tid < 7) x_start_f[tid] = sh.ctl.x[tid];
-        __syncthreads();
-        solver_lm_fast<DEBLUR>(rd, rc, b, nC, total, x_start_f, rc.ceres_max_iterations, sh.n_active, s_flag, sh);
-    }
-    lm_iters += sh.ctl.iteration;
-    solve_epilogue(rc, st, sh, lm_iters);
-#ifdef LL_SOLVE_TIMING
-    LL_TACC(5, t_total);
-    if (tid == 0)
-        for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
-#endif
-}
-#endif  // LL_AB_PATHS
 
 
-// ---------------------------------------------------------------------------------------------------------
-// Round-2 fast path (scan_is_compact()).  What changed against solve_fast, and why (round-1 profile: the
-// solver launch moved 9.4x its algorithmic bytes, re-reading 49 B per plane block on each of ~9 cost evaluations at the
-// ~13 B/clk a single CU pulls from beyond its L2):
-//   * plane blocks are packed: 48 bytes (f fp32, normal and offset fp64) in three coalesced 16-byte planes, the flag in
-//     LDS.  A 32-byte form with the normal in Q1.31 fixed point was built first (solver 285 us per B = 256 launch) and
-//     withdrawn: its 4e-10 rad rounding of the normal is harmless in itself (pose change 1e-11 m on most scans) but ten
-//     forced ICP iterations amplify any deviation from the reference arithmetic through the fp32 rounding of the query
-//     positions and the discrete neighbour / inlier decisions -- one of 20 audited scans ended 1.4e-4 m away from the
-//     oracle, outside the 1e-4 m contract.  The blocks are therefore bit-identical to the other paths' again;
-//   * the first PC_RECS plane blocks of the scan are kept in LDS across the evaluations of a solve: 120 KB of
-//     s_table are idle while the LM iterations run (the set de-duplication needs them only between the two solves), so
-//     the first evaluation of each solve copies the records it streams into LDS and the later evaluations -- and the L1
-//     pass after the prerun -- read those blocks from LDS instead of HBM / Infinity Cache;
-//   * the thread <-> block map puts the planes first (thread t owns planes t, t + 512, ...; lines follow from the next
-//     whole round), so cached and streamed blocks are separate loops with no divergence;
-//   * the LM controller is inlined (ll_reg_core.h LL_LM_FN): no calling-convention spills on the lane everyone waits for.
-// The arithmetic per block, the reduction order inside a thread (planes, then lines), the wave / workgroup reduction and
-// everything after the L1 pass are those of solve_fast.
-#ifdef LL_AB_PATHS  // round-2 form: an A/B reference for tests and bench.py --packed48-solver, not in the product library
-#define PC_RECS 2560  // plane records cached in LDS (3 x 16 B each, 120 KB of s_table); a multiple of RS_THREADS
-
-struct PRec {
-    int4 a, b, c;
-};
-__device__ __forceinline__ void prec_load(const int4 *pa, const int4 *pb, const int4 *pc, int p, PRec &r)
-{
-    r.a = gload_i4(pa + p);
-    r.b = gload_i4(pb + p);
-    r.c = gload_i4(pc + p);
-}
-__device__ __forceinline__ void prec_decode(const PRec &r, double f[3], double a[3], double v[3])
-{
-    f[0] = (double)__int_as_float(r.a.x);
-    f[1] = (double)__int_as_float(r.a.y);
-    f[2] = (double)__int_as_float(r.a.z);
-    v[0] = __hiloint2double(r.b.y, r.b.x);
-    v[1] = __hiloint2double(r.b.w, r.b.z);
-    v[2] = __hiloint2double(r.c.y, r.c.x);
-    a[0] = __hiloint2double(r.c.w, r.c.z);  // n'.a'
-    a[1] = 0.0;
-    a[2] = 0.0;
-}
-
-// workgroup evaluation of cost / g / H at x over the active blocks -> sh.sum.  FILL: first evaluation of a solve, every
-// plane record is streamed and the first PC_RECS are copied to the LDS cache; otherwise those come from the cache.
-// L1OUT: this may be the last evaluation of the prerun solve -- also store every active block's loss-corrected L1 norm
-// (the quantity of PCR:476-483) into rd.blk_l1, so that the inlier pass does not have to sweep the blocks again when
-// the candidate is accepted (solve_fast2).
-template <bool FILL, bool L1OUT, bool GROUPED>
-__device__ __noinline__ void solver_eval2(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a,
-                                          const unsigned char *s_flag, int4 *cA, int4 *cB, const double *q_last_g, SolveShared &sh)
-{
-    constexpr int DEBLUR = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double q_last[4] = {0.0, 0.0, 0.0, 1.0};
-    if (L1OUT) {
-        q_last[0] = q_last_g[0];
-        q_last[1] = q_last_g[1];
-        q_last[2] = q_last_g[2];
-        q_last[3] = q_last_g[3];
-    }
-    double *l1_planes = rd.blk_l1 + (size_t)b * rd.cap + rd.cap_c;  // slot order: [0, cap_c) corner queries, then surface
-    double *l1_lines = rd.blk_l1 + (size_t)b * rd.cap;
-    LL_CTX_DECL(x)
-    double acc[LL_NACC];
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
-    const int4 *pa = rd.blk_pa + (size_t)b * rd.cap_s;
-    const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
-    const int4 *pc = rd.blk_pc + (size_t)b * rd.cap_s;
-    int4 *cC = cB + PC_RECS;
-    // The thread's k-th plane block is p0 + k * GS (one workgroup per scan: G = 1, the familiar tid + k * RS_THREADS); its
-    // first PC_RECS / RS_THREADS visits live in the LDS record cache at tid + k * RS_THREADS.
-    // (GROUPED is a template parameter so that the one-workgroup form keeps compile-time strides: as run-time values they cost
-    // the B = 256 launch 3 %)
-    constexpr int G = GROUPED ? LL_GRP : 1, GS = G * RS_THREADS;
-    constexpr int gshift = GROUPED ? 12 : 9;  // log2(GS): RS_THREADS = 512, LL_GRP = 8
-    static_assert(RS_THREADS == 512 && LL_GRP == 8 && PC_RECS % RS_THREADS == 0, "gshift assumes 512 threads and groups of 8");
-    const int p0 = GROUPED ? sh.grp_g * RS_THREADS + tid : tid;
-    int p = p0;
-    if (!FILL) {
-        const int ncached = nS < PC_RECS ? nS : PC_RECS;
-        for (int k = 0; GROUPED ? (k < PC_RECS / RS_THREADS && p < nS) : p < ncached; k++, p += GS) {
-            const int c = GROUPED ? tid + k * RS_THREADS : p;
-            PRec r;
-            r.a = cA[c];
-            r.b = cB[c];
-            r.c = cC[c];
-            if (s_flag[p] & BLK_ACTIVE) {
-                double f[3], a[3], v[3];
-                prec_decode(r, f, a, v);
-                block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);
-                if (L1OUT) gstore_f64(l1_planes + p, block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last));
-            }
-        }
-    }
-    {
-        // streamed planes, two records ahead (96 B per lane in flight); the loop is unrolled three times by hand so that
-        // the register sets rotate by name (a rolled loop spends a dozen 64-bit moves per block on r0 = r1, r1 = r2), and
-        // each record's flag byte is fetched from LDS together with it
-#define LL_PLANE_LOAD(R, FL, P)              \
-    if ((P) < nS) {                          \
-        prec_load(pa, pb, pc, (P), R);       \
-        FL = s_flag[(P)];                    \
-    }
-#define LL_PLANE_USE(R, FL, P)                                                                         \
-    if ((P) < nS) {                                                                                    \
-        if (FILL) {                                                                                    \
-            const int kk_ = ((P) - p0) >> gshift;                                                      \
-            const int c_ = GROUPED ? tid + kk_ * RS_THREADS : (P); /* one workgroup: the slot is the block index */ \
-            if (GROUPED ? kk_ < PC_RECS / RS_THREADS : (P) < PC_RECS) {                                \
-                cA[c_] = R.a;                                                                          \
-                cB[c_] = R.b;                                                                          \
-                cC[c_] = R.c;                                                                          \
-            }                                                                                          \
-        }                                                                                              \
-        if (FL & BLK_ACTIVE) {                                                                         \
-            double f[3], a[3], v[3];                                                                   \
-            prec_decode(R, f, a, v);                                                                   \
-            block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);                                \
-            if (L1OUT) gstore_f64(l1_planes + (P), block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last)); \
-        }                                                                                              \
-    }
-        PRec r0, r1, r2;
-        r0.a = r0.b = r0.c = r1.a = r1.b = r1.c = r2.a = r2.b = r2.c = make_int4(0, 0, 0, 0);
-        unsigned char f0 = 0, f1 = 0, f2 = 0;
-        constexpr int S = GS;
-        LL_PLANE_LOAD(r0, f0, p)
-        LL_PLANE_LOAD(r1, f1, p + S)
-        while (p < nS) {
-            LL_PLANE_LOAD(r2, f2, p + 2 * S)
-            LL_PLANE_USE(r0, f0, p)
-            LL_PLANE_LOAD(r0, f0, p + 3 * S)
-            LL_PLANE_USE(r1, f1, p + S)
-            LL_PLANE_LOAD(r1, f1, p + 4 * S)
-            LL_PLANE_USE(r2, f2, p + 2 * S)
-            p += 3 * S;
-        }
-#undef LL_PLANE_LOAD
-#undef LL_PLANE_USE
-    }
-    {
-        // line blocks (a few hundred per Mid-40 scan): the 65-byte fp64 form
-        const size_t sb = (size_t)b * rd.cap;
-        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-        const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
-        for (int l = p0; l < nC; l += GS) {
-            if (!(s_flag[nSp + l] & BLK_ACTIVE)) continue;
-            BlkRegs br;
-            load_blk(rd, sb, av, l, br);
-            const double a[3] = {br.a0, br.a1, br.a2};
-            const double v[3] = {br.v0, br.v1, br.v2};
-            LL_CTX_ACCUM(BLK_LINE, br.f, a, v, huber_a, acc);
-            if (L1OUT) {
-                double l1;
-                LL_CTX_L1(l1, BLK_LINE, br.f, a, v, huber_a, q_last);
-                l1_lines[l] = l1;
-            }
-        }
-    }
-    wave_sum_acc(acc, sh.red[wave], lane);
-    __syncthreads();
-    if (tid < LL_NACC) {
-        double s = 0.0;
-        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
-        sh.sum[tid] = s;
-    }
-    __syncthreads();
-    if (GROUPED) {
-        LL_T0(t_grp);  // LL_SOLVE_TIMING: the exchange's share of the evaluation (slot 9 also counts the L1 shortcut, by ones)
-        group_reduce<L1OUT>(rd, b, sh);  // the evaluation that writes the L1 values publishes them with its exchange
-        LL_TACC(9, t_grp);
-    }
-}
-
-// one ceres::Solve on the compact layout: starts at x0, leaves the result in sh.ctl
-template <bool WANT_L1, bool GROUPED>
-__device__ __forceinline__ void solver_lm2(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
-                                           int n_active, const unsigned char *s_flag, int4 *cA, int4 *cB, const double *q_last,
-                                           SolveShared &sh)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        lm_begin(sh.ctl, x0, max_iter, rc.bound);
-        sh.l1_valid = 0;
-    }
-    __syncthreads();
-    {
-        LL_T0(t0);
-        solver_eval2<true, false, GROUPED>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, s_flag, cA, cB, q_last, sh);
-        LL_TACC(0, t0);
-    }
-    {
-        LL_T0(t1);
-        if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
-        __syncthreads();
-        LL_TACC(1, t1);
-    }
-    while (sh.need) {
-        // the solve cannot go beyond iteration max_iter: if this candidate is accepted it is the solve's result
-        const bool spec = WANT_L1 && sh.ctl.iteration >= max_iter;
-        LL_T0(t0);
-        if (spec)
-            solver_eval2<false, true, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
-        else
-            solver_eval2<false, false, GROUPED>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, s_flag, cA, cB, q_last, sh);
-        LL_TACC(0, t0);
-        LL_T0(t1);
-        if (tid == 0) {
-            sh.need = lm_update(sh.ctl, sh.sum);
-            sh.l1_valid = (spec && !sh.need && sh.ctl.last_accept == 1) ? 1 : 0;
-        }
-        __syncthreads();
-        LL_TACC(1, t1);
-    }
-}
-
-// L1 values of the blocks at the prerun result -> inlier threshold -> prune (PCR:476-499).  A function of its own, not
-// inlined: the 48-entry register tile of L1 values then has the register file to itself instead of competing with the
-// inlined LM controller for it (inlined into solve_fast2 the compiler spilled half of the tile to scratch and every pass
-// over it -- de-duplication, rank select, prune -- ran at memory latency).
-template <int NK>
-__device__ __noinline__ void inlier_phase2(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh,
-                                           unsigned long long *s_table, unsigned char *s_flag, int nC, int nS)
-{
-    constexpr int DEBLUR = 0;
-    const int tid = threadIdx.x;
-    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
-    const int totp = nSp + nC;
-    const size_t sb = (size_t)b * rd.cap;
-    int4 *cA = (int4 *)s_table, *cB = cA + PC_RECS;
-    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483).  Usually the prerun's last evaluation was
-    //      accepted and has left them in blk_l1; otherwise one more pass over the blocks writes them there (a plain
-    //      rolled loop: this is the rare path), the cached planes from LDS ------------------------------------------
-    LL_T0(t_l1);
-    double *l1g = rd.blk_l1 + sb;
-    if (!sh.l1_valid) {
-        LL_CTX_DECL(sh.ctl.x)
-        const int4 *pa = rd.blk_pa + (size_t)b * rd.cap_s;
-        const int4 *pb = rd.blk_pb + (size_t)b * rd.cap_s;
-        const int4 *pc = rd.blk_pc + (size_t)b * rd.cap_s;
-        const int4 *cC = cB + PC_RECS;
-        const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-        for (int j = tid; j < totp; j += RS_THREADS) {
-            if (!(s_flag[j] & BLK_ACTIVE)) continue;
-            if (j < nS) {
-                PRec r;
-                if (j < PC_RECS && sh.grp_G == 1) {  // (a group member's cache holds its own share, in its own order)
-                    r.a = cA[j];
-                    r.b = cB[j];
-                    r.c = cC[j];
-                } else {
-                    prec_load(pa, pb, pc, j, r);
-                }
-                double f[3], a[3], v[3];
-                prec_decode(r, f, a, v);
-                l1g[rd.cap_c + j] = block_l1(BLK_PLANE, R_, t_, f, a, v, rc.huber_a, st->pose_last);
-            } else {
-                BlkRegs br;
-                load_blk(rd, sb, av, j - nSp, br);
-                const double a[3] = {br.a0, br.a1, br.a2};
-                const double v[3] = {br.v0, br.v1, br.v2};
-                double l1;
-                LL_CTX_L1(l1, BLK_LINE, br.f, a, v, rc.huber_a, st->pose_last);
-                l1g[j - nSp] = l1;
-            }
-        }
-        __syncthreads();  // every thread reads back only what it wrote itself; the barrier orders the LDS cache reads
-                          // above against the table writes below
-    } else if (tid == 0) {
-        sh.tcyc[9] += 1;  // LL_SOLVE_TIMING: how often the shortcut was taken
-    }
-    double l1r[NK];  // the thread's register tile: block j = tid + k * RS_THREADS
-    {
-        const int kt = (totp + RS_THREADS - 1) / RS_THREADS;
-#pragma unroll
-        for (int k = 0; k < NK; k++) {  // unconditional loads from clamped addresses: all in flight together
-            const int j = tid + k * RS_THREADS;
-            double v = -1.0;
-            if (k < kt) {
-                const int jc = j < totp ? j : 0;
-                const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
-                v = gload_f64(l1g + src);
-            }
-            l1r[k] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NK; k++) {
-            const int j = tid + k * RS_THREADS;
-            const bool act = j < totp && (s_flag[j < totp ? j : 0] & BLK_ACTIVE);
-            l1r[k] = act ? l1r[k] : -1.0;
-        }
-    }
-    __syncthreads();
-    LL_TACC(2, t_l1);
-
-    inlier_threshold_regs<NK>(l1r, totp, s_table, sh, rc);  // overwrites the LDS block cache; the final solve refills it
-
-    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
-    LL_T0(t_prune);
-    {
-        const double thr = sh.thr;
-        int na = 0;
-#pragma unroll
-        for (int k = 0; k < NK; k++) {
-            const int j = tid + k * RS_THREADS;
-            if (j >= totp) continue;
-            const unsigned char fl = s_flag[j];
-            if (!(fl & BLK_ACTIVE)) continue;
-            if (l1r[k] > thr)
-                s_flag[j] = fl & ~BLK_ACTIVE;
-            else
-                na++;
-        }
-        na = block_sum_int(na, sh);
-        if (tid == 0) sh.n_active = na;
-        __syncthreads();
-    }
-    LL_TACC(7, t_prune);
-}
-
-template <bool GROUPED>
-__device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, unsigned long long *s_table,
-                            unsigned char *s_flag)
-{
-    constexpr int DEBLUR = 0;
-    const int tid = threadIdx.x;
-    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
-    const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;  // lines start at a whole round
-    const int totp = nSp + nC;                                        // <= FAST_MAX_BLOCKS (scan_is_compact)
-    const size_t sb = (size_t)b * rd.cap;
-    int4 *cA = (int4 *)s_table, *cB = cA + PC_RECS;
-    if (tid < 16) sh.tcyc[tid] = 0;
-    __syncthreads();
-    LL_T0(t_total);
-    LL_T0(t_census);
-
-    // ---- flags -> LDS in the solver's order (planes, padding, lines), census (PCR:325,425) -------------------------
-    {
-        int na = 0, nca = 0, nsa = 0;
-        // eight independent byte loads per thread and trip (clamped addresses, selected afterwards): a conditional load per
-        // trip made this loop a chain of ~34 cold memory round trips (35 us of a 380 us launch)
-        for (int j0 = tid; j0 < totp; j0 += 8 * RS_THREADS) {
-            unsigned char fl8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u * RS_THREADS;
-                const int jc = j < totp ? j : 0;
-                const size_t src = jc < nS ? (size_t)rd.cap_c + jc : (jc >= nSp ? (size_t)(jc - nSp) : (size_t)rd.cap_c);
-                fl8[u] = rd.blk_flag0[sb + src];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u * RS_THREADS;
-                if (j >= totp) continue;
-                const unsigned char fl = (j < nS || j >= nSp) ? fl8[u] : (unsigned char)0;
-                s_flag[j] = fl;
-                na += (fl & BLK_ACTIVE) ? 1 : 0;
-                if (fl & 8) {
-                    if (j >= nSp) nca++; else nsa++;
-                }
-            }
-        }
-        na = block_sum_int(na, sh);
-        nca = block_sum_int(nca, sh);
-        nsa = block_sum_int(nsa, sh);
-        if (rc.subsample_seed && na > rc.max_blocks) {  // a13 (PCR:438-458); the random stream is indexed by the block's
-            int kept = 0;                               // position in the reference's order: corners, then surfaces
-            for (int j = tid; j < totp; j += RS_THREADS) {
-                const unsigned char fl = s_flag[j];
-                if (!(fl & BLK_ACTIVE)) continue;
-                const int jref = j >= nSp ? j - nSp : nC + j;
-                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, jref, na, rc.max_blocks))
-                    s_flag[j] = fl & ~BLK_ACTIVE;
-                else
-                    kept++;
-            }
-            na = block_sum_int(kept, sh);
-        }
-        if (tid == 0) {
-            sh.n_active = na;
-            sh.n_corner_avail = nca;
-            sh.n_surf_avail = nsa;
-        }
-        __syncthreads();
-    }
-    LL_TACC(6, t_census);
-
-    // ---- prerun solve (PCR:463-474); its last evaluation also leaves the per-block L1 values in blk_l1 ------------
-    solver_lm2<true, GROUPED>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
-    int lm_iters = sh.ctl.iteration;
-
-    if (totp <= 36 * RS_THREADS)  // the Mid-40 configurations: a 36-entry register tile per thread
-        inlier_phase2<36>(rd, rc, b, st, sh, s_table, s_flag, nC, nS);
-    else
-        inlier_phase2<FAST_MAXK>(rd, rc, b, st, sh, s_table, s_flag, nC, nS);
-
-    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
-    {
-        __shared__ double x_start_2[7];
-        if (tid < 7) x_start_2[tid] = sh.ctl.x[tid];
-        __syncthreads();
-        solver_lm2<false, GROUPED>(rd, rc, b, nC, nS, x_start_2, rc.ceres_max_iterations, sh.n_active, s_flag, cA, cB, st->pose_last, sh);
-    }
-    lm_iters += sh.ctl.iteration;
-    LL_T0(t_epi);
-    if (GROUPED) {
-        group_barrier<false>(rd, b, sh);  // nobody reads st->inc / st->pose_last any more
-        if (sh.grp_g != 0) return;
-        if (sh.grp_abort) {  // a barrier timed out: nothing this group computed can be trusted (reg_finalize_kernel rejects the scan)
-            if (tid == 0) {
-                st->aborted = 1;
-                st->done = 1;
-                st->icp_iters += 1;
-            }
-            return;
-        }
-    }
-    solve_epilogue(rc, st, sh, lm_iters);
-    LL_TACC(8, t_epi);
-#ifdef LL_SOLVE_TIMING
-    LL_TACC(5, t_total);
-    if (tid == 0)
-        for (int i = 0; i < 16; i++) st->dbg_cycles[i] += sh.tcyc[i];
-#endif
-}
-#endif  // LL_AB_PATHS
 
 
 // ---------------------------------------------------------------------------------------------------------
 // Round-3 compact path (scan_is_compact(), default): PLANE TABLE.  A scan's ~17 k plane blocks are built from only 2.4 - 4.6 k
 // distinct ordered (nn0, nn2, nn4) neighbour triples (the queries of a wall patch share their nearest map points), and every
-// block with the same triple carries bit-identical {n', c} -- 32 of the 48 bytes solve_fast2 re-streams on each of ~7 cost
+// block with the same triple carries bit-identical {n', c} -- 32 of the 48 bytes a per-block record form re-streams on each of ~7 cost
 // evaluations.  Here the solver workgroup de-duplicates the triples itself at the start of every launch:
 //   1. census: block flags -> a 64-bit activity mask per thread (bit k <-> block tid + k * 512 in the planes / padding / lines
-//      order of solve_fast2; no flag array in LDS);
+//      order; no flag array in LDS);
 //   2. every active plane block's triple (rd.nn) goes into an LDS hash table of 8192 16-byte slots: the key is claimed with a
 //      64-bit compare-and-swap on {p0, p1} and a 32-bit one on p2 -- whoever loses either moves on to the next slot, nobody
 //      ever waits for another lane -- and the slot index is parked in rd.blk_id;
@@ -1996,8 +1354,7 @@ __device__ void solve_fast2(const RegDev &rd, const RegConst &rc, int b, RegStat
 //      id) instead of 48 and reads the plane from LDS (ids beyond the LDS part: one 32-byte gather from the table in L2);
 //      whatever LDS the table leaves free caches the first records {f, id} of the scan across the evaluations of a solve.
 // Every block still evaluates the numbers the other paths evaluate ({n', c} from block_plane, bit for bit), in the same order;
-// the compiler contracts the multiply-adds of the two evaluation loops differently, so results agree with solve_fast2's to
-// rounding (pose 1e-12) and iteration for iteration with the oracle's (tests/test_gpu_reg.py).
+// results agree with the general path's to rounding (pose 1e-12) and iteration for iteration with the oracle's (tests/test_gpu_reg.py).
 #define PT_SLOTS 8192
 #define PT_MAX_PROBE 192
 #define PT_LDS_BYTES 155648           // s_raw of reg_solve_kernel: 152 KB
@@ -2463,7 +1820,7 @@ struct Pl3 {
         }                                                              \
     }
 
-// workgroup evaluation of cost / g / H at x over the active blocks -> sh.sum (FILL / L1OUT / GROUPED as in solver_eval2)
+// workgroup evaluation of cost / g / H at x over the active blocks -> sh.sum (FILL: this evaluation writes the LDS record cache; L1OUT: it also leaves the L1 values; GROUPED: a group member's share)
 template <bool FILL, bool L1OUT, bool GROUPED>
 __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a, unsigned long long act,
                                           uint4 *s_raw, const double *q_last_g, SolveShared &sh)
@@ -2784,12 +2141,11 @@ template <int DEBLUR>
 __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc, const f4 *map_surf)
 {
     __shared__ SolveShared sh;
-    // 152 KB shared by the paths: the round-1 / round-2 forms use 128 KB of tables + 24 KB of block flags, the plane-table form
-    // all of it (hash table -> plane table + record cache; the inlier phase's tables in between)
+    // 152 KB shared by the two paths: the plane-table form uses all of it (hash table -> plane table + record cache; the inlier
+    // phase's tables in between), the general path the first 128 KB for its de-duplication / select tables
     __shared__ uint4 s_raw[PT_LDS_BYTES / 16];
-    static_assert(PT_LDS_BYTES == HT_SIZE * 8 + FAST_MAX_BLOCKS, "s_raw = s_table + s_flag of the older paths");
+    static_assert(PT_LDS_BYTES >= HT_SIZE * 8, "s_raw holds the general path's tables");
     unsigned long long *s_table = (unsigned long long *)s_raw;
-    unsigned char *s_flag = (unsigned char *)s_raw + HT_SIZE * 8;
     int b = blockIdx.x, g = 0, G = 1;
     if (!DEBLUR && rc.solve_group > 1) {  // grouped launch (n_scans * G workgroups): scan and rank by ticket, see group_barrier
         if (threadIdx.x == 0) sh.grp_seq = atomicAdd(rd.grp_ctl, 1);
@@ -2815,18 +2171,8 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
         sh.grp_abort = (rc.test_group_abort && G > 1) ? 1 : 0;  // test switch: behave as if the first barrier had timed out
     }
     __syncthreads();
-    const int total = rd.n_corner[b] + rd.n_surf[b];
-    // The product library carries two forms: the plane-table path for compact scans (every Mid-40 configuration) and the general
-    // path (motion de-blurring, scans beyond FAST_MAX_BLOCKS).  The round-1 / round-2 forms exist only in a -DLL_AB_PATHS build
-    // (ll_reg_set_debug bits 4 and 6 are refused otherwise, ll_api.hip).
-#ifdef LL_AB_PATHS
-    if (compact && rc.solver_packed48 && G > 1) return solve_fast2<true>(rd, rc, b, st, sh, s_table, s_flag);
-    if (compact && rc.solver_packed48) return solve_fast2<false>(rd, rc, b, st, sh, s_table, s_flag);
-    if (!compact && rc.solver_legacy && total <= FAST_MAX_BLOCKS && !rc.force_general) return solve_fast<DEBLUR>(rd, rc, b, st, sh, s_table, s_flag);
-#else
-    (void)s_flag;
-    (void)total;
-#endif
+    // two forms: the plane-table path for compact scans (every Mid-40 configuration) and the general path (motion de-blurring,
+    // scans beyond FAST_MAX_BLOCKS)
     if (compact && G > 1)
         solve_fast3<true>(rd, rc, map_surf, b, st, sh, s_raw);
     else if (compact)

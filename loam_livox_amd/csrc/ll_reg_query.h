@@ -124,7 +124,7 @@ __device__ __forceinline__ bool scan_is_compact(const RegDev &rd, const RegConst
 {
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
     const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
-    return !rc.if_motion_deblur && !rc.force_general && !rc.solver_legacy && nSp + nC <= FAST_MAX_BLOCKS;
+    return !rc.if_motion_deblur && !rc.force_general && nSp + nC <= FAST_MAX_BLOCKS;
 }
 
 __device__ __forceinline__ void transform_query(const RegState *st, const RegConst &rc, const float4 &f, float pw[3])
@@ -288,7 +288,7 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
             if (rc.icp_plane) {
                 const f4 p2 = g.pts[nn.z];
                 const double pc[3] = {(double)p2.x, (double)p2.y, (double)p2.z};
-                if (!rc.solver_packed48 && scan_is_compact(rd, rc, b)) {
+                if (scan_is_compact(rd, rc, b)) {
                     // plane-table path: only the flag is decided here; the solver computes {n', c} once per distinct
                     // (nn0, nn2, nn4) triple from rd.nn (solve_fast3)
                     rd.blk_flag0[sb + slot] = plane_degenerate(pa, pb, pc) ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
@@ -299,18 +299,11 @@ __device__ __forceinline__ void build_one(const RegDev &rd, const RegConst &rc, 
         }
         if (flag & BLK_ACTIVE) {
             const float4 f = load_feature(rd, b, kind, q);
-            if (kind == 1 && scan_is_compact(rd, rc, b)) {
-                // packed plane block: 48 bytes in three coalesced 16-byte planes (ll_device.h blk_pa / blk_pb / blk_pc)
-                const size_t ps = (size_t)b * rd.cap_s + q;
-                rd.blk_pa[ps] = make_int4(__float_as_int(f.x), __float_as_int(f.y), __float_as_int(f.z), 0);
-                rd.blk_pb[ps] = make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1]));
-                rd.blk_pc[ps] = make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0]));
-            } else {
-                const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
-                rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
-                double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-                av_store(av, rd.cap, slot, kind == 0, a_out, v_out);  // line blocks keep the full a'; plane blocks only the scalar n'.a'
-            }
+            // (a compact scan's plane blocks returned above: their constants live in the solver's plane table)
+            const float sblur = rc.if_motion_deblur ? refine_blur(1, f.w, rc.min_ts, rc.max_ts) : 1.0f;
+            rd.blk_f[sb + slot] = make_float4(f.x, f.y, f.z, sblur);
+            double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
+            av_store(av, rd.cap, slot, kind == 0, a_out, v_out);  // line blocks keep the full a'; plane blocks only the scalar n'.a'
         }
     }
     rd.blk_flag0[sb + slot] = flag;  // the solver works on a copy (LDS, or blk_flag in the general path)

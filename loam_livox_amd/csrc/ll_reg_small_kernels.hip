@@ -683,7 +683,7 @@ static void launch_small(const SmallArgs &a, const RegConst &rc, int n_scans, hi
 
 bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns)
 {
-    return !rc.if_motion_deblur && !rc.force_general && !rc.solver_legacy && !rc.solver_packed48 && !rc.no_small_solver && max_nc + max_ns > 0 &&
+    return !rc.if_motion_deblur && !rc.force_general && !rc.no_small_solver && max_nc + max_ns > 0 &&
            max_nc + max_ns <= LL_SMALL_MAX_BLOCKS && max_nc <= 1024;  // (line blocks take 16 B more of LDS each)
 }
 

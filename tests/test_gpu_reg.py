@@ -22,105 +22,20 @@ def dev_map(gpu_lib, small_world):
     m.close()
 
 
-def ab_library():
-    """the -DLL_AB_PATHS build of the library: the product code + the round-1 / round-2 solver forms kept as A/B references"""
-    import os
-    from loam_livox_amd import capi
-    if not os.path.exists(capi.AB_LIB_PATH):
-        pytest.skip("libloamlivox_hip_ab.so not built (LL_LIB_OUT=.../libloamlivox_hip_ab.so LL_EXTRA_HIPCC_FLAGS=-DLL_AB_PATHS python -m loam_livox_amd.build)")
-    return capi.use_library(capi.AB_LIB_PATH)
-
-
-@pytest.fixture(scope="module")
-def ab_map(gpu_lib, small_world):
-    with ab_library():
-        m = Map_buffer()
-    m.setInputCloud(Map_buffer.CORNER, small_world["corner"])
-    m.setInputCloud(Map_buffer.SURF, small_world["surf"])
-    yield m
-    m.close()
-
-
-def set_params(reg, icp=10, ceres=20, force=1):
-    p = reg.params
-    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = icp, ceres, force
-    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 100.0
-    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
-    return p
-
-
-def test_knn5_identical_to_oracle(dev_map, small_world, scans):
-    for sc in scans[:2]:
-        _, _, _, _, fc, fs = oracle_features(sc)
-        qs = synth.transform_points(sc.pose_init, fs[:, :3])
-        oi, od = small_world["tree_s"].knn(qs, 5)
-        gi, gd = dev_map.nearestKSearch(Map_buffer.SURF, qs, 50.0)
-        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
-        qc = synth.transform_points(sc.pose_init, fc[:, :3])
-        oi, od = small_world["tree_c"].knn(qc, 5)
-        gi, gd = dev_map.nearestKSearch(Map_buffer.CORNER, qc, 2.0)   # a few hundred queries: one WAVEFRONT per query (ll_knn_coop.h)
-        inside = od < 2.0
-        assert np.array_equal(np.where(inside, oi, -1), gi)
-        assert np.array_equal(np.where(inside, od, np.inf), gd)
-        # both forms of the search on both maps: batches of up to 8192 queries go one per wavefront, larger ones one per lane
-        reps = 8192 // len(qc) + 1
-        gi2, gd2 = dev_map.nearestKSearch(Map_buffer.CORNER, np.tile(qc, (reps, 1)), 2.0)
-        assert np.array_equal(gi2.reshape(reps, -1, 5), np.broadcast_to(gi, (reps,) + gi.shape))
-        assert np.array_equal(gd2.reshape(reps, -1, 5), np.broadcast_to(gd, (reps,) + gd.shape))
-        oi, od = small_world["tree_s"].knn(qs[:3000], 5)
-        gi, gd = dev_map.nearestKSearch(Map_buffer.SURF, qs[:3000], 50.0)
-        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
-
-
-def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
-    rng = np.random.default_rng(2)
-    pts = rng.uniform(0, 30, (4000, 3)).astype(np.float32)
-    pts[100:104] = pts[100]
-    pts[7, 0] = np.nan
-    m = Map_buffer()
-    m.setInputCloud(Map_buffer.SURF, pts, 0.7)
-    tree = orc.KdTree(np.where(np.isfinite(pts), pts, 1e9).astype(np.float32))
-    q = np.concatenate([rng.uniform(-8, 38, (500, 3)), pts[100:101], [[1e6, 0, 0]], [[np.nan, 0, 0]]]).astype(np.float32)
-    gi, gd = m.nearestKSearch(Map_buffer.SURF, q, 50.0)      # 503 queries: one wavefront per query, rings and the cube sweep included
-    oi, od = tree.knn(np.nan_to_num(q, nan=1e9), 5)
-    inside = od < 50.0
-    assert np.array_equal(np.where(inside, oi, -1)[:-2], gi[:-2])
-    assert np.array_equal(np.where(inside, od, np.inf)[:-2], gd[:-2])
-    gi_l, gd_l = m.nearestKSearch(Map_buffer.SURF, np.tile(q, (17, 1)), 50.0)   # 8551 queries: one lane per query
-    assert np.array_equal(gi_l.reshape(17, -1, 5), np.broadcast_to(gi, (17,) + gi.shape))
-    assert np.array_equal(gd_l.reshape(17, -1, 5), np.broadcast_to(gd, (17,) + gd.shape))
-    assert np.all(gi[-2:] == -1)
-    assert gi[500].tolist()[:4] == [100, 101, 102, 103]
-    # xyzi stride-4 input gives the same answer
-    m2 = Map_buffer()
-    m2.setInputCloud(Map_buffer.SURF, np.c_[pts, np.ones(len(pts), np.float32)], 0.7)
-    gi2, _ = m2.nearestKSearch(Map_buffer.SURF, q, 50.0)
-    assert np.array_equal(gi, gi2)
-    m.close(); m2.close()
-
-
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 @pytest.mark.parametrize("force", [0, 1])
-@pytest.mark.parametrize("general", [False, "single", True, "legacy", "packed48", "packed48_single"])
+@pytest.mark.parametrize("general", [False, "single", True])
 def test_registration_matches_oracle(request, dev_map, small_world, scans, k, force, general):
     """general=False: round-3 compact path (plane table: {n', c} once per distinct neighbour triple, 18-byte block records) in
     the form a batch of one takes: the scan spread over a group of 8 workgroups; "single": the same path with one workgroup
     per scan, as batches of more than 16 scans run it; True: the HBM-resident path used by scans with more than 24576
-    residual blocks (forced here on a normal scan); "legacy": the round-1 fast path (blocks re-read on every evaluation) and
-    "packed48[_single]": the round-2 compact path (48-byte packed plane records), both kept as A/B references in the
-    -DLL_AB_PATHS build of the library only (the product library refuses the switches)."""
-    import contextlib
-    ab = general in ("legacy", "packed48", "packed48_single")
-    if ab:
-        dev_map = request.getfixturevalue("ab_map")
+    residual blocks (forced here on a normal scan)."""
     sc = scans[k]
     _, _, _, _, fc, fs = oracle_features(sc)
     prm = orc.RegParams.defaults(icp_iters=10, ceres_iters=20, force_all=force)
     ret, pc, pi, rep = orc.reg_solve(small_world["tree_c"], small_world["tree_s"], fc, fs, prm, sc.pose_init, sc.pose_init)
-    with (ab_library() if ab else contextlib.nullcontext()):
-        reg = Point_cloud_registration(max_scans=1, max_features=24000)
-    reg.set_debug(True, force_general_solver=(general is True), legacy_solver=(general == "legacy"),
-                  no_solver_groups=(general in ("single", "packed48_single")), packed48_solver=str(general).startswith("packed48"))
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(True, force_general_solver=(general is True), no_solver_groups=(general == "single"))
     set_params(reg, 10, 20, force)
     reg.m_pose_w_last = sc.pose_init.copy()
     reg.m_pose_w_curr = sc.pose_init.copy()
@@ -148,8 +63,7 @@ def test_registration_matches_oracle(request, dev_map, small_world, scans, k, fo
     reg.close()
 
 
-@pytest.mark.parametrize("packed48", [False, True])
-def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans, packed48):
+def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans):
     """A group barrier of the small-batch solver that does not complete (bounded spin; forced here) must not hand back a NaN
     pose as an accepted result: the scan is rejected with its pose restored and ll_reg_collect reports the failure."""
     import ctypes as C
@@ -158,12 +72,8 @@ def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans, packed48)
     sc = scans[0]
     _, _, _, _, fc, fs = oracle_features(sc)
     assert len(fc) + len(fs) >= 6000  # large enough for the grouped form
-    import contextlib
-    if packed48:
-        dev_map = request.getfixturevalue("ab_map")
-    with (ab_library() if packed48 else contextlib.nullcontext()):
-        reg = Point_cloud_registration(max_scans=1, max_features=24000)
-    reg.set_debug(False, test_group_abort=True, packed48_solver=packed48)
+    reg = Point_cloud_registration(max_scans=1, max_features=24000)
+    reg.set_debug(False, test_group_abort=True)
     set_params(reg, 4, 20, 1)
     reg.upload_features([fc], [fs])
     pl = sc.pose_init.reshape(1, 7).copy()
@@ -174,7 +84,7 @@ def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans, packed48)
     assert rc == 1 and b"timed out" in reg.L.ll_last_error()   # one aborted scan: reported, not an error of the call
     assert res[0] == 0 and reps[0].accepted == 0 and reps[0].aborted == 1 and np.array_equal(pc[0], sc.pose_init) and np.all(np.isfinite(pc))
     # the handle is usable afterwards
-    reg.set_debug(False, packed48_solver=packed48)
+    reg.set_debug(False)
     reg.enqueue_uploaded(dev_map, 1, pl, pl)
     res2, pc2, _, reps2 = reg.collect(1)
     assert res2[0] == 1 and np.all(np.isfinite(pc2)) and not np.array_equal(pc2[0], sc.pose_init) and reps2[0].aborted == 0
@@ -183,28 +93,25 @@ def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans, packed48)
 
 @pytest.mark.parametrize("groups", [False, True])
 @pytest.mark.parametrize("world", ["rooms", "random_cloud"])
-def test_plane_table_agrees_with_packed_records(ab_map, scans, groups, world):
-    """The plane-table solver path evaluates, block for block and in the same order, the numbers of the round-2 path that
-    stores {n', c} with every block (the compiler contracts the two instantiations' multiply-adds differently, so they agree to
-    rounding, not to the bit) -- on the synthetic rooms (a few thousand distinct neighbour triples: the whole table in LDS) and
+def test_plane_table_agrees_with_per_block_records(dev_map, scans, groups, world):
+    """The plane-table solver path evaluates, block for block, the numbers of the general path, which stores {n', c} with every
+    block (different evaluation loops and summation grouping, so they agree to rounding, not to the bit) -- on the synthetic rooms (a few thousand distinct neighbour triples: the whole table in LDS) and
     against a uniform random cloud, where nearly every block has a triple of its own: the LDS hash table fills up (private
     table entries), the table overflows its LDS part (planes gathered from HBM) and nothing is de-duplicated."""
     sc = scans[1]
     _, _, _, _, fc, fs = oracle_features(sc)
     if world == "rooms":
-        m = ab_map
+        m = dev_map
     else:
         rng = np.random.default_rng(5)
         lo, hi = synth.transform_points(sc.pose_init, fs[:, :3]).min(0) - 1.0, synth.transform_points(sc.pose_init, fs[:, :3]).max(0) + 1.0
-        with ab_library():
-            m = Map_buffer()
+        m = Map_buffer()
         m.setInputCloud(Map_buffer.CORNER, rng.uniform(lo, hi, (60000, 3)).astype(np.float32))
         m.setInputCloud(Map_buffer.SURF, rng.uniform(lo, hi, (400000, 3)).astype(np.float32))
     out = []
-    for packed in (False, True):   # (both forms from the A/B build: the same compiler run)
-        with ab_library():
-            reg = Point_cloud_registration(max_scans=1, max_features=24000)
-        reg.set_debug(False, packed48_solver=packed, no_solver_groups=not groups)
+    for per_block in (False, True):
+        reg = Point_cloud_registration(max_scans=1, max_features=24000)
+        reg.set_debug(False, force_general_solver=per_block, no_solver_groups=not groups)
         set_params(reg, 2 if world != "rooms" else 4, 20, 1)
         reg.m_pose_w_last = sc.pose_init.copy()
         reg.m_pose_w_curr = sc.pose_init.copy()
@@ -711,13 +618,13 @@ def test_map_refresh_while_registering_uses_immutable_snapshots(gpu_lib, small_w
     assert seen == {0, 1}  # the refresher really did swap maps under the registrars
 
 
-def test_product_library_refuses_the_ab_solver_forms(gpu_lib):
-    """ll_reg_set_debug bits 4 / 6 (round-1 / round-2 solver forms) exist only in a -DLL_AB_PATHS build"""
-    from loam_livox_amd.capi import LoamLivoxError
+def test_library_refuses_the_retired_solver_forms(gpu_lib):
+    """ll_reg_set_debug bits 4 / 6 selected the round-1 / round-2 solver forms, retired in round 6: refused, not ignored"""
+    from loam_livox_amd.capi import LoamLivoxError, check
     reg = Point_cloud_registration(max_scans=1, max_features=1000)
-    for kw in ({"legacy_solver": True}, {"packed48_solver": True}):
-        with pytest.raises(LoamLivoxError, match="LL_AB_PATHS"):
-            reg.set_debug(False, **kw)
+    for bits in (16, 64):
+        with pytest.raises(LoamLivoxError, match="retired"):
+            check(reg.L.ll_reg_set_debug(reg.h, bits), "ll_reg_set_debug")
     reg.set_debug(False)
     reg.close()
 

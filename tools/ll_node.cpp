@@ -2,8 +2,14 @@
 // path, running on include/loam_livox_adapter.hpp (and through it the C ABI / the HIP library):
 //
 //   Laser_feature::laserCloudHandler, Livox branch      source/laser_feature_extractor.hpp:241-392
-//   Laser_mapping::process_new_scan (+ the three cloud  source/laser_mapping.hpp:1316-1520, 836-868
+//   Laser_mapping::process_new_scan (+ the three cloud  source/laser_mapping.hpp:1316-1520, 749-780
 //   handlers and init_pointcloud_registration)          source/laser_mapping.hpp:1266-1297
+//   Laser_mapping::process, the queue of complete       source/laser_mapping.hpp:89-120, 633-647, 1697-1711
+//   triples and the maximum_mapping_buffer drop rule
+//   the node's outputs: /velodyne_cloud_registered,     source/laser_mapping.hpp:1570-1575, 1613-1653
+//   /aft_mapped_to_init, /aft_mapped_path, the
+//   camera_init -> aft_mapped transform
+//   service_pub_surround_pts: /laser_cloud_surround     source/laser_mapping.hpp:1151-1200, 1567
 //
 // ROS is absent from the image, so the node/topic surface is kept in shape only: messages are PointCloud2-shaped structs
 // (header, fields, point_step, byte payload), nodes talk through named in-process topics with the reference's names
@@ -11,12 +17,22 @@
 // with the reference's parameter names.  What the reference does on service threads (update_buff_for_matching,
 // laser_mapping.hpp:568-594) is done synchronously after every accepted frame, so a run is reproducible.
 //
-//   ll_node --in seq.bin --out log.txt [--param name=value ...]
+//   ll_node --in seq.bin --out log.txt [--param name=value ...] [--dump-io io.bin]
+//   ll_node --replay-io io.bin --out log.txt [--param name=value ...]
+//
+// Outputs are message-shaped structs with the field layout and frame ids of nav_msgs/Odometry, nav_msgs/Path,
+// geometry_msgs/PoseStamped, tf::StampedTransform and sensor_msgs/PointCloud2, published on the reference's topic names; a
+// recorder subscribed to every output topic writes one log line per message (ODOM / PATH / TF / CLOUD).  --dump-io records
+// what the mapping node was handed (handler calls, process passes, publish calls); --replay-io drives the same handler /
+// queue / publish code from such a record without touching the GPU -- tests/test_ll_node_outputs.py runs the reference's
+// own text (laser_mapping.hpp:89-120, 633-647, 749-780, 1701-1711, 1570-1575, 1613-1653 compiled against stub ROS types) on
+// the same record and compares every field.
 //
 // seq.bin: "LLSEQ001", int32 n_messages, then per message { int32 lidar_index, float64 stamp, int32 n_points,
 // n_points x 4 float32 (x, y, z, intensity) } -- tools/ll_sequence.py writes it.  log.txt gets one line per published
-// piece (PUB: sizes and hashes of the three clouds) and one per processed scan (REG: result, pose, stack and
-// match-buffer sizes); tests/test_ll_node.py compares it with the Python mirrors (feature_node.py / mapping.py).
+// piece (PUB: sizes and hashes of the three clouds), one per processed scan (REG: result, pose, stack and
+// match-buffer sizes) and one per output message; tests/test_ll_node.py compares PUB / REG with the Python mirrors
+// (feature_node.py / mapping.py).
 #include <cinttypes>
 #include <cstdint>
 #include <cstdio>
@@ -53,6 +69,52 @@ struct PointCloud2 {
     uint32_t point_step = 0, row_step = 0;
     std::vector<uint8_t> data;
     bool is_dense = true;
+};
+
+// geometry_msgs / nav_msgs / tf shapes (field names and nesting of the ROS messages the reference fills, laser_mapping.hpp:1613-1653)
+struct Point {
+    double x = 0, y = 0, z = 0;
+};
+struct Quaternion {
+    double x = 0, y = 0, z = 0, w = 1;
+};
+struct Pose {
+    Point position;
+    Quaternion orientation;
+};
+struct PoseWithCovariance {
+    Pose pose;
+    double covariance[36] = {0};
+};
+struct Vector3 {
+    double x = 0, y = 0, z = 0;
+};
+struct Twist {
+    Vector3 linear, angular;
+};
+struct TwistWithCovariance {
+    Twist twist;
+    double covariance[36] = {0};
+};
+struct Odometry {  // nav_msgs/Odometry
+    Header header;
+    std::string child_frame_id;
+    PoseWithCovariance pose;
+    TwistWithCovariance twist;
+};
+struct PoseStamped {  // geometry_msgs/PoseStamped
+    Header header;
+    Pose pose;
+};
+struct Path {  // nav_msgs/Path
+    Header header;
+    std::vector<PoseStamped> poses;
+};
+struct StampedTransform {  // tf::StampedTransform( transform, stamp, frame_id, child_frame_id )
+    double stamp_ = 0;
+    std::string frame_id_, child_frame_id_;
+    double origin[3] = {0, 0, 0};
+    double rotation[4] = {0, 0, 0, 1};  // x, y, z, w
 };
 
 struct PointXYZI {
@@ -108,11 +170,12 @@ static void fromROSMsg(const PointCloud2 &m, Cloud &c)
 }
 
 // ------------------------------------------------------------------------------------------------ topics, parameters
-class Topics {
+template <class Msg>
+class Bus {
    public:
-    typedef std::function<void(const PointCloud2 &)> Callback;
+    typedef std::function<void(const Msg &)> Callback;
     void subscribe(const std::string &name, Callback cb) { subs_[name].push_back(cb); }
-    void publish(const std::string &name, const PointCloud2 &m)
+    void publish(const std::string &name, const Msg &m)
     {
         auto it = subs_.find(name);
         if (it == subs_.end()) return;
@@ -121,6 +184,16 @@ class Topics {
 
    private:
     std::map<std::string, std::vector<Callback>> subs_;
+};
+class Topics {
+   public:
+    typedef Bus<PointCloud2>::Callback Callback;
+    void subscribe(const std::string &name, Callback cb) { clouds.subscribe(name, cb); }
+    void publish(const std::string &name, const PointCloud2 &m) { clouds.publish(name, m); }
+    Bus<PointCloud2> clouds;
+    Bus<Odometry> odometry;
+    Bus<Path> paths;
+    Bus<StampedTransform> tf;  // tf::TransformBroadcaster::sendTransform -> "/tf"
 };
 
 class Params {
@@ -141,6 +214,39 @@ class Params {
    private:
     std::map<std::string, std::string> table_;
 };
+
+static uint64_t cloud_hash(const Cloud &c);
+static uint64_t msg_hash(const PointCloud2 &m)  // of the payload as the subscriber decodes it
+{
+    Cloud c;
+    fromROSMsg(m, c);
+    return cloud_hash(c);
+}
+
+// The recorder of the node's outputs: one log line per message on every output topic, all fields.
+static void record_outputs(Topics &topics, FILE *log)
+{
+    for (const char *name : {"/velodyne_cloud_registered", "/laser_cloud_surround"})
+        topics.clouds.subscribe(name, [log, name](const PointCloud2 &m) {
+            std::fprintf(log, "CLOUD %s %.17g %s %u %u %u %d %016" PRIx64 "\n", name, m.header.stamp, m.header.frame_id.c_str(), m.width, m.height, m.point_step,
+                         (int)m.fields.size(), msg_hash(m));
+        });
+    topics.odometry.subscribe("/aft_mapped_to_init", [log](const Odometry &o) {
+        std::fprintf(log, "ODOM /aft_mapped_to_init %.17g %s %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", o.header.stamp, o.header.frame_id.c_str(),
+                     o.child_frame_id.c_str(), o.pose.pose.position.x, o.pose.pose.position.y, o.pose.pose.position.z, o.pose.pose.orientation.x,
+                     o.pose.pose.orientation.y, o.pose.pose.orientation.z, o.pose.pose.orientation.w);
+    });
+    topics.paths.subscribe("/aft_mapped_path", [log](const Path &p) {
+        const PoseStamped &l = p.poses.back();
+        std::fprintf(log, "PATH /aft_mapped_path %.17g %s %zu %.17g %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", p.header.stamp, p.header.frame_id.c_str(),
+                     p.poses.size(), l.header.stamp, l.header.frame_id.c_str(), l.pose.position.x, l.pose.position.y, l.pose.position.z, l.pose.orientation.x,
+                     l.pose.orientation.y, l.pose.orientation.z, l.pose.orientation.w);
+    });
+    topics.tf.subscribe("/tf", [log](const StampedTransform &t) {
+        std::fprintf(log, "TF %.17g %s %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t.stamp_, t.frame_id_.c_str(), t.child_frame_id_.c_str(), t.origin[0], t.origin[1],
+                     t.origin[2], t.rotation[0], t.rotation[1], t.rotation[2], t.rotation[3]);
+    });
+}
 
 static uint64_t cloud_hash(const Cloud &c)  // position-weighted sum of the cloud's 32-bit words, mod 2^64 (tools/ll_sequence.py: cloud_hash)
 {
