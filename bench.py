@@ -214,10 +214,14 @@ def dry_run(args, rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     per = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(per, torch.tensor([args.batch * args.steps / elapsed], dtype=torch.float64))
+    # the HIP device every rank's handles would be created on: main() passes `dev` = LOCAL_RANK to every ll_*_create (tests/test_bench_helpers.py
+    # checks the call sites)
+    devs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(devs, torch.tensor([int(os.environ.get("LOCAL_RANK", "0"))], dtype=torch.int64))
     if rank == 0:
         print(json.dumps({"metric": "scans_per_s", "dry_run": True, "n_gpus": dist.get_world_size(), "requested_gpus": args.gpus,
                           "value": round(args.batch * args.steps * world / float(t.item()), 2),
-                          "per_rank_scans_per_s": [round(float(x.item()), 2) for x in per]}))
+                          "per_rank_scans_per_s": [round(float(x.item()), 2) for x in per], "devices": [int(x.item()) for x in devs]}))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -508,6 +508,7 @@ class Points_cloud_map {
     enum Feature_type { e_feature_sphere = 0, e_feature_line = 1, e_feature_plane = 2 };  // cell_map_keyframe.hpp:46-51
 
     explicit Points_cloud_map(int64_t max_points, float resolution = 1.0f, int m_minimum_revisit_threshold = 2147483647, int device = 0)
+        : capacity_(max_points)
     {
         runtime_hints();
         check(ll_cellmap_create(device, max_points, resolution, m_minimum_revisit_threshold, &h_), "ll_cellmap_create");
@@ -553,6 +554,30 @@ class Points_cloud_map {
     {
         check(ll_cellmap_device_view(h_, dev_xyz0, dev_point_keys, n_points, n_cells), "ll_cellmap_device_view");
     }
+    // grows the capacity (doubling) so that n_more points fit: the reference's map grows on the heap without bound
+    void reserve_for(size_t n_more)
+    {
+        int64_t n_pts = 0, cap = capacity_;
+        check(ll_cellmap_stats(h_, nullptr, &n_pts, nullptr), "ll_cellmap_stats");
+        if (cap <= 0) cap = 1;
+        while (cap < n_pts + (int64_t)n_more) cap *= 2;
+        if (cap != capacity_) {
+            reserve(cap);
+            capacity_ = cap;
+        }
+    }
+    // find_cells_in_radius( centre, radius ) (:761-788) followed by what service_pub_surround_pts does with the cells
+    // (laser_mapping.hpp:1172-1187): every cell's cloud through pcl::VoxelGrid( leaf ) on its own, concatenated in ascending cell order;
+    // nothing is stored back.  pose[4..6] is the centre (no field-of-view test: maximum_in_fov_angle >= 360 switches it off).
+    template <class Cloud>
+    void find_cells_in_radius_filtered(const double pose[7], float radius, float leaf, Cloud &out)
+    {
+        int64_t n_sel = 0, n_out = 0;
+        check(ll_cellmap_query_filter(h_, pose, radius, 360.0f, leaf, 0, &n_sel, &n_out), "ll_cellmap_query_filter");
+        std::vector<float> v((size_t)(n_out > 0 ? n_out : 0) * 4);
+        if (n_out > 0 && ll_cellmap_result(h_, v.data(), n_out) < 0) check(-1, "ll_cellmap_result");
+        xyzi_to_cloud(v.data(), (int)n_out, out);
+    }
     int64_t get_cells_size() const  // :551-554
     {
         int64_t n = 0;
@@ -585,6 +610,7 @@ class Points_cloud_map {
 
    private:
     ll_cellmap *h_ = nullptr;
+    int64_t capacity_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------

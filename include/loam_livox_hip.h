@@ -382,6 +382,8 @@ int ll_history_map_cloud_device(ll_history *h, int32_t kind, const float **dev_x
  * ll_cellmap_query_filter: the cells whose centre lies within `radius` of the pose's translation and within
  * maximum_in_fov_angle degrees of its x axis, each passed through pcl::VoxelGrid(leaf) on its own, concatenated;
  * down_sample_replace != 0 stores the filtered points back into the cells (laser_mapping.hpp:492-495).
+ * maximum_in_fov_angle >= 360 switches the field-of-view test off: find_cells_in_radius on its own, as service_pub_surround_pts
+ * uses it for /laser_cloud_surround (laser_mapping.hpp:1172-1187).
  * Order of the result: cells ascending by (ix, iy, iz) -- the reference's order is that of a PCL octree traversal and
  * is not reproducible; within a cell, PCL's leaf order.  Non-finite points and points beyond +-2^20 cells are dropped. */
 typedef struct ll_cellmap ll_cellmap;

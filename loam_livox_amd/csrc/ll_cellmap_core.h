@@ -73,8 +73,10 @@ LL_HD bool cell_in_radius(const float c[3], const float sp[3], float radius)
 }
 
 // Laser_mapping::if_pt_in_fov (LM:310-324) on a cell centre; q = (x, y, z, w), t = translation of the current pose
+// maximum_in_fov_angle >= 360: no field-of-view test at all (find_cells_in_radius on its own, CMK:761-788 as service_pub_surround_pts calls it, LM:1172)
 LL_HD bool cell_in_fov(const float c[3], const double q[4], const double t[3], double maximum_in_fov_angle)
 {
+    if (maximum_in_fov_angle >= 360.0) return true;
     const double v[3] = {(double)c[0] - t[0], (double)c[1] - t[1], (double)c[2] - t[2]};
     // Eigen: q.inverse() = conjugate / squaredNorm, then the quaternion-vector product v + w * 2(u x v) + u x 2(u x v)
     const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];

@@ -102,6 +102,8 @@ class CellMap:
         return out
 
     def select(self, pose, radius, maximum_in_fov_angle):
+        if maximum_in_fov_angle >= 360.0:  # find_cells_in_radius on its own, as service_pub_surround_pts calls it (LM:1172): no field-of-view test
+            return list(self.cells_in_radius(pose[4:], radius))
         return [key for key in self.cells_in_radius(pose[4:], radius) if self.in_fov(self.centre(key), pose, maximum_in_fov_angle)]
 
     # LM:481-497 (corners) / :499-513 (planes)

@@ -90,6 +90,39 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert d["value"] == 2 * 4 * 2 / 0.020  # all ranks' scans over the slowest rank's time
 
 
+def test_bench_gpus_8_dry_run_and_every_handle_binds_local_rank():
+    """The first hardware run with 8 ranks is the driver's: it must not be the first time 8 ranks meet.  `bench.py --gpus 8 --dry-run`
+    (gloo, no GPU): one line, world size 8, every rank reporting its own LOCAL_RANK as the device it would bind -- and, read off
+    the source, every device handle bench.py / bench_c4.py create is given that device (`device=dev`, dev = LOCAL_RANK)."""
+    import ast
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--batch", "4", "--steps", "2"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["devices"] == list(range(8)) and len(d["per_rank_scans_per_s"]) == 8
+    assert d["value"] == 8 * 4 * 2 / 0.080
+    handles = {"Livox_laser", "Map_buffer", "Point_cloud_registration", "VoxelGrid", "History_buffer", "Cell_map", "Laser_mapping"}
+    for script in ("bench.py", "bench_c4.py"):
+        tree = ast.parse(open(os.path.join(root, script)).read())
+        calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in handles]
+        assert len(calls) >= 3, script
+        for c in calls:
+            kw = {k.arg: k.value for k in c.keywords}
+            assert "device" in kw and isinstance(kw["device"], ast.Name) and kw["device"].id in ("dev", "local_rank"), (script, c.lineno)
+        for a in (n for n in ast.walk(tree) if isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "dev" for t in n.targets)):
+            assert "local_rank" in ast.unparse(a.value), script   # dev = LOCAL_RANK
+        for a in (n for n in ast.walk(tree) if isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "local_rank" for t in n.targets)):
+            assert "LOCAL_RANK" in ast.unparse(a.value), script
+
+
 @pytest.mark.parametrize("n_slots", [1, 2, 3, 4])
 @pytest.mark.parametrize("k_steps", [1, 2, 5, 20])
 def test_pipeline_schedule_starts_and_collects_every_batch_once_and_never_reuses_a_busy_slot(n_slots, k_steps):

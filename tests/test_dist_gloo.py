@@ -202,3 +202,69 @@ def test_gather_cell_maps_world2_gloo(tmp_path):
                           "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("cell maps ok") == 2
+
+
+CELLMAP8_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from loam_livox_amd.multigpu import cell_keys, gather_cell_maps, gather_submaps
+from oracle.orc_cellmap import CellMap
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+SIZES = [700, 0, 1900, 130, 0, 2600, 1, 940]   # ragged, two ranks with nothing, one with a single point
+
+
+def rank_rows(r):
+    rng = np.random.default_rng(900 + r)
+    m = CellMap(1.0)
+    n = SIZES[r]
+    if n:
+        m.append(np.c_[rng.uniform(-6 + 2 * r, 4 + 2 * r, (n, 3)), np.zeros(n)].astype(np.float32))
+    xyz, ijk, start, _ = m.dump()
+    return np.c_[xyz, np.zeros(len(xyz), np.float32)].astype(np.float32).reshape(-1, 4), np.repeat(cell_keys(ijk), np.diff(start)).astype(np.int64)
+
+
+pts, keys = rank_rows(rank)
+mp, mk, cell_start, counts = gather_cell_maps(torch.from_numpy(pts), torch.from_numpy(keys))
+assert counts == SIZES, counts
+union = CellMap(1.0)
+for r in range(world):
+    p, _ = rank_rows(r)
+    if len(p):
+        union.append(p)
+uxyz, uijk, ustart, _ = union.dump()
+assert np.array_equal(mp.numpy()[:, :3], uxyz) and np.array_equal(mk.numpy(), np.repeat(cell_keys(uijk), np.diff(ustart)))
+assert np.array_equal(cell_start.numpy(), ustart.astype(np.int64))
+# every rank holds the same union (checksum of checksums over the ranks)
+chk = torch.tensor([float(mp.double().sum()), float(mk.double().sum())], dtype=torch.float64)
+allchk = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(allchk, chk)
+assert all(torch.equal(c, allchk[0]) for c in allchk)
+# the plain sub-map gather with the same ragged sizes, every rank empty but one, and everyone empty
+out, c2 = gather_submaps(torch.from_numpy(pts))
+assert c2 == SIZES and out.shape[0] == sum(SIZES)
+lone = torch.from_numpy(pts) if rank == 5 else torch.zeros((0, 4))
+out3, c3 = gather_submaps(lone)
+assert c3 == [0, 0, 0, 0, 0, SIZES[5], 0, 0] and torch.equal(out3, torch.from_numpy(rank_rows(5)[0]))
+out4, c4 = gather_submaps(torch.zeros((0, 4)))
+assert c4 == [0] * 8 and out4.shape == (0, 4)
+print("rank", rank, "cell maps of eight ok")
+dist.destroy_process_group()
+"""
+
+
+def test_gather_cell_maps_world8_ragged_and_empty_ranks_gloo(tmp_path):
+    """eight ranks (the node the driver measures on) with ragged cell maps, two of them empty, one holding a single point: counts,
+    the union in cell-map layout against the oracle's cell map fed rank by rank, the same union on every rank; and the sub-map
+    gather when only one rank / no rank has anything to send"""
+    script = tmp_path / "cellmap8_worker.py"
+    script.write_text(CELLMAP8_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("cell maps of eight ok") == 8

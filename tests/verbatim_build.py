@@ -1152,3 +1152,357 @@ def build_cell_refresh(force=False):
         subprocess.check_call(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", stubs, "-I", os.path.join(REF, "source"),
                                "-I", os.path.join(REF, "include"), "-I", os.path.join(REF, "include", "tools"), "-o", EXE_CELLREFRESH, src])
     return EXE_CELLREFRESH
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The mapping node's message surface (output side): the three cloud handlers with the queue of complete triples, the
+# body of Laser_mapping::process's loop with the maximum_mapping_buffer drop rule, and what process_new_scan publishes after a
+# registration -- the reference's own text compiled against stub ROS message types (ROS is absent from the image), driven by the io record
+# tools/ll_node.cpp writes (--dump-io) and replays (--replay-io).  Verbatim line ranges of source/laser_mapping.hpp:
+#   89-120     struct Data_pair                                 633-647    get_data_pair
+#   749-780    the three handlers                               1701-1733, 1735  loop body of process(): drop rule, take, fromROSMsg
+#   1570-1575  /velodyne_cloud_registered                       1613-1653  /aft_mapped_to_init, /aft_mapped_path, camera_init -> aft_mapped
+# The harness logs every message a stub publisher / the stub broadcaster receives in the format of ll_node's recorder.
+EXE_MAPIO = os.path.join(OUT, "verbatim_mapping_io")
+MAPIO_HARNESS = r'''
+#include <cinttypes>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <vector>
+#include <unistd.h>
+#include <Eigen/Eigen>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include "tools/common.h"
+#include "tools/tools_logger.hpp"
+#include "tools/tools_timer.hpp"
+using namespace std;
+
+// ---- stub ROS message types: the fields the excerpts touch, named and nested as in ROS ------------------------------------------
+namespace ros
+{
+struct Time
+{
+    double t = 0;
+    Time &fromSec( double s ) { t = s; return *this; }
+    double toSec() const { return t; }
+};
+} // namespace ros
+namespace std_msgs
+{
+struct Header
+{
+    uint32_t    seq = 0;
+    ros::Time   stamp;
+    std::string frame_id;
+};
+} // namespace std_msgs
+namespace sensor_msgs
+{
+struct PointField
+{
+    std::string name;
+    uint32_t    offset = 0;
+    uint8_t     datatype = 7;
+    uint32_t    count = 1;
+};
+struct PointCloud2
+{
+    std_msgs::Header        header;
+    uint32_t                height = 1, width = 0;
+    std::vector<PointField> fields;
+    bool                    is_bigendian = false;
+    uint32_t                point_step = 0, row_step = 0;
+    std::vector<uint8_t>    data;
+    bool                    is_dense = true;
+};
+typedef std::shared_ptr<const PointCloud2> PointCloud2ConstPtr;
+} // namespace sensor_msgs
+namespace geometry_msgs
+{
+struct Point { double x = 0, y = 0, z = 0; };
+struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
+struct Pose { Point position; Quaternion orientation; };
+struct PoseWithCovariance { Pose pose; double covariance[ 36 ] = { 0 }; };
+struct PoseStamped { std_msgs::Header header; Pose pose; };
+} // namespace geometry_msgs
+namespace nav_msgs
+{
+struct Odometry
+{
+    std_msgs::Header                  header;
+    std::string                       child_frame_id;
+    geometry_msgs::PoseWithCovariance pose;
+};
+struct Path
+{
+    std_msgs::Header                        header;
+    std::vector<geometry_msgs::PoseStamped> poses;
+};
+} // namespace nav_msgs
+namespace pcl
+{
+// pcl::toROSMsg / fromROSMsg for PointXYZI: the point structs copied as they lie (32 bytes: x, y, z at 0 / 4 / 8, intensity at 16)
+inline void toROSMsg( const PointCloud<PointXYZI> &c, sensor_msgs::PointCloud2 &m )
+{
+    static const char *names[ 4 ] = { "x", "y", "z", "intensity" };
+    static const uint32_t offs[ 4 ] = { 0, 4, 8, 16 };
+    m.fields.resize( 4 );
+    for ( int i = 0; i < 4; i++ ) { m.fields[ i ].name = names[ i ]; m.fields[ i ].offset = offs[ i ]; m.fields[ i ].datatype = 7; m.fields[ i ].count = 1; }
+    m.height = 1;
+    m.width = ( uint32_t ) c.points.size();
+    m.point_step = sizeof( PointXYZI );
+    m.row_step = m.point_step * m.width;
+    m.data.resize( ( size_t ) m.row_step );
+    if ( m.width ) memcpy( m.data.data(), c.points.data(), m.data.size() );
+}
+inline void fromROSMsg( const sensor_msgs::PointCloud2 &m, PointCloud<PointXYZI> &c )
+{
+    int off[ 4 ] = { -1, -1, -1, -1 };
+    for ( const auto &f : m.fields )
+    {
+        if ( f.name == "x" ) off[ 0 ] = f.offset;
+        if ( f.name == "y" ) off[ 1 ] = f.offset;
+        if ( f.name == "z" ) off[ 2 ] = f.offset;
+        if ( f.name == "intensity" ) off[ 3 ] = f.offset;
+    }
+    const size_t n = ( size_t ) m.width * m.height;
+    c.points.assign( n, PointXYZI() );
+    for ( size_t i = 0; i < n; i++ )
+    {
+        const uint8_t *p = m.data.data() + i * m.point_step;
+        memcpy( &c.points[ i ].x, p + off[ 0 ], 4 );
+        memcpy( &c.points[ i ].y, p + off[ 1 ], 4 );
+        memcpy( &c.points[ i ].z, p + off[ 2 ], 4 );
+        if ( off[ 3 ] >= 0 ) memcpy( &c.points[ i ].intensity, p + off[ 3 ], 4 );
+    }
+}
+} // namespace pcl
+
+static FILE *g_log = nullptr;
+static uint64_t cloud_hash( const pcl::PointCloud<PointType> &c ) // tools/ll_sequence.py: cloud_hash over (x, y, z, intensity)
+{
+    uint64_t h = 0, i = 0;
+    for ( const auto &p : c.points )
+    {
+        uint32_t w[ 4 ];
+        memcpy( &w[ 0 ], &p.x, 4 ); memcpy( &w[ 1 ], &p.y, 4 ); memcpy( &w[ 2 ], &p.z, 4 ); memcpy( &w[ 3 ], &p.intensity, 4 );
+        for ( int k = 0; k < 4; k++, i++ ) h += ( uint64_t ) w[ k ] * ( uint64_t )( 2 * i + 1 );
+    }
+    return h;
+}
+namespace ros
+{
+struct Publisher
+{
+    std::string topic;
+    void publish( const sensor_msgs::PointCloud2 &m ) const
+    {
+        pcl::PointCloud<PointType> c;
+        pcl::fromROSMsg( m, c );
+        fprintf( g_log, "CLOUD %s %.17g %s %u %u %u %d %016" PRIx64 "\n", topic.c_str(), m.header.stamp.toSec(), m.header.frame_id.c_str(), m.width, m.height,
+                 m.point_step, ( int ) m.fields.size(), cloud_hash( c ) );
+    }
+    void publish( const nav_msgs::Odometry &o ) const
+    {
+        fprintf( g_log, "ODOM %s %.17g %s %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", topic.c_str(), o.header.stamp.toSec(), o.header.frame_id.c_str(),
+                 o.child_frame_id.c_str(), o.pose.pose.position.x, o.pose.pose.position.y, o.pose.pose.position.z, o.pose.pose.orientation.x,
+                 o.pose.pose.orientation.y, o.pose.pose.orientation.z, o.pose.pose.orientation.w );
+    }
+    void publish( const nav_msgs::Path &p ) const
+    {
+        const geometry_msgs::PoseStamped &l = p.poses.back();
+        fprintf( g_log, "PATH %s %.17g %s %zu %.17g %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", topic.c_str(), p.header.stamp.toSec(), p.header.frame_id.c_str(),
+                 p.poses.size(), l.header.stamp.toSec(), l.header.frame_id.c_str(), l.pose.position.x, l.pose.position.y, l.pose.position.z, l.pose.orientation.x,
+                 l.pose.orientation.y, l.pose.orientation.z, l.pose.orientation.w );
+    }
+};
+} // namespace ros
+namespace tf
+{
+struct Vector3
+{
+    double v[ 3 ];
+    Vector3( double x = 0, double y = 0, double z = 0 ) : v{ x, y, z } {}
+};
+struct Quaternion
+{
+    double x = 0, y = 0, z = 0, w = 1;
+    void setW( double a ) { w = a; }
+    void setX( double a ) { x = a; }
+    void setY( double a ) { y = a; }
+    void setZ( double a ) { z = a; }
+};
+struct Transform
+{
+    Vector3    origin;
+    Quaternion rotation;
+    void setOrigin( const Vector3 &o ) { origin = o; }
+    void setRotation( const Quaternion &q ) { rotation = q; }
+};
+struct StampedTransform : Transform
+{
+    ros::Time   stamp_;
+    std::string frame_id_, child_frame_id_;
+    StampedTransform( const Transform &t, const ros::Time &s, const std::string &f, const std::string &c ) : Transform( t ), stamp_( s ), frame_id_( f ), child_frame_id_( c ) {}
+};
+struct TransformBroadcaster
+{
+    void sendTransform( const StampedTransform &t )
+    {
+        fprintf( g_log, "TF %.17g %s %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t.stamp_.toSec(), t.frame_id_.c_str(), t.child_frame_id_.c_str(), t.origin.v[ 0 ],
+                 t.origin.v[ 1 ], t.origin.v[ 2 ], t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w );
+    }
+};
+} // namespace tf
+
+// ---- verbatim: laser_mapping.hpp:89-120
+@DATA_PAIR@
+// ---- end of excerpt
+
+#define ROS_WARN( ... ) fprintf( g_log, "DROP %.17g\n", m_queue_avail_data.front()->m_pc_corner->header.stamp.toSec() )
+
+class Laser_mapping_harness
+{
+  public:
+    int    m_current_frame_index = 0, m_max_buffer_size = 5;
+    double m_time_pc_corner_past = 0;
+    double m_para_buffer_RT[ 7 ] = { 0, 0, 0, 1, 0, 0, 0 };
+    Eigen::Map<Eigen::Quaterniond> m_q_w_curr = Eigen::Map<Eigen::Quaterniond>( m_para_buffer_RT );
+    Eigen::Map<Eigen::Vector3d>    m_t_w_curr = Eigen::Map<Eigen::Vector3d>( m_para_buffer_RT + 4 );
+    std::mutex m_mutex_buf, m_mutex_querypointcloud, m_mutex_ros_pub;
+    std::map<double, Data_pair *> m_map_data_pair;   // :215
+    std::queue<Data_pair *>       m_queue_avail_data; // :216
+    Common_tools::File_logger m_logger_common, m_logger_timer;
+    Common_tools::Timer       m_timer;
+    pcl::PointCloud<PointType>::Ptr m_laser_cloud_corner_last{ new pcl::PointCloud<PointType>() }, m_laser_cloud_surf_last{ new pcl::PointCloud<PointType>() },
+        m_laser_cloud_full_res{ new pcl::PointCloud<PointType>() };
+    ros::Publisher m_pub_laser_cloud_full_res{ "/velodyne_cloud_registered" }, m_pub_odom_aft_mapped{ "/aft_mapped_to_init" },
+        m_pub_laser_aft_mapped_path{ "/aft_mapped_path" }; // :611, 612, 614
+    nav_msgs::Path m_laser_after_mapped_path;
+
+// ---- verbatim: laser_mapping.hpp:633-647
+@GET_PAIR@
+// ---- verbatim: laser_mapping.hpp:749-780
+@HANDLERS@
+// ---- end of excerpt
+
+    void process_pass()
+    {
+        double first_time_stamp = 0;
+        if ( m_queue_avail_data.empty() ) return; // (the reference waits, :1697-1700)
+// ---- verbatim: laser_mapping.hpp:1701-1733
+@PROCESS@
+// ---- end of excerpt
+        fprintf( g_log, "TAKE %.17g %.17g %.17g %zu %zu %zu %016" PRIx64 " %016" PRIx64 " %016" PRIx64 "\n", current_data_pair->m_pc_corner->header.stamp.toSec(),
+                 current_data_pair->m_pc_plane->header.stamp.toSec(), current_data_pair->m_pc_full->header.stamp.toSec(), m_laser_cloud_corner_last->points.size(),
+                 m_laser_cloud_surf_last->points.size(), m_laser_cloud_full_res->points.size(), cloud_hash( *m_laser_cloud_corner_last ),
+                 cloud_hash( *m_laser_cloud_surf_last ), cloud_hash( *m_laser_cloud_full_res ) );
+// ---- verbatim: laser_mapping.hpp:1735
+@DELETE@
+// ---- end of excerpt
+    }
+
+    void publish_excerpt( pcl::PointCloud<PointType> &current_laser_cloud_full, double time_odom )
+    {
+// ---- verbatim: laser_mapping.hpp:1570-1575 (takes m_mutex_ros_pub)
+@PUB_CLOUD@
+// ---- verbatim: laser_mapping.hpp:1613-1653
+@PUB_ODOM@
+// ---- end of excerpt
+        m_mutex_ros_pub.unlock();
+    }
+};
+
+static bool rd( FILE *f, void *p, size_t n ) { return n == 0 || fread( p, 1, n, f ) == n; }
+static void read_cloud( FILE *f, pcl::PointCloud<PointType> &c )
+{
+    int32_t n = 0;
+    if ( !rd( f, &n, 4 ) || n < 0 ) { fprintf( stderr, "truncated io record\n" ); exit( 1 ); }
+    c.points.assign( ( size_t ) n, PointType() );
+    for ( int32_t i = 0; i < n; i++ )
+    {
+        float v[ 4 ];
+        if ( !rd( f, v, 16 ) ) { fprintf( stderr, "truncated io record\n" ); exit( 1 ); }
+        c.points[ i ].x = v[ 0 ]; c.points[ i ].y = v[ 1 ]; c.points[ i ].z = v[ 2 ]; c.points[ i ].intensity = v[ 3 ];
+    }
+}
+
+int main( int argc, char **argv )
+{
+    if ( argc < 3 ) { fprintf( stderr, "usage: verbatim_mapping_io io.bin log.txt [maximum_mapping_buffer]\n" ); return 2; }
+    FILE *fi = fopen( argv[ 1 ], "rb" );
+    g_log = fopen( argv[ 2 ], "w" );
+    char magic[ 8 ];
+    if ( !fi || !g_log || !rd( fi, magic, 8 ) || memcmp( magic, "LLIO0001", 8 ) != 0 ) { fprintf( stderr, "cannot open / not an LLIO0001 file\n" ); return 1; }
+    Laser_mapping_harness node;
+    if ( argc > 3 ) node.m_max_buffer_size = atoi( argv[ 3 ] );
+    for ( int type = fgetc( fi ); type != EOF; type = fgetc( fi ) )
+    {
+        if ( type == 'C' || type == 'S' || type == 'F' )
+        {
+            double stamp = 0;
+            rd( fi, &stamp, 8 );
+            pcl::PointCloud<PointType> c;
+            read_cloud( fi, c );
+            std::shared_ptr<sensor_msgs::PointCloud2> m( new sensor_msgs::PointCloud2() );
+            pcl::toROSMsg( c, *m );
+            m->header.stamp.fromSec( stamp );
+            m->header.frame_id = "camera_init";
+            if ( type == 'C' ) node.laserCloudCornerLastHandler( m );
+            if ( type == 'S' ) node.laserCloudSurfLastHandler( m );
+            if ( type == 'F' ) node.laserCloudFullResHandler( m );
+        }
+        else if ( type == 'P' )
+        {
+            node.process_pass();
+        }
+        else if ( type == 'U' )
+        {
+            int32_t frame_index = 0;
+            double  time_odom = 0;
+            rd( fi, &frame_index, 4 );
+            rd( fi, &time_odom, 8 );
+            rd( fi, node.m_para_buffer_RT, 56 );
+            pcl::PointCloud<PointType> c;
+            read_cloud( fi, c );
+            node.m_current_frame_index = frame_index;
+            node.publish_excerpt( c, time_odom );
+        }
+        else { fprintf( stderr, "unknown event\n" ); return 1; }
+    }
+    fclose( g_log );
+    return 0;
+}
+'''
+
+
+def build_mapping_io(force=False):
+    """-> the harness executable (built where /root/reference exists; elsewhere whatever travelled with the tree, or None)"""
+    if not have_reference():
+        return EXE_MAPIO if os.path.exists(EXE_MAPIO) else None
+    deps = [os.path.abspath(__file__)] + [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(ROOT, "oracle", "ref_stubs")) for f in fs]
+    if not force and os.path.exists(EXE_MAPIO) and all(os.path.getmtime(d) <= os.path.getmtime(EXE_MAPIO) for d in deps):
+        return EXE_MAPIO
+    os.makedirs(OUT, exist_ok=True)
+    lm = "source/laser_mapping.hpp"
+    tu = (MAPIO_HARNESS.replace("@DATA_PAIR@", _lines(lm, 89, 120)).replace("@GET_PAIR@", _lines(lm, 633, 647)).replace("@HANDLERS@", _lines(lm, 749, 780))
+          .replace("@PROCESS@", _lines(lm, 1701, 1733)).replace("@DELETE@", _lines(lm, 1735, 1735)).replace("@PUB_CLOUD@", _lines(lm, 1570, 1575))
+          .replace("@PUB_ODOM@", _lines(lm, 1613, 1653)))
+    stubs = os.path.join(ROOT, "oracle", "ref_stubs")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "verbatim_mapping_io.cpp")
+        with open(src, "w") as f:
+            f.write(tu)
+        inc = ["-I", os.path.join(stubs, "override"), "-I-", "-I", stubs, "-I", os.path.join(REF, "source"), "-I", os.path.join(REF, "include"),
+               "-I", os.path.join(REF, "include", "tools")]
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-w"] + inc + [src, "-o", EXE_MAPIO, "-lpthread"])
+    return EXE_MAPIO
