@@ -116,6 +116,18 @@ def pmc_traffic_bytes(kernel: str, batch: int):
     return (None, None) if best is None else (int(best[1]), os.path.relpath(path, ROOT))
 
 
+def traffic_stamp(rel_path):
+    """which kernel sources the committed counter summary was taken on, and whether they are the ones running now (tools/build_id.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_id import build_id, read_stamp
+    if not rel_path:
+        return {}
+    bid, commit = read_stamp(os.path.join(ROOT, rel_path))
+    now = build_id()
+    return {"traffic_source_build": bid, "traffic_source_commit": commit, "build": now,
+            "traffic_is_current": (bid == now) if bid else None}  # None: a summary from before the stamps (round <= 5)
+
+
 def pmc_valu_fp64(kernel: str, batch: int):
     """fp64 VALU work per launch of `kernel` from the newest committed instruction-mix summary (profiles/r*_pmc_valu.csv:
     rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 / SQ_INSTS_VALU passes of this command at batch 256, tools/gpu_pmc.sh).
@@ -594,6 +606,7 @@ def main():
                                if dom == 1 else "VALU issue of the searches (map patch is cache resident), not HBM bandwidth"),
                 # what the kernel really moves (rocprofv3 PMC passes, profiles/) against the same peak
                 "traffic_frac": None if traffic is None else round(traffic / (avg_ms * 1e-3) / 8e12, 4)}
+    roofline.update(traffic_stamp(traffic_src))  # does the committed counter summary belong to the kernels running now?
 
     # The solver's arithmetic is fp64 VALU (no MFMA shape on this path): the same launch against the fp64 vector peak
     # (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s = half the guide's 157.3 TFLOP/s fp32 vector figure).

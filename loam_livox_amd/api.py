@@ -259,8 +259,9 @@ class History_buffer:
 
     def cell_map(self, kind: int) -> "Cell_map":
         h = self.L.ll_history_cell_map(self.h, kind)
-        if not h:
-            raise RuntimeError("cell maps are not enabled")
+        if not h:  # not enabled, or the service thread failed: the library says which
+            msg = self.L.ll_last_error()
+            raise capi.LoamLivoxError(f"ll_history_cell_map: {msg.decode() if msg else 'error'}")
         return Cell_map(resolution=self._cell_resolution, _borrowed=h)
 
     def refresh_cells(self, map_buffer: "Map_buffer", pose, maximum_search_range_corner: float = 100.0,
@@ -615,7 +616,12 @@ class Point_cloud_registration:
                  | (128 if test_group_abort else 0) | (256 if no_knn_coop else 0) | (512 if no_knn_tile else 0)
                  | (1024 if knn_tile_with_reuse else 0) | (2048 if knn_tile_small_batches else 0) | (4096 if no_line_cache else 0)
                  | (32768 if no_small_solver else 0) | {0: 0, 1: 65536, 4: 131072, 2: 65536 | 131072}[int(small_solver_waves)] | (262144 if no_solve_order else 0))
-        check(self.L.ll_reg_set_debug(self.h, flags), "ll_reg_set_debug")
+        self.set_debug_flags(flags)
+
+    def set_debug_flags(self, flags: int):
+        """ll_reg_set_debug with the raw flag word (kept in self.debug_flags, so a caller can add a bit and put the word back)"""
+        check(self.L.ll_reg_set_debug(self.h, int(flags)), "ll_reg_set_debug")
+        self.debug_flags = int(flags)
 
     def set_debug_knn_iteration(self, icp_iteration: int):
         """the ICP iteration whose neighbour lists debug_knn() returns (default 0)"""

@@ -696,20 +696,25 @@ extern "C" int ll_map_knn5_device(ll_map *m, int32_t kind, const float *dev_quer
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_queries == 0) return 0;
     HC(hipSetDevice(m->device));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HC(hipEventCreate(&e0));
-    HC(hipEventCreate(&e1));
+    struct Events {  // (destroyed on every return path)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    HC(hipEventCreate(&ev.e0));
+    HC(hipEventCreate(&ev.e1));
     HC(hipDeviceSynchronize());  // (the caller's buffers may have been written on another stream)
-    HC(hipEventRecord(e0, m->stream));
+    HC(hipEventRecord(ev.e0, m->stream));
     launch_knn5(snap->mk.grid, dev_queries_xyz, (int)n_queries, max_sq_dis, dev_idx5, dev_sq_dis5, m->stream);
-    HC(hipEventRecord(e1, m->stream));
+    HC(hipEventRecord(ev.e1, m->stream));
     HC(hipGetLastError());
     HC(hipStreamSynchronize(m->stream));
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
     if (kernel_ms) *kernel_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return 0;
 }
 
@@ -1313,7 +1318,9 @@ extern "C" int ll_reg_enqueue_fe_downsampled(ll_reg *r, const ll_map *map, ll_fe
 }
 
 // ---------------------------------------------------------------------------------------------------- cell map
+struct ll_history;
 struct ll_cellmap {
+    ll_history *owner = nullptr;  // a history's own cell map (ll_history_enable_cell_map): fed by the history, possibly on its service thread
     int device = 0;
     hipStream_t stream = nullptr;
     CellMapDev dev{};
@@ -1335,6 +1342,12 @@ static void cellmap_release(ll_cellmap *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+// A cell map owned by a history may be fed on that history's service thread (ll_history_set_cell_map_async): every public entry point
+// that reads or changes a map first waits for the frames handed over so far (and reports the feeder's failure, if any), so a handle
+// borrowed from ll_history_cell_map never sees an append in flight or a map swapped by cellmap_grow under it.
+static int history_cells_drain(ll_history *h);
+static int cellmap_settle(const ll_cellmap *c) { return (c && c->owner) ? history_cells_drain(c->owner) : 0; }
 
 extern "C" int ll_cellmap_create(int32_t device, int64_t max_points, float resolution, int32_t minimum_revisit_threshold, ll_cellmap **out)
 {
@@ -1360,6 +1373,7 @@ extern "C" void ll_cellmap_destroy(ll_cellmap *c) { cellmap_release(c); }
 extern "C" int ll_cellmap_reserve(ll_cellmap *c, int64_t max_points)
 {
     if (!c) return set_err("ll_cellmap_reserve", "null argument");
+    if (cellmap_settle(c)) return -1;
     if (max_points < 1 || max_points >= 0x3fffffffLL) return set_err("ll_cellmap_reserve", "max_points out of range");
     if (max_points <= c->dev.cap) return 0;
     HC(hipSetDevice(c->device));
@@ -1379,6 +1393,7 @@ extern "C" int ll_cellmap_reserve(ll_cellmap *c, int64_t max_points)
 extern "C" int ll_cellmap_append(ll_cellmap *c, const float *xyzi, int32_t n)
 {
     if (!c || (n > 0 && !xyzi)) return set_err("ll_cellmap_append", "null argument");
+    if (cellmap_settle(c)) return -1;
     if (n < 0 || n > c->dev.cap) return set_err("ll_cellmap_append", "cloud exceeds max_points");
     HC(hipSetDevice(c->device));
     if (n > 0) HC(hipMemcpyAsync(c->d_in, xyzi, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -1392,6 +1407,7 @@ extern "C" int ll_cellmap_append_touched(ll_cellmap *c, const float *xyzi, int32
                                          int64_t capacity_cells, int64_t *n_touched)
 {
     if (!c || (n > 0 && !xyzi) || !n_touched) return set_err("ll_cellmap_append_touched", "null argument");
+    if (cellmap_settle(c)) return -1;
     if (n < 0 || n > c->dev.cap) return set_err("ll_cellmap_append_touched", "cloud exceeds max_points");
     HC(hipSetDevice(c->device));
     const bool first = c->dev.n_cells == 0;  // set_point_cloud: every cell that received a point (CMK:596-607)
@@ -1425,6 +1441,7 @@ extern "C" int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], floa
                                        int32_t down_sample_replace, int64_t *n_cells_selected, int64_t *n_out)
 {
     if (!c || !pose) return set_err("ll_cellmap_query_filter", "null argument");
+    if (cellmap_settle(c)) return -1;
     if (!(radius >= 0.f)) return set_err("ll_cellmap_query_filter", "radius must not be negative");
     HC(hipSetDevice(c->device));
     HC(hipMemcpyAsync(c->d_pose, pose, 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1440,6 +1457,7 @@ extern "C" int ll_cellmap_query_filter(ll_cellmap *c, const double pose[7], floa
 extern "C" int64_t ll_cellmap_result(ll_cellmap *c, float *xyzi, int64_t capacity_points)
 {
     if (!c) return set_err("ll_cellmap_result", "null argument");
+    if (cellmap_settle(c)) return -1;
     const int64_t n = c->dev.n_filt;
     if (!xyzi) return n;
     if (capacity_points < n) return set_err("ll_cellmap_result", "buffer too small");
@@ -1452,6 +1470,7 @@ extern "C" int64_t ll_cellmap_result(ll_cellmap *c, float *xyzi, int64_t capacit
 extern "C" int ll_cellmap_stats(const ll_cellmap *c, int64_t *n_cells, int64_t *n_points, int32_t *frame_idx)
 {
     if (!c) return set_err("ll_cellmap_stats", "null argument");
+    if (cellmap_settle(c)) return -1;
     if (n_cells) *n_cells = c->dev.n_cells;
     if (n_points) *n_points = c->dev.n_pts;
     if (frame_idx) *frame_idx = c->dev.frame;
@@ -1462,6 +1481,7 @@ extern "C" int ll_cellmap_features(ll_cellmap *c, int32_t *feature_type, float *
                                    int64_t capacity_cells)
 {
     if (!c) return set_err("ll_cellmap_features", "null argument");
+    if (cellmap_settle(c)) return -1;
     const int nc = c->dev.n_cells;
     if (capacity_cells < nc) return set_err("ll_cellmap_features", "buffer too small");
     if (nc == 0) return 0;
@@ -1489,6 +1509,7 @@ extern "C" int ll_cellmap_keyframe_images(ll_cellmap *c, float roi_ratio, float 
                                           int32_t *n_vectors, float *centre_and_range)
 {
     if (!c) return set_err("ll_cellmap_keyframe_images", "null argument");
+    if (cellmap_settle(c)) return -1;
     if (!(roi_ratio >= 0.f && roi_ratio <= 1.f)) return set_err("ll_cellmap_keyframe_images", "roi_ratio must lie in [0, 1]");
     HC(hipSetDevice(c->device));
     if (!c->d_stats) DM(c->d_stats, (size_t)c->dev.cap);
@@ -1532,6 +1553,7 @@ extern "C" int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_poin
                                int32_t *cell_last_update, int64_t capacity_cells)
 {
     if (!c) return set_err("ll_cellmap_dump", "null argument");
+    if (cellmap_settle(c)) return -1;
     const int np = c->dev.n_pts, nc = c->dev.n_cells;
     if ((xyzi && capacity_points < np) || ((cell_ijk || cell_start || cell_last_update) && capacity_cells < nc))
         return set_err("ll_cellmap_dump", "buffer too small");
@@ -1558,6 +1580,7 @@ extern "C" int ll_cellmap_dump(ll_cellmap *c, float *xyzi, int64_t capacity_poin
 extern "C" int ll_cellmap_device_view(ll_cellmap *c, const float **dev_xyz0, const uint64_t **dev_point_keys, int64_t *n_points, int64_t *n_cells)
 {
     if (!c || !dev_xyz0 || !dev_point_keys || !n_points) return set_err("ll_cellmap_device_view", "null argument");
+    if (cellmap_settle(c)) return -1;
     HC(hipSetDevice(c->device));
     HC(hipStreamSynchronize(c->stream));
     *dev_xyz0 = (const float *)c->dev.pts;
@@ -1621,16 +1644,23 @@ static int history_cells_append(ll_history *h, int kind, const float4 *d_src, in
     if ((long long)c->dev.n_pts + n > c->dev.cap) {
         long long want = 2LL * c->dev.cap;
         while (want < (long long)c->dev.n_pts + n) want *= 2;
-        if (want >= 0x3fffffffLL || cellmap_grow(c->dev, (int)want, c->stream, &err)) {
+        if (want >= 0x3fffffffLL) {
+            *why = "cell map cannot grow further";
+            return -1;
+        }
+        // the staging buffer of the new capacity first: a failure then leaves the map as it was (capacity and staging size agree)
+        float4 *d_new = nullptr;
+        if (hipMalloc((void **)&d_new, (size_t)want * sizeof(float4)) != hipSuccess) {
+            *why = "allocation failed";
+            return -1;
+        }
+        if (cellmap_grow(c->dev, (int)want, c->stream, &err)) {
+            (void)hipFree(d_new);
             *why = err ? err : "cell map cannot grow further";
             return -1;
         }
         if (c->d_in) (void)hipFree(c->d_in);
-        c->d_in = nullptr;
-        if (hipMalloc((void **)&c->d_in, (size_t)want * sizeof(float4)) != hipSuccess) {
-            *why = "allocation failed";
-            return -1;
-        }
+        c->d_in = d_new;
         if (c->d_stats) {
             (void)hipFree(c->d_stats);
             c->d_stats = nullptr;
@@ -1661,7 +1691,14 @@ static void history_feeder_main(ll_history *h)
         }
         std::string why;
         bool failed = false;
-        if (hipEventSynchronize(job.ready) != hipSuccess) {
+        bool skip = false;
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            skip = !h->feed_error.empty();  // latched: after a failure nothing more is appended (a map that silently lacks one frame is worse than none)
+        }
+        if (skip) {
+            (void)hipEventSynchronize(job.ready);
+        } else if (hipEventSynchronize(job.ready) != hipSuccess) {
             failed = true;
             why = "staging copy failed";
         } else if (history_cells_append(h, job.kind, h->stage[job.kind][job.slot], job.n, &why)) {
@@ -1677,17 +1714,15 @@ static void history_feeder_main(ll_history *h)
     }
 }
 
-// every frame handed to the feeder has been appended; 0, or -1 with the feeder's first error
+// every frame handed to the feeder has been appended; 0, or -1 with the feeder's first error.  The error is LATCHED: the feeder stops
+// appending at its first failure and every reader / ll_history_add* reports it until ll_history_set_cell_map_async(h, 0) acknowledges
+// it (the cell maps then lack the frames from the failing one on; the caller decides whether to go on inline or to start over).
 static int history_cells_drain(ll_history *h)
 {
     if (!h->cells_async) return 0;
     std::unique_lock<std::mutex> lk(h->mu);
     h->cv_idle.wait(lk, [h] { return h->in_flight == 0; });
-    if (!h->feed_error.empty()) {
-        const std::string e = h->feed_error;
-        h->feed_error.clear();
-        return set_err("ll_history (cell-map feeder)", e.c_str());
-    }
+    if (!h->feed_error.empty()) return set_err("ll_history (cell-map feeder)", ("feeding stopped at its first failure: " + h->feed_error).c_str());
     return 0;
 }
 
@@ -1800,11 +1835,7 @@ static int history_push_kind(ll_history *h, int kind, const float4 *d_src, int n
         {
             std::unique_lock<std::mutex> lk(h->mu);
             h->cv_idle.wait(lk, [h] { return h->in_flight < ll_history::kStage; });
-            if (!h->feed_error.empty()) {
-                const std::string e = h->feed_error;
-                h->feed_error.clear();
-                return set_err("ll_history_add (cell-map feeder)", e.c_str());
-            }
+            if (!h->feed_error.empty()) return set_err("ll_history_add (cell-map feeder)", ("feeding stopped at its first failure: " + h->feed_error).c_str());
         }
         const int slot = h->stage_next[kind];
         h->stage_next[kind] = (slot + 1) % ll_history::kStage;
@@ -2016,6 +2047,7 @@ extern "C" int ll_history_enable_cell_map(ll_history *h, int64_t max_points, flo
              hipMalloc((void **)&h->d_cmap[k], (size_t)max_points * sizeof(float4)) == hipSuccess;
     }
     if (ok && voxel_alloc(h->vox_cells, 1, (int)max_points, &err)) ok = false;
+    if (ok) h->cells[0]->owner = h->cells[1]->owner = h;  // (every ll_cellmap_* call on them settles the service thread first, cellmap_settle)
     if (!ok) {  // all or nothing: a half-enabled history would fail later in ll_history_refresh_cells
         const std::string why = err ? std::string(err) : g_err;
         voxel_free(h->vox_cells);
@@ -2030,10 +2062,17 @@ extern "C" int ll_history_enable_cell_map(ll_history *h, int64_t max_points, flo
     return 0;
 }
 
+// NULL with ll_last_error() set: bad argument, cell maps not enabled, or the service thread failed.  The handle stays the history's: every
+// ll_cellmap_* call on it waits for the frames handed to the service thread so far, so it may be kept across ll_history_add*; what
+// ll_cellmap_device_view returns for it is valid only until the next ll_history_add* (which may grow and move the map).
 extern "C" ll_cellmap *ll_history_cell_map(ll_history *h, int32_t kind)
 {
     if (!h || kind < 0 || kind > 1) {
         set_err("ll_history_cell_map", "bad argument");
+        return nullptr;
+    }
+    if (!h->cells[kind]) {
+        set_err("ll_history_cell_map", "cell maps are not enabled (ll_history_enable_cell_map)");
         return nullptr;
     }
     if (history_cells_drain(h)) return nullptr;  // (the caller is about to read the map)
@@ -2050,8 +2089,10 @@ extern "C" int ll_history_set_cell_map_async(ll_history *h, int32_t enable)
     if (!h->cells[0]) return set_err("ll_history_set_cell_map_async", "cell maps are not enabled (ll_history_enable_cell_map)");
     HC(hipSetDevice(h->device));
     if (!enable) {
-        const int rc = history_cells_drain(h);
+        const int rc = history_cells_drain(h);  // (reports a latched feeder error one last time ...)
         h->cells_async = false;
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->feed_error.clear();                  // (... and acknowledges it)
         return rc;
     }
     if (h->cells_async) return 0;

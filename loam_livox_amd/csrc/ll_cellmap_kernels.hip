@@ -579,16 +579,23 @@ int cellmap_grow(CellMapDev &m, int new_cap, hipStream_t s, const char **err)
         cellmap_free(n);
         return -1;
     }
-    if (m.n_pts > 0) {
-        CMCHK(hipMemcpyAsync(n.pts, m.pts, (size_t)m.n_pts * sizeof(float4), hipMemcpyDeviceToDevice, s));
-        CMCHK(hipMemcpyAsync(n.pkey, m.pkey, (size_t)m.n_pts * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    }
+    hipError_t e = hipSuccess;  // (a failing copy must not leak the ~25 arrays of the new map)
+    auto copy = [&](void *dst, const void *src, size_t bytes) {
+        if (e == hipSuccess && bytes > 0) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    };
+    copy(n.pts, m.pts, (size_t)m.n_pts * sizeof(float4));
+    copy(n.pkey, m.pkey, (size_t)m.n_pts * sizeof(u64));
     if (m.n_cells > 0) {
-        CMCHK(hipMemcpyAsync(n.ckey, m.ckey, (size_t)m.n_cells * sizeof(u64), hipMemcpyDeviceToDevice, s));
-        CMCHK(hipMemcpyAsync(n.cstart, m.cstart, (size_t)(m.n_cells + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
-        CMCHK(hipMemcpyAsync(n.clast, m.clast, (size_t)m.n_cells * sizeof(int), hipMemcpyDeviceToDevice, s));
+        copy(n.ckey, m.ckey, (size_t)m.n_cells * sizeof(u64));
+        copy(n.cstart, m.cstart, (size_t)(m.n_cells + 1) * sizeof(int));
+        copy(n.clast, m.clast, (size_t)m.n_cells * sizeof(int));
     }
-    CMCHK(hipStreamSynchronize(s));
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        cellmap_free(n);
+        *err = hipGetErrorString(e);
+        return -1;
+    }
     n.frame = m.frame;
     n.n_pts = m.n_pts;
     n.n_cells = m.n_cells;

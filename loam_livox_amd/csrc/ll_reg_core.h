@@ -761,18 +761,16 @@ LL_HD double lm_cubic_min_step(double f0, double g0, double x1, double f1, doubl
 // sample) minimises the QUINTIC through the start (0, f0, g0), the current trial (x1, f1, g1) and the previous one (x2, f2, g2)
 // over [lo, hi] -- the polynomial of FindInterpolatingPolynomial (polynomial.cc solves a 6 x 6 Vandermonde system; here the same
 // interpolant in Newton form, by divided differences: no pivot search, so nothing is indexed dynamically and the whole fit stays in
-// registers on the controller lane -- an LU with row/column swaps put its matrix in scratch and cost ~30 us per fit), then the
-// better end point or a real root of the derivative inside the interval (MinimizePolynomial).  The roots are bracketed by the
-// sign changes of the derivative on a fixed grid of the interval and bisected, operation for operation as
-// oracle/ll_oracle_reg.c quintic_min_step.  Out of line: this runs only when a bound on t_inc is active and the first
-// interpolated step still fails the Armijo test.
-// AN APPROXIMATION OF CERES HERE, not a restatement: Ceres' MinimizePolynomial takes the roots of the derivative as the eigenvalues of
-// its companion matrix (Eigen, third party) and so sees every real root; 32 cells + bisection miss a pair of roots that falls
-// inside one cell (a minimum narrower than 1/32 of [lo, hi] = [0.001, 0.6] x the step), in which case the better end point or
-// another root is returned -- still a valid contraction for the Armijo search, but not the step Ceres would take.  Near-coincident
-// samples (|x2 - x1| tiny but non-zero) are only guarded against exact zero.  The oracle and the compiled stand-in share this
-// algorithm, so the parity tests cannot see such a divergence from Ceres itself; DESIGN.md section 5 lists it with the other
-// third-party restatements.
+// registers on the controller lane), then the better end point or a real root of the derivative inside the interval
+// (MinimizePolynomial).  Ceres takes the roots of the quartic derivative as the eigenvalues of its companion matrix (Eigen, third
+// party) and so sees every real root.  So does this restatement (round 6; rounds 2 - 5 bracketed sign changes on a 32-cell grid and
+// could miss a pair of roots inside one cell): the roots are ISOLATED EXACTLY by the derivative chain -- the quartic p' is monotone
+// between consecutive roots of the cubic p'', which is monotone between the roots of the quadratic p''' (closed form) -- so every
+// interval between consecutive break points holds at most one root, found by its sign change and bisected.  A root without a sign
+// change (even multiplicity) is an inflection of p, never its minimum; the real parts of complex roots, which Ceres also tries, are
+// not stationary and cannot beat the true minimiser.  Operation for operation the same in oracle/ll_oracle_reg.c quintic_min_step and
+// in the Ceres stand-in of oracle/_ref (ll_stub_ceres_solver.h quintic_min); tests/test_hostcheck.py holds all three to a dense
+// companion-matrix root finder on adversarial fits (two stationary points 1e-4 of the interval apart).
 // the interpolant in Newton form: p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0))))
 struct Quintic {
     double x1, x2, f0, e01, a0, b0, c0, d0;
@@ -817,71 +815,134 @@ LL_HD void quintic_eval(const Quintic &q, double x, double &pv, double &dv)
     pv = b;
     dv = db;
 }
-// k-th grid point of [lo, hi] cut into ng cells
-LL_HD double quintic_grid(double lo, double hi, int k, int ng) { return (k == ng) ? hi : lo + (hi - lo) * ((double)k / (double)ng); }
-// does the derivative change sign over a cell with end derivatives da, db (or vanish at its right end)?
-LL_HD bool quintic_cell_has_root(double da, double db) { return (da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0; }
-// the root of the derivative inside such a cell [xa, xb]: 40 bisections
-LL_HD double quintic_cell_root(const Quintic &q, double xa, double xb, double da, double db)
+// monomial coefficients of the derivative chain: p' = dq[0] + dq[1] x + .. + dq[4] x^4, p'' = d2[0] + .. + d2[3] x^3 (d2[4] = 0),
+// p''' = A x^2 + B x + C.  From the Newton form by three synthetic multiplications with (x - node), every step one fused multiply-add.
+struct QuinticChain {
+    double dq[5], d2[5], A, B, C;
+};
+LL_HD void quintic_chain(const Quintic &q, QuinticChain &c)
 {
-    double l = xa, r = xb, dl = da;
-    if (db != 0.0) {
-        for (int it = 0; it < 40; it++) {
-            const double m = 0.5 * (l + r);
-            double pm, dm;
-            quintic_eval(q, m, pm, dm);
-            (void)pm;
-            if (dm == 0.0) {
-                l = r = m;
-                break;
-            }
-            if ((dl < 0.0) == (dm < 0.0)) {
-                l = m;
-                dl = dm;
-            } else {
-                r = m;
+    const double s1 = q.d0, s0 = fma(-q.x2, q.d0, q.c0);                              // c0 + (x - x2) d0
+    const double t2 = s1, t1 = fma(-q.x1, s1, s0), t0 = fma(-q.x1, s0, q.b0);         // b0 + (x - x1) (..)
+    const double u3 = t2, u2 = fma(-q.x1, t2, t1), u1 = fma(-q.x1, t1, t0), u0 = fma(-q.x1, t0, q.a0);  // a0 + (x - x1) (..)
+    // p(x) = u3 x^5 + u2 x^4 + u1 x^3 + u0 x^2 + e01 x + f0
+    c.dq[4] = 5.0 * u3, c.dq[3] = 4.0 * u2, c.dq[2] = 3.0 * u1, c.dq[1] = 2.0 * u0, c.dq[0] = q.e01;
+    c.d2[4] = 0.0, c.d2[3] = 20.0 * u3, c.d2[2] = 12.0 * u2, c.d2[1] = 6.0 * u1, c.d2[0] = 2.0 * u0;
+    c.A = 60.0 * u3, c.B = 24.0 * u2, c.C = 6.0 * u1;
+}
+LL_HD double quintic_poly4(const double k[5], double x) { return fma(fma(fma(fma(k[4], x, k[3]), x, k[2]), x, k[1]), x, k[0]); }
+// real roots of A x^2 + B x + C strictly inside (lo, hi), ascending; returns how many (0 .. 2)
+LL_HD int quintic_quadratic_roots(double A, double B, double C, double lo, double hi, double r[2])
+{
+    double c0 = 0.0, c1 = 0.0;
+    int n = 0;
+    if (A == 0.0) {
+        if (B != 0.0) c0 = -C / B, n = 1;
+    } else {
+        const double disc = fma(B, B, -4.0 * A * C);
+        if (disc >= 0.0) {
+            const double sq = sqrt(disc);
+            const double qq = -0.5 * (B + (B < 0.0 ? -sq : sq));  // the numerically stable pair: qq / A and C / qq
+            c0 = qq / A;
+            n = 1;
+            if (qq != 0.0) {
+                c1 = C / qq;
+                n = 2;
+                if (c1 < c0) {
+                    const double t = c0;
+                    c0 = c1;
+                    c1 = t;
+                }
             }
         }
-    } else {
-        l = r = xb;
     }
-    return 0.5 * (l + r);
+    int m = 0;
+    if (n >= 1 && c0 > lo && c0 < hi) r[m++] = c0;
+    if (n >= 2 && c1 > lo && c1 < hi && !(m == 1 && c1 == r[0])) r[m++] = c1;
+    return m;
 }
-#define LL_QUINTIC_CELLS 32 /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
+#define LL_QUINTIC_BISECTIONS 60 /* an interval is halved until it cannot shrink (m == l or m == r) or 60 times */
+// the root of the polynomial k in (a, b], where it is monotone: found by the sign change of its end values va, vb (or vb == 0).
+// Returns false when there is none.
+LL_HD bool quintic_interval_root(const double k[5], double a, double b, double va, double vb, double *root)
+{
+    if (vb == 0.0) {
+        *root = b;
+        return true;
+    }
+    if (!((va < 0.0 && vb > 0.0) || (va > 0.0 && vb < 0.0))) return false;
+    double l = a, r = b, vl = va;
+    for (int it = 0; it < LL_QUINTIC_BISECTIONS; it++) {
+        const double m = 0.5 * (l + r);
+        if (m == l || m == r) break;
+        const double vm = quintic_poly4(k, m);
+        if (vm == 0.0) {
+            l = r = m;
+            break;
+        }
+        if ((vl < 0.0) == (vm < 0.0)) {
+            l = m;
+            vl = vm;
+        } else {
+            r = m;
+        }
+    }
+    *root = 0.5 * (l + r);
+    return true;
+}
+// roots of k inside (lo, hi] given its break points bp[0 .. nb) (ascending, strictly inside (lo, hi)): at most nb + 1, ascending
+LL_HD int quintic_roots_between(const double k[5], double lo, double hi, const double *bp, int nb, double *roots)
+{
+    int n = 0;
+    double a = lo, va = quintic_poly4(k, lo);
+    for (int i = 0; i <= nb; i++) {
+        const double b = (i == nb) ? hi : bp[i];
+        const double vb = quintic_poly4(k, b);
+        double r;
+        if (quintic_interval_root(k, a, b, va, vb, &r)) roots[n++] = r;
+        a = b;
+        va = vb;
+    }
+    return n;
+}
+// MinimizePolynomial's choice among the stationary points: the better end point unless a root's value is strictly smaller, roots in
+// ascending order
+LL_HD double quintic_pick(const Quintic &q, double lo, double hi, const double *roots, int n)
+{
+    double best_x = lo, best_v, vh, dl, dh;
+    quintic_eval(q, lo, best_v, dl);
+    quintic_eval(q, hi, vh, dh);
+    (void)dl;
+    (void)dh;
+    if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
+        best_v = vh;
+        best_x = hi;
+    }
+    for (int i = 0; i < n; i++) {
+        double v, dv;
+        quintic_eval(q, roots[i], v, dv);
+        (void)dv;
+        if (v < best_v) {
+            best_v = v;
+            best_x = roots[i];
+        }
+    }
+    return best_x;
+}
 
 LL_HD_NOINLINE double lm_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo,
                                           double hi)
 {
     Quintic q;
     if (!quintic_fit(f0, g0, x1, f1, g1, x2, f2, g2, q)) return fmin(fmax(0.5 * x1, lo), hi); /* coincident samples: bisect like an invalid sample */
-    double best_x = lo, best_v, vh, da, dh;
-    quintic_eval(q, lo, best_v, da);
-    quintic_eval(q, hi, vh, dh);
-    (void)dh;
-    if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
-        best_v = vh;
-        best_x = hi;
-    }
-    double xa = lo;
-    for (int k = 1; k <= LL_QUINTIC_CELLS; k++) {
-        const double xb = quintic_grid(lo, hi, k, LL_QUINTIC_CELLS);
-        double pb, db;
-        quintic_eval(q, xb, pb, db);
-        if (quintic_cell_has_root(da, db)) {
-            const double root = quintic_cell_root(q, xa, xb, da, db);
-            double v, dv;
-            quintic_eval(q, root, v, dv);
-            (void)dv;
-            if (v < best_v) {
-                best_v = v;
-                best_x = root;
-            }
-        }
-        (void)pb;
-        xa = xb;
-        da = db;
-    }
-    return best_x;
+    QuinticChain c;
+    quintic_chain(q, c);
+    double r3[2], r2[3], r1[4];
+    const int n3 = quintic_quadratic_roots(c.A, c.B, c.C, lo, hi, r3);   // p''' = 0: where p'' turns
+    int n2 = quintic_roots_between(c.d2, lo, hi, r3, n3, r2);            // p''  = 0: where p' turns
+    if (n2 > 0 && !(r2[n2 - 1] < hi)) n2--;                              // (a break point lies strictly inside; hi closes the last interval anyway)
+    const int n1 = quintic_roots_between(c.dq, lo, hi, r2, n2, r1);      // p'   = 0: the stationary points
+    return quintic_pick(q, lo, hi, r1, n1);
 }
 
 // The controller runs on one lane while the workgroup waits.  As out-of-line device functions (round 1) each call paid

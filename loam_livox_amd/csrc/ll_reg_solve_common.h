@@ -126,53 +126,69 @@ __device__ void solve_epilogue(const RegConst &rc, RegState *st, SH &sh, int lm_
     }
 }
 
-// lm_quintic_min_step (ll_reg_core.h) on the controller's whole wavefront.  The sequential form evaluates the interpolant at 33 grid
-// points one after the other and bisects every cell with a sign change of the derivative 40 times in turn: ~75 dependent
-// ten-step sweeps for one root, ~12 k cycles on one lane while the workgroup -- and the launch, whose length is its slowest
-// scan's -- waits.  Here lane k takes grid point k, the cells with a root are bisected side by side (each lane runs the very
-// loop of quintic_cell_root on its own cell), and the sequential "strictly smaller wins" scan over the roots becomes a
-// (value, cell) minimum: the same operations on the same operands for every number that is kept, so the same bits (compared
-// on random fits by tests/test_gpu_reg.py through ll_debug_quintic).  All 64 lanes must call it.
+// lm_quintic_min_step (ll_reg_core.h) on the controller's wavefront.  The sequential form isolates the roots level by level -- the
+// cubic p'' on the (at most three) intervals between the roots of the quadratic p''', then the quartic p' on the (at most four)
+// intervals between the roots of p'' -- bisecting one interval after the other: up to seven dependent 60-step bisections on one lane
+// while the workgroup -- and the launch, whose length is its slowest scan's -- waits.  Here lane i takes interval i of a level, so a fit is
+// two bisections deep; the break points travel by __shfl.  Every lane runs the very functions of the sequential form on the same
+// operands, and the roots are gathered in interval order, so the step has the same bits (compared on random and adversarial fits by
+// tests/test_gpu_reg.py through ll_debug_quintic).  All 64 lanes must call it.
 __device__ __forceinline__ double lm_quintic_min_step_wave(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2,
                                                            double lo, double hi, int lane)
 {
     Quintic q;
     if (!quintic_fit(f0, g0, x1, f1, g1, x2, f2, g2, q)) return fmin(fmax(0.5 * x1, lo), hi);  // (uniform: every lane has the same arguments)
-    const int k = lane <= LL_QUINTIC_CELLS ? lane : LL_QUINTIC_CELLS;  // the lanes above the grid repeat its last point; nothing of theirs is kept
-    const double xk = (k == 0) ? lo : quintic_grid(lo, hi, k, LL_QUINTIC_CELLS);
-    double pk, dk;
-    quintic_eval(q, xk, pk, dk);
-    const double v_lo = __shfl(pk, 0), v_hi = __shfl(pk, LL_QUINTIC_CELLS);
-    double best_x = lo, best_v = v_lo;
-    if (!(best_v < v_hi)) {
-        best_v = v_hi;
+    QuinticChain c;
+    quintic_chain(q, c);
+    double r3[2] = {hi, hi};
+    const int n3 = quintic_quadratic_roots(c.A, c.B, c.C, lo, hi, r3);  // (uniform)
+    // ---- p'' on the intervals [lo, r3_0], [r3_0, r3_1], [r3_1, hi] (the ones beyond n3 do not exist) ----
+    const double P1 = n3 >= 1 ? r3[0] : hi, P2 = n3 >= 2 ? r3[1] : hi;
+    double R0, R1, R2;
+    int n2;
+    {
+        const double a = lane == 0 ? lo : (lane == 1 ? P1 : P2), b = lane == 0 ? P1 : (lane == 1 ? P2 : hi);
+        double root = 0.0;
+        const bool has = lane <= n3 && lane < 3 && quintic_interval_root(c.d2, a, b, quintic_poly4(c.d2, a), quintic_poly4(c.d2, b), &root);
+        const int h0 = __shfl((int)has, 0), h1 = __shfl((int)has, 1), h2 = __shfl((int)has, 2);
+        const double y0 = __shfl(root, 0), y1 = __shfl(root, 1), y2 = __shfl(root, 2);
+        n2 = h0 + h1 + h2;
+        R0 = h0 ? y0 : (h1 ? y1 : y2);
+        R1 = (h0 && h1) ? y1 : y2;
+        R2 = y2;
+        const double last = n2 == 3 ? R2 : (n2 == 2 ? R1 : R0);
+        if (n2 > 0 && !(last < hi)) n2--;  // (a break point lies strictly inside; hi closes the last interval anyway)
+    }
+    // ---- p' on the intervals between lo, the roots of p'' and hi ----
+    const double Q1 = n2 >= 1 ? R0 : hi, Q2 = n2 >= 2 ? R1 : hi, Q3 = n2 >= 3 ? R2 : hi;
+    const double a = lane == 0 ? lo : (lane == 1 ? Q1 : (lane == 2 ? Q2 : Q3)), b = lane == 0 ? Q1 : (lane == 1 ? Q2 : (lane == 2 ? Q3 : hi));
+    double root = 0.0;
+    const bool has = lane <= n2 && lane < 4 && quintic_interval_root(c.dq, a, b, quintic_poly4(c.dq, a), quintic_poly4(c.dq, b), &root);
+    // ---- MinimizePolynomial's choice (quintic_pick), the roots in interval order ----
+    double best_x = lo, best_v, vh, dl, dh;
+    quintic_eval(q, lo, best_v, dl);
+    quintic_eval(q, hi, vh, dh);
+    (void)dl;
+    (void)dh;
+    if (!(best_v < vh)) {
+        best_v = vh;
         best_x = hi;
     }
-    const double xa = __shfl_up(xk, 1), da = __shfl_up(dk, 1);  // cell k = [x_(k-1), x_k]
-    const bool mine = lane >= 1 && lane <= LL_QUINTIC_CELLS && quintic_cell_has_root(da, dk);
-    double root = 0.0, v = 0.0;
-    if (mine) {
-        root = quintic_cell_root(q, xa, xk, da, dk);
-        double dv;
-        quintic_eval(q, root, v, dv);
-        (void)dv;
-    }
-    // the scan  `if (v < best_v) take it`  over the cells in order ends on the smallest value below the end points' best, the first
-    // cell among equal values
-    const bool cand = mine && (v < best_v);
-    double bv = cand ? v : INFINITY;
-    int bl = cand ? lane : 64;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(bv, off);
-        const int ol = __shfl_xor(bl, off);
-        if (ol < 64 && (bl >= 64 || ov < bv || (ov == bv && ol < bl))) {
-            bv = ov;
-            bl = ol;
+    for (int i = 0; i < 4; i++) {
+        const int hi_ = __shfl((int)has, i);
+        const double xi = __shfl(root, i);
+        if (hi_) {  // (uniform)
+            double v, dv;
+            quintic_eval(q, xi, v, dv);
+            (void)dv;
+            if (v < best_v) {
+                best_v = v;
+                best_x = xi;
+            }
         }
     }
-    const double r = __shfl(root, bl & 63);
-    return bl < 64 ? r : best_x;
+    return best_x;
 }
 
 // the fit with its ten arguments in LDS (written by lane 0).  (Out of line -- a real call inside the solver kernel -- it cost the WHOLE

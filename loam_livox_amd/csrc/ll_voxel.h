@@ -9,7 +9,8 @@ namespace ll {
 struct VoxelDev {
     int max_clouds, stride;
     int out_stride;              // stride of `out` after the last filter call (= the input stride of that call)
-    int block_path;              // 1 (default): up to 16 clouds of up to 24 576 points are filtered by one workgroup each (vox_block_kernel); 0 = A/B off
+    int block_path;              // 1 (default): every cloud of up to 24 576 points is filtered by one workgroup of its own, whatever the batch size (vox_block_kernel);
+                                 // 0 (LL_VOXEL_GENERAL_PATH, tests/test_gpu_voxel.py): every cloud through the multi-kernel pipeline, which larger clouds always take
     float4 *in;                  // [max_clouds][stride]  staging for host inputs
     float4 *out;                 // [n_clouds][out_stride] filtered clouds
     int *n, *n_out, *status;     // [max_clouds]

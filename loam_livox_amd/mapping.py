@@ -145,17 +145,21 @@ class Laser_mapping:
             self._extract(self._fe_pair[other], next_xyzi, next_time_stamp)
             self._prefetched = (next_xyzi, next_time_stamp, self._fe_pair[other], next_scan_id)
         res, pc, _, reps = reg.collect(1)
+        flags = getattr(reg, "debug_flags", 0)
         if reps[0].aborted:
-            # not a rejection the reference would have made: a bounded wait of the grouped solver ran out (the device was oversubscribed,
-            # e.g. by the prefetched extraction beside it).  Counted apart, and the scan is registered once more on one workgroup.
             self.aborted_solves += 1
-            reg.set_debug(False, no_solver_groups=True)
+        if reps[0].aborted and not (flags & 32):
+            # not a rejection the reference would have made: a bounded wait of the grouped solver ran out (the device was oversubscribed,
+            # e.g. by the prefetched extraction beside it).  Counted apart, and the scan is registered once more on one workgroup -- with
+            # the caller's other debug / A-B flags left as they are.  (An abort with the groups already off has another cause -- the small
+            # solver could not hold the scan -- which a repeat would not cure: the scan stays rejected.)
+            reg.set_debug_flags(flags | 32)
             if self.m_if_input_downsample_mode:
                 reg.enqueue_fe_downsampled(self.map, fe, self.vox[0], self.vox[1], self.line_res, self.plane_res, 1, pose, pose)
             else:
                 reg.enqueue_fe(self.map, fe, 1, pose, pose)
             res, pc, _, reps = reg.collect(1)
-            reg.set_debug(False)
+            reg.set_debug_flags(flags)
         self.last_report = reps[0]
         t1 = time.perf_counter()
         self.stage_s[0] += t1 - t0

@@ -189,6 +189,7 @@ typedef struct {
  * interpolation ran) */
 int orc_dbg_ls_max_contractions(int reset);
 long long orc_dbg_ls_quintic_fits(int reset);
+double orc_dbg_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi);
 int orc_reg_solve(const orc_kdtree *tree_corner, const float *map_corner, int64_t n_map_corner,
                   const orc_kdtree *tree_surf, const float *map_surf, int64_t n_map_surf, int map_stride,
                   const float *scan_corner, int n_corner, const float *scan_surf, int n_surf,

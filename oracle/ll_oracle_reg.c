@@ -451,9 +451,12 @@ static double gradient_max_norm(const double x[7], const double g[6], double bou
  * interpolant in Newton form by divided differences -- the two agree to rounding, checked against a dense solve in
  * tests/test_hostcheck.py), minimised over [lo, hi]
  * (MinimizePolynomial: the better end point, then every real root of the derivative inside the interval).  Ceres takes the roots
- * from the eigenvalues of the companion matrix; here the quartic derivative is bracketed on a fixed grid of the interval and each
- * sign change refined by bisection (a real root without a sign change is no minimum; real parts of complex roots, which Ceres
- * also evaluates, can never beat the stationary points and end points).  The first contraction keeps the two-sample cubic below. */
+ * from the eigenvalues of the companion matrix and so sees every real root of the quartic derivative.  So does this restatement
+ * (round 6): the roots are isolated exactly by the derivative chain -- p' is monotone between consecutive roots of the cubic p'',
+ * which is monotone between the roots of the quadratic p''' (closed form) -- so every interval between consecutive break points holds
+ * at most one root, found by its sign change and bisected.  (A real root without a sign change is no minimum; real parts of complex
+ * roots, which Ceres also evaluates, can never beat the stationary points and end points.)  Rounds 2 - 5 bracketed sign changes on a
+ * fixed 32-cell grid and could miss two roots inside one cell.  The first contraction keeps the two-sample cubic below. */
 static int g_ls_max_contractions = 0; /* test instrumentation: deepest line search seen */
 static long long g_ls_quintic_fits = 0; /* ... and how many three-sample fits ran */
 int orc_dbg_ls_max_contractions(int reset)
@@ -468,6 +471,49 @@ long long orc_dbg_ls_quintic_fits(int reset)
     if (reset) g_ls_quintic_fits = 0;
     return v;
 }
+static double qm_poly4(const double k[5], double x) { return fma(fma(fma(fma(k[4], x, k[3]), x, k[2]), x, k[1]), x, k[0]); }
+/* the root of the polynomial k in (a, b], where it is monotone (sign change of the end values, or vb == 0); 0 when there is none */
+static int qm_interval_root(const double k[5], double a, double b, double va, double vb, double *root)
+{
+    if (vb == 0.0) {
+        *root = b;
+        return 1;
+    }
+    if (!((va < 0.0 && vb > 0.0) || (va > 0.0 && vb < 0.0))) return 0;
+    double l = a, r = b, vl = va;
+    for (int it = 0; it < 60; it++) { /* halved until the interval cannot shrink, or 60 times */
+        const double m = 0.5 * (l + r);
+        if (m == l || m == r) break;
+        const double vm = qm_poly4(k, m);
+        if (vm == 0.0) {
+            l = r = m;
+            break;
+        }
+        if ((vl < 0.0) == (vm < 0.0)) {
+            l = m;
+            vl = vm;
+        } else {
+            r = m;
+        }
+    }
+    *root = 0.5 * (l + r);
+    return 1;
+}
+/* roots of k inside (lo, hi] given its break points bp[0 .. nb) (ascending, strictly inside): at most nb + 1, ascending */
+static int qm_roots_between(const double k[5], double lo, double hi, const double *bp, int nb, double *roots)
+{
+    int n = 0;
+    double a = lo, va = qm_poly4(k, lo);
+    for (int i = 0; i <= nb; i++) {
+        const double b = (i == nb) ? hi : bp[i];
+        const double vb = qm_poly4(k, b);
+        double r;
+        if (qm_interval_root(k, a, b, va, vb, &r)) roots[n++] = r;
+        a = b;
+        va = vb;
+    }
+    return n;
+}
 static double quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi)
 {
     /* Newton form on the nodes z = {0, 0, x1, x1, x2} (the sixth, x2 again, closes the table): divided differences with the
@@ -480,8 +526,7 @@ static double quintic_min_step(double f0, double g0, double x1, double f1, doubl
     const double c0 = (b1 - b0) / h2, c1 = (b2 - b1) / h2;
     const double d0 = (c1 - c0) / h2;
     /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep of
-     * explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and on the device; half the dependent
-     * chain of a multiply and an add per step, and the sweep runs ~100 times per fit on the controller lane) */
+     * explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and on the device) */
 #define LL_Q_EVAL(X, PV, DV)                         \
     do {                                             \
         const double x_ = (X);                       \
@@ -500,57 +545,71 @@ static double quintic_min_step(double f0, double g0, double x1, double f1, doubl
         (PV) = b_;                                   \
         (DV) = db_;                                  \
     } while (0)
+    /* monomial coefficients: three synthetic multiplications with (x - node) give p = u3 x^5 + u2 x^4 + u1 x^3 + u0 x^2 + e01 x + f0 */
+    const double s1 = d0, s0 = fma(-x2, d0, c0);
+    const double t2 = s1, t1 = fma(-x1, s1, s0), t0 = fma(-x1, s0, b0);
+    const double u3 = t2, u2 = fma(-x1, t2, t1), u1 = fma(-x1, t1, t0), u0 = fma(-x1, t0, a0);
+    const double dq[5] = {e01, 2.0 * u0, 3.0 * u1, 4.0 * u2, 5.0 * u3};    /* p'   */
+    const double d2[5] = {2.0 * u0, 6.0 * u1, 12.0 * u2, 20.0 * u3, 0.0};  /* p''  */
+    const double A = 60.0 * u3, B = 24.0 * u2, C = 6.0 * u1;               /* p''' */
+    /* roots of p''' strictly inside (lo, hi), ascending */
+    double r3[2];
+    int n3 = 0;
+    {
+        double q0 = 0.0, q1 = 0.0;
+        int n = 0;
+        if (A == 0.0) {
+            if (B != 0.0) q0 = -C / B, n = 1;
+        } else {
+            const double disc = fma(B, B, -4.0 * A * C);
+            if (disc >= 0.0) {
+                const double sq = sqrt(disc);
+                const double qq = -0.5 * (B + (B < 0.0 ? -sq : sq));
+                q0 = qq / A;
+                n = 1;
+                if (qq != 0.0) {
+                    q1 = C / qq;
+                    n = 2;
+                    if (q1 < q0) {
+                        const double t = q0;
+                        q0 = q1;
+                        q1 = t;
+                    }
+                }
+            }
+        }
+        if (n >= 1 && q0 > lo && q0 < hi) r3[n3++] = q0;
+        if (n >= 2 && q1 > lo && q1 < hi && !(n3 == 1 && q1 == r3[0])) r3[n3++] = q1;
+    }
+    double r2[3], r1[4];
+    int n2 = qm_roots_between(d2, lo, hi, r3, n3, r2);
+    if (n2 > 0 && !(r2[n2 - 1] < hi)) n2--;
+    const int n1 = qm_roots_between(dq, lo, hi, r2, n2, r1);
     double best_x = lo, best_v, vh, da, dh;
     LL_Q_EVAL(lo, best_v, da);
     LL_Q_EVAL(hi, vh, dh);
+    (void)da;
     (void)dh;
     if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
         best_v = vh;
         best_x = hi;
     }
-    const int NG = 32; /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
-    double xa = lo;
-    for (int k = 1; k <= NG; k++) {
-        const double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
-        double pb, db;
-        LL_Q_EVAL(xb, pb, db);
-        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
-            double l = xa, r = xb, dl = da;
-            if (db != 0.0) {
-                for (int it = 0; it < 40; it++) {
-                    const double m = 0.5 * (l + r);
-                    double pm, dm;
-                    LL_Q_EVAL(m, pm, dm);
-                    (void)pm;
-                    if (dm == 0.0) {
-                        l = r = m;
-                        break;
-                    }
-                    if ((dl < 0.0) == (dm < 0.0)) {
-                        l = m;
-                        dl = dm;
-                    } else {
-                        r = m;
-                    }
-                }
-            } else {
-                l = r = xb;
-            }
-            const double root = 0.5 * (l + r);
-            double v, dv;
-            LL_Q_EVAL(root, v, dv);
-            (void)dv;
-            if (v < best_v) {
-                best_v = v;
-                best_x = root;
-            }
+    for (int i = 0; i < n1; i++) {
+        double v, dv;
+        LL_Q_EVAL(r1[i], v, dv);
+        (void)dv;
+        if (v < best_v) {
+            best_v = v;
+            best_x = r1[i];
         }
-        (void)pb;
-        xa = xb;
-        da = db;
     }
 #undef LL_Q_EVAL
     return best_x;
+}
+/* test tap (tests/test_hostcheck.py: the adversarial fits) */
+double orc_dbg_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi)
+{
+    return quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi);
 }
 
 /* minimiser of the cubic Hermite interpolant through (0,f0,g0) and (x1,f1,g1) on [lo,hi] */

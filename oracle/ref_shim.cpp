@@ -316,4 +316,10 @@ double ref_reg_inlier_threshold( void *h, const double *residuals, int n, double
     return ( ( RefReg * ) h )->reg.compute_inlier_residual_threshold( v, ratio );
 }
 
+// the line search's three-sample fit of the Ceres stand-in (ll_stub_ceres_solver.h quintic_min): test tap for the adversarial fits
+double ref_quintic_min( double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi )
+{
+    return ceres::ll_solver::quintic_min( f0, g0, x1, f1, g1, x2, f2, g2, lo, hi );
+}
+
 } // extern "C"

@@ -201,9 +201,56 @@ inline bool cholesky_solve( int n, std::vector<double> A, const std::vector<doub
 // with value and gradient -> the quintic interpolant (polynomial.cc FindInterpolatingPolynomial solves the 6 x 6 system with a
 // row [x^5 .. 1] per value and [5 x^4 .. 0] per gradient by fully pivoted LU; here the same polynomial in Newton form by divided
 // differences, the arithmetic the oracle and the device share), minimised over [lo, hi] by MinimizePolynomial: the better end
-// point, then the real roots of the derivative inside the interval.  (Ceres: companion-matrix eigenvalues; here: sign changes of
-// the derivative on a grid of the interval, bisected -- a root without a sign change is no minimum, and the real parts of complex
-// roots that Ceres also tries cannot beat the stationary points.)
+// point, then the real roots of the derivative inside the interval.  (Ceres: companion-matrix eigenvalues, i.e. every real root;
+// here every real root as well, isolated by the derivative chain -- p' is monotone between the roots of p'', p'' between the roots of
+// the quadratic p''' -- and bisected.  A root without a sign change is no minimum, and the real parts of complex roots that Ceres
+// also tries cannot beat the stationary points.)
+inline double quintic_poly4( const double k[ 5 ], double x ) { return std::fma( std::fma( std::fma( std::fma( k[ 4 ], x, k[ 3 ] ), x, k[ 2 ] ), x, k[ 1 ] ), x, k[ 0 ] ); }
+inline bool quintic_interval_root( const double k[ 5 ], double a, double b, double va, double vb, double *root )
+{
+    if ( vb == 0.0 )
+    {
+        *root = b;
+        return true;
+    }
+    if ( !( ( va < 0.0 && vb > 0.0 ) || ( va > 0.0 && vb < 0.0 ) ) ) return false;
+    double l = a, r = b, vl = va;
+    for ( int it = 0; it < 60; it++ )
+    {
+        const double m = 0.5 * ( l + r );
+        if ( m == l || m == r ) break;
+        const double vm = quintic_poly4( k, m );
+        if ( vm == 0.0 )
+        {
+            l = r = m;
+            break;
+        }
+        if ( ( vl < 0.0 ) == ( vm < 0.0 ) )
+        {
+            l = m;
+            vl = vm;
+        }
+        else
+            r = m;
+    }
+    *root = 0.5 * ( l + r );
+    return true;
+}
+inline int quintic_roots_between( const double k[ 5 ], double lo, double hi, const double *bp, int nb, double *roots )
+{
+    int    n = 0;
+    double a = lo, va = quintic_poly4( k, lo );
+    for ( int i = 0; i <= nb; i++ )
+    {
+        const double b = ( i == nb ) ? hi : bp[ i ];
+        const double vb = quintic_poly4( k, b );
+        double       r;
+        if ( quintic_interval_root( k, a, b, va, vb, &r ) ) roots[ n++ ] = r;
+        a = b;
+        va = vb;
+    }
+    return n;
+}
 inline double quintic_min( double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi )
 {
     /* Newton form on the nodes z = {0, 0, x1, x1, x2} (the sixth, x2 again, closes the table): divided differences with the
@@ -216,8 +263,7 @@ inline double quintic_min( double f0, double g0, double x1, double f1, double g1
     const double c0 = (b1 - b0) / h2, c1 = (b2 - b1) / h2;
     const double d0 = (c1 - c0) / h2;
     /* p(x) = f0 + x (e01 + x (a0 + (x - x1) (b0 + (x - x1) (c0 + (x - x2) d0)))); value and derivative by one nested sweep of
-     * explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and on the device; half the dependent
-     * chain of a multiply and an add per step, and the sweep runs ~100 times per fit on the controller lane) */
+     * explicitly fused multiply-adds (IEEE: the same bits in the oracle, the stand-in and on the device) */
 #define LL_Q_EVAL(X, PV, DV)                         \
     do {                                             \
         const double x_ = (X);                       \
@@ -236,54 +282,65 @@ inline double quintic_min( double f0, double g0, double x1, double f1, double g1
         (PV) = b_;                                   \
         (DV) = db_;                                  \
     } while (0)
+    /* monomial coefficients: p = u3 x^5 + u2 x^4 + u1 x^3 + u0 x^2 + e01 x + f0 */
+    const double s1 = d0, s0 = std::fma( -x2, d0, c0 );
+    const double t2 = s1, t1 = std::fma( -x1, s1, s0 ), t0 = std::fma( -x1, s0, b0 );
+    const double u3 = t2, u2 = std::fma( -x1, t2, t1 ), u1 = std::fma( -x1, t1, t0 ), u0 = std::fma( -x1, t0, a0 );
+    const double dq[ 5 ] = { e01, 2.0 * u0, 3.0 * u1, 4.0 * u2, 5.0 * u3 };
+    const double d2[ 5 ] = { 2.0 * u0, 6.0 * u1, 12.0 * u2, 20.0 * u3, 0.0 };
+    const double A = 60.0 * u3, B = 24.0 * u2, C = 6.0 * u1;
+    double r3[ 2 ];
+    int    n3 = 0;
+    {
+        double q0 = 0.0, q1 = 0.0;
+        int    n = 0;
+        if ( A == 0.0 )
+        {
+            if ( B != 0.0 ) q0 = -C / B, n = 1;
+        }
+        else
+        {
+            const double disc = std::fma( B, B, -4.0 * A * C );
+            if ( disc >= 0.0 )
+            {
+                const double sq = std::sqrt( disc );
+                const double qq = -0.5 * ( B + ( B < 0.0 ? -sq : sq ) );
+                q0 = qq / A;
+                n = 1;
+                if ( qq != 0.0 )
+                {
+                    q1 = C / qq;
+                    n = 2;
+                    if ( q1 < q0 ) std::swap( q0, q1 );
+                }
+            }
+        }
+        if ( n >= 1 && q0 > lo && q0 < hi ) r3[ n3++ ] = q0;
+        if ( n >= 2 && q1 > lo && q1 < hi && !( n3 == 1 && q1 == r3[ 0 ] ) ) r3[ n3++ ] = q1;
+    }
+    double r2[ 3 ], r1[ 4 ];
+    int    n2 = quintic_roots_between( d2, lo, hi, r3, n3, r2 );
+    if ( n2 > 0 && !( r2[ n2 - 1 ] < hi ) ) n2--;
+    const int n1 = quintic_roots_between( dq, lo, hi, r2, n2, r1 );
     double best_x = lo, best_v, vh, da, dh;
     LL_Q_EVAL(lo, best_v, da);
     LL_Q_EVAL(hi, vh, dh);
+    (void)da;
     (void)dh;
     if (!(best_v < vh)) { /* MinimizePolynomial: x_min wins only when strictly smaller */
         best_v = vh;
         best_x = hi;
     }
-    const int NG = 32; /* sign changes of the derivative on 32 sub-intervals, each bisected 40 times */
-    double xa = lo;
-    for (int k = 1; k <= NG; k++) {
-        const double xb = (k == NG) ? hi : lo + (hi - lo) * ((double)k / (double)NG);
-        double pb, db;
-        LL_Q_EVAL(xb, pb, db);
-        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0) || db == 0.0) {
-            double l = xa, r = xb, dl = da;
-            if (db != 0.0) {
-                for (int it = 0; it < 40; it++) {
-                    const double m = 0.5 * (l + r);
-                    double pm, dm;
-                    LL_Q_EVAL(m, pm, dm);
-                    (void)pm;
-                    if (dm == 0.0) {
-                        l = r = m;
-                        break;
-                    }
-                    if ((dl < 0.0) == (dm < 0.0)) {
-                        l = m;
-                        dl = dm;
-                    } else {
-                        r = m;
-                    }
-                }
-            } else {
-                l = r = xb;
-            }
-            const double root = 0.5 * (l + r);
-            double v, dv;
-            LL_Q_EVAL(root, v, dv);
-            (void)dv;
-            if (v < best_v) {
-                best_v = v;
-                best_x = root;
-            }
+    for ( int i = 0; i < n1; i++ )
+    {
+        double v, dv;
+        LL_Q_EVAL( r1[ i ], v, dv );
+        (void)dv;
+        if ( v < best_v )
+        {
+            best_v = v;
+            best_x = r1[ i ];
         }
-        (void)pb;
-        xa = xb;
-        da = db;
     }
 #undef LL_Q_EVAL
     return best_x;

@@ -41,6 +41,11 @@ def test_summarize_rocprof_generic_and_trace(tmp_path):
         w.writerow(["void ll::reg_solve_kernel<0>(ll::RegDev, ll::RegConst)", 512, "SQ_INSTS_VALU", 7.0])
         w.writerow(["void other::kernel()", 64, "SQ_INSTS_VALU", 99.0])
     out = subprocess.run([sys.executable, tool, "generic", str(pmc)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    # first line: which kernel sources the numbers belong to (tools/build_id.py; bench.py compares it with the tree it runs on)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_id import build_id
+    assert out[0] == "# build " + build_id()
+    out = out[1:]
     assert out[0] == "kernel,grid_threads,dispatches,SQ_INSTS_VALU_avg"
     assert out[1] == "ll::reg_solve_kernel<0>,131072,2,20.0" and out[2] == "ll::reg_solve_kernel<0>,512,1,7.0" and len(out) == 3
     trace = tmp_path / "kernel_trace.csv"
@@ -50,7 +55,10 @@ def test_summarize_rocprof_generic_and_trace(tmp_path):
                     "Start_Timestamp", "End_Timestamp"])
         w.writerow(["void ll::reg_knn_kernel(ll::RegDev)", 1024, 2, 1, 128, 56, 0, 0, 1000, 3000])
         w.writerow(["void ll::reg_knn_kernel(ll::RegDev)", 1024, 2, 1, 128, 56, 0, 0, 5000, 9000])
-    out = subprocess.run([sys.executable, tool, "trace", str(trace)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    out = subprocess.run([sys.executable, tool, "trace", str(trace)], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, LL_GIT_COMMIT="abc1234")).stdout.strip().split("\n")
+    assert out[0] == "# build " + build_id() + " commit abc1234"
+    out = out[1:]
     assert out[1] == "ll::reg_knn_kernel,2048,128,56,0,0,2,0.006,3.0,2.0,4.0"
 
 
@@ -63,6 +71,8 @@ def test_summarize_rocprof_reads_register_counts_from_the_code_object():
         pytest.skip("library not built")
     tool = os.path.join(ROOT, "tools", "summarize_rocprof.py")
     out = subprocess.run([sys.executable, tool, "codeobj", lib], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert out[0].startswith("# build ")
+    out = out[1:]
     assert out[0] == "kernel,vgpr,agpr,sgpr,vgpr_spill,sgpr_spill,scratch_bytes,lds_bytes,waves_per_simd"
     rows = {r.split(",")[0]: r.split(",") for r in out[1:]}
     sol = rows["ll::reg_solve_kernel<0>"]

@@ -578,3 +578,37 @@ def test_append_touched_with_a_short_buffer_truncates_and_does_not_fail(gpu_lib)
     assert np.array_equal(ijk, want[:8])               # the first capacity_cells entries
     assert short.stats() == full.stats()               # the cloud is in exactly once
     full.close(); short.close()
+
+
+@pytest.mark.gpu
+def test_borrowed_cell_map_handle_settles_the_service_thread_on_every_read(gpu_lib):
+    """a handle borrowed from ll_history_cell_map is kept across ll_history_add* while the history feeds its cell maps on
+    the service thread -- which also grows them (cellmap_grow frees and swaps every array).  Every ll_cellmap_* entry point now waits for
+    the frames handed over so far: stats / dump / device_view on the OLD handle, straight after the adds and without any explicit sync,
+    see every frame; and a history without cell maps says so instead of returning a bare NULL."""
+    from loam_livox_amd.api import History_buffer
+    from loam_livox_amd.capi import LoamLivoxError
+    rng = np.random.default_rng(11)
+    frames = [(rng.uniform(-20, 20, (300, 4)).astype(np.float32), rng.uniform(-20, 20, (2500, 4)).astype(np.float32)) for _ in range(24)]
+    pose = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+    out = []
+    for async_ in (True, False):
+        h = History_buffer(maximum_history_size=30, max_points_per_frame=4000, line_res=0.05, plane_res=0.05)
+        if async_:
+            with pytest.raises(LoamLivoxError, match="not enabled"):
+                h.cell_map(1)
+        h.enable_cell_map(max_points=3000, cell_resolution=1.0)   # far too small: the maps double several times on the way
+        h.set_cell_map_async(async_)
+        borrowed = [h.cell_map(0), h.cell_map(1)]                 # taken BEFORE any frame is in
+        seen = []
+        for k, (c, s) in enumerate(frames):
+            h.add(c, s, pose)
+            if k % 5 == 4:
+                seen.append(borrowed[1].stats()[:2])              # no sync: the call itself settles the service thread
+        dumps = [b.dump() for b in borrowed]
+        out.append((seen, dumps))
+        assert seen[-1][1] > 20000 and borrowed[1].stats()[1] == len(dumps[1][0])
+        h.close()
+    assert out[0][0] == out[1][0]
+    for k in (0, 1):
+        assert all(np.array_equal(a, b) for a, b in zip(out[0][1][k], out[1][1][k]))
