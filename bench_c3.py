@@ -157,10 +157,10 @@ def main():
     ms_launch = float(kms[1] / max(1.0, kn[1]))
     traffic = src = None
     import csv, glob
-    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_c3_pmc_hbm_bytes.csv")))
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_c3_pmc_hbm_bytes.csv")))
     if hits:
         best = None
-        for r in csv.DictReader(open(hits[-1])):
+        for r in csv.DictReader(l for l in open(hits[-1]) if not l.startswith("#")):
             if "reg_solve_kernel" in r["kernel"] and (best is None or int(r["grid_threads"]) > int(best["grid_threads"])):
                 best = r
         if best is not None and int(best["grid_threads"]) == B * 512:
@@ -173,6 +173,12 @@ def main():
                        "limited_by": "HBM traffic of the general path -- every block's 49 / 65 B is streamed again by each of the ~9 cost evaluations and the "
                                      "flag / L1 passes of a launch (counters: ~10 x the algorithmic bytes, a third of the HBM peak) -- together with the "
                                      "fp64 issue of the motion-deblur evaluations (one sincos + the interpolated rotation per block)"}
+    cyc = np.array([[int(v) for v in reg.debug_cycles(b)] for b in range(B)], np.float64)
+    if cyc.any():  # a -DLL_SOLVE_TIMING build (LOAM_LIVOX_LIB=...): shader-clock cycles per scan, summed over the registration's launches
+        out["solver_phase_cycles_mean_over_scans"] = [int(v) for v in cyc.mean(0)]
+        out["solver_phase_cycles_of_the_slowest_scan"] = [int(v) for v in cyc[int(np.argmax(cyc[:, 5]))]]
+        out["solver_phase_cycles_first_scans"] = [[int(v) for v in cyc[b]] for b in range(min(B, args.distinct))]
+        out["solver_phase_cycles_legend"] = "0 evaluations, 1 controller, 2 L1 pass, 3 set de-duplication, 4 rank select (+ prune), 5 whole solver call, 6.. path specific (ll_device.h RegState::dbg_cycles)"
     if args.cpu_scans > 0:
         from oracle import orc
         tb = time.perf_counter()

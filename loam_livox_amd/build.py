@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 # and load it with LL_LIB_PATH (capi.py); the default is the product library.
 LIB = os.environ.get("LL_LIB_OUT") or os.path.join(HERE, "libloamlivox_hip.so")
 SOURCES = ["ll_api.hip", "ll_fe_kernels.hip", "ll_map_kernels.hip", "ll_reg_kernels.hip", "ll_reg_small_kernels.hip", "ll_knn_kernels.hip", "ll_voxel_kernels.hip", "ll_cellmap_kernels.hip"]
-HEADERS = ["ll_device.h", "ll_fe_core.h", "ll_knn_core.h", "ll_knn_coop.h", "ll_knn_tile.h", "ll_reg_query.h", "ll_reg_solve_common.h", "ll_reg_core.h", "ll_voxel.h", "ll_voxel_core.h", "ll_cellmap.h", "ll_cellmap_core.h", "../../include/loam_livox_hip.h"]
+HEADERS = ["ll_device.h", "ll_fe_core.h", "ll_knn_core.h", "ll_knn_coop.h", "ll_knn_tile.h", "ll_reg_query.h", "ll_reg_big_path.h", "ll_reg_solve_common.h", "ll_reg_core.h", "ll_voxel.h", "ll_voxel_core.h", "ll_cellmap.h", "ll_cellmap_core.h", "../../include/loam_livox_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 FLAGS += os.environ.get("LL_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DLL_SOLVE_TIMING (instrumented solver, ll_reg_debug_cycles)
 

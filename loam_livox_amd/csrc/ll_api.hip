@@ -797,8 +797,8 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.blk_av, B * 6 * d.cap);
     DM(d.blk_id, B * d.cap_s);
     {
-        const int lim = d.cap_s < 24576 ? d.cap_s : 24576;  // FAST_MAX_BLOCKS: larger scans never take the plane-table path
-        d.tab_cap = (lim + 4095) / 4096 * 4096;
+        const int lim = d.cap_s < 61440 ? d.cap_s : 61440;  // LL_TABLE_MAX_BLOCKS: larger scans never take a plane-table path
+        d.tab_cap = (lim + 4095) / 4096 * 4096;             // (<= 61440: private entries count down from tab_cap - 1, below the 16-bit sentinels)
     }
     DM(d.pl_tab, B * (size_t)d.tab_cap * 2);
     DM(d.blk_flag, B * d.cap);

@@ -159,7 +159,7 @@ struct RegDev {
     // (a scan's ~17 k plane blocks share 2.4 - 4.6 k triples), built by the solver itself at the start of every launch
     unsigned short *blk_id;       // [B][cap_s] plane id of every surface block (relative to its solver workgroup's table region)
     int4 *pl_tab;                 // [B][tab_cap][2] plane table: {n'.x, n'.y}, {n'.z, c = n'.a'} (fp64), frame of pose_last
-    int tab_cap;                  // entries per scan: min(cap_s, 24576) rounded up to 4096 (LL_GRP regions of whole 512-thread rounds)
+    int tab_cap;                  // entries per scan: min(cap_s, 61440) rounded up to 4096 (LL_GRP regions of whole 512-thread rounds)
     float4 *qw;                   // [B][cap]  queries transformed into the map frame (K6t -> K6a)
     float4 *ref_q;                // [B][cap]  query position where the neighbour list was established, w = m_strong
     int4 *ref_p;                  // [B][cap]  its neighbours 0..3 (positions in the cell-sorted array)
@@ -196,6 +196,7 @@ void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, c
                          bool fused, hipStream_t s);
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s);
 bool reg_solve_small_eligible(const RegConst &rc, int max_nc, int max_ns);
+bool reg_solve_fast_eligible(const RegConst &rc, int max_nc, int max_ns);
 void launch_reg_solve_small(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s);
 int reg_solve_small_waves(const RegConst &rc, int n_scans, int max_nc, int max_ns);
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s);

@@ -401,6 +401,24 @@ LL_HD void block_accumulate(int kind, const double R[9], const double t[3], cons
 // for the Ceres perturbation R_inc+ = Exp(2 d) R_inc,
 //     d(R_s f)/dd = -[R_s f]x M,   M = 2 s J_l(s w) J_l(w)^-1 = m0 (I + beta K + gamma K^2)
 // (left Jacobians of SO(3); both are polynomials in K, K^3 = -K).  d p/d t_inc = s I.
+// cross3 / dot3 with the multiply-adds fused (the motion-deblur block functions below: round 6; the plain forms above keep the
+// un-contracted arithmetic the block constants were pinned with)
+LL_HD void cross3c(const double a[3], const double b[3], double o[3])
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+LL_HD double dot3c(const double a[3], const double b[3])
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
 struct MbRot {
     double n[3];       // rotation axis of the increment
     double W;          // rotation angle of the increment
@@ -464,30 +482,60 @@ LL_HD void sincos_small(double x, double *sn, double *cs)
 }
 
 // y = R_s f and the coefficients (m0, beta, gamma) of M for blur ratio s
+// For a small angle x (|x| < 0.25) everything mb_block needs of it comes from two even polynomials, no division:
+//   B(z) = (1 - sin x / x) / z = 1/3! - z/5! + z^2/7! - ...      C(z) = (1 - cos x) / z = 1/2! - z/4! + z^2/6! - ...      (z = x^2)
+//   sin x = x - x z B,   1 - cos x = z C,   a = (1 - cos x) / x = x C,   b = 1 - sin x / x = z B
+// (first neglected terms z^7/17! and z^8/18!: below 1e-24 at |x| = 0.25.)  Round 6: the two divisions by s W of the general form below
+// cost as much as both Taylor polynomials of sincos_small together, per residual block and cost evaluation.
+LL_HD void mb_small_angle(double x, double *sn, double *omc, double *a, double *b)
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    const double z = x * x;
+    double pb = -1.0 / 1307674368000.0;  // -1/15!
+    pb = pb * z + 1.0 / 6227020800.0;    //  1/13!
+    pb = pb * z - 1.0 / 39916800.0;      // -1/11!
+    pb = pb * z + 1.0 / 362880.0;        //  1/9!
+    pb = pb * z - 1.0 / 5040.0;          // -1/7!
+    pb = pb * z + 1.0 / 120.0;           //  1/5!
+    pb = pb * z - 1.0 / 6.0;             // -1/3!   (pb = -B)
+    double pc = 1.0 / 20922789888000.0;  //  1/16!
+    pc = pc * z - 1.0 / 87178291200.0;   // -1/14!
+    pc = pc * z + 1.0 / 479001600.0;     //  1/12!
+    pc = pc * z - 1.0 / 3628800.0;       // -1/10!
+    pc = pc * z + 1.0 / 40320.0;         //  1/8!
+    pc = pc * z - 1.0 / 720.0;           // -1/6!
+    pc = pc * z + 1.0 / 24.0;            //  1/4!
+    pc = pc * z - 0.5;                   // -1/2!   (pc = -C)
+    const double zb = z * pb;            // -(1 - sin x / x)
+    *sn = x + x * zb;
+    *omc = -(z * pc);
+    *a = -(x * pc);
+    *b = -zb;
+}
+
 LL_HD void mb_block(const MbRot &m, double s, const double f[3], double y[3], double coef[3])
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     const double sW = s * m.W;
-    double sn, cs;
+    double sn, omc, a, b;  // sin, 1 - cos, and J_l(s w) = I + a K + b K^2
     if (fabs(sW) < 0.25) {
-        sincos_small(sW, &sn, &cs);
+        mb_small_angle(sW, &sn, &omc, &a, &b);
     } else {
         sn = sin(sW);
-        cs = cos(sW);
+        omc = 1.0 - cos(sW);
+        a = omc / sW;
+        b = 1.0 - sn / sW;
     }
     double nf[3], nnf[3];
-    cross3(m.n, f, nf);
-    cross3(m.n, nf, nnf);
-    y[0] = f[0] + sn * nf[0] + (1.0 - cs) * nnf[0];
-    y[1] = f[1] + sn * nf[1] + (1.0 - cs) * nnf[1];
-    y[2] = f[2] + sn * nf[2] + (1.0 - cs) * nnf[2];
-    double a, b;  // J_l(s w) = I + a K + b K^2
-    if (fabs(sW) > 1e-4) {
-        a = (1.0 - cs) / sW;
-        b = 1.0 - sn / sW;
-    } else {
-        a = 0.5 * sW;
-        b = sW * sW / 6.0;
-    }
+    cross3c(m.n, f, nf);
+    cross3c(m.n, nf, nnf);
+    y[0] = f[0] + sn * nf[0] + omc * nnf[0];
+    y[1] = f[1] + sn * nf[1] + omc * nnf[1];
+    y[2] = f[2] + sn * nf[2] + omc * nnf[2];
     const double c = m.c_half, d = m.d;
     coef[0] = 2.0 * s;
     coef[1] = a + c - a * d - b * c;
@@ -497,9 +545,12 @@ LL_HD void mb_block(const MbRot &m, double s, const double f[3], double y[3], do
 // M^T z = m0 (z - beta K z + gamma K^2 z)
 LL_HD void mb_Mt(const MbRot &m, const double coef[3], const double z[3], double o[3])
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     double kz[3], kkz[3];
-    cross3(m.n, z, kz);
-    cross3(m.n, kz, kkz);
+    cross3c(m.n, z, kz);
+    cross3c(m.n, kz, kkz);
     o[0] = coef[0] * (z[0] - coef[1] * kz[0] + coef[2] * kkz[0]);
     o[1] = coef[0] * (z[1] - coef[1] * kz[1] + coef[2] * kkz[1]);
     o[2] = coef[0] * (z[2] - coef[1] * kz[2] + coef[2] * kkz[2]);
@@ -509,28 +560,34 @@ LL_HD void mb_Mt(const MbRot &m, const double coef[3], const double z[3], double
 LL_HD double block_residual_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
                                const double v[3], double y[3], double coef[3], double r[3], double *dd_out)
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     mb_block(m, s, f, y, coef);
     double dd;
     if (kind == BLK_LINE) {
         const double d[3] = {y[0] + s * t[0] - a[0], y[1] + s * t[1] - a[1], y[2] + s * t[2] - a[2]};
-        dd = dot3(d, v);
+        dd = dot3c(d, v);
         r[0] = d[0] - dd * v[0];
         r[1] = d[1] - dd * v[1];
         r[2] = d[2] - dd * v[2];
     } else {
         const double p[3] = {y[0] + s * t[0], y[1] + s * t[1], y[2] + s * t[2]};
-        dd = dot3(p, v) - a[0];  // a[0] = n'.a'
+        dd = dot3c(p, v) - a[0];  // a[0] = n'.a'
         r[0] = dd * v[0];
         r[1] = dd * v[1];
         r[2] = dd * v[2];
     }
     *dd_out = dd;
-    return dot3(r, r);
+    return dot3c(r, r);
 }
 
 LL_HD void block_accumulate_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
                                const double v[3], double huber_a, double acc[LL_NACC])
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     double y[3], coef[3], r[3], dd, rho0, w;
     const double ss = block_residual_mb(kind, m, t, s, f, a, v, y, coef, r, &dd);
     huber(huber_a, ss, &rho0, &w);
@@ -538,10 +595,10 @@ LL_HD void block_accumulate_mb(int kind, const MbRot &m, const double t[3], doub
     if (kind == BLK_PLANE) {
         // J = n (B^T n)^T with B^T n = [M^T (y x n) ; s n]
         double yxn[3], top[3];
-        cross3(y, v, yxn);
+        cross3c(y, v, yxn);
         mb_Mt(m, coef, yxn, top);
         const double cv[6] = {top[0], top[1], top[2], s * v[0], s * v[1], s * v[2]};
-        const double nn2 = dot3(v, v);
+        const double nn2 = dot3c(v, v);
         const double wn = w * nn2, gs = wn * dd;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -557,11 +614,11 @@ LL_HD void block_accumulate_mb(int kind, const MbRot &m, const double t[3], doub
         for (int j = 0; j < 3; j++) {
             const double ej[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
             double kz[3], kkz[3], me[3], bj[3];
-            cross3(m.n, ej, kz);
-            cross3(m.n, kz, kkz);
+            cross3c(m.n, ej, kz);
+            cross3c(m.n, kz, kkz);
             for (int i = 0; i < 3; i++) me[i] = coef[0] * (ej[i] + coef[1] * kz[i] + coef[2] * kkz[i]);  // M e_j
-            cross3(me, y, bj);                                                                        // -[y]x M e_j
-            const double ub = dot3(v, bj);
+            cross3c(me, y, bj);                                                                        // -[y]x M e_j
+            const double ub = dot3c(v, bj);
             for (int i = 0; i < 3; i++) J[i][j] = bj[i] - ub * v[i];
             const double us = s * v[j];
             for (int i = 0; i < 3; i++) J[i][3 + j] = (i == j ? s : 0.0) - us * v[i];
@@ -578,6 +635,9 @@ LL_HD void block_accumulate_mb(int kind, const MbRot &m, const double t[3], doub
 LL_HD double block_l1_mb(int kind, const MbRot &m, const double t[3], double s, const double f[3], const double a[3],
                          const double v[3], double huber_a, const double q_last[4])
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     double y[3], coef[3], r[3], dd, rho0, w, rw[3];
     const double ss = block_residual_mb(kind, m, t, s, f, a, v, y, coef, r, &dd);
     huber(huber_a, ss, &rho0, &w);

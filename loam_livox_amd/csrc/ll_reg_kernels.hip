@@ -523,53 +523,6 @@ __device__ __forceinline__ void group_reduce(const RegDev &rd, int b, SolveShare
     __syncthreads();
 }
 
-// workgroup evaluation of cost / g / H at x (LDS) over the active blocks -> sh.sum
-template <int DEBLUR>
-__device__ __noinline__ void solver_eval(const RegDev &rd, int b, int nC, int nS, const double *x, double huber_a, int deblur, SolveShared &sh)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t sb = (size_t)b * rd.cap;
-    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-    LL_CTX_DECL(x)
-    double acc[LL_NACC];
-#pragma unroll
-    for (int i = 0; i < LL_NACC; i++) acc[i] = 0.0;
-    const int total = nC + nS;
-    // software-pipelined one block ahead (flag included): with two waves per SIMD nothing else hides the loads
-    int j = tid;
-    float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
-    double na0 = 0, na1 = 0, na2 = 0, nv0 = 0, nv1 = 0, nv2 = 0;
-    unsigned char nfl = 0;
-    if (j < total) {
-        const int slot = slot_of(j, nC, rd.cap_c);
-        nfl = rd.blk_flag[sb + slot];
-        nf = rd.blk_f[sb + slot];
-        av_load(av, rd.cap, slot, slot < rd.cap_c, na0, na1, na2, nv0, nv1, nv2);
-    }
-    while (j < total) {
-        const unsigned char fl = nfl;
-        const float4 ff = nf;
-        const double a[3] = {na0, na1, na2}, v[3] = {nv0, nv1, nv2};
-        const int jn = j + RS_THREADS;
-        if (jn < total) {
-            const int slot = slot_of(jn, nC, rd.cap_c);
-            nfl = rd.blk_flag[sb + slot];
-            nf = rd.blk_f[sb + slot];
-            av_load(av, rd.cap, slot, slot < rd.cap_c, na0, na1, na2, nv0, nv1, nv2);
-        }
-        if (fl & BLK_ACTIVE) LL_CTX_ACCUM(fl & 3, ff, a, v, huber_a, acc);
-        j = jn;
-    }
-    wave_sum_acc(acc, sh.red[wave], lane);
-    __syncthreads();
-    if (tid < LL_NACC) {
-        double s = 0.0;
-        for (int w = 0; w < RS_WAVES; w++) s += sh.red[w][tid];
-        sh.sum[tid] = s;
-    }
-    __syncthreads();
-}
-
 // three counts (each < 2^20) in one reduction: a | b << 20 | c << 40
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, SolveShared &sh)
 {
@@ -595,24 +548,6 @@ __device__ int block_sum_int(int v, SolveShared &sh)
     for (int w = 0; w < RS_WAVES; w++) s += sh.isum[w];
     __syncthreads();
     return s;
-}
-
-// one ceres::Solve: starts at x0 (global/LDS), leaves the result in sh.ctl
-template <int DEBLUR>
-__device__ void solver_lm(const RegDev &rd, const RegConst &rc, int b, int nC, int nS, const double *x0, int max_iter,
-                          int n_active, SolveShared &sh)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) lm_begin(sh.ctl, x0, max_iter, rc.bound);
-    __syncthreads();
-    solver_eval<DEBLUR>(rd, b, nC, nS, sh.ctl.x, rc.huber_a, DEBLUR, sh);
-    if (tid == 0) sh.need = lm_init(sh.ctl, sh.sum, n_active);
-    __syncthreads();
-    while (sh.need) {
-        solver_eval<DEBLUR>(rd, b, nC, nS, sh.ctl.cand, rc.huber_a, DEBLUR, sh);
-        if (tid == 0) sh.need = lm_update(sh.ctl, sh.sum);
-        __syncthreads();
-    }
 }
 
 __device__ __forceinline__ unsigned long long hash64(unsigned long long k)
@@ -645,384 +580,6 @@ __device__ __forceinline__ unsigned long long hash64(unsigned long long k)
 #define DD2_LIST 2048  // twice-contested keys compared exactly; more (heavily duplicated input): hash every key instead
 #define SEL_BINS 4096  // value-range bins of the rank select (must be a multiple of RS_THREADS)
 #define SEL_CAND 1024  // keys of the selected bin ranked exactly; more -> radix-select fallback
-
-
-// General path: any number of blocks per scan; flags, L1 values and the de-duplication table live in HBM.
-template <int DEBLUR>
-__device__ void solve_general(const RegDev &rd, const RegConst &rc, int b, RegState *st, SolveShared &sh, unsigned long long *s_table)
-{
-    const int tid = threadIdx.x;
-    const int nC = rd.n_corner[b], nS = rd.n_surf[b];
-    const int total = nC + nS;
-    const size_t sb = (size_t)b * rd.cap;
-    const double *av = rd.blk_av + (size_t)b * 6 * rd.cap;
-
-    // ---- census: active blocks, corner_avail / surf_avail (PCR:325,425) -----------------------------------
-    {
-        int na = 0, nca = 0, nsa = 0;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const int slot0 = slot_of(j, nC, rd.cap_c);
-            const unsigned char fl = rd.blk_flag0[sb + slot0];
-            rd.blk_flag[sb + slot0] = fl;  // working copy: the prune below clears BLK_ACTIVE in place
-            na += (fl & BLK_ACTIVE) ? 1 : 0;
-            if (fl & 8) {
-                if (j < nC) nca++; else nsa++;
-            }
-        }
-        na = block_sum_int(na, sh);
-        nca = block_sum_int(nca, sh);
-        nsa = block_sum_int(nsa, sh);
-        if (rc.subsample_seed && na > rc.max_blocks) {  // a13: "Number of residual blocks too Large, drop them" (PCR:438-458)
-            int kept = 0;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot0 = slot_of(j, nC, rd.cap_c);
-                const unsigned char fl = rd.blk_flag[sb + slot0];
-                if (!(fl & BLK_ACTIVE)) continue;
-                if (subsample_drop_block(rc.subsample_seed, st->icp_iters, j, na, rc.max_blocks))
-                    rd.blk_flag[sb + slot0] = fl & ~BLK_ACTIVE;
-                else
-                    kept++;
-            }
-            na = block_sum_int(kept, sh);
-        }
-        if (tid == 0) {
-            sh.n_active = na;
-            sh.n_corner_avail = nca;
-            sh.n_surf_avail = nsa;
-        }
-        __syncthreads();
-    }
-
-    if (tid < 6) sh.tcyc[tid] = 0;
-    __syncthreads();
-    LL_T0(t_total);
-    // ---- prerun solve (PCR:463-474) -------------------------------------------------------------------------
-    {
-        LL_T0(t_e);
-        solver_lm<DEBLUR>(rd, rc, b, nC, nS, st->inc, rc.ceres_prerun_times, sh.n_active, sh);
-        LL_TACC(0, t_e);
-    }
-    int lm_iters = sh.ctl.iteration;
-    LL_T0(t_l1);
-
-    // ---- loss-corrected L1 per block at the prerun result (PCR:476-483) -----------------------------------
-    {
-        LL_CTX_DECL(sh.ctl.x)
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const int slot = slot_of(j, nC, rd.cap_c);
-            const unsigned char fl = rd.blk_flag[sb + slot];
-            if (!(fl & BLK_ACTIVE)) continue;
-            const float4 ff = rd.blk_f[sb + slot];
-            double a[3], v[3];
-            av_load(av, rd.cap, slot, slot < rd.cap_c, a[0], a[1], a[2], v[0], v[1], v[2]);
-            double l1v;
-            LL_CTX_L1(l1v, fl & 3, ff, a, v, rc.huber_a, st->pose_last);
-            rd.blk_l1[sb + slot] = l1v;
-        }
-    }
-    __syncthreads();
-
-    LL_TACC(2, t_l1);
-    LL_T0(t_dd);
-    // ---- std::set semantics: which L1 values are distinct (first occurrences get flag bit 16), how many ------------
-    // Same scheme as the fast path -- LDS bitmap, contested keys through an exact table -- with the keys read back
-    // from HBM and split by hash into partitions of at most ~FAST_MAX_BLOCKS keys, so the LDS tables keep their size.
-    // Heavily duplicated inputs fall back to one compare-and-swap table in HBM.
-    {
-        unsigned int *bm = (unsigned int *)s_table;
-        unsigned int *cb = bm + DD_BM_WORDS;
-        unsigned long long *ex = (unsigned long long *)(cb + DD_CB_SIZE);
-        const int parts = (total + FAST_MAX_BLOCKS - 1) / FAST_MAX_BLOCKS;
-        int my = 0;
-        bool overflow = false;
-        for (int part = 0; part < parts && !overflow; part++) {
-            __syncthreads();
-            for (int e = tid; e < DD_BM_WORDS; e += RS_THREADS) bm[e] = 0u;
-            for (int e = tid; e < DD_CB_SIZE; e += RS_THREADS) cb[e] = 0xffffffffu;
-            for (int e = tid; e < DD_EX_SIZE; e += RS_THREADS) ex[e] = HASH_EMPTY;
-            __syncthreads();
-            int ncoll = 0;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot = slot_of(j, nC, rd.cap_c);
-                const unsigned char fl = rd.blk_flag[sb + slot];
-                if (!(fl & BLK_ACTIVE)) continue;
-                const double l1 = rd.blk_l1[sb + slot];
-                if (!(l1 == l1)) continue;  // NaN never enters the set
-                const unsigned long long hk = hash64((unsigned long long)__double_as_longlong(l1));
-                if ((int)((hk >> 44) % (unsigned long long)parts) != part) continue;
-                const unsigned int hb = (unsigned int)hk & (DD_BM_WORDS * 32 - 1);
-                const unsigned int bit = 1u << (hb & 31);
-                if (atomicOr(&bm[hb >> 5], bit) & bit) {
-                    rd.blk_flag[sb + slot] = fl | 32;  // contested bit: its index goes to the set below
-                    ncoll++;
-                }
-            }
-            const int total_coll = block_sum_int(ncoll, sh);
-            if (total_coll > DD_MAX_COLL) {
-                overflow = true;
-                break;
-            }
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot = slot_of(j, nC, rd.cap_c);
-                const unsigned char fl = rd.blk_flag[sb + slot];
-                if (!(fl & 32)) continue;
-                rd.blk_flag[sb + slot] = fl & ~32;
-                const unsigned int hb = (unsigned int)hash64((unsigned long long)__double_as_longlong(rd.blk_l1[sb + slot])) & (DD_BM_WORDS * 32 - 1);
-                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
-                for (;;) {
-                    const unsigned int old = atomicCAS(&cb[h], 0xffffffffu, hb);
-                    if (old == 0xffffffffu || old == hb) break;
-                    h = (h + 1u) & (DD_CB_SIZE - 1);
-                }
-            }
-            __syncthreads();
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot = slot_of(j, nC, rd.cap_c);
-                const unsigned char fl = rd.blk_flag[sb + slot];
-                if (!(fl & BLK_ACTIVE)) continue;
-                const double l1 = rd.blk_l1[sb + slot];
-                if (!(l1 == l1)) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
-                const unsigned long long hk = hash64(key);
-                if ((int)((hk >> 44) % (unsigned long long)parts) != part) continue;
-                const unsigned int hb = (unsigned int)hk & (DD_BM_WORDS * 32 - 1);
-                bool contested = false;
-                unsigned int h = (hb * 2654435761u) >> (32 - DD_CB_LOG2);
-                for (;;) {
-                    const unsigned int c = cb[h];
-                    if (c == 0xffffffffu) break;
-                    if (c == hb) {
-                        contested = true;
-                        break;
-                    }
-                    h = (h + 1u) & (DD_CB_SIZE - 1);
-                }
-                bool first = !contested;
-                if (contested) {
-                    unsigned int h2 = (unsigned int)(hk >> 24) & (DD_EX_SIZE - 1);
-                    for (;;) {
-                        const unsigned long long old = atomicCAS(&ex[h2], HASH_EMPTY, key);
-                        if (old == HASH_EMPTY) {
-                            first = true;
-                            break;
-                        }
-                        if (old == key) break;
-                        h2 = (h2 + 1u) & (DD_EX_SIZE - 1);
-                    }
-                }
-                if (first) {
-                    rd.blk_flag[sb + slot] = fl | 16;
-                    my++;
-                }
-            }
-        }
-        if (overflow) {  // uniform: every thread saw the same total_coll
-            __syncthreads();
-            my = 0;
-            unsigned long long *table = rd.hash + (size_t)b * rd.hash_cap;
-            for (int k = tid; k < rd.hash_cap; k += RS_THREADS) table[k] = HASH_EMPTY;
-            __syncthreads();
-            const unsigned long long mask = (unsigned long long)rd.hash_cap - 1ull;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot = slot_of(j, nC, rd.cap_c);
-                const unsigned char fl0 = rd.blk_flag[sb + slot] & ~(16 | 32);
-                rd.blk_flag[sb + slot] = fl0;
-                if (!(fl0 & BLK_ACTIVE)) continue;
-                const double l1 = rd.blk_l1[sb + slot];
-                if (!(l1 == l1)) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
-                unsigned long long h = hash64(key) & mask;
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&table[h], HASH_EMPTY, key);
-                    if (old == HASH_EMPTY) {
-                        rd.blk_flag[sb + slot] = fl0 | 16;
-                        my++;
-                        break;
-                    }
-                    if (old == key) break;
-                    h = (h + 1ull) & mask;
-                }
-            }
-        }
-        const int nu = block_sum_int(my, sh);
-        if (tid == 0) {
-            sh.n_unique = nu;
-            sh.sel_prefix = 0ull;
-            int target = (int)(rc.inlier_ratio * (double)nu);  // PCR:160
-            if (target > nu - 1) target = nu - 1;
-            sh.sel_rank = target;
-        }
-        __syncthreads();
-    }
-    LL_TACC(3, t_dd);
-    LL_T0(t_sel);
-    if (sh.n_unique > 0) {
-        // rank select of the distinct values: value-range bins in LDS, then an exact ranking of the selected bin's keys
-        // (the fast path's scheme, keys read from HBM); a crowded bin falls back to the radix select below
-        int *bins = (int *)s_table;
-        unsigned long long *cand = s_table + SEL_BINS / 2;
-        const int lane = tid & 63, wave = tid >> 6;
-        double kmin = INFINITY, kmax = -INFINITY;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const int slot = slot_of(j, nC, rd.cap_c);
-            if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
-            const double l1 = rd.blk_l1[sb + slot];
-            kmin = fmin(kmin, l1);
-            kmax = fmax(kmax, l1);
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            kmin = fmin(kmin, __shfl_down(kmin, off));
-            kmax = fmax(kmax, __shfl_down(kmax, off));
-        }
-        __syncthreads();
-        if (lane == 0) {
-            sh.red[wave][0] = kmin;
-            sh.red[wave][1] = kmax;
-        }
-        for (int e = tid; e < SEL_BINS; e += RS_THREADS) bins[e] = 0;
-        __syncthreads();
-        double lo = sh.red[0][0], hi = sh.red[0][1];
-        for (int w = 1; w < RS_WAVES; w++) {
-            lo = fmin(lo, sh.red[w][0]);
-            hi = fmax(hi, sh.red[w][1]);
-        }
-        const double scale = (hi > lo) ? (double)(SEL_BINS - 1) / (hi - lo) : 0.0;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const int slot = slot_of(j, nC, rd.cap_c);
-            if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
-            int bi = (int)((rd.blk_l1[sb + slot] - lo) * scale);
-            bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
-            atomicAdd(&bins[bi], 1);
-        }
-        __syncthreads();
-        {
-            const int per = SEL_BINS / RS_THREADS;
-            int part = 0;
-            for (int e = 0; e < per; e++) part += bins[tid * per + e];
-            int incl = part;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int y = __shfl_up(incl, off);
-                if (lane >= off) incl += y;
-            }
-            if (lane == 63) sh.isum[wave] = incl;
-            if (tid == 0) sh.n_cand = 0;
-            __syncthreads();
-            int below = incl - part;
-            for (int w = 0; w < wave; w++) below += sh.isum[w];
-            const int rank = sh.sel_rank;
-            __syncthreads();
-            const bool last_thread = tid == RS_THREADS - 1;
-            if ((rank >= below && rank < below + part) || (last_thread && rank >= below + part)) {
-                int cum = below, bi = tid * per;
-                for (; bi < tid * per + per - 1; bi++) {
-                    if (cum + bins[bi] > rank) break;
-                    cum += bins[bi];
-                }
-                sh.sel_bin = bi;
-                sh.sel_rank = rank - cum;
-                sh.sel_cnt = bins[bi];
-            }
-            __syncthreads();
-        }
-        if (sh.sel_cnt <= SEL_CAND) {
-            const int sel_bin = sh.sel_bin;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot = slot_of(j, nC, rd.cap_c);
-                if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
-                const double l1 = rd.blk_l1[sb + slot];
-                int bi = (int)((l1 - lo) * scale);
-                bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
-                if (bi == sel_bin) cand[atomicAdd(&sh.n_cand, 1)] = (unsigned long long)__double_as_longlong(l1);
-            }
-            __syncthreads();
-            const int m = sh.n_cand;
-            for (int i = tid; i < m; i += RS_THREADS) {
-                const unsigned long long ki = cand[i];
-                int rk = 0;
-                for (int jj = 0; jj < m; jj++) rk += (cand[jj] < ki) ? 1 : 0;  // keys are distinct
-                if (rk == sh.sel_rank) sh.sel_prefix = ki;
-            }
-            __syncthreads();
-        } else {
-        // MSB-first radix select (8 bits per pass) over the distinct keys of that bin; non-negative doubles order like uint64
-        const int sel_bin = sh.sel_bin;
-        if (tid == 0) sh.sel_prefix = 0ull;
-        __syncthreads();
-        for (int pass = 0; pass < 8; pass++) {
-            const int shift = 56 - 8 * pass;
-            for (int k = tid; k < 256; k += RS_THREADS) sh.hist[k] = 0;
-            __syncthreads();
-            const unsigned long long prefix = sh.sel_prefix;
-            for (int j = tid; j < total; j += RS_THREADS) {
-                const int slot = slot_of(j, nC, rd.cap_c);
-                if ((rd.blk_flag[sb + slot] & (BLK_ACTIVE | 16)) != (BLK_ACTIVE | 16)) continue;
-                const double l1 = rd.blk_l1[sb + slot];
-                int bi = (int)((l1 - lo) * scale);
-                bi = bi < 0 ? 0 : (bi > SEL_BINS - 1 ? SEL_BINS - 1 : bi);
-                if (bi != sel_bin) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(l1);
-                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(int)((key >> shift) & 255ull)], 1);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int rank = sh.sel_rank, d = 0, cum = 0;
-                for (d = 0; d < 256; d++) {
-                    if (cum + sh.hist[d] > rank) break;
-                    cum += sh.hist[d];
-                }
-                if (d > 255) d = 255;
-                sh.sel_rank = rank - cum;
-                sh.sel_prefix = (prefix << 8) | (unsigned long long)d;
-            }
-            __syncthreads();
-        }
-        }
-        if (tid == 0) sh.thr = fmax(rc.inliner_dis, __longlong_as_double((long long)sh.sel_prefix));  // PCR:485
-    } else {
-        if (tid == 0) sh.thr = rc.inliner_dis;  // empty set: defined deviation (PCR:160 would dereference end())
-    }
-    __syncthreads();
-    // ---- prune (PCR:487-499) ---------------------------------------------------------------------------------
-    {
-        const double thr = sh.thr;
-        int na = 0;
-        for (int j = tid; j < total; j += RS_THREADS) {
-            const int slot = slot_of(j, nC, rd.cap_c);
-            unsigned char fl = rd.blk_flag[sb + slot];
-            if (!(fl & BLK_ACTIVE)) continue;
-            fl &= ~16;
-            if (rd.blk_l1[sb + slot] > thr)
-                fl &= ~BLK_ACTIVE;
-            else
-                na++;
-            rd.blk_flag[sb + slot] = fl;
-        }
-        na = block_sum_int(na, sh);
-        if (tid == 0) sh.n_active = na;
-        __syncthreads();
-    }
-
-    // ---- final solve (PCR:501-508) -----------------------------------------------------------------------------
-    {
-        // the prerun result is the start; copy it out of ctl before lm_begin overwrites ctl.x
-        __shared__ double x_start[7];
-        if (tid < 7) x_start[tid] = sh.ctl.x[tid];
-        __syncthreads();
-        LL_TACC(4, t_sel);
-        LL_T0(t_e);
-        solver_lm<DEBLUR>(rd, rc, b, nC, nS, x_start, rc.ceres_max_iterations, sh.n_active, sh);
-        LL_TACC(0, t_e);
-    }
-    lm_iters += sh.ctl.iteration;
-
-    solve_epilogue(rc, st, sh, lm_iters);
-#ifdef LL_SOLVE_TIMING
-    LL_TACC(5, t_total);
-    if (tid == 0)
-        for (int i = 0; i < 6; i++) st->dbg_cycles[i] += sh.tcyc[i];
-#endif
-}
 
 
 // std::set de-duplication + rank select of the loss-corrected L1 values held in registers (l1r[k] = value of the
@@ -1387,6 +944,7 @@ __device__ __forceinline__ unsigned int pt_hash(unsigned int p0, unsigned int p1
 // slot of the triple (inserting it if new), or PT_PRIVATE.  Lock-free and wait-free per probe: a slot belongs to the first
 // {p0, p1} that lands on its `a` word AND the first p2 that lands on its `b` word; a lane that loses either race (or finds
 // another key) probes on, and every lane with the same triple walks the same probe sequence to the same slot.
+template <int MAX_PROBE = PT_MAX_PROBE>
 __device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned int p0, unsigned int p1, unsigned int p2)
 {
     const unsigned long long A = ((unsigned long long)p0 << 32) | (unsigned long long)p1;
@@ -1396,7 +954,7 @@ __device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned
     // probing some lane of nearly every wavefront sat in one of the long clusters (2 - 3 k cycles per round of 64 inserts
     // at 43 % load)
     const unsigned int step = ((hh >> 13) | 1u) & (PT_SLOTS - 1);
-    for (int probe = 0; probe < PT_MAX_PROBE; probe++) {
+    for (int probe = 0; probe < MAX_PROBE; probe++) {
         // two independent relaxed reads decide the common case (four of five blocks find their triple already there); each
         // word of a slot is written once, by an atomic, so a stale or half-claimed view only sends the lane through the
         // compare-and-swaps.  (Not `volatile`: the memory legalizer brackets a volatile access with waits for every outstanding
@@ -2137,17 +1695,15 @@ __device__ void solve_fast3(const RegDev &rd, const RegConst &rc, const f4 *map_
 #endif
 }
 
-template <int DEBLUR>
+// The Mid-40 batches: no motion deblur, every scan within FAST_MAX_BLOCKS (launch_reg_solve decides per batch from the host's feature
+// counts; everything else goes to reg_solve_big_kernel, ll_reg_big_path.h).
 __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegConst rc, const f4 *map_surf)
 {
     __shared__ SolveShared sh;
-    // 152 KB shared by the two paths: the plane-table form uses all of it (hash table -> plane table + record cache; the inlier
-    // phase's tables in between), the general path the first 128 KB for its de-duplication / select tables
+    // 152 KB: hash table -> plane table + record cache; the inlier phase's tables in between
     __shared__ uint4 s_raw[PT_LDS_BYTES / 16];
-    static_assert(PT_LDS_BYTES >= HT_SIZE * 8, "s_raw holds the general path's tables");
-    unsigned long long *s_table = (unsigned long long *)s_raw;
     int b = blockIdx.x, g = 0, G = 1;
-    if (!DEBLUR && rc.solve_group > 1) {  // grouped launch (n_scans * G workgroups): scan and rank by ticket, see group_barrier
+    if (rc.solve_group > 1) {  // grouped launch (n_scans * G workgroups): scan and rank by ticket, see group_barrier
         if (threadIdx.x == 0) sh.grp_seq = atomicAdd(rd.grp_ctl, 1);
         __syncthreads();
         G = rc.solve_group;
@@ -2157,10 +1713,17 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
     }
     RegState *st = rd.state + b;
     if (st->done) return;  // the same answer for every member: the epilogue that sets it runs behind the group's barriers
-    const bool compact = !DEBLUR && scan_is_compact(rd, rc, b);
-    if (!compact) {
-        if (g != 0) return;  // only the compact path knows groups
-        G = 1;
+    {
+        const int nS_ = rd.n_surf[b], nC_ = rd.n_corner[b];
+        if ((nS_ + RS_THREADS - 1) / RS_THREADS * RS_THREADS + nC_ > FAST_MAX_BLOCKS || !scan_is_compact(rd, rc, b)) {
+            // cannot happen (the host launches this kernel only for batches it holds): fail loudly -- rejected and reported -- instead of answering
+            if (g == 0 && threadIdx.x == 0) {
+                st->aborted = 1;
+                st->done = 1;
+                st->icp_iters += 1;
+            }
+            return;
+        }
     }
     if (threadIdx.x == 0) {
         sh.grp_g = g;
@@ -2171,15 +1734,13 @@ __global__ __launch_bounds__(RS_THREADS) void reg_solve_kernel(RegDev rd, RegCon
         sh.grp_abort = (rc.test_group_abort && G > 1) ? 1 : 0;  // test switch: behave as if the first barrier had timed out
     }
     __syncthreads();
-    // two forms: the plane-table path for compact scans (every Mid-40 configuration) and the general path (motion de-blurring,
-    // scans beyond FAST_MAX_BLOCKS)
-    if (compact && G > 1)
+    if (G > 1)
         solve_fast3<true>(rd, rc, map_surf, b, st, sh, s_raw);
-    else if (compact)
-        solve_fast3<false>(rd, rc, map_surf, b, st, sh, s_raw);
     else
-        solve_general<DEBLUR>(rd, rc, b, st, sh, s_table);
+        solve_fast3<false>(rd, rc, map_surf, b, st, sh, s_raw);
 }
+
+#include "ll_reg_big_path.h"
 
 __global__ void reg_finalize_kernel(RegDev rd, RegConst rc, int n_scans)
 {
@@ -2277,14 +1838,21 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
         hipLaunchKernelGGL(reg_build_kernel, grid, dim3(KB_THREADS), 0, s, rd, rc, gc, gs, 0);
     }
 }
+// batches reg_solve_kernel holds: no motion deblur, the largest scan within FAST_MAX_BLOCKS (planes padded to whole rounds + lines)
+bool reg_solve_fast_eligible(const RegConst &rc, int max_nc, int max_ns)
+{
+    return !rc.if_motion_deblur && !rc.force_general && (max_ns + RS_THREADS - 1) / RS_THREADS * RS_THREADS + max_nc <= FAST_MAX_BLOCKS;
+}
 void launch_reg_solve(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_nc, int max_ns, int iter, hipStream_t s)
 {
     if (reg_solve_small_eligible(rc, max_nc, max_ns))  // voxel-filtered scans: one or four wavefronts per scan (ll_reg_small_kernels.hip)
         launch_reg_solve_small(rd, rc, gs, n_scans, max_nc, max_ns, iter, s);
+    else if (reg_solve_fast_eligible(rc, max_nc, max_ns))  // Mid-40 batches: solve_fast3 (one workgroup per scan, or a group of them for small batches)
+        hipLaunchKernelGGL(reg_solve_kernel, dim3(n_scans * (rc.solve_group > 1 ? rc.solve_group : 1)), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
     else if (rc.if_motion_deblur)
-        hipLaunchKernelGGL(reg_solve_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
+        hipLaunchKernelGGL(reg_solve_big_kernel<1>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
     else
-        hipLaunchKernelGGL(reg_solve_kernel<0>, dim3(n_scans * (rc.solve_group > 1 ? rc.solve_group : 1)), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
+        hipLaunchKernelGGL(reg_solve_big_kernel<0>, dim3(n_scans), dim3(RS_THREADS), 0, s, rd, rc, gs.pts);
 }
 void launch_reg_finalize(const RegDev &rd, const RegConst &rc, int n_scans, hipStream_t s)
 {

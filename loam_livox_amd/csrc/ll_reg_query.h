@@ -116,15 +116,18 @@ __device__ __forceinline__ void av_load(const double *av, int cap, int slot, boo
     }
 }
 
-// Scans whose blocks go to the round-2 fast path of the solver (solve_fast2): no motion deblur (its blocks carry a blur
-// ratio and take the round-1 path), planes padded to whole 512-thread rounds + lines within the register budget of the
-// L1 phase.
+// Scans whose plane blocks live in a per-scan PLANE TABLE built by the solver ({n', c} once per distinct neighbour triple; the build stage
+// only decides their flags): planes padded to whole 512-thread rounds + lines within LL_TABLE_MAX_BLOCKS -- 120 rounds, the 128-bit
+// activity mask of solve_big (ll_reg_big_path.h) and the 16-bit plane ids.  Within FAST_MAX_BLOCKS and without motion deblur a batch
+// takes solve_fast3 (64-bit masks, register tiles); launch_reg_solve decides that per batch.  Larger scans and the force_general
+// test switch: per-block constants in HBM (solve_general).
 #define FAST_MAX_BLOCKS 24576
+#define LL_TABLE_MAX_BLOCKS 61440
 __device__ __forceinline__ bool scan_is_compact(const RegDev &rd, const RegConst &rc, int b)
 {
     const int nC = rd.n_corner[b], nS = rd.n_surf[b];
     const int nSp = (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
-    return !rc.if_motion_deblur && !rc.force_general && nSp + nC <= FAST_MAX_BLOCKS;
+    return !rc.force_general && nSp + nC <= LL_TABLE_MAX_BLOCKS;
 }
 
 __device__ __forceinline__ void transform_query(const RegState *st, const RegConst &rc, const float4 &f, float pw[3])

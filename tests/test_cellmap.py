@@ -597,7 +597,7 @@ def test_borrowed_cell_map_handle_settles_the_service_thread_on_every_read(gpu_l
         if async_:
             with pytest.raises(LoamLivoxError, match="not enabled"):
                 h.cell_map(1)
-        h.enable_cell_map(max_points=3000, cell_resolution=1.0)   # far too small: the maps double several times on the way
+        h.enable_cell_map(max_points=4000, cell_resolution=1.0)   # one frame's worth: the maps double several times on the way
         h.set_cell_map_async(async_)
         borrowed = [h.cell_map(0), h.cell_map(1)]                 # taken BEFORE any frame is in
         seen = []

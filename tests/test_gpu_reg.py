@@ -22,6 +22,64 @@ def dev_map(gpu_lib, small_world):
     m.close()
 
 
+def set_params(reg, icp=10, ceres=20, force=1):
+    p = reg.params
+    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = icp, ceres, force
+    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 100.0
+    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+    return p
+
+
+def test_knn5_identical_to_oracle(dev_map, small_world, scans):
+    for sc in scans[:2]:
+        _, _, _, _, fc, fs = oracle_features(sc)
+        qs = synth.transform_points(sc.pose_init, fs[:, :3])
+        oi, od = small_world["tree_s"].knn(qs, 5)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.SURF, qs, 50.0)
+        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
+        qc = synth.transform_points(sc.pose_init, fc[:, :3])
+        oi, od = small_world["tree_c"].knn(qc, 5)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.CORNER, qc, 2.0)   # a few hundred queries: one WAVEFRONT per query (ll_knn_coop.h)
+        inside = od < 2.0
+        assert np.array_equal(np.where(inside, oi, -1), gi)
+        assert np.array_equal(np.where(inside, od, np.inf), gd)
+        # both forms of the search on both maps: batches of up to 8192 queries go one per wavefront, larger ones one per lane
+        reps = 8192 // len(qc) + 1
+        gi2, gd2 = dev_map.nearestKSearch(Map_buffer.CORNER, np.tile(qc, (reps, 1)), 2.0)
+        assert np.array_equal(gi2.reshape(reps, -1, 5), np.broadcast_to(gi, (reps,) + gi.shape))
+        assert np.array_equal(gd2.reshape(reps, -1, 5), np.broadcast_to(gd, (reps,) + gd.shape))
+        oi, od = small_world["tree_s"].knn(qs[:3000], 5)
+        gi, gd = dev_map.nearestKSearch(Map_buffer.SURF, qs[:3000], 50.0)
+        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
+
+
+def test_knn5_sparse_outside_ties_nonfinite(gpu_lib):
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(0, 30, (4000, 3)).astype(np.float32)
+    pts[100:104] = pts[100]
+    pts[7, 0] = np.nan
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.SURF, pts, 0.7)
+    tree = orc.KdTree(np.where(np.isfinite(pts), pts, 1e9).astype(np.float32))
+    q = np.concatenate([rng.uniform(-8, 38, (500, 3)), pts[100:101], [[1e6, 0, 0]], [[np.nan, 0, 0]]]).astype(np.float32)
+    gi, gd = m.nearestKSearch(Map_buffer.SURF, q, 50.0)      # 503 queries: one wavefront per query, rings and the cube sweep included
+    oi, od = tree.knn(np.nan_to_num(q, nan=1e9), 5)
+    inside = od < 50.0
+    assert np.array_equal(np.where(inside, oi, -1)[:-2], gi[:-2])
+    assert np.array_equal(np.where(inside, od, np.inf)[:-2], gd[:-2])
+    gi_l, gd_l = m.nearestKSearch(Map_buffer.SURF, np.tile(q, (17, 1)), 50.0)   # 8551 queries: one lane per query
+    assert np.array_equal(gi_l.reshape(17, -1, 5), np.broadcast_to(gi, (17,) + gi.shape))
+    assert np.array_equal(gd_l.reshape(17, -1, 5), np.broadcast_to(gd, (17,) + gd.shape))
+    assert np.all(gi[-2:] == -1)
+    assert gi[500].tolist()[:4] == [100, 101, 102, 103]
+    # xyzi stride-4 input gives the same answer
+    m2 = Map_buffer()
+    m2.setInputCloud(Map_buffer.SURF, np.c_[pts, np.ones(len(pts), np.float32)], 0.7)
+    gi2, _ = m2.nearestKSearch(Map_buffer.SURF, q, 50.0)
+    assert np.array_equal(gi, gi2)
+    m.close(); m2.close()
+
+
 @pytest.mark.parametrize("k", [0, 1, 2, 3])
 @pytest.mark.parametrize("force", [0, 1])
 @pytest.mark.parametrize("general", [False, "single", True])

@@ -193,6 +193,6 @@ def test_real_run_publishes_what_the_reference_text_publishes(tmp_path, gpu_lib)
             last = e[1]
             cells, _ = cm.query_filter(e[3], 1000.0, 360.0, 0.4, 0)
             out = orc.voxel_grid(cells, 0.4)[1]
-            assert int(sur[k][5]) == len(out) and int(sur[k][9], 16) == cloud_hash(out) and float(sur[k][2]) == e[2] and sur[k][3] == "camera_init"
+            assert int(sur[k][4]) == len(out) and int(sur[k][8], 16) == cloud_hash(out) and float(sur[k][2]) == e[2] and sur[k][3] == "camera_init"
             k += 1
     assert k == len(sur)
