@@ -494,7 +494,7 @@ def main():
     # than CUs to pay, so the figure is taken at --q-pipe-batch scans per batch (default 2048) as well as at the headline's batch size.
     q_pipe_extra = None
     if not vox and not args.no_q_pipe:
-        def q_pipe_figure(Bq, shipped_cap=False, in_flight=0):
+        def q_pipe_figure(Bq, shipped_cap=False, in_flight=0, audit=False):
             rq = np.random.default_rng(777 + rank)
             idx = np.arange(Bq) % B
             init_q = init if Bq == B else np.stack([
@@ -545,6 +545,8 @@ def main():
                                        "peak": 8000.0, "frac": round(alg_q / (solver_ms * 1e-3) / 1e9 / 8000.0, 5),
                                        "limited_by": "dependent fp64 issue of the per-scan Levenberg-Marquardt controller and the evaluations of "
                                                      "a few hundred blocks per wavefront (latency chains), not HBM bandwidth"}}
+            if audit:
+                fig["parity_audit_vs_oracle"] = qpipe_oracle_audit(args, synth, corner, surf, scans, idx, init_q, out_q, p)
             if in_flight > 1:
                 # A voxel-filtered batch ends with its slowest scan's last line search; batches are independent: with several in flight the
                 # CUs of the early finishers run the other batches' scans
@@ -564,7 +566,8 @@ def main():
             return fig
 
         Bq = max(B, args.q_pipe_batch)
-        q_pipe_extra = q_pipe_figure(Bq, in_flight=(max(2, args.q_pipe_in_flight) if slots is not None else 0))
+        q_pipe_extra = q_pipe_figure(Bq, in_flight=(max(2, args.q_pipe_in_flight) if slots is not None else 0),
+                                     audit=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         q_pipe_extra["note"] = ("device VoxelGrid (leaf 0.1 / 0.4 m, laser_mapping.hpp:1367-1373) between extraction and registration; small-scan solver "
                                 "(one / two wavefronts per scan in batches of >= 512 scans, four below)")
         if Bq != B:
@@ -698,15 +701,75 @@ def main():
         dist.destroy_process_group()
 
 
+_ORACLE_TREES = {}
+
+
+def oracle_trees(corner, surf):
+    """the oracle's k-d trees of the bench map, built once per process (the Q-pipe audit and the CPU legs share them)"""
+    from oracle import orc
+    if "t" not in _ORACLE_TREES:
+        tb = time.perf_counter()
+        _ORACLE_TREES["t"] = (orc.KdTree(corner), orc.KdTree(surf), 0.0)
+        _ORACLE_TREES["t"] = _ORACLE_TREES["t"][:2] + (time.perf_counter() - tb,)
+    return _ORACLE_TREES["t"]
+
+
+def qpipe_oracle_audit(args, synth, corner, surf, scans, idx, init_q, out_q, p):
+    """Every scan of a Q-pipe batch (voxel-filtered features, small-scan solver) against the CPU oracle run from the same raw scan and the same
+    initial guess: pose, accept / reject, residual-block and iteration counts (VERDICT r5 next #9 ii: the Q-pipe legs printed bit-equality
+    between their own runs but no oracle audit).  One oracle run per slot, spread over the host's cores (ctypes releases the GIL)."""
+    from oracle import orc
+    tc, ts, _ = oracle_trees(corner, surf)
+    res_q, pc_q, _, reps_q = out_q
+    Bq = len(idx)
+    prm = orc.RegParams.defaults(icp_iters=int(p.icp_max_iterations), ceres_iters=int(p.ceres_max_iterations), force_all=int(p.force_all_iterations))
+    prm.max_final_cost = float(p.max_final_cost)
+    feats = {}
+    lock = threading.Lock()
+
+    def features(i):
+        with lock:
+            hit = feats.get(i)
+        if hit is None:
+            o = orc.fe_extract(scans[i], 1.0)
+            ci, si, _ = orc.fe_get_features(o, 0.0, 1.0)
+            hit = (orc.voxel_grid(orc.feature_cloud(o, ci), 0.1)[1], orc.voxel_grid(orc.feature_cloud(o, si), 0.4)[1])
+            with lock:
+                feats[i] = hit
+        return hit
+
+    rows = [None] * Bq
+    n_thr = max(1, min(Bq, args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1)))
+
+    def worker(t):
+        for b in range(t, Bq, n_thr):
+            fc_o, fs_o = features(int(idx[b]))
+            ret, opc, _, orep = orc.reg_solve(tc, ts, fc_o, fs_o, prm, init_q[b], init_q[b])
+            dt, dr = synth.pose_error(pc_q[b], opc)
+            rows[b] = (dt, dr, ret == res_q[b], orep.n_blocks_last == reps_q[b].n_blocks_last and orep.corner_avail == reps_q[b].corner_avail
+                       and orep.surf_avail == reps_q[b].surf_avail, orep.lm_iterations_total == reps_q[b].lm_iterations_total,
+                       orep.icp_iterations == reps_q[b].icp_iterations)
+
+    tb = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    r = np.array([[float(v) for v in row] for row in rows])
+    return {"scans": Bq, "max_pose_err_m": float(r[:, 0].max()), "max_pose_err_rad": float(r[:, 1].max()),
+            "accept_reject_identical": bool(r[:, 2].all()), "block_counts_identical": bool(r[:, 3].all()),
+            "lm_iteration_counts_identical": int(r[:, 4].sum()), "icp_iteration_counts_identical": int(r[:, 5].sum()),
+            "host_threads": n_thr, "seconds": round(time.perf_counter() - tb, 1)}
+
+
 def cpu_legs(args, synth, corner, surf, scans, init, B, vox, pc, res, reps, nc, ns, nc_fe, ns_fe):
     """CPU baseline: the oracle (C restatement of the reference algorithm, gcc -O3 -- pinned to the reference's own code,
     oracle/README.md; the reference binary itself needs PCL / Ceres / ROS) on the host cores of this box.  It is the
     checker, never the product."""
     from oracle import orc
     out = {}
-    tb = time.perf_counter()
-    tc, ts = orc.KdTree(corner), orc.KdTree(surf)
-    t_tree = time.perf_counter() - tb
+    tc, ts, t_tree = oracle_trees(corner, surf)
 
     def one_scan(b, prm, q_pipe=False):
         o = orc.fe_extract(scans[b], 1.0)

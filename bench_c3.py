@@ -148,10 +148,10 @@ def main():
            "ms_per_step": round(1e3 * el / args.steps, 2), "batches_in_flight": max(1, args.in_flight), "one_batch_at_a_time": sequential, "kernel_ms_per_step": {"knn+build": round(float(kms[0] / args.steps), 2), "solver": round(float(kms[1] / args.steps), 2)},
            "accepted_frac": float(np.mean(res)), "median_err_vs_truth_m": float(np.median([e[0] for e in err])), "median_err_vs_truth_rad": float(np.median([e[1] for e in err])),
            "blocks_last": float(np.mean([r.n_blocks_last for r in reps])), "map_upload_grid_build_s": round(t_map, 2), "feature_upload_s" if args.features_resident else "scan_upload_s": round(t_upload, 3)}
-    # ---- roofline of the dominant kernel: the general-path solver (reg_solve_kernel<1>, motion-deblur residuals), one launch per ICP
-    #      iteration; algorithmic bytes = every residual block's constants once per launch (49 B per plane block: fp32 point +
-    #      blur ratio, {a0, v0}, {v1, v2}, flag; 65 B per line block) + 224 B of state out per scan; duration from the HIP events around
-    #      the solver launches on the registrar's stream (one batch at a time)
+    # ---- roofline of the dominant kernel: the plane-table solver of large / motion-deblur scans (reg_solve_big_kernel<1>, ll_reg_big_path.h), one
+    #      launch per ICP iteration; algorithmic bytes (definition unchanged since round 1) = every residual block's constants once per
+    #      launch (49 B per plane block: fp32 point + blur ratio, {a0, v0}, {v1, v2}, flag; 65 B per line block) + 224 B of state out per scan;
+    #      duration from the HIP events around the solver launches on the registrar's stream (one batch at a time)
     n_line = float(np.sum([r.corner_avail for r in reps])), float(np.sum([r.surf_avail for r in reps]))
     alg = n_line[0] * 65.0 + n_line[1] * 49.0 + 224.0 * B
     ms_launch = float(kms[1] / max(1.0, kn[1]))
@@ -161,18 +161,23 @@ def main():
     if hits:
         best = None
         for r in csv.DictReader(l for l in open(hits[-1]) if not l.startswith("#")):
-            if "reg_solve_kernel" in r["kernel"] and (best is None or int(r["grid_threads"]) > int(best["grid_threads"])):
+            if "reg_solve_big_kernel" in r["kernel"] and (best is None or int(r["grid_threads"]) > int(best["grid_threads"])):
                 best = r
         if best is not None and int(best["grid_threads"]) == B * 512:
             traffic, src = int(float(best["fetch_kib_avg"]) * 2048 + float(best["write_kib_avg"]) * 1024), os.path.relpath(hits[-1], ROOT)
-    out["roofline"] = {"bound": "hbm", "kernel": "reg_solve_kernel<1>", "achieved": round(alg / (ms_launch * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+    out["roofline"] = {"bound": "hbm", "kernel": "reg_solve_big_kernel<1>", "achieved": round(alg / (ms_launch * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                        "frac": round(alg / (ms_launch * 1e-3) / 1e9 / 8000.0, 4), "avg_launch_ms": round(ms_launch, 4), "launches_timed": int(kn[1]),
                        "algorithmic_bytes_per_launch": int(alg), "traffic": traffic, "traffic_source": src,
                        "traffic_over_algorithmic": (round(traffic / alg, 2) if traffic else None),
                        "hbm_gb_per_s_from_counters": (round(traffic / (ms_launch * 1e-3) / 1e9, 1) if traffic else None),
-                       "limited_by": "HBM traffic of the general path -- every block's 49 / 65 B is streamed again by each of the ~9 cost evaluations and the "
-                                     "flag / L1 passes of a launch (counters: ~10 x the algorithmic bytes, a third of the HBM peak) -- together with the "
-                                     "fp64 issue of the motion-deblur evaluations (one sincos + the interpolated rotation per block)"}
+                       "limited_by": "fp64 VALU issue of the motion-deblur evaluations (the interpolated rotation, its Jacobian and the 27 accumulator updates per "
+                                     "block: ~250 wave instructions per block and evaluation, two wavefronts per SIMD), then the per-launch census / hash "
+                                     "de-duplication of the neighbour triples and the five L1 sweeps of the inlier threshold -- not HBM bandwidth"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from build_id import build_id, read_stamp
+    if src:
+        bid, commit = read_stamp(os.path.join(ROOT, src))
+        out["roofline"].update({"traffic_source_build": bid, "traffic_source_commit": commit, "build": build_id(), "traffic_is_current": (bid == build_id()) if bid else None})
     cyc = np.array([[int(v) for v in reg.debug_cycles(b)] for b in range(B)], np.float64)
     if cyc.any():  # a -DLL_SOLVE_TIMING build (LOAM_LIVOX_LIB=...): shader-clock cycles per scan, summed over the registration's launches
         out["solver_phase_cycles_mean_over_scans"] = [int(v) for v in cyc.mean(0)]

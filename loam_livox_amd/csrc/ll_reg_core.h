@@ -395,6 +395,73 @@ LL_HD void block_accumulate(int kind, const double R[9], const double t[3], cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------- scaled plane blocks (round 6)
+// A plane block's residual is r = dd n' with dd = n'.p - c and n' NOT normalised (ceres_icp.hpp:328-366), its Jacobian J = n' (B^T n')^T.
+// With m = |n'| n' and beta = |n'| c the block is the SCALAR residual e = m.p - beta (= |n'| dd, so e^2 = |r|^2) with Jacobian row
+// (B^T m)^T:  J^T J = (B^T m)(B^T m)^T,  J^T r = e B^T m,  and r = e m / |m|.  The plane-table solver (solve_fast3) stores {m, beta} per
+// distinct neighbour triple, which takes |n'|^2, the vector r and its square out of every block evaluation; the factor 2 of
+// B^T m = [2 y x m ; m] is left out of the accumulation and put back once per evaluation (plane_unfold2: exact, powers of two).
+// Same numbers as block_accumulate / block_l1 up to rounding (tests/test_hostcheck.py: 1e-13 relative on random blocks).
+LL_HD void plane_scale(const double v[3], double a0, double m[3], double *beta)
+{
+    const double nn = sqrt(dot3(v, v));
+    m[0] = v[0] * nn;
+    m[1] = v[1] * nn;
+    m[2] = v[2] * nn;
+    *beta = a0 * nn;
+}
+// acc += the block's cost / gradient / Gauss-Newton terms, rotation rows and columns WITHOUT their factor 2 (plane_unfold2)
+LL_HD void plane_accumulate_scaled(const double R[9], const double t[3], const double f[3], const double m[3], double beta, double huber_a,
+                                   double acc[LL_NACC])
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    const double p0 = R[0] * f[0] + R[1] * f[1] + R[2] * f[2], p1 = R[3] * f[0] + R[4] * f[1] + R[5] * f[2], p2 = R[6] * f[0] + R[7] * f[1] + R[8] * f[2];
+    const double e = m[0] * (p0 + t[0]) + m[1] * (p1 + t[1]) + m[2] * (p2 + t[2]) - beta;
+    double rho0, w;
+    huber(huber_a, e * e, &rho0, &w);
+    acc[27] += 0.5 * rho0;
+    const double cv[6] = {p1 * m[2] - p2 * m[1], p2 * m[0] - p0 * m[2], p0 * m[1] - p1 * m[0], m[0], m[1], m[2]};  // [y x m ; m]
+    const double we = w * e;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        acc[21 + i] += we * cv[i];
+        const double wi = w * cv[i];
+#pragma unroll
+        for (int j = i; j < 6; j++) acc[hidx(i, j)] += wi * cv[j];
+    }
+}
+// the factors 2 of the rotation part, once per thread and evaluation (before any line block is added): H_rr x 4, H_rt x 2, g_r x 2
+LL_HD void plane_unfold2(double acc[LL_NACC])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        acc[21 + i] *= 2.0;
+#pragma unroll
+        for (int j = i; j < 6; j++) acc[hidx(i, j)] *= (j < 3 ? 4.0 : 2.0);
+    }
+}
+// loss-corrected L1 norm of the world-frame residual (block_l1) of a scaled plane block
+LL_HD double plane_l1_scaled(const double R[9], const double t[3], const double f[3], const double m[3], double beta, double huber_a,
+                             const double q_last[4])
+{
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    const double p0 = R[0] * f[0] + R[1] * f[1] + R[2] * f[2], p1 = R[3] * f[0] + R[4] * f[1] + R[5] * f[2], p2 = R[6] * f[0] + R[7] * f[1] + R[8] * f[2];
+    const double e = m[0] * (p0 + t[0]) + m[1] * (p1 + t[1]) + m[2] * (p2 + t[2]) - beta;
+    double rho0, w;
+    huber(huber_a, e * e, &rho0, &w);
+    const double mm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+    const double k = mm > 0.0 ? e / sqrt(mm) : 0.0;  // r = e m / |m|
+    const double r[3] = {k * m[0], k * m[1], k * m[2]};
+    double rw[3];
+    quat_rot(q_last, r, rw);
+    const double sq = sqrt(w);
+    return fabs(sq * rw[0]) + fabs(sq * rw[1]) + fabs(sq * rw[2]);
+}
+
 // ---------------------------------------------------------------------------------------------- motion-deblur blocks
 // ceres_icp_point2line_mb / point2plane_mb (ceres_icp.hpp:81-233):  p = q_last (slerp(I, q_inc, s) f + s t_inc) + t_last.
 // With w = Log(R_inc) (rotation vector, |w| = W, axis n, K = [n]x) the interpolated rotation is R_s = Exp(s w) and,

@@ -977,6 +977,8 @@ __device__ __forceinline__ unsigned int pt_insert(LL_AS_LDS PtSlot *ht, unsigned
 }
 
 // {n', c} of one neighbour triple -> two int4 (the arithmetic of reg_build_kernel's plane blocks: block_plane)
+// SCALED: {m, beta} of ll_reg_core.h plane_scale (solve_fast3) instead of {n', c} (solve_big)
+template <bool SCALED = false>
 __device__ __forceinline__ void pt_plane(const f4 *map_pts, const double *pose_last, unsigned int i0, unsigned int i1, unsigned int i2, int4 &ob, int4 &oc)
 {
     const f4 m0 = gload_pt(map_pts + i0), m1 = gload_pt(map_pts + i1), m2 = gload_pt(map_pts + i2);
@@ -985,6 +987,11 @@ __device__ __forceinline__ void pt_plane(const f4 *map_pts, const double *pose_l
     const double pc[3] = {(double)m2.x, (double)m2.y, (double)m2.z};
     double a_out[3] = {0.0, 0.0, 0.0}, v_out[3] = {0.0, 0.0, 0.0};
     (void)block_plane(pose_last, pa, pb, pc, a_out, v_out);  // degenerate triples never reach the table (build_one clears their flag)
+    if (SCALED) {
+        double m_[3], beta_;
+        plane_scale(v_out, a_out[0], m_, &beta_);
+        v_out[0] = m_[0], v_out[1] = m_[1], v_out[2] = m_[2], a_out[0] = beta_;
+    }
     ob = make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1]));
     oc = make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0]));
 }
@@ -1161,6 +1168,11 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             const double pc[3] = {(double)m[u][2].x, (double)m[u][2].y, (double)m[u][2].z};
             double a_out[3] = {0.0, 0.0, 0.0}, v_out[3] = {0.0, 0.0, 0.0};
             (void)block_plane(pose_last, pa, pb, pc, a_out, v_out);  // degenerate triples never reach the table (build_one clears their flag)
+            {  // the table holds the SCALED plane {m = |n'| n', beta = |n'| c} (ll_reg_core.h plane_scale)
+                double m_[3], beta_;
+                plane_scale(v_out, a_out[0], m_, &beta_);
+                v_out[0] = m_[0], v_out[1] = m_[1], v_out[2] = m_[2], a_out[0] = beta_;
+            }
             if (id < T) {
                 gstore_i4(tabG + 2 * id, make_int4(__double2loint(v_out[0]), __double2hiint(v_out[0]), __double2loint(v_out[1]), __double2hiint(v_out[1])));
                 gstore_i4(tabG + 2 * id + 1, make_int4(__double2loint(v_out[2]), __double2hiint(v_out[2]), __double2loint(a_out[0]), __double2hiint(a_out[0])));
@@ -1215,7 +1227,7 @@ __device__ __noinline__ unsigned long long census_and_plane_table(const RegDev &
             pid++;
             const int4 t = gload_i4(nn + p);
             int4 ob, oc;
-            pt_plane(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
+            pt_plane<true>(map_pts, pose_last, (unsigned int)t.x, (unsigned int)t.y, (unsigned int)t.z, ob, oc);
             gstore_i4(tabG + 2 * id, ob);
             gstore_i4(tabG + 2 * id + 1, oc);
             gstore_u16(ids + p, (unsigned short)id);
@@ -1341,9 +1353,9 @@ struct Pl3 {
         if (pp_ < nS && ((act >> (g + G * (K))) & 1ull)) { /* (a group member's last round may reach into the lines' bits) */ \
             const double f[3] = {(double)__int_as_float(R.fx), (double)__int_as_float(R.fy), (double)__int_as_float(R.fz)}; \
             const double v[3] = {__hiloint2double(Q.b.y, Q.b.x), __hiloint2double(Q.b.w, Q.b.z), __hiloint2double(Q.c.y, Q.c.x)}; \
-            const double a[3] = {__hiloint2double(Q.c.w, Q.c.z), 0.0, 0.0};                                \
-            block_accumulate(BLK_PLANE, R_, t_, f, a, v, huber_a, acc);                                    \
-            if (L1OUT) gstore_f64(l1_planes + pp_, block_l1(BLK_PLANE, R_, t_, f, a, v, huber_a, q_last)); \
+            const double beta_ = __hiloint2double(Q.c.w, Q.c.z);                                           \
+            plane_accumulate_scaled(R_, t_, f, v, beta_, huber_a, acc);                                    \
+            if (L1OUT) gstore_f64(l1_planes + pp_, plane_l1_scaled(R_, t_, f, v, beta_, huber_a, q_last)); \
         }                                                                                                  \
     }
 #define LL3_PIPE(FROM_CACHE, KB, KE)                                   \
@@ -1417,6 +1429,7 @@ __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int n
         if (!FILL) LL3_PIPE(true, 0, kc)
         LL3_PIPE(false, FILL ? 0 : kc, kp)
     }
+    plane_unfold2(acc);  // the factors 2 of the planes' rotation rows and columns (plane_accumulate_scaled leaves them out), before the lines are added
     {
         // line blocks (a few hundred per Mid-40 scan): the 65-byte fp64 form
         const size_t sb = (size_t)b * rd.cap;
@@ -1576,8 +1589,7 @@ __device__ __noinline__ unsigned long long inlier_phase3(const RegDev &rd, const
             const int4 qb = gload_i4(tabG + 2 * id), qc = gload_i4(tabG + 2 * id + 1);
             const double f[3] = {(double)ff.x, (double)ff.y, (double)ff.z};
             const double v[3] = {__hiloint2double(qb.y, qb.x), __hiloint2double(qb.w, qb.z), __hiloint2double(qc.y, qc.x)};
-            const double a[3] = {__hiloint2double(qc.w, qc.z), 0.0, 0.0};
-            l1g[rd.cap_c + p] = block_l1(BLK_PLANE, R_, t_, f, a, v, rc.huber_a, st->pose_last);
+            l1g[rd.cap_c + p] = plane_l1_scaled(R_, t_, f, v, __hiloint2double(qc.w, qc.z), rc.huber_a, st->pose_last);  // (the table holds scaled planes)
         }
         const int kpl = nSp / RS_THREADS;
         k = 0;

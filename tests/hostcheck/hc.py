@@ -273,3 +273,13 @@ def quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi):
     L.hc_quintic_min_step.restype = C.c_double
     L.hc_quintic_min_step.argtypes = [C.c_double] * 10
     return L.hc_quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi)
+
+
+def plane_scaled(R, t, f, v, a0, huber_a, q_last):
+    """(scaled accumulators [28], block_accumulate's [28], scaled L1, block_l1) of one plane block: ll_reg_core.h plane_* against the un-scaled forms"""
+    L = lib()
+    out = np.zeros(58)
+    arrs = [np.ascontiguousarray(x, np.float64) for x in (R, t, f, v, q_last)]
+    L.hc_plane_scaled.argtypes = [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.hc_plane_scaled(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, float(a0), float(huber_a), arrs[4].ctypes.data, out.ctypes.data)
+    return out[:28], out[28:56], out[56], out[57]

@@ -187,6 +187,22 @@ int hc_grid_set_guard(hc_grid *G, float guard)
 }
 
 /* the three-sample line-search interpolation of ll_reg_core.h, for the check against a dense Vandermonde solve */
+// scaled plane blocks (ll_reg_core.h plane_scale / plane_accumulate_scaled / plane_unfold2 / plane_l1_scaled) against the un-scaled forms:
+// out[0..27] scaled accumulators (unfolded), out[28..55] block_accumulate's, out[56] scaled L1, out[57] block_l1
+void hc_plane_scaled(const double *R, const double *t, const double *f, const double *v, double a0, double huber_a, const double *q_last, double *out)
+{
+    double m[3], beta, acc[LL_NACC], ref[LL_NACC];
+    for (int i = 0; i < LL_NACC; i++) acc[i] = ref[i] = 0.0;
+    ll::plane_scale(v, a0, m, &beta);
+    ll::plane_accumulate_scaled(R, t, f, m, beta, huber_a, acc);
+    ll::plane_unfold2(acc);
+    const double a[3] = {a0, 0.0, 0.0};
+    ll::block_accumulate(ll::BLK_PLANE, R, t, f, a, v, huber_a, ref);
+    for (int i = 0; i < LL_NACC; i++) out[i] = acc[i], out[LL_NACC + i] = ref[i];
+    out[2 * LL_NACC] = ll::plane_l1_scaled(R, t, f, m, beta, huber_a, q_last);
+    out[2 * LL_NACC + 1] = ll::block_l1(ll::BLK_PLANE, R, t, f, a, v, huber_a, q_last);
+}
+
 double hc_quintic_min_step(double f0, double g0, double x1, double f1, double g1, double x2, double f2, double g2, double lo, double hi)
 {
     return ll::lm_quintic_min_step(f0, g0, x1, f1, g1, x2, f2, g2, lo, hi);

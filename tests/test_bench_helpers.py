@@ -75,7 +75,7 @@ def test_summarize_rocprof_reads_register_counts_from_the_code_object():
     out = out[1:]
     assert out[0] == "kernel,vgpr,agpr,sgpr,vgpr_spill,sgpr_spill,scratch_bytes,lds_bytes,waves_per_simd"
     rows = {r.split(",")[0]: r.split(",") for r in out[1:]}
-    sol = rows["ll::reg_solve_kernel<0>"]
+    sol = rows["ll::reg_solve_kernel"]
     assert int(sol[1]) == 256 and int(sol[7]) > 150000 and int(sol[8]) == 2   # one 512-thread workgroup per CU, two waves per SIMD
     assert 64 <= int(rows["ll::reg_knn_kernel"][1]) <= 128 and int(rows["ll::reg_knn_kernel"][6]) == 0
 

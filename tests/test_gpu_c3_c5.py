@@ -71,10 +71,11 @@ def c3_sweeps(c3):
     return dict(sweeps=sweeps, corners=corners, surfs=surfs, pose_last=pose_last, oracle=oracle)
 
 
-@pytest.mark.parametrize("B", [2, 17])
+@pytest.mark.parametrize("B", [2, 17, 256])
 def test_c3_mid100_deblur_20m_map_matches_oracle(c3, c3_sweeps, B):
     """B = 2: the small-batch forms (wavefront-per-query corner searches, short work lists); B = 17: what batches of more than 16
-    scans run -- the configuration bench_c3.py measures at B = 256 (VERDICT r4, next #1c)"""
+    scans run; B = 256: the batch size bench_c3.py measures at (VERDICT r5, next #9 ii) -- every one of the 256 results against the
+    oracle's for its sweep.  Round 6: these scans take solve_big (ll_reg_big_path.h: plane table, 128-bit activity masks)."""
     S = len(c3_sweeps["sweeps"])
     corners = [c3_sweeps["corners"][b % S] for b in range(B)]
     surfs = [c3_sweeps["surfs"][b % S] for b in range(B)]
@@ -92,7 +93,7 @@ def test_c3_mid100_deblur_20m_map_matches_oracle(c3, c3_sweeps, B):
     reg.close()
     for b in range(B):
         ret, opc, opi, orep = c3_sweeps["oracle"][b % S]
-        assert orep.n_blocks_last > 24576  # the compact one-workgroup solver cannot hold this scan: general path, not forced
+        assert orep.n_blocks_last > 24576  # beyond solve_fast3's 64-bit masks and register tiles: reg_solve_big_kernel<1>, not forced
         dt, dr = synth.pose_error(pc[b], opc)
         assert res[b] == ret == 1 and dt <= 1e-4 and dr <= 1e-4  # the north-star tolerance ...
         assert dt < 1e-7 and dr < 1e-7                           # ... and what identical fp64 algorithms give

@@ -578,3 +578,38 @@ def test_quintic_minimiser_degenerate_shapes():
         got = hc.quintic_min_step(*args, lo, hi)
         assert lo <= got <= hi, name
         assert np.polyval(coef, got) - want_v <= 1e-12 * max(1.0, abs(want_v)), (name, got, want_x)
+
+
+def test_scaled_plane_blocks_equal_the_unscaled_forms():
+    """Round 6: solve_fast3 stores the SCALED plane {m = |n'| n', beta = |n'| c} per distinct neighbour triple and evaluates a plane block as
+    the scalar residual e = m.p - beta with Jacobian row (B^T m)^T, the factor 2 of the rotation rows put back once per evaluation
+    (ll_reg_core.h plane_accumulate_scaled / plane_unfold2 / plane_l1_scaled).  Same cost / gradient / Gauss-Newton terms and the same
+    loss-corrected L1 value as block_accumulate / block_l1 (which tests above hold to the oracle's forward-mode duals), to rounding --
+    in the quadratic and in the linear region of the Huber loss, for un-normalised normals of any length."""
+    rng = np.random.default_rng(66)
+    worst = 0.0
+    n_linear = 0
+    for trial in range(400):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        ang = rng.uniform(0, 0.05)
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        qi = np.r_[np.sin(ang / 2) * ax, np.cos(ang / 2)]
+        x, y, z, w = qi
+        R = np.array([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                      2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)])
+        t = rng.normal(size=3) * 0.1
+        f = rng.uniform(-30, 30, 3)
+        n = rng.normal(size=3); n *= rng.uniform(0.05, 1.0) / np.linalg.norm(n)       # |n'| = sin of the angle between the two edges: anything in (0, 1]
+        p = R.reshape(3, 3) @ f + t
+        dist = rng.choice([rng.normal() * 0.02, rng.normal() * 0.5])                  # a few centimetres, or well into the linear Huber region
+        a0 = float(n @ p - dist * np.linalg.norm(n))
+        acc, ref, l1, l1_ref = hc.plane_scaled(R, t, f, n, a0, 0.1, q)
+        n_linear += abs(dist) * np.linalg.norm(n) ** 2 > 0.1
+        scale = np.abs(ref).max() + 1e-300
+        # (the residual n'.p - c cancels two numbers of size |n'| |p| ~ 20: both forms carry that rounding, 1e-15 absolute; it is what a
+        #  residual of a few microns is measured against, so the L1 values are compared on that scale)
+        l1_tol = 1e-13 * np.linalg.norm(n) * (np.linalg.norm(p) + 1.0) + 1e-12 * abs(l1_ref)
+        worst = max(worst, np.abs(acc - ref).max() / scale, abs(l1 - l1_ref) / l1_tol * 1e-12)
+        assert np.allclose(acc, ref, rtol=0, atol=1e-11 * scale), trial
+        assert abs(l1 - l1_ref) <= l1_tol, trial
+    assert worst < 1e-11 and n_linear > 50
