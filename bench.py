@@ -757,7 +757,12 @@ def qpipe_oracle_audit(args, synth, corner, surf, scans, idx, init_q, out_q, p):
     for t in th:
         t.join()
     r = np.array([[float(v) for v in row] for row in rows])
+    worst = np.argsort(-r[:, 0])[:4]
     return {"scans": Bq, "max_pose_err_m": float(r[:, 0].max()), "max_pose_err_rad": float(r[:, 1].max()),
+            "pose_err_m_quantiles": {"q": [50, 90, 99, 99.9], "v": [float(v) for v in np.percentile(r[:, 0], [50, 90, 99, 99.9])]},
+            "scans_beyond_1e-7_m": int((r[:, 0] > 1e-7).sum()), "scans_beyond_1e-4_m": int((r[:, 0] > 1e-4).sum()),
+            "worst_scans": [{"slot": int(b), "distinct_scan": int(idx[b]), "pose_err_m": float(r[b, 0]), "lm_equal": bool(r[b, 4]), "icp_equal": bool(r[b, 5]),
+                             "device_lm": int(reps_q[b].lm_iterations_total), "device_final_cost": float(reps_q[b].final_cost), "accepted": int(res_q[b])} for b in worst],
             "accept_reject_identical": bool(r[:, 2].all()), "block_counts_identical": bool(r[:, 3].all()),
             "lm_iteration_counts_identical": int(r[:, 4].sum()), "icp_iteration_counts_identical": int(r[:, 5].sum()),
             "host_threads": n_thr, "seconds": round(time.perf_counter() - tb, 1)}

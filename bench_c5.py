@@ -35,11 +35,11 @@ PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 def pmc_bytes(kernel_substr):
     """(fetch x 2 + write) bytes per dispatch of the largest-grid instance of a kernel, from the newest committed C5 counter summary"""
-    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_c5_pmc_hbm_bytes.csv")))
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_c5_pmc_hbm_bytes.csv")))
     if not hits:
         return None, None
     best = None
-    for r in csv.DictReader(open(hits[-1])):
+    for r in csv.DictReader(l for l in open(hits[-1]) if not l.startswith("#")):
         if kernel_substr in r["kernel"] and (best is None or int(r["grid_threads"]) > int(best["grid_threads"])):
             best = r
     if best is None:
@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--parity-queries", type=int, default=32)
     ap.add_argument("--jitter", type=float, default=0.03)
     ap.add_argument("--only", default="", help="comma list of per_lane_fp32,tile_fp32,per_lane_fp16 (profiling runs: one kernel shape per run)")
-    ap.add_argument("--headline", default="per_lane_fp16")
+    ap.add_argument("--headline", default="per_lane_fp32", help="the run `value` quotes (round 6: the fp16-record variant is slower than fp32 -- a gather costs a cache line whatever the record size -- and is reported beside it, not as the headline)")
+    ap.add_argument("--query-order", default="scan", choices=["scan", "cell"],
+                    help="scan: the chunks' points in map-array order (default); cell: every scan's queries sorted by the 0.6 m map cell they fall into, x fastest (experiment: what a cell-ordered query stream gives the per-lane search)")
     args = ap.parse_args()
     import torch
     from loam_livox_amd import synth
@@ -79,6 +81,12 @@ def main():
         B = min(B, args.max_scans)
     sel = order[: B * Q]
     q = (surf[sel, :3] + rng.normal(0.0, args.jitter, (B * Q, 3))).astype(np.float32)
+    if args.query_order == "cell":
+        c = np.floor((q - q.min(0)) / np.float32(0.6)).astype(np.int64)
+        k2 = (c[:, 2] * (c[:, 1].max() + 1) + c[:, 1]) * (c[:, 0].max() + 1) + c[:, 0]
+        k2 += (np.arange(B * Q) // Q) * (k2.max() + 1)   # inside each scan
+        q = q[np.argsort(k2, kind="stable")]
+        del c, k2
     del cell, key, order
     max_d2 = 50.0
     want = [w for w in args.only.split(",") if w] or ["per_lane_fp32", "tile_fp32", "per_lane_fp16"]

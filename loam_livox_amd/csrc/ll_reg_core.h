@@ -988,9 +988,13 @@ LL_HD int quintic_quadratic_roots(double A, double B, double C, double lo, doubl
     if (n >= 2 && c1 > lo && c1 < hi && !(m == 1 && c1 == r[0])) r[m++] = c1;
     return m;
 }
-#define LL_QUINTIC_BISECTIONS 60 /* an interval is halved until it cannot shrink (m == l or m == r) or 60 times */
-// the root of the polynomial k in (a, b], where it is monotone: found by the sign change of its end values va, vb (or vb == 0).
-// Returns false when there is none.
+#define LL_QUINTIC_ROOT_STEPS 64 /* bound on the steps of one root refinement (it ends on its own after ~10) */
+// the root of the polynomial k in (a, b], where it is monotone: found by the sign change of its end values va, vb (or vb == 0) and refined
+// by the ILLINOIS form of regula falsi -- the secant through the bracket's ends, the retained end's value halved whenever the same end is
+// replaced twice in a row, a bisection step whenever rounding puts the secant point on an end -- which keeps the root bracketed like
+// bisection and converges superlinearly: ~10 polynomial evaluations instead of 60 (the fit sits on the critical path of every scan
+// whose step runs into the bounds: with 60-step bisections the small-scan solver lost a third of its speed).  Ends when the iterate
+// stops moving, hits a zero, or the bracket cannot shrink.  Returns false when there is no root.
 LL_HD bool quintic_interval_root(const double k[5], double a, double b, double va, double vb, double *root)
 {
     if (vb == 0.0) {
@@ -998,23 +1002,33 @@ LL_HD bool quintic_interval_root(const double k[5], double a, double b, double v
         return true;
     }
     if (!((va < 0.0 && vb > 0.0) || (va > 0.0 && vb < 0.0))) return false;
-    double l = a, r = b, vl = va;
-    for (int it = 0; it < LL_QUINTIC_BISECTIONS; it++) {
-        const double m = 0.5 * (l + r);
-        if (m == l || m == r) break;
-        const double vm = quintic_poly4(k, m);
-        if (vm == 0.0) {
-            l = r = m;
+    double l = a, r = b, wl = va, wr = vb;  // bracket and the (possibly halved) values the secant uses; sign(wl) = sign of k at l, likewise r
+    const bool neg_left = va < 0.0;
+    double x = b;
+    int side = 0;
+    for (int it = 0; it < LL_QUINTIC_ROOT_STEPS; it++) {
+        double c = (wl * r - wr * l) / (wl - wr);
+        if (!(c > l && c < r)) c = 0.5 * (l + r);
+        if (c == l || c == r || c == x) {  // adjacent doubles, or no progress: done
+            x = c;
             break;
         }
-        if ((vl < 0.0) == (vm < 0.0)) {
-            l = m;
-            vl = vm;
+        x = c;
+        const double vc = quintic_poly4(k, c);
+        if (vc == 0.0) break;
+        if ((vc < 0.0) == neg_left) {
+            l = c;
+            wl = vc;
+            if (side == -1) wr *= 0.5;
+            side = -1;
         } else {
-            r = m;
+            r = c;
+            wr = vc;
+            if (side == 1) wl *= 0.5;
+            side = 1;
         }
     }
-    *root = 0.5 * (l + r);
+    *root = x;
     return true;
 }
 // roots of k inside (lo, hi] given its break points bp[0 .. nb) (ascending, strictly inside (lo, hi)): at most nb + 1, ascending

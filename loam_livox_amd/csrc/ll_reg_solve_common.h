@@ -164,12 +164,14 @@ __device__ __forceinline__ double lm_quintic_min_step_wave(double f0, double g0,
     const double a = lane == 0 ? lo : (lane == 1 ? Q1 : (lane == 2 ? Q2 : Q3)), b = lane == 0 ? Q1 : (lane == 1 ? Q2 : (lane == 2 ? Q3 : hi));
     double root = 0.0;
     const bool has = lane <= n2 && lane < 4 && quintic_interval_root(c.dq, a, b, quintic_poly4(c.dq, a), quintic_poly4(c.dq, b), &root);
-    // ---- MinimizePolynomial's choice (quintic_pick), the roots in interval order ----
-    double best_x = lo, best_v, vh, dl, dh;
-    quintic_eval(q, lo, best_v, dl);
-    quintic_eval(q, hi, vh, dh);
-    (void)dl;
-    (void)dh;
+    // ---- MinimizePolynomial's choice (quintic_pick), the roots in interval order: lanes 0 .. 3 evaluate the interpolant at their root, lanes 4 / 5
+    //      at the interval's ends -- one sweep for all six values instead of six in a row; the comparisons then run as in the sequential form ----
+    const double xe = lane == 4 ? lo : (lane == 5 ? hi : root);
+    double ve, de;
+    quintic_eval(q, xe, ve, de);
+    (void)de;
+    double best_x = lo, best_v = __shfl(ve, 4);
+    const double vh = __shfl(ve, 5);
     if (!(best_v < vh)) {
         best_v = vh;
         best_x = hi;
@@ -177,15 +179,10 @@ __device__ __forceinline__ double lm_quintic_min_step_wave(double f0, double g0,
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int hi_ = __shfl((int)has, i);
-        const double xi = __shfl(root, i);
-        if (hi_) {  // (uniform)
-            double v, dv;
-            quintic_eval(q, xi, v, dv);
-            (void)dv;
-            if (v < best_v) {
-                best_v = v;
-                best_x = xi;
-            }
+        const double xi = __shfl(root, i), v = __shfl(ve, i);
+        if (hi_ && v < best_v) {  // (uniform)
+            best_v = v;
+            best_x = xi;
         }
     }
     return best_x;

@@ -472,7 +472,10 @@ long long orc_dbg_ls_quintic_fits(int reset)
     return v;
 }
 static double qm_poly4(const double k[5], double x) { return fma(fma(fma(fma(k[4], x, k[3]), x, k[2]), x, k[1]), x, k[0]); }
-/* the root of the polynomial k in (a, b], where it is monotone (sign change of the end values, or vb == 0); 0 when there is none */
+/* the root of the polynomial k in (a, b], where it is monotone (sign change of the end values, or vb == 0); 0 when there is none.
+ * Refined by the Illinois form of regula falsi: the secant through the bracket's ends, the retained end's value halved whenever the same
+ * end is replaced twice in a row, a bisection step whenever rounding puts the secant point on an end; ends when the iterate stops
+ * moving, hits a zero, or the bracket cannot shrink (ll_reg_core.h quintic_interval_root: the same operations) */
 static int qm_interval_root(const double k[5], double a, double b, double va, double vb, double *root)
 {
     if (vb == 0.0) {
@@ -480,23 +483,33 @@ static int qm_interval_root(const double k[5], double a, double b, double va, do
         return 1;
     }
     if (!((va < 0.0 && vb > 0.0) || (va > 0.0 && vb < 0.0))) return 0;
-    double l = a, r = b, vl = va;
-    for (int it = 0; it < 60; it++) { /* halved until the interval cannot shrink, or 60 times */
-        const double m = 0.5 * (l + r);
-        if (m == l || m == r) break;
-        const double vm = qm_poly4(k, m);
-        if (vm == 0.0) {
-            l = r = m;
+    double l = a, r = b, wl = va, wr = vb;
+    const int neg_left = va < 0.0;
+    double x = b;
+    int side = 0;
+    for (int it = 0; it < 64; it++) {
+        double c = (wl * r - wr * l) / (wl - wr);
+        if (!(c > l && c < r)) c = 0.5 * (l + r);
+        if (c == l || c == r || c == x) {
+            x = c;
             break;
         }
-        if ((vl < 0.0) == (vm < 0.0)) {
-            l = m;
-            vl = vm;
+        x = c;
+        const double vc = qm_poly4(k, c);
+        if (vc == 0.0) break;
+        if ((vc < 0.0) == neg_left) {
+            l = c;
+            wl = vc;
+            if (side == -1) wr *= 0.5;
+            side = -1;
         } else {
-            r = m;
+            r = c;
+            wr = vc;
+            if (side == 1) wl *= 0.5;
+            side = 1;
         }
     }
-    *root = 0.5 * (l + r);
+    *root = x;
     return 1;
 }
 /* roots of k inside (lo, hi] given its break points bp[0 .. nb) (ascending, strictly inside): at most nb + 1, ascending */

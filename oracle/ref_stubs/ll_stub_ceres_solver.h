@@ -208,32 +208,45 @@ inline bool cholesky_solve( int n, std::vector<double> A, const std::vector<doub
 inline double quintic_poly4( const double k[ 5 ], double x ) { return std::fma( std::fma( std::fma( std::fma( k[ 4 ], x, k[ 3 ] ), x, k[ 2 ] ), x, k[ 1 ] ), x, k[ 0 ] ); }
 inline bool quintic_interval_root( const double k[ 5 ], double a, double b, double va, double vb, double *root )
 {
+    // Illinois regula falsi on the bracket (the same operations as ll_reg_core.h quintic_interval_root / the oracle's qm_interval_root)
     if ( vb == 0.0 )
     {
         *root = b;
         return true;
     }
     if ( !( ( va < 0.0 && vb > 0.0 ) || ( va > 0.0 && vb < 0.0 ) ) ) return false;
-    double l = a, r = b, vl = va;
-    for ( int it = 0; it < 60; it++ )
+    double     l = a, r = b, wl = va, wr = vb;
+    const bool neg_left = va < 0.0;
+    double     x = b;
+    int        side = 0;
+    for ( int it = 0; it < 64; it++ )
     {
-        const double m = 0.5 * ( l + r );
-        if ( m == l || m == r ) break;
-        const double vm = quintic_poly4( k, m );
-        if ( vm == 0.0 )
+        double c = ( wl * r - wr * l ) / ( wl - wr );
+        if ( !( c > l && c < r ) ) c = 0.5 * ( l + r );
+        if ( c == l || c == r || c == x )
         {
-            l = r = m;
+            x = c;
             break;
         }
-        if ( ( vl < 0.0 ) == ( vm < 0.0 ) )
+        x = c;
+        const double vc = quintic_poly4( k, c );
+        if ( vc == 0.0 ) break;
+        if ( ( vc < 0.0 ) == neg_left )
         {
-            l = m;
-            vl = vm;
+            l = c;
+            wl = vc;
+            if ( side == -1 ) wr *= 0.5;
+            side = -1;
         }
         else
-            r = m;
+        {
+            r = c;
+            wr = vc;
+            if ( side == 1 ) wl *= 0.5;
+            side = 1;
+        }
     }
-    *root = 0.5 * ( l + r );
+    *root = x;
     return true;
 }
 inline int quintic_roots_between( const double k[ 5 ], double lo, double hi, const double *bp, int nb, double *roots )
