@@ -90,8 +90,11 @@ def parse():
 
 
 def newest_profile(pattern):
+    """the newest committed summary of the DEFAULT line's passes (round tags sort lexicographically; the Q-pipe / C3 / C5 passes of a round carry
+    their own infix and are not this command's)"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern))
+                   if not any(t in os.path.basename(f) for t in ("_qpipe_", "_c3_", "_c4_", "_c5_")))
     return files[-1] if files else None
 
 
