@@ -106,6 +106,34 @@ def test_c3_mid100_deblur_20m_map_matches_oracle(c3, c3_sweeps, B):
             assert np.array_equal(pc[b], pc[b % S])
 
 
+def test_c3_mid100_without_deblur_matches_oracle(c3, c3_sweeps):
+    """the same merged Mid-100 scans registered WITHOUT motion deblur: > 24 576 residual blocks per scan and no blur ratio -- the batch takes
+    reg_solve_big_kernel<0> (128-bit activity masks, the un-scaled plane table, block_accumulate), which no other test reaches"""
+    B = 2
+    corners, surfs = c3_sweeps["corners"][:B], c3_sweeps["surfs"][:B]
+    pose_last = c3_sweeps["pose_last"][:B]
+    tc, ts = orc.KdTree(c3["corner"]), orc.KdTree(c3["surf"])
+    prm = orc.RegParams.defaults(icp_iters=4, ceres_iters=20, force_all=1, deblur=0)
+    prm.max_final_cost, prm.maximum_allow_residual_block = 1000.0, 3 * N
+    reg = Point_cloud_registration(max_scans=B, max_features=max(max(len(c) for c in corners), max(len(s) for s in surfs)))
+    p = reg.params
+    p.if_motion_deblur = 0
+    p.icp_max_iterations, p.ceres_max_iterations, p.force_all_iterations = 4, 20, 1
+    p.para_max_angular_rate, p.para_max_speed, p.max_final_cost = 20.0, 0.3, 1000.0
+    p.current_frame_index, p.mapping_init_accumulate_frames = 100, 50
+    p.maximum_allow_residual_block = 3 * N
+    reg.upload_features(corners, surfs)
+    reg.enqueue_uploaded(c3["map"], B, pose_last, pose_last)
+    res, pc, pi, reps = reg.collect(B)
+    reg.close()
+    for b in range(B):
+        ret, opc, opi, orep = orc.reg_solve(tc, ts, corners[b], surfs[b], prm, pose_last[b], pose_last[b])
+        assert orep.n_blocks_last > 24576
+        dt, dr = synth.pose_error(pc[b], opc)
+        assert res[b] == ret and dt < 1e-7 and dr < 1e-7
+        assert reps[b].n_blocks_last == orep.n_blocks_last and reps[b].lm_iterations_total == orep.lm_iterations_total and reps[b].icp_iterations == orep.icp_iterations
+
+
 def test_c3_heads_merged_on_the_device_equal_the_host_merge(c3):
     """ll_reg_enqueue_fe_merged: the three heads of a sweep extracted as three slots of one batch and concatenated on the
     device give bit for bit the registration of the host-side concatenation (laser_feature_extractor.hpp:348-358)."""

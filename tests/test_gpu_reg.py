@@ -149,15 +149,17 @@ def test_group_barrier_abort_rejects_the_scan(request, dev_map, scans):
     reg.close()
 
 
-@pytest.mark.parametrize("groups", [False, True])
+@pytest.mark.parametrize("groups,deblur", [(False, 0), (True, 0), (False, 1)])
 @pytest.mark.parametrize("world", ["rooms", "random_cloud"])
-def test_plane_table_agrees_with_per_block_records(dev_map, scans, groups, world):
+def test_plane_table_agrees_with_per_block_records(dev_map, scans, groups, deblur, world):
     """The plane-table solver path evaluates, block for block, the numbers of the general path, which stores {n', c} with every
     block (different evaluation loops and summation grouping, so they agree to rounding, not to the bit) -- on the synthetic rooms (a few thousand distinct neighbour triples: the whole table in LDS) and
     against a uniform random cloud, where nearly every block has a triple of its own: the LDS hash table fills up (private
-    table entries), the table overflows its LDS part (planes gathered from HBM) and nothing is de-duplicated."""
+    table entries), the table overflows its LDS part (planes gathered from HBM) and nothing is de-duplicated.
+    deblur = 1: the same for solve_big (ll_reg_big_path.h: use-ranked ids, the clamped L2 gather for what LDS does not hold, private entries
+    after 32 probes) with the motion-deblur residuals."""
     sc = scans[1]
-    _, _, _, _, fc, fs = oracle_features(sc)
+    fe_o, _, _, _, fc, fs = oracle_features(sc)
     if world == "rooms":
         m = dev_map
     else:
@@ -170,7 +172,9 @@ def test_plane_table_agrees_with_per_block_records(dev_map, scans, groups, world
     for per_block in (False, True):
         reg = Point_cloud_registration(max_scans=1, max_features=24000)
         reg.set_debug(False, force_general_solver=per_block, no_solver_groups=not groups)
-        set_params(reg, 2 if world != "rooms" else 4, 20, 1)
+        pp = set_params(reg, 2 if world != "rooms" else 4, 20, 1)
+        if deblur:
+            pp.if_motion_deblur, pp.minimum_pt_time_stamp, pp.maximum_pt_time_stamp = 1, float(fe_o.time_stamp.min()), float(fe_o.time_stamp.max())
         reg.m_pose_w_last = sc.pose_init.copy()
         reg.m_pose_w_curr = sc.pose_init.copy()
         ret = reg.find_out_incremental_transfrom(m, fc, fs)
