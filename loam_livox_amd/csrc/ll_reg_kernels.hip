@@ -1430,6 +1430,108 @@ __device__ __noinline__ void solver_eval3(const RegDev &rd, int b, int nC, int n
         LL3_PIPE(false, FILL ? 0 : kc, kp)
     }
     plane_unfold2(acc);  // the factors 2 of the planes' rotation rows and columns (plane_accumulate_scaled leaves them out), before the lines are added
+#ifdef LL_EXP_MOMENT_EVAL
+    // EXPERIMENT (-DLL_EXP_MOMENT_EVAL together with -DLL_SOLVE_TIMING, never in the product library): what ONE evaluation in
+    // per-plane moment form would cost, run IN ADDITION to the real one so that control flow and evaluation count stay the same -- the
+    // difference of the evaluation phase's cycles between this build and the plain timing build is the cost of a moment-form evaluation:
+    //   (1) per block: the record (streamed again), the plane from the LDS table, the scalar residual and the Huber test (which blocks
+    //       are in the linear region) -- no accumulation;
+    //   (2) per distinct plane: the plane + ten moments {N, S1, S2} (80 B, streamed from HBM: 112 B x T does not fit LDS; the scan's unused
+    //       plane slots of blk_av stand in for the moment array) and the quadratic-region cost / gradient / Gauss-Newton terms from them.
+    // Not included (so this is a LOWER bound of the real thing): the two moment builds per launch and the per-block correction of the
+    // linear-region blocks.  The results of (1) and (2) go nowhere (a never-true test keeps them alive).
+    {
+        double xacc[LL_NACC];
+#pragma unroll
+        for (int i = 0; i < LL_NACC; i++) xacc[i] = 0.0;
+        int n_lin = 0;
+        for (int k0 = 0; k0 < kp; k0 += 8) {  // eight rounds' records in flight (the real loop keeps five)
+            float fx8[8], fy8[8], fz8[8];
+            unsigned int id8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int pp = p0 + (k0 + u) * GS;
+                const int pc = pp < nS ? pp : 0;
+                gload_f3(feat + pc, fx8[u], fy8[u], fz8[u]);
+                id8[u] = gload_u16(ids + pc);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + u, pp = p0 + k * GS;
+                const unsigned int idl = id8[u] < (unsigned int)Tl ? id8[u] : 0u;
+                const int4 qb = lds_load_i4(tabL + 2 * idl), qc = lds_load_i4(tabL + 2 * idl + 1);
+                const double f[3] = {(double)fx8[u], (double)fy8[u], (double)fz8[u]};
+                const double m[3] = {__hiloint2double(qb.y, qb.x), __hiloint2double(qb.w, qb.z), __hiloint2double(qc.y, qc.x)};
+                const double beta = __hiloint2double(qc.w, qc.z);
+                const double q0 = R_[0] * f[0] + R_[1] * f[1] + R_[2] * f[2] + t_[0], q1 = R_[3] * f[0] + R_[4] * f[1] + R_[5] * f[2] + t_[1],
+                             q2 = R_[6] * f[0] + R_[7] * f[1] + R_[8] * f[2] + t_[2];
+                const double e = m[0] * q0 + m[1] * q1 + m[2] * q2 - beta;
+                if (k < kp && pp < nS && ((act >> (g + G * k)) & 1ull) && e * e > huber_a * huber_a) n_lin++;
+            }
+        }
+        const double *mom = rd.blk_av + (size_t)b * 6 * rd.cap + 2 * (size_t)rd.cap_c;  // (stand-in storage: 80 B per plane id)
+        for (int id = tid; id < sh.pt_T && id < Tl; id += RS_THREADS) {
+            const int4 qb = lds_load_i4(tabL + 2 * id), qc = lds_load_i4(tabL + 2 * id + 1);
+            const double m[3] = {__hiloint2double(qb.y, qb.x), __hiloint2double(qb.w, qb.z), __hiloint2double(qc.y, qc.x)};
+            const double beta = __hiloint2double(qc.w, qc.z);
+            double mo[10];
+#pragma unroll
+            for (int i = 0; i < 10; i += 2) {
+                const double2 v2 = gload_d2(reinterpret_cast<const double2 *>(mom + (size_t)id * 10 + i));
+                mo[i] = v2.x;
+                mo[i + 1] = v2.y;
+            }
+            // sensor-frame normal and offset, then the quadratic form in the moments (the algebra of DESIGN section 8's analysis)
+            const double ms[3] = {R_[0] * m[0] + R_[3] * m[1] + R_[6] * m[2], R_[1] * m[0] + R_[4] * m[1] + R_[7] * m[2], R_[2] * m[0] + R_[5] * m[1] + R_[8] * m[2]};
+            const double bs = m[0] * t_[0] + m[1] * t_[1] + m[2] * t_[2] - beta;
+            const double N = mo[0], S1[3] = {mo[1], mo[2], mo[3]};
+            const double S2[9] = {mo[4], mo[5], mo[6], mo[5], mo[7], mo[8], mo[6], mo[8], mo[9]};
+            double u[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) u[i] = S2[3 * i] * ms[0] + S2[3 * i + 1] * ms[1] + S2[3 * i + 2] * ms[2];
+            const double l1 = ms[0] * S1[0] + ms[1] * S1[1] + ms[2] * S1[2];
+            xacc[27] += 0.5 * (ms[0] * u[0] + ms[1] * u[1] + ms[2] * u[2] + 2.0 * bs * l1 + N * bs * bs);
+            const double w[3] = {u[0] + bs * S1[0], u[1] + bs * S1[1], u[2] + bs * S1[2]};
+            double gt[3], sx[3];
+            cross3(w, ms, gt);
+            cross3(S1, ms, sx);
+            const double gb = l1 + N * bs;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                xacc[21 + i] += 2.0 * gt[i];
+                xacc[24 + i] += gb * ms[i];
+            }
+            // H_rr = 4 [ms]x S2 [ms]x^T, H_rt = 2 (S1 x ms) ms^T, H_tt = N ms ms^T (sensor frame; the common rotation is applied once at the end)
+            double A[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double row[3] = {S2[3 * r], S2[3 * r + 1], S2[3 * r + 2]};
+                double c[3];
+                cross3(row, ms, c);
+                A[3 * r] = c[0], A[3 * r + 1] = c[1], A[3 * r + 2] = c[2];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double col[3] = {A[c], A[3 + c], A[6 + c]};
+                double h[3];
+                cross3(ms, col, h);
+#pragma unroll
+                for (int r = 0; r <= c; r++) xacc[hidx(r, c)] += 4.0 * h[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    xacc[hidx(i, 3 + j)] += 2.0 * sx[i] * ms[j];
+                    if (j >= i) xacc[hidx(3 + i, 3 + j)] += N * ms[i] * ms[j];
+                }
+        }
+        double xs = (double)n_lin;
+#pragma unroll
+        for (int i = 0; i < LL_NACC; i++) xs += xacc[i];
+        if (xs == 1.2345678e300) acc[27] += xs;  // (never: keeps the experiment's arithmetic and loads alive)
+    }
+#endif
     {
         // line blocks (a few hundred per Mid-40 scan): the 65-byte fp64 form
         const size_t sb = (size_t)b * rd.cap;
