@@ -196,25 +196,110 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 }
 
 #define KT_THREADS 256
-// One-dimensional grid: first corner_blocks workgroups for every scan (scan fastest), then surf_blocks workgroups per scan.
-// corner_blocks > 0: those first workgroups search the scans' corner queries one per lane (and build their blocks) -- dispatched
-// before any tile, their long ring searches (~100 dependent loads per lane) overlap the tiles instead of forming a launch of their
-// own or a tail behind the last tile.
-#ifndef KT_WAVES_PER_EU
-#define KT_WAVES_PER_EU 4  // (A/B: a register cap for more resident wavefronts spills in the per-lane fall-back)
-#endif
+// One-dimensional grid, surf_blocks workgroups per scan.  The kernel holds the tile search and nothing else (84 VGPRs: five wavefronts per
+// SIMD): what a lane cannot finish here -- the ring search of a query the tile does not settle (sparse surroundings, an exact tie, more
+// than a cell outside the grid: a dozen per scan), or the fp64 block constants of a scan without a plane table -- goes onto the scan's work list
+// (rd.work_search, surface segment; rd.work_cnt[4 b + 2], zeroed by the launcher) and reg_knn_lane_kernel, the next launch, takes it
+// (round 5 ran those lanes in here: 117 VGPRs, four wavefronts per SIMD, and 3 % of the wavefronts executed a ring search for a third
+// of their lanes -- nearly all of them queries on the map's outer walls, a centimetre outside the grid: tile_query now adopts the
+// nearest cell for them).
+#define KT_LIST_BUILD_ONLY 0x80000000u  // list entry: slot | this bit when the neighbours are stored and only build_one is left
 template <bool FUSED>
-__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(KT_WAVES_PER_EU, 8)))
-void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int n_scans, int corner_blocks, int surf_blocks)
+__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gs, int iter, int surf_blocks)
 {
     __shared__ float4 s_tile[KT_THREADS / 64][LL_TILE_CAP + 4];
+    const int bid = blockIdx.x;
+    const int b = bid / surf_blocks, sblk = bid - b * surf_blocks;
+    const RegState *st = rd.state + b;
+    if (st->done) return;
+    const size_t sb = (size_t)b * rd.cap;
+    const int nS = rd.n_surf[b];
+    const int i = sblk * KT_THREADS + threadIdx.x;  // position in the scan's cell order
+    if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
+    const bool valid = i < nS;
+#ifdef LL_TILE_TIMING
+    // instrumented build: wall clocks of this wavefront per phase, added to the scan's RegState::dbg_cycles by lane 0 --
+    // 0 tile_query, 1 round set-up, 2 staging, 3 offers, 4 winners + finish test, 5 query position (order + transform), 6 sum of tile
+    // sizes, 7 rounds, 8 store of final lanes, 9 list append, 10 block flag, 11 whole wavefront, 12 wavefronts, 13 wavefronts with a
+    // listed lane, 14 listed lanes
+    long long tt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = clock64();
+    long long tw = t_begin;
+#endif
+    // segment base + index in the segment; the segment is the same for the whole wavefront (LL_KNN_TILE_SEG is a multiple of 64): scalar
+    const int seg_base = (__builtin_amdgcn_readfirstlane(i) / LL_KNN_TILE_SEG) * LL_KNN_TILE_SEG;
+    const int q = valid ? seg_base + (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
+    const int slot = rd.cap_c + q;
+    const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
+    const float max_d2 = rc.max_d2_plane;
+    Knn5 r;
+    bool fin;
+    int degenerate;  // of the plane through neighbours 0, 2, 4 (1 / 0), -1 = not known (tile of several passes)
+    LL_TT(5, tw);
+    knn5_tile_wave(gs, valid, pw.x, pw.y, pw.z, max_d2, s_tile[threadIdx.x >> 6], r, fin, degenerate LL_TT_PASS);
+#ifdef LL_TILE_TIMING
+    tw = clock64();
+#endif
+    bool listed = valid && !fin;  // sparse surroundings, an exact tie, a query outside the grid or not finite: per-lane search
+    if (valid && fin) {
+        if (rc.debug_knn && iter == rc.debug_knn_iter) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
+        }
+        knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
+        LL_TT(8, tw);
+        if (!rc.check_plane_pca && rc.icp_plane && scan_is_compact(rd, rc, b)) {
+            // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
+            // has just seen in LDS -- no second look at rd.nn or the map
+            // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)
+            if (degenerate < 0) {
+                const f4 p0 = gs.pts[r.pos[0]], p1 = gs.pts[r.pos[2]], p2 = gs.pts[r.pos[4]];
+                degenerate = ((p1.x == p0.x && p1.y == p0.y && p1.z == p0.z) || (p2.x == p0.x && p2.y == p0.y && p2.z == p0.z)) ? 1 : 0;
+            }
+            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
+        } else {
+            listed = true;  // block constants in fp64 (or the PCA check): build_one, in the lane kernel
+        }
+        LL_TT(10, tw);
+    }
+    if (listed && !fin && FUSED) rd.qw[sb + slot] = pw;
+    const unsigned long long lm = __ballot(listed);
+    if (lm) {  // (uniform) one atomic per wavefront reserves its entries
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&rd.work_cnt[4 * b + 2], (int)__popcll(lm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (listed)
+            rd.work_search[sb + rd.cap_c + base + (int)__popcll(lm & ((1ull << lane) - 1ull))] = (int)((unsigned int)slot | (fin ? KT_LIST_BUILD_ONLY : 0u));
+    }
+#ifdef LL_TILE_TIMING
+    LL_TT(9, tw);
+    tt[13] = lm ? 1 : 0;
+    tt[14] = __popcll(lm);
+    tt[11] = clock64() - t_begin;
+    tt[12] = 1;
+    if ((threadIdx.x & 63) == 0)
+        for (int k_ = 0; k_ < 16; k_++) atomicAdd((unsigned long long *)&rd.state[b].dbg_cycles[k_], (unsigned long long)tt[k_]);
+#endif
+}
+
+// The queries the tile kernel leaves behind, one per lane: a scan's corner queries (a few hundred ring searches on the sparse corner map,
+// ~100 dependent loads each; corner_blocks workgroups per scan, dispatched first) and the entries of its work list (list_blocks
+// workgroups per scan, striding over the list).  Search (knn_one) where it is still due, then the block constants (build_one).
+#define KL_THREADS 64
+#define KL_COOP_PER 4  // lists of up to this many entries per list workgroup are searched one wavefront per entry
+template <bool FUSED>
+__global__ __launch_bounds__(KL_THREADS) void reg_knn_lane_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int n_scans, int corner_blocks,
+                                                                  int list_blocks)
+{
     const int bid = blockIdx.x, n_corner_wg = corner_blocks * n_scans;
     if (bid < n_corner_wg) {
         const int b = bid % n_scans, cblk = bid / n_scans;
         const RegState *st = rd.state + b;
         if (st->done) return;
         const size_t sb = (size_t)b * rd.cap;
-        const int q = cblk * KT_THREADS + threadIdx.x, nC = rd.n_corner[b];
+        const int q = cblk * KL_THREADS + threadIdx.x, nC = rd.n_corner[b];
         if (q >= nC) return;
         if (FUSED) {
             float pw[3];
@@ -226,45 +311,27 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int
         build_one(rd, rc, gc, gs, b, q);
         return;
     }
-    const int b = (bid - n_corner_wg) / surf_blocks, sblk = (bid - n_corner_wg) - b * surf_blocks;
-    const RegState *st = rd.state + b;
-    if (st->done) return;
+    const int b = (bid - n_corner_wg) % n_scans, lblk = (bid - n_corner_wg) / n_scans;
+    if (rd.state[b].done) return;
     const size_t sb = (size_t)b * rd.cap;
-    const int nS = rd.n_surf[b];
-    const int i = sblk * KT_THREADS + threadIdx.x;  // position in the scan's cell order
-    if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
-    const bool valid = i < nS;
-    // segment base + index in the segment; the segment is the same for the whole wavefront (LL_KNN_TILE_SEG is a multiple of 64): scalar
-    const int seg_base = (__builtin_amdgcn_readfirstlane(i) / LL_KNN_TILE_SEG) * LL_KNN_TILE_SEG;
-    const int q = valid ? seg_base + (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
-    const int slot = rd.cap_c + q;
-    const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
-    const float max_d2 = rc.max_d2_plane;
-    Knn5 r;
-    bool fin;
-    knn5_tile_wave(gs, valid, pw.x, pw.y, pw.z, max_d2, s_tile[threadIdx.x >> 6], r, fin);
-    if (!valid) return;
-    if (fin) {
-        if (rc.debug_knn && iter == rc.debug_knn_iter) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) r.idx[k] = as_int(gs.pts[r.pos[k]].w);
+    const int n = rd.work_cnt[4 * b + 2];
+    if (n <= KL_COOP_PER * list_blocks) {
+        // a short list (the usual case: a dozen queries with their neighbours metres away, each a chain of a hundred dependent loads for
+        // one lane): one wavefront per entry (ll_knn_coop.h), lane 0 stores and builds
+        for (int k = lblk; k < n; k += list_blocks) {
+            const unsigned int e = (unsigned int)rd.work_search[sb + rd.cap_c + k];
+            const int slot = (int)(e & ~KT_LIST_BUILD_ONLY);
+            if (!(e & KT_LIST_BUILD_ONLY)) knn_one_coop(rd, rc, gc, gs, b, slot, iter);  // (uniform)
+            if (threadIdx.x == 0) build_one(rd, rc, gc, gs, b, slot);
         }
-        knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
-        if (!rc.check_plane_pca && rc.icp_plane && scan_is_compact(rd, rc, b)) {
-            // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
-            // still knows -- no second look at rd.nn
-            // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)
-            const f4 p0 = gs.pts[r.pos[0]], p1 = gs.pts[r.pos[2]], p2 = gs.pts[r.pos[4]];
-            const bool degenerate = (p1.x == p0.x && p1.y == p0.y && p1.z == p0.z) || (p2.x == p0.x && p2.y == p0.y && p2.z == p0.z);
-            rd.blk_flag0[sb + slot] = degenerate ? BLK_NONE : (BLK_PLANE | BLK_ACTIVE | 8);
-            return;
-        }
-    } else {
-        // sparse surroundings, an exact tie, a query outside the grid or not finite
-        if (FUSED) rd.qw[sb + slot] = pw;
-        knn_one(rd, rc, gc, gs, b, slot, iter);
+        return;
     }
-    build_one(rd, rc, gc, gs, b, slot);
+    for (int k = lblk * KL_THREADS + threadIdx.x; k < n; k += list_blocks * KL_THREADS) {
+        const unsigned int e = (unsigned int)rd.work_search[sb + rd.cap_c + k];
+        const int slot = (int)(e & ~KT_LIST_BUILD_ONLY);
+        if (!(e & KT_LIST_BUILD_ONLY)) knn_one(rd, rc, gc, gs, b, slot, iter);
+        build_one(rd, rc, gc, gs, b, slot);
+    }
 }
 
 void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s)
@@ -286,16 +353,24 @@ void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int 
 #undef LL_QSORT
 }
 
-// max_nc > 0: the corner queries are searched (per lane) and built by the first workgroups of the same launch
+// max_nc > 0: the corner queries are searched (per lane) and built by the first workgroups of the lane kernel's launch.
+// (Measured and withdrawn, HISTORY.md round 6: the corner searches as a launch of their own on a second stream beside the tile search --
+//  one batch at a time 43.3 k -> 44.3 k scans/s, three batches in flight 49.9 k -> 48.0 k: the other batches fill the chip already.)
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
                          bool fused, hipStream_t s)
 {
-    const int cb = (max_nc + KT_THREADS - 1) / KT_THREADS, sbk = (max_ns + KT_THREADS - 1) / KT_THREADS;
-    const dim3 grid((unsigned int)((cb + sbk) * n_scans));
-    if (fused)
-        hipLaunchKernelGGL(reg_knn_tile_kernel<true>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, sbk);
-    else
-        hipLaunchKernelGGL(reg_knn_tile_kernel<false>, grid, dim3(KT_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, sbk);
+    const int sbk = (max_ns + KT_THREADS - 1) / KT_THREADS;
+    const int cb = (max_nc + KL_THREADS - 1) / KL_THREADS;
+    int lb = (max_ns + 1023) / 1024;  // list workgroups per scan: a dozen queries are listed, a scan in the open may list all of them
+    lb = lb < 4 ? 4 : (lb > 32 ? 32 : lb);
+    (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);
+    if (fused) {
+        hipLaunchKernelGGL(reg_knn_tile_kernel<true>, dim3((unsigned int)(sbk * n_scans)), dim3(KT_THREADS), 0, s, rd, rc, gs, iter, sbk);
+        hipLaunchKernelGGL(reg_knn_lane_kernel<true>, dim3((unsigned int)((cb + lb) * n_scans)), dim3(KL_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, lb);
+    } else {
+        hipLaunchKernelGGL(reg_knn_tile_kernel<false>, dim3((unsigned int)(sbk * n_scans)), dim3(KT_THREADS), 0, s, rd, rc, gs, iter, sbk);
+        hipLaunchKernelGGL(reg_knn_lane_kernel<false>, dim3((unsigned int)((cb + lb) * n_scans)), dim3(KL_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, lb);
+    }
 }
 
 }  // namespace ll

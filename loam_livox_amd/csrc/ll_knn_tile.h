@@ -149,11 +149,15 @@ LL_HD float tile_key_lower(unsigned int k)
     return v.f;
 }
 
-// Where a query sits in the grid: the quantities knn5_search_t derives at its start, operation for operation.
+// Where a query sits in the grid: the quantities knn5_search_t derives at its start, operation for operation -- except that a query
+// up to one cell OUTSIDE the grid takes the nearest cell of the grid as its own (the grid is the bounding box of the map's points, so
+// every scan point on an outer wall lies a centimetre outside it half of the time: 1 % of the C2 queries).  Its distance to the walls
+// of that cell is then 0 on the side it sticks out of, so m = 0 (less the slack) and the finishing bound is h: valid -- a point outside the
+// 3 x 3 x 3 block around the adopted cell is at least one cell away along some axis from a query that lies in or beyond that cell.
 struct TileQ {
     int cx, cy, cz;
     float m;      // distance (metres, shrunk by slack) from the query to the nearest wall of its own cell
-    bool ingrid;  // finite, and its cell is a cell of the grid (otherwise the query goes to knn5_search)
+    bool ingrid;  // finite, and its cell (or the cell it adopts) is a cell of the grid (otherwise the query goes to knn5_search)
 };
 
 LL_HD void tile_query(const Grid &g, float qx, float qy, float qz, TileQ &o)
@@ -163,9 +167,11 @@ LL_HD void tile_query(const Grid &g, float qx, float qy, float qz, TileQ &o)
     o.ingrid = false;
     if (!ll_isfinite(qx) || !ll_isfinite(qy) || !ll_isfinite(qz)) return;
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-    if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.nx && fy < (float)g.ny && fz < (float)g.nz)) return;
-    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-    if (cx >= g.nx || cy >= g.ny || cz >= g.nz) return;  // (rounding of the int -> float conversions above)
+    if (!(fx >= -1.0f && fy >= -1.0f && fz >= -1.0f && fx < (float)g.nx + 1.0f && fy < (float)g.ny + 1.0f && fz < (float)g.nz + 1.0f)) return;
+    int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);  // (also the rounding of the int -> float conversions above)
+    cy = cy < 0 ? 0 : (cy >= g.ny ? g.ny - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
     const float slack = g.slack;
     const float xm = fmaxf((fx - (float)cx) * g.h - slack, 0.0f), xp = fmaxf(((float)(cx + 1) - fx) * g.h - slack, 0.0f);
     const float ym = fmaxf((fy - (float)cy) * g.h - slack, 0.0f), yp = fmaxf(((float)(cy + 1) - fy) * g.h - slack, 0.0f);
@@ -174,6 +180,9 @@ LL_HD void tile_query(const Grid &g, float qx, float qy, float qz, TileQ &o)
     o.cy = cy;
     o.cz = cz;
     o.m = fminf(fminf(fminf(xm, xp), fminf(ym, yp)), fminf(zm, zp));
+    // an adopted cell: the query is at least 0 beyond the wall it sticks out of -- less the slack that the in-cell distances above
+    // already carry
+    if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.nx && fy < (float)g.ny && fz < (float)g.nz)) o.m = -slack;
     o.ingrid = true;
 }
 
@@ -210,16 +219,38 @@ LL_HD bool tile5_finish(const Grid &g, const Tile5 &t, const TileQ &tq, float ma
 // All 64 lanes call it together (whole wavefronts, one-dimensional blocks).  q*: the lane's query (any value when !active);
 // tile: this wavefront's LDS staging buffer, LL_TILE_CAP + 4 entries {x, y, z, bits(position)}.  On return `final` says whether r
 // holds the lane's exact result; lanes with active && !final must run knn5_search.
+// degenerate: whether neighbours 0, 2, 4 of a final lane coincide as float points (1 / 0), -1 = not known (a tile of several passes).
 #define LL_TILE_FAR 1.0e18f  // coordinate of a padding entry: its distance is huge and finite or +inf, never NaN
+#ifdef LL_TILE_TIMING  // instrumented builds only (tools/gpu_r6_tile.sh): shader clocks per phase of this wavefront
+#define LL_TT_ARG , long long *tt
+#define LL_TT_PASS , tt
+#define LL_TT(slot, var)                  \
+    do {                                  \
+        const long long now_ = clock64(); \
+        tt[slot] += now_ - var;           \
+        var = now_;                       \
+    } while (0)
+#define LL_TT_ADD(slot, v) tt[slot] += (v)
+#else
+#define LL_TT_ARG
+#define LL_TT_PASS
+#define LL_TT(slot, var)
+#define LL_TT_ADD(slot, v)
+#endif
 __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float qx, float qy, float qz, float max_d2, float4 *tile,
-                                               Knn5 &r, bool &final)
+                                               Knn5 &r, bool &final, int &degenerate LL_TT_ARG)
 {
+    degenerate = -1;
+#ifdef LL_TILE_TIMING
+    long long tw = clock64();
+#endif
     const int lane = threadIdx.x & 63;
     TileQ tq;
     tile_query(g, qx, qy, qz, tq);
     const bool ingrid = active && tq.ingrid;
     final = false;
     unsigned long long todo = __ballot(ingrid);
+    LL_TT(0, tw);  // tile_query
     while (todo != 0ull) {  // (uniform) one round per group of lanes whose cells lie within +-1 of the leader's: 1.05 rounds on C2
         const int leader = (int)__ffsll((long long)todo) - 1;
         const int lx = __builtin_amdgcn_readlane(tq.cx, leader), ly = __builtin_amdgcn_readlane(tq.cy, leader),
@@ -254,6 +285,9 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
         }
         const int T = __builtin_amdgcn_readlane(incl, LL_TILE_MAX_ROWS - 1);  // (rows beyond nrows count 0)
         const int excl = incl - cnt;
+        LL_TT(1, tw);  // round set-up: participants, box, row table
+        LL_TT_ADD(6, T);
+        LL_TT_ADD(7, 1);
         Tile5 t;  // the round's exact result (participants); every lane starts a round empty
         tile5_init(t);
         bool collided = false;
@@ -297,6 +331,7 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            LL_TT(2, tw);  // staging
             TileK tk;
             tilek_init(tk);
             for (int jj = 0; jj < np; jj += 4) {  // (uniform) two pairs per trip: broadcast reads, four independent offers
@@ -313,18 +348,22 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
                     tilek_offer(tk, ((unsigned int)__float_as_int(rr2.y) & keep) | (unsigned int)(jj + u + 1));
                 }
             }
+            LL_TT(3, tw);  // offers
             collided = collided || tilek_collision(tk);
             // the five winners again, exactly (their order is the true one unless `collided`)
             const float lbv = tile_key_lower(tk.k[5]);
+            float wx[5], wy[5], wz[5];  // (k = 0, 2, 4 are used: the points of the query's plane, PCR:416-418)
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 float d = INFINITY;
                 int pos = -1;
+                wx[k] = wy[k] = wz[k] = 0.0f;
                 if (tk.k[k] != LL_TILE_KEY_EMPTY) {
                     const int jw = (int)(tk.k[k] & (LL_TILE_CAP - 1));
                     const float *e = tile_f + (jw >> 1) * 8 + (jw & 1);
                     pos = __float_as_int(e[6]);
-                    d = pos >= 0 ? dist2_xyz(qx, qy, qz, e[0], e[2], e[4]) : INFINITY;
+                    wx[k] = e[0], wy[k] = e[2], wz[k] = e[4];
+                    d = pos >= 0 ? dist2_xyz(qx, qy, qz, wx[k], wy[k], wz[k]) : INFINITY;
                 }
                 if (c0 == 0) {  // (uniform) the first pass fills the list, later ones (tiles of > LL_TILE_CAP points) merge into it
                     t.d[k] = d;
@@ -334,8 +373,12 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
                 }
             }
             t.lb = fminf(t.lb, lbv);
+            // a one-pass tile: the list is these five, in this order (final lanes only: no collision, five real points)
+            if (part && T <= LL_TILE_CAP)
+                degenerate = ((wx[2] == wx[0] && wy[2] == wy[0] && wz[2] == wz[0]) || (wx[4] == wx[0] && wy[4] == wy[0] && wz[4] == wz[0])) ? 1 : 0;
         }
         if (part) final = !collided && tile5_finish(g, t, tq, max_d2, r);
+        LL_TT(4, tw);  // winners again + finish test
     }
 }
 #endif  // __HIPCC__

@@ -141,6 +141,37 @@ def test_tile_search_sparse_dense_ties_and_outside(cell, max_d2, npts):
         assert stats[2] < 0.5 * len(q)  # a dense cloud: the tiles settle most lanes
 
 
+def test_tile_search_settles_queries_just_outside_the_grid():
+    """The grid is the bounding box of the map's points, so scan points on an outer wall fall outside it half of the time (1 % of the
+    C2 queries).  tile_query adopts the nearest cell for a query up to one cell outside: same lists as knn5_search, and the tile
+    settles them -- only queries farther out (or with their fifth neighbour beyond one cell) take the per-lane search."""
+    rng = np.random.default_rng(77)
+    n = 60000
+    wall = np.c_[rng.normal(0.0, 0.01, n), rng.uniform(0, 20, n), rng.uniform(0, 6, n)].astype(np.float32)      # the outer wall x = 0
+    floor = np.c_[rng.uniform(0, 20, n), rng.uniform(0, 20, n), rng.normal(0.0, 0.01, n)].astype(np.float32)   # and the floor z = 0
+    pts = np.concatenate([wall, floor])
+    g = hc.Grid(pts, 0.6)
+    lo = pts.min(axis=0)
+    nq = 4096
+    q = np.c_[lo[0] - rng.uniform(0.0, 0.05, nq), rng.uniform(1, 19, nq), rng.uniform(1, 5, nq)].astype(np.float32)     # outside in -x
+    q2 = np.c_[rng.uniform(1, 19, nq), rng.uniform(1, 19, nq), lo[2] - rng.uniform(0.0, 0.5, nq)].astype(np.float32)    # outside in -z, up to a cell
+    q3 = np.c_[lo[0] - rng.uniform(0.61, 3.0, 256), rng.uniform(1, 19, 256), rng.uniform(1, 5, 256)].astype(np.float32)  # more than a cell out
+    for qq, settled in ((q, True), (q2, None), (q3, False)):
+        qq = qq[_cell_order(qq, 0.6, lo)]
+        hi, hd = g.knn5(qq, 50.0)
+        ti, td, lb2, stats = g.knn5_tile(qq, 50.0)
+        assert np.array_equal(hi, ti) and np.array_equal(hd, td)
+        assert (ti[:, 4] >= 0).all()
+        if settled is True:
+            assert stats[2] < 0.02 * len(qq), stats
+        if settled is False:
+            assert stats[2] == len(qq), stats
+        P = pts.astype(np.float64)
+        for i in range(0, len(qq), 97):  # lb2 stays a valid bound on everything outside the list
+            d2_all = ((qq[i].astype(np.float64) - P) ** 2).sum(-1)
+            assert lb2[i] <= np.delete(d2_all, ti[i]).min() * (1 + 1e-5) + 1e-6
+
+
 def test_tile_offer_network_equals_ordered_insertion():
     """tile5_offer against a sort: random streams with repeated values"""
     rng = np.random.default_rng(5)
