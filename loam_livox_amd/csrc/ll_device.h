@@ -179,6 +179,8 @@ struct RegDev {
     int n_chunks;                 // chunks of 256 queries (RQ_THREADS) per (scan, kind): the re-query kernel's grid
     int4 *nn;                     // [B][cap]  neighbour positions (cell-sorted order) + found flag (K6a -> K6b)
     unsigned short *qperm;        // [B][cap_s] surface queries of a scan ordered by the map cell they fall into at ICP iteration 0 (reg_qsort_kernel)
+    float4 *qsorted;              // [B][cap_s] the surface FEATURES (sensor frame) in that order, written with qperm when the tile kernel transforms
+                                  // the queries itself (no motion deblur): its loads are then coalesced and independent of each other
     unsigned char *blk_flag;      // [B][cap]  BLK_* bits
     double *blk_l1;               // [B][cap]  scratch for the inlier threshold
     unsigned long long *hash;     // [B][hash_cap] dedup table for the std::set semantics of PCR:155-160

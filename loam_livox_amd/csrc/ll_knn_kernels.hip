@@ -153,6 +153,7 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
         val[u] = (unsigned short)i;
     }
     unsigned short *perm = rd.qperm + (size_t)b * rd.cap_s + q0;
+    float4 *qs = rd.qsorted + (size_t)b * rd.cap_s + q0;  // the features in the same order (FUSED: the tile kernel reads them instead of gathering)
     if (kmax + 2u <= (unsigned int)QS_BINS) {
         // ---- counting sort (uniform branch: the scan's cell box has at most QS_BINS cells -- every C2 scan): one LDS histogram over
         //      the box, the atomic's return value is the query's rank inside its cell, one scan over the bins, one scatter.  The
@@ -181,7 +182,11 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 #pragma unroll
         for (int u = 0; u < ITEMS; u++) {
             const int i = u * QS_THREADS + tid;
-            if (i < nS) perm[s_hist[key[u]] + (int)val[u]] = (unsigned short)i;
+            if (i < nS) {
+                const int dst = s_hist[key[u]] + (int)val[u];
+                perm[dst] = (unsigned short)i;
+                if (FUSED) qs[dst] = load_feature(rd, b, 1, q0 + i);
+            }
         }
         return;
     }
@@ -191,12 +196,15 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const int pos = tid * ITEMS + u;  // (blocked arrangement after the sort)
-        if (pos < nS) perm[pos] = val[u];
+        if (pos < nS) {
+            perm[pos] = val[u];
+            if (FUSED) qs[pos] = load_feature(rd, b, 1, q0 + (int)val[u]);
+        }
     }
 }
 
 #define KT_THREADS 256
-// One-dimensional grid, surf_blocks workgroups per scan.  The kernel holds the tile search and nothing else (84 VGPRs: five wavefronts per
+// One-dimensional grid, surf_blocks workgroups per scan.  The kernel holds the tile search and nothing else (80 VGPRs: six wavefronts per
 // SIMD): what a lane cannot finish here -- the ring search of a query the tile does not settle (sparse surroundings, an exact tie, more
 // than a cell outside the grid: a dozen per scan), or the fp64 block constants of a scan without a plane table -- goes onto the scan's work list
 // (rd.work_search, surface segment; rd.work_cnt[4 b + 2], zeroed by the launcher) and reg_knn_lane_kernel, the next launch, takes it
@@ -205,19 +213,26 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 // nearest cell for them).
 #define KT_LIST_BUILD_ONLY 0x80000000u  // list entry: slot | this bit when the neighbours are stored and only build_one is left
 template <bool FUSED>
-__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ __launch_bounds__(KT_THREADS) __attribute__((amdgpu_waves_per_eu(FUSED ? 6 : 5, 8)))  // (the gather of rd.qw costs the sixth)
 void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gs, int iter, int surf_blocks)
 {
     __shared__ float4 s_tile[KT_THREADS / 64][LL_TILE_CAP + 4];
     const int bid = blockIdx.x;
     const int b = bid / surf_blocks, sblk = bid - b * surf_blocks;
     const RegState *st = rd.state + b;
-    if (st->done) return;
-    const size_t sb = (size_t)b * rd.cap;
-    const int nS = rd.n_surf[b];
     const int i = sblk * KT_THREADS + threadIdx.x;  // position in the scan's cell order
-    if ((i & ~63) >= nS) return;                                                  // (whole wavefronts)
+    // The order entry and the sorted feature are read side by side (round 5: order -> feature gather, two dependent round trips), with a
+    // clamped index ahead of the bounds test (the arrays hold cap_s entries per scan).  (Hoisting the pose and the done / count words
+    // into the same batch with explicit scalar loads was measured: no change at six wavefronts per SIMD.)
+    const int done = st->done, nS = rd.n_surf[b], nC = rd.n_corner[b];
+    const int ic = i < rd.cap_s ? i : rd.cap_s - 1;
+    const int pq = (int)rd.qperm[(size_t)b * rd.cap_s + ic];
+    float4 feat = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FUSED) feat = rd.qsorted[(size_t)b * rd.cap_s + ic];
+    if (done || (i & ~63) >= nS) return;  // (whole wavefronts)
+    const size_t sb = (size_t)b * rd.cap;
     const bool valid = i < nS;
+    const bool compact = !rc.force_general && (nS + RS_THREADS - 1) / RS_THREADS * RS_THREADS + nC <= LL_TABLE_MAX_BLOCKS;  // scan_is_compact
 #ifdef LL_TILE_TIMING
     // instrumented build: wall clocks of this wavefront per phase, added to the scan's RegState::dbg_cycles by lane 0 --
     // 0 tile_query, 1 round set-up, 2 staging, 3 offers, 4 winners + finish test, 5 query position (order + transform), 6 sum of tile
@@ -229,9 +244,18 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gs, int iter, int surf_blo
 #endif
     // segment base + index in the segment; the segment is the same for the whole wavefront (LL_KNN_TILE_SEG is a multiple of 64): scalar
     const int seg_base = (__builtin_amdgcn_readfirstlane(i) / LL_KNN_TILE_SEG) * LL_KNN_TILE_SEG;
-    const int q = valid ? seg_base + (int)rd.qperm[(size_t)b * rd.cap_s + i] : 0;
+    const int q = valid ? seg_base + pq : 0;
     const int slot = rd.cap_c + q;
-    const float4 pw = tile_query_pos<FUSED>(rd, rc, st, b, q, nS);
+    float4 pw;
+    if (FUSED) {
+        // transform_plain + the a13 rule of tile_query_pos, from the values read above
+        float o[3];
+        transform_plain(st, feat, o);
+        if (subsample_skip_feature(rc.subsample_seed, 1, st->icp_iters, q, nS, rc.max_blocks)) o[0] = o[1] = o[2] = NAN;
+        pw = make_float4(o[0], o[1], o[2], 0.f);
+    } else {
+        pw = rd.qw[sb + rd.cap_c + q];
+    }
     const float max_d2 = rc.max_d2_plane;
     Knn5 r;
     bool fin;
@@ -249,7 +273,7 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gs, int iter, int surf_blo
         }
         knn_finish(rd, rc, sb, slot, 1, iter, pw, max_d2, r);
         LL_TT(8, tw);
-        if (!rc.check_plane_pca && rc.icp_plane && scan_is_compact(rd, rc, b)) {
+        if (!rc.check_plane_pca && rc.icp_plane && compact) {
             // plane-table path (build_one's early return): only the block's flag is decided here, from the three neighbours the lane
             // has just seen in LDS -- no second look at rd.nn or the map
             // (plane_degenerate: |b - a| == 0 or |c - a| == 0 in double  <=>  the float points coincide)
