@@ -207,7 +207,7 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
 // One-dimensional grid, surf_blocks workgroups per scan.  The kernel holds the tile search and nothing else (80 VGPRs: six wavefronts per
 // SIMD): what a lane cannot finish here -- the ring search of a query the tile does not settle (sparse surroundings, an exact tie, more
 // than a cell outside the grid: a dozen per scan), or the fp64 block constants of a scan without a plane table -- goes onto the scan's work list
-// (rd.work_search, surface segment; rd.work_cnt[4 b + 2], zeroed by the launcher) and reg_knn_lane_kernel, the next launch, takes it
+// (rd.work_search, surface segment; rd.work_cnt[4 b + 2 + (iter & 1)]) and reg_knn_lane_kernel, the next launch, takes it
 // (round 5 ran those lanes in here: 117 VGPRs, four wavefronts per SIMD, and 3 % of the wavefronts executed a ring search for a third
 // of their lanes -- nearly all of them queries on the map's outer walls, a centimetre outside the grid: tile_query now adopts the
 // nearest cell for them).
@@ -292,7 +292,7 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gs, int iter, int surf_blo
     if (lm) {  // (uniform) one atomic per wavefront reserves its entries
         const int lane = threadIdx.x & 63;
         int base = 0;
-        if (lane == 0) base = atomicAdd(&rd.work_cnt[4 * b + 2], (int)__popcll(lm));
+        if (lane == 0) base = atomicAdd(&rd.work_cnt[4 * b + 2 + (iter & 1)], (int)__popcll(lm));
         base = __builtin_amdgcn_readfirstlane(base);
         if (listed)
             rd.work_search[sb + rd.cap_c + base + (int)__popcll(lm & ((1ull << lane) - 1ull))] = (int)((unsigned int)slot | (fin ? KT_LIST_BUILD_ONLY : 0u));
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(KL_THREADS) void reg_knn_lane_kernel(RegDev rd, Reg
     const int b = (bid - n_corner_wg) % n_scans, lblk = (bid - n_corner_wg) / n_scans;
     if (rd.state[b].done) return;
     const size_t sb = (size_t)b * rd.cap;
-    const int n = rd.work_cnt[4 * b + 2];
+    const int n = rd.work_cnt[4 * b + 2 + (iter & 1)];
+    if (lblk == 0 && threadIdx.x == 0) rd.work_cnt[4 * b + 2 + ((iter & 1) ^ 1)] = 0;  // the other counter, for the next ICP iteration's tile kernel
     if (n <= KL_COOP_PER * list_blocks) {
         // a short list (the usual case: a dozen queries with their neighbours metres away, each a chain of a hundred dependent loads for
         // one lane): one wavefront per entry (ll_knn_coop.h), lane 0 stores and builds
@@ -387,7 +388,9 @@ void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, c
     const int cb = (max_nc + KL_THREADS - 1) / KL_THREADS;
     int lb = (max_ns + 1023) / 1024;  // list workgroups per scan: a dozen queries are listed, a scan in the open may list all of them
     lb = lb < 4 ? 4 : (lb > 32 ? 32 : lb);
-    (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);
+    // the list counters alternate between two words per scan (ICP iteration parity): the lane kernel clears the one the next iteration
+    // appends to, so only a registration's first search needs a memset (ten fill launches per registration were 1 % of a step)
+    if (iter == 0) (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);
     if (fused) {
         hipLaunchKernelGGL(reg_knn_tile_kernel<true>, dim3((unsigned int)(sbk * n_scans)), dim3(KT_THREADS), 0, s, rd, rc, gs, iter, sbk);
         hipLaunchKernelGGL(reg_knn_lane_kernel<true>, dim3((unsigned int)((cb + lb) * n_scans)), dim3(KL_THREADS), 0, s, rd, rc, gc, gs, iter, n_scans, cb, lb);
