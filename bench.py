@@ -693,6 +693,7 @@ def main():
         result["solver_phase_cycles_mean_over_scans"] = [int(v) for v in allc.mean(0)]
         result["solver_phase_cycles_of_the_slowest_scan"] = [int(v) for v in allc[int(np.argmax(allc[:, 5]))]]
         qs = [0, 10, 25, 50, 75, 90, 99, 100]
+        result["phase_cycles_slot14_quantiles_over_scans"] = [int(v) for v in np.percentile(allc[:, 14], qs)]  # (-DLL_TILE_TIMING: listed lanes per registration)
         result["solver_cycles_per_registration_quantiles"] = {"q": qs, "total": [int(v) for v in np.percentile(tot, qs)], "mean_total": int(tot.mean()),
                                                               "lm_controller": [int(v) for v in np.percentile(ctl, qs)], "mean_lm_controller": int(ctl.mean())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg belongs to the N = 1 line only

@@ -805,6 +805,7 @@ static int reg_create_impl(int32_t device, int32_t max_scans, int32_t max_featur
     DM(d.nn, B * d.cap);
     DM(d.qperm, B * d.cap_s);
     DM(d.qsorted, B * d.cap_s);
+    DM(d.qperm_c, B * LL_QSORT_CORNER_MAX);
     DM(d.qw, B * d.cap);
     DM(d.ref_q, B * d.cap);
     DM(d.ref_p, B * d.cap);
@@ -854,7 +855,7 @@ extern "C" void ll_reg_destroy(ll_reg *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     RegDev &d = r->dev;
-    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qsorted, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.solve_order, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
+    void *ptrs[] = {d.state, d.blk_f, d.blk_av, d.blk_id, d.pl_tab, d.blk_flag, d.nn, d.qperm, d.qsorted, d.qperm_c, d.qw, d.ref_q, d.ref_p, d.ref_s, d.blk_flag0, d.work_search, d.work_build, d.work_cnt, d.work_off, d.grp_ctl, d.solve_order, d.grp_part, d.grp_xch, d.blk_l1, d.hash, d.dbg_idx, d.dbg_d2,
                     r->d_corner, r->d_surf, r->d_nc, r->d_ns, r->d_pose_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

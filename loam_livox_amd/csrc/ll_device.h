@@ -179,6 +179,8 @@ struct RegDev {
     int n_chunks;                 // chunks of 256 queries (RQ_THREADS) per (scan, kind): the re-query kernel's grid
     int4 *nn;                     // [B][cap]  neighbour positions (cell-sorted order) + found flag (K6a -> K6b)
     unsigned short *qperm;        // [B][cap_s] surface queries of a scan ordered by the map cell they fall into at ICP iteration 0 (reg_qsort_kernel)
+    unsigned short *qperm_c;      // [B][LL_QSORT_CORNER_MAX] a scan's corner queries in the order of the corner map's cells (scans with more corner
+                                  // queries than that keep the feature order)
     float4 *qsorted;              // [B][cap_s] the surface FEATURES (sensor frame) in that order, written with qperm when the tile kernel transforms
                                   // the queries itself (no motion deblur): its loads are then coalesced and independent of each other
     unsigned char *blk_flag;      // [B][cap]  BLK_* bits
@@ -192,7 +194,8 @@ struct RegDev {
 
 void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter,
                           int max_nc, int max_ns, hipStream_t s);
-void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s);
+#define LL_QSORT_CORNER_MAX 2048
+void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int max_nc, int max_ns, bool fused, hipStream_t s);
 void launch_debug_quintic(const double *args, int n, double *out_seq, double *out_wave, hipStream_t s);
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
                          bool fused, hipStream_t s);

@@ -203,6 +203,56 @@ __global__ __launch_bounds__(QS_THREADS) void reg_qsort_kernel(RegDev rd, RegCon
     }
 }
 
+// The corner queries of a scan (a few hundred) in the order of the corner map's cells, so that the 64 queries of a wavefront of the lane
+// kernel share one or two tiles instead of a dozen (in feature order a wavefront's queries lie all over the room: ten to twenty rounds of
+// ~100 candidates each, no faster than a ring search per lane).  One workgroup per scan, block radix sort over the bits of the grid's
+// cell count; scans with more than LL_QSORT_CORNER_MAX corner queries keep the feature order (the lane kernel does not read the
+// order then).  Same iterations as the surface sort.
+#define QC_THREADS 256
+#define QC_ITEMS (LL_QSORT_CORNER_MAX / QC_THREADS)
+template <bool FUSED>
+__global__ __launch_bounds__(QC_THREADS) void reg_qsort_corner_kernel(RegDev rd, RegConst rc, Grid gc)
+{
+    typedef hipcub::BlockRadixSort<unsigned int, QC_THREADS, QC_ITEMS, unsigned short> Sort;
+    __shared__ typename Sort::TempStorage sort;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const RegState *st = rd.state + b;
+    const int nC = rd.n_corner[b];
+    if (st->done || nC > LL_QSORT_CORNER_MAX) return;
+    const size_t sb = (size_t)b * rd.cap;
+    const long long ncell = (long long)gc.nx * gc.ny * gc.nz;
+    unsigned int key[QC_ITEMS];
+    unsigned short val[QC_ITEMS];
+#pragma unroll
+    for (int u = 0; u < QC_ITEMS; u++) {
+        const int i = tid * QC_ITEMS + u;  // (blocked arrangement)
+        unsigned int k = 0xffffffffu;      // padding: behind everything
+        if (i < nC) {
+            float4 p;
+            if (FUSED) {
+                float o[3];
+                transform_plain(st, load_feature(rd, b, 0, i), o);
+                p = make_float4(o[0], o[1], o[2], 0.f);
+            } else {
+                p = rd.qw[sb + i];
+            }
+            TileQ tq;
+            tile_query(gc, p.x, p.y, p.z, tq);
+            // (a grid of more than 2^31 cells degrades to one key: correct, just not grouped)
+            k = !tq.ingrid ? 0xfffffffeu : (ncell > 0x7fffffffll ? 0u : (unsigned int)((tq.cz * gc.ny + tq.cy) * gc.nx + tq.cx));
+        }
+        key[u] = k;
+        val[u] = (unsigned short)i;
+    }
+    Sort(sort).Sort(key, val);
+    unsigned short *perm = rd.qperm_c + (size_t)b * LL_QSORT_CORNER_MAX;
+#pragma unroll
+    for (int u = 0; u < QC_ITEMS; u++) {
+        const int pos = tid * QC_ITEMS + u;
+        if (pos < nC) perm[pos] = val[u];
+    }
+}
+
 #define KT_THREADS 256
 // One-dimensional grid, surf_blocks workgroups per scan.  The kernel holds the tile search and nothing else (80 VGPRs: six wavefronts per
 // SIMD): what a lane cannot finish here -- the ring search of a query the tile does not settle (sparse surroundings, an exact tie, more
@@ -303,36 +353,89 @@ void reg_knn_tile_kernel(RegDev rd, RegConst rc, Grid gs, int iter, int surf_blo
     tt[14] = __popcll(lm);
     tt[11] = clock64() - t_begin;
     tt[12] = 1;
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0 && LL_TILE_TIMING != 2)
         for (int k_ = 0; k_ < 16; k_++) atomicAdd((unsigned long long *)&rd.state[b].dbg_cycles[k_], (unsigned long long)tt[k_]);
 #endif
 }
 
-// The queries the tile kernel leaves behind, one per lane: a scan's corner queries (a few hundred ring searches on the sparse corner map,
-// ~100 dependent loads each; corner_blocks workgroups per scan, dispatched first) and the entries of its work list (list_blocks
-// workgroups per scan, striding over the list).  Search (knn_one) where it is still due, then the block constants (build_one).
+// What the tile kernel does not do.  First corner_blocks workgroups per scan (scan fastest): the scan's CORNER queries, 64 per wavefront in
+// the order of the corner map's cells, through the same tile search on the corner map: the line radius (1.41 m) lies inside one cell of that map (1.45 m), so
+// the 3 x 3 x 3 tile settles every query whose list has no tie -- with five neighbours or with fewer (tile5_finish) --, a handful of rounds
+// per wavefront instead of a ring search per lane (round 5 and the first half of round 6: ~100 dependent loads per lane, 78 us per
+// launch whatever the batch); then their line constants (build_one).  Then list_blocks workgroups per scan for the surface list the tile
+// kernel wrote: the search where it is still due, then the block constants.  A short list -- a dozen queries with their neighbours
+// metres away -- is taken one wavefront per entry (ll_knn_coop.h); a long one (a scan without a plane table lists everything) one lane
+// per entry.  (The corner queries in the tile kernel itself, as its first workgroups: 43 spilled VGPRs at its 80-register budget.)
 #define KL_THREADS 64
 #define KL_COOP_PER 4  // lists of up to this many entries per list workgroup are searched one wavefront per entry
 template <bool FUSED>
 __global__ __launch_bounds__(KL_THREADS) void reg_knn_lane_kernel(RegDev rd, RegConst rc, Grid gc, Grid gs, int iter, int n_scans, int corner_blocks,
                                                                   int list_blocks)
 {
+    __shared__ float4 s_tile[LL_TILE_CAP + 4];
     const int bid = blockIdx.x, n_corner_wg = corner_blocks * n_scans;
     if (bid < n_corner_wg) {
         const int b = bid % n_scans, cblk = bid / n_scans;
         const RegState *st = rd.state + b;
-        if (st->done) return;
+        const int i = cblk * KL_THREADS + threadIdx.x, nC = rd.n_corner[b];
+        if (st->done || cblk * KL_THREADS >= nC) return;  // (whole wavefronts)
         const size_t sb = (size_t)b * rd.cap;
-        const int q = cblk * KL_THREADS + threadIdx.x, nC = rd.n_corner[b];
-        if (q >= nC) return;
+        const bool valid = i < nC;
+        const int slot = !valid ? 0 : (nC > LL_QSORT_CORNER_MAX ? i : (int)rd.qperm_c[(size_t)b * LL_QSORT_CORNER_MAX + i]);  // cell order (reg_qsort_corner_kernel)
+        float4 pw;
         if (FUSED) {
-            float pw[3];
-            transform_plain(st, load_feature(rd, b, 0, q), pw);
-            if (subsample_skip_feature(rc.subsample_seed, 0, st->icp_iters, q, nC, rc.max_blocks)) pw[0] = pw[1] = pw[2] = NAN;
-            rd.qw[sb + q] = make_float4(pw[0], pw[1], pw[2], 0.f);
+            float o[3];
+            transform_plain(st, load_feature(rd, b, 0, slot), o);
+            if (subsample_skip_feature(rc.subsample_seed, 0, st->icp_iters, slot, nC, rc.max_blocks)) o[0] = o[1] = o[2] = NAN;
+            pw = make_float4(o[0], o[1], o[2], 0.f);
+        } else {
+            pw = rd.qw[sb + slot];
         }
-        knn_one(rd, rc, gc, gs, b, q, iter);
-        build_one(rd, rc, gc, gs, b, q);
+        const float max_d2 = rc.max_d2_line;
+        Knn5 r;
+        bool fin;
+        int degenerate;
+#ifdef LL_TILE_TIMING
+        long long tt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (-DLL_TILE_TIMING=2: the corner wavefronts are clocked instead of the surface ones)
+        const long long t_begin = clock64();
+#endif
+        knn5_tile_wave<true>(gc, valid, pw.x, pw.y, pw.z, max_d2, s_tile, r, fin, degenerate LL_TT_PASS);
+#if defined(LL_TILE_TIMING) && LL_TILE_TIMING == 2
+        {
+            const long long t_tile = clock64();
+            const unsigned long long fb = __ballot(valid && !fin);
+            if (valid) {
+                if (fin) knn_finish(rd, rc, sb, slot, 0, iter, pw, max_d2, r);
+                else { if (FUSED) rd.qw[sb + slot] = pw; knn_one(rd, rc, gc, gs, b, slot, iter); }
+            }
+            const long long t_search = clock64();
+            if (valid) build_one(rd, rc, gc, gs, b, slot);
+            const long long t_end = clock64();
+            tt[5] = t_tile - t_begin;  // transform + tile wave
+            tt[8] = t_search - t_tile; // store / per-lane fall-back
+            tt[10] = t_end - t_search; // build_one
+            tt[11] = t_end - t_begin;
+            tt[12] = 1;
+            tt[13] = fb ? 1 : 0;
+            tt[14] = __popcll(fb);
+            if ((threadIdx.x & 63) == 0)
+                for (int k_ = 0; k_ < 16; k_++) atomicAdd((unsigned long long *)&rd.state[b].dbg_cycles[k_], (unsigned long long)tt[k_]);
+            return;
+        }
+#endif
+        if (!valid) return;
+        if (fin) {
+            if (rc.debug_knn && iter == rc.debug_knn_iter) {
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    if (k < r.count) r.idx[k] = as_int(gc.pts[r.pos[k]].w);
+            }
+            knn_finish(rd, rc, sb, slot, 0, iter, pw, max_d2, r);
+        } else {  // a tie, a query more than a cell outside the grid, not finite
+            if (FUSED) rd.qw[sb + slot] = pw;
+            knn_one(rd, rc, gc, gs, b, slot, iter);
+        }
+        build_one(rd, rc, gc, gs, b, slot);
         return;
     }
     const int b = (bid - n_corner_wg) % n_scans, lblk = (bid - n_corner_wg) / n_scans;
@@ -341,8 +444,6 @@ __global__ __launch_bounds__(KL_THREADS) void reg_knn_lane_kernel(RegDev rd, Reg
     const int n = rd.work_cnt[4 * b + 2 + (iter & 1)];
     if (lblk == 0 && threadIdx.x == 0) rd.work_cnt[4 * b + 2 + ((iter & 1) ^ 1)] = 0;  // the other counter, for the next ICP iteration's tile kernel
     if (n <= KL_COOP_PER * list_blocks) {
-        // a short list (the usual case: a dozen queries with their neighbours metres away, each a chain of a hundred dependent loads for
-        // one lane): one wavefront per entry (ll_knn_coop.h), lane 0 stores and builds
         for (int k = lblk; k < n; k += list_blocks) {
             const unsigned int e = (unsigned int)rd.work_search[sb + rd.cap_c + k];
             const int slot = (int)(e & ~KT_LIST_BUILD_ONLY);
@@ -359,8 +460,15 @@ __global__ __launch_bounds__(KL_THREADS) void reg_knn_lane_kernel(RegDev rd, Reg
     }
 }
 
-void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int n_scans, int max_ns, bool fused, hipStream_t s)
+// max_nc > 0: the corner queries are ordered too (they take the tile search of the lane kernel)
+void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int max_nc, int max_ns, bool fused, hipStream_t s)
 {
+    if (max_nc > 0) {
+        if (fused)
+            hipLaunchKernelGGL(reg_qsort_corner_kernel<true>, dim3(n_scans), dim3(QC_THREADS), 0, s, rd, rc, gc);
+        else
+            hipLaunchKernelGGL(reg_qsort_corner_kernel<false>, dim3(n_scans), dim3(QC_THREADS), 0, s, rd, rc, gc);
+    }
     const int nseg = (max_ns + LL_KNN_TILE_SEG - 1) / LL_KNN_TILE_SEG;
 #define LL_QSORT(ITEMS)                                                                                                        \
     do {                                                                                                                       \
@@ -378,7 +486,7 @@ void launch_reg_qsort(const RegDev &rd, const RegConst &rc, const Grid &gs, int 
 #undef LL_QSORT
 }
 
-// max_nc > 0: the corner queries are searched (per lane) and built by the first workgroups of the lane kernel's launch.
+// max_nc > 0: the corner queries are searched (tiles on the corner map) and built by the first workgroups of the lane kernel's launch.
 // (Measured and withdrawn, HISTORY.md round 6: the corner searches as a launch of their own on a second stream beside the tile search --
 //  one batch at a time 43.3 k -> 44.3 k scans/s, three batches in flight 49.9 k -> 48.0 k: the other batches fill the chip already.)
 void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, const Grid &gs, int n_scans, int iter, int max_nc, int max_ns,
@@ -386,8 +494,11 @@ void launch_reg_knn_tile(const RegDev &rd, const RegConst &rc, const Grid &gc, c
 {
     const int sbk = (max_ns + KT_THREADS - 1) / KT_THREADS;
     const int cb = (max_nc + KL_THREADS - 1) / KL_THREADS;
-    int lb = (max_ns + 1023) / 1024;  // list workgroups per scan: a dozen queries are listed, a scan in the open may list all of them
-    lb = lb < 4 ? 4 : (lb > 32 ? 32 : lb);
+    // list workgroups per scan: a dozen queries are listed in the median scan, a hundred in the worst of a C2 batch (one wavefront per entry
+    // up to KL_COOP_PER entries per workgroup: a list of 115 at 17 workgroups fell to the per-lane path, one 60 us chain per lane), a scan
+    // in the open may list all of its queries
+    int lb = (max_ns + 255) / 256;
+    lb = lb < 8 ? 8 : (lb > 64 ? 64 : lb);
     // the list counters alternate between two words per scan (ICP iteration parity): the lane kernel clears the one the next iteration
     // appends to, so only a registration's first search needs a memset (ten fill launches per registration were 1 % of a step)
     if (iter == 0) (void)hipMemsetAsync(rd.work_cnt, 0, (size_t)n_scans * 4 * sizeof(int), s);

@@ -129,12 +129,16 @@ LL_HD void tilek_offer(TileK &t, unsigned int c)
     t.k[5] = n5;
 }
 
-// two of the six smallest keys share all their distance bits: the truncated order may not be the true one (or it is a true tie)
-LL_HD bool tilek_collision(const TileK &t)
+// two of the six smallest keys share all their distance bits: the truncated order may not be the true one (or it is a true tie).
+// Pairs that lie wholly beyond the match radius do not count (their order never reaches a result; the padding entries of a tile with
+// fewer than six points are such pairs).
+LL_HD bool tilek_collision(const TileK &t, float max_d2)
 {
     const int s = LL_TILE_IDX_BITS;
-    return (t.k[0] >> s) == (t.k[1] >> s) || (t.k[1] >> s) == (t.k[2] >> s) || (t.k[2] >> s) == (t.k[3] >> s) ||
-           (t.k[3] >> s) == (t.k[4] >> s) || (t.k[4] >> s) == (t.k[5] >> s);
+    const unsigned int lim = ((unsigned int)as_int(max_d2) >> s) + 1u;  // truncated distances from here on are > max_d2
+    bool c = false;
+    for (int i = 0; i < 5; i++) c = c || ((t.k[i] >> s) == (t.k[i + 1] >> s) && (t.k[i] >> s) < lim);
+    return c;
 }
 
 // a lower bound on the squared distance behind a key (truncation rounds towards zero); +inf for "nothing"
@@ -189,14 +193,41 @@ LL_HD void tile_query(const Grid &g, float qx, float qy, float qz, TileQ &o)
 // The lane has been offered every point of a tile that contains the 3 x 3 x 3 block of cells around its own cell (clipped to
 // the grid).  Returns true and fills r (the list and bounds knn5_search would be allowed to return) when that settles the
 // answer: five neighbours inside the match radius, the fifth closer than anything outside the block can be (the k = 1 test of
-// knn5_search_t: bound = h + m), no tie.  Otherwise false: search again with knn5_search.  r.idx is not filled (callers that
-// need original indices read pts[pos].w).
+// knn5_search_t: bound = h + m), no tie -- or fewer than five inside a radius that the block covers.  Otherwise false: search again
+// with knn5_search.  r.idx is 0 for the entries of the list (callers that need original indices read pts[pos].w), LL_KNN_EMPTY beyond.
+// SHORT_LISTS false: the "fewer than five" case is always left to knn5_search (the surface search of the tile kernel: its radius is 7 m,
+// and the code it does not carry keeps the kernel inside 80 registers).
+template <bool SHORT_LISTS = true>
 LL_HD bool tile5_finish(const Grid &g, const Tile5 &t, const TileQ &tq, float max_d2, Knn5 &r)
 {
-    if (!(t.d[4] < max_d2)) return false;  // fewer than five inside the radius: only the rings can tell (7 m at the plane radius)
-    if (tile5_has_tie(t)) return false;
     const float bound = g.h + tq.m;
     const float b2 = bound * bound;
+    if (!(t.d[4] < max_d2)) {
+        if (!SHORT_LISTS) return false;
+        // Fewer than five inside the radius.  When the radius reaches beyond the block only the rings can tell (7 m at the plane radius);
+        // when the block covers it (the line radius, 1.41 m, on the corner map's 1.45 m cells) nothing else can turn up: the answer is the
+        // points found so far -- "no five neighbours" for the caller (PCR:249-254) -- with the list and bounds knn5_search leaves behind.
+        if (!(max_d2 <= b2)) return false;
+        knn5_init(r);
+        int n = 0;
+        for (int i = 0; i < 4; i++) {
+            if (t.d[i] < max_d2) {
+                if (t.d[i] == t.d[i + 1]) return false;  // an exact tie inside the radius: the index rule orders it
+                r.d2[i] = t.d[i];
+                r.pos[i] = t.p[i];
+                r.idx[i] = 0;
+                n = i + 1;
+            }
+        }
+        float first_out = t.d[4];  // the nearest point at or beyond the radius that was seen (static indices: registers on the device)
+        for (int i = 3; i >= 0; i--)
+            if (!(t.d[i] < max_d2)) first_out = t.d[i];
+        r.count = n;
+        r.lb2 = fminf(b2, max_d2);         // (everything outside the list is at or beyond the radius)
+        r.out2 = fminf(first_out, b2);     // ... or the block's edge
+        return true;
+    }
+    if (tile5_has_tie(t)) return false;
     // (when the block covers the whole grid every point has been offered and the test below is only conservative)
     if (!(t.d[4] < b2)) return false;
     for (int i = 0; i < 5; i++) {
@@ -237,6 +268,7 @@ LL_HD bool tile5_finish(const Grid &g, const Tile5 &t, const TileQ &tq, float ma
 #define LL_TT(slot, var)
 #define LL_TT_ADD(slot, v)
 #endif
+template <bool SHORT_LISTS = false>
 __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float qx, float qy, float qz, float max_d2, float4 *tile,
                                                Knn5 &r, bool &final, int &degenerate LL_TT_ARG)
 {
@@ -349,7 +381,7 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
                 }
             }
             LL_TT(3, tw);  // offers
-            collided = collided || tilek_collision(tk);
+            collided = collided || tilek_collision(tk, max_d2);
             // the five winners again, exactly (their order is the true one unless `collided`)
             const float lbv = tile_key_lower(tk.k[5]);
             float wx[5], wy[5], wz[5];  // (k = 0, 2, 4 are used: the points of the query's plane, PCR:416-418)
@@ -377,7 +409,7 @@ __device__ __forceinline__ void knn5_tile_wave(const Grid &g, bool active, float
             if (part && T <= LL_TILE_CAP)
                 degenerate = ((wx[2] == wx[0] && wy[2] == wy[0] && wz[2] == wz[0]) || (wx[4] == wx[0] && wy[4] == wy[0] && wz[4] == wz[0])) ? 1 : 0;
         }
-        if (part) final = !collided && tile5_finish(g, t, tq, max_d2, r);
+        if (part) final = !collided && tile5_finish<SHORT_LISTS>(g, t, tq, max_d2, r);
         LL_TT(4, tw);  // winners again + finish test
     }
 }

@@ -1934,7 +1934,7 @@ void launch_reg_knn_build(const RegDev &rd, const RegConst &rc, const Grid &gc, 
             hipLaunchKernelGGL(reg_transform_kernel, dim3((mt + KB_THREADS - 1) / KB_THREADS, n_scans, 2), dim3(KB_THREADS), 0, s, rd, rc, skip);
         }
     }
-    if (tile && iter <= rc.knn_tile_last_sort) launch_reg_qsort(rd, rc, gs, n_scans, max_ns, fused, s);
+    if (tile && iter <= rc.knn_tile_last_sort) launch_reg_qsort(rd, rc, gc, gs, n_scans, corner_in_tile ? max_nc : 0, max_ns, fused, s);
     if (coop_kinds) {
         const int mq = (coop_kinds & 2) ? mx : max_nc;
         hipLaunchKernelGGL(reg_knn_coop_kernel, dim3((mq * 64 + KC_THREADS - 1) / KC_THREADS, n_scans, 2), dim3(KC_THREADS), 0, s, rd, rc, gc, gs, iter, coop_kinds);

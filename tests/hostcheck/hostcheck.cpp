@@ -379,7 +379,7 @@ int hc_knn5_tile(const hc_grid *G, const float *q, int nq, float max_d2, int32_t
                         else dd = dist2_xyz(qx, qy, qz, 1.0e18f, 0.0f, 0.0f);
                         tilek_offer(tk, tile_key(dd, jj));
                     }
-                    collided = collided || tilek_collision(tk);
+                    collided = collided || tilek_collision(tk, max_d2);
                     const float lbv = tile_key_lower(tk.k[5]);
                     for (int k = 0; k < 5; k++) {
                         float d = INFINITY;
@@ -406,7 +406,7 @@ int hc_knn5_tile(const hc_grid *G, const float *q, int nq, float max_d2, int32_t
         for (int l = 0; l < nl; l++) {
             const int i = w0 + l;
             if (fin[l]) {
-                for (int k = 0; k < 5; k++) r[l].idx[k] = as_int(g.pts[r[l].pos[k]].w);
+                for (int k = 0; k < r[l].count; k++) r[l].idx[k] = as_int(g.pts[r[l].pos[k]].w);
             } else {
                 stats[2]++;
                 knn5_search(g, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_d2, r[l]);

@@ -114,7 +114,9 @@ def test_tile_search_equals_per_lane_search_on_the_scan_workload(small_world, sc
 
 
 @pytest.mark.parametrize("cell,max_d2,npts", [(0.7, 50.0, 4000), (0.5, 2.0, 30000), (1.3, 9.0, 1500), (0.6, 50.0, 200000),
-                                               (1.5, 9.0, 200000)])  # (the last one: tiles of more than 256 points, several passes)
+                                               (1.5, 9.0, 200000),   # tiles of more than 256 points, several passes
+                                               (1.45, 2.0, 3000), (1.45, 2.0, 40000)])  # the corner map: the radius lies inside one cell -- a tile
+                                                                                         # settles "fewer than five" too
 def test_tile_search_sparse_dense_ties_and_outside(cell, max_d2, npts):
     rng = np.random.default_rng(21)
     pts = rng.uniform(0, 30, (npts, 3)).astype(np.float32)
@@ -139,6 +141,10 @@ def test_tile_search_sparse_dense_ties_and_outside(cell, max_d2, npts):
             assert lb2[i] <= rest.min() * (1 + 1e-5) + 1e-6
     if npts >= 200000:
         assert stats[2] < 0.5 * len(q)  # a dense cloud: the tiles settle most lanes
+    if cell == 1.45:
+        # only ties, queries more than a cell outside and non-finite ones are left to the per-lane search -- although most lists are short
+        assert (ti[:, 4] < 0).sum() > 0.1 * len(q) or npts > 3000
+        assert stats[2] < 0.2 * len(q), stats
 
 
 def test_tile_search_settles_queries_just_outside_the_grid():
