@@ -399,6 +399,55 @@ def test_tile_search_sparse_map_ties_and_strays(gpu_lib):
     m.close()
 
 
+def test_corner_queries_take_the_tile_search_in_large_batches(gpu_lib):
+    """Batches of more than 16 scans: the corner queries go through the tile search on the corner map inside reg_knn_lane_kernel
+    (cell-ordered by reg_qsort_corner_kernel; scans with more than 2 048 corner queries keep the feature order).  A sparse corner map:
+    most queries have fewer than five neighbours inside the line radius -- the tile settles those too, because a 3 x 3 x 3 block of
+    1.45 m cells covers the radius --, exact duplicates (ties by index), queries outside the grid and non-finite ones.  The lists of
+    ICP iteration 0 against the per-lane search and against the k-d tree, for a scan on either side of the 2 048 limit."""
+    rng = np.random.default_rng(11)
+    corner = rng.uniform(0, 20, (9000, 3)).astype(np.float32)
+    corner[50:54] = corner[50]
+    surf = rng.uniform(0, 20, (40000, 3)).astype(np.float32)
+    m = Map_buffer()
+    m.setInputCloud(Map_buffer.CORNER, corner)
+    m.setInputCloud(Map_buffer.SURF, surf, 0.6)
+    tree = orc.KdTree(corner)
+    n = 20
+    fcs, fss = [], []
+    for b in range(n):
+        nc = 3000 if b % 2 == 0 else 700
+        fc = np.zeros((nc, 4), np.float32)
+        fc[:, :3] = rng.uniform(-2, 22, (nc, 3))
+        fc[0, :3] = corner[50]
+        fc[1, :3] = [1e5, 0, 0]
+        fc[2, 1] = np.nan
+        fs = np.zeros((2000, 4), np.float32)
+        fs[:, :3] = rng.uniform(0, 20, (2000, 3))
+        fcs.append(fc)
+        fss.append(fs)
+    ident = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], np.float64), (n, 1))
+    res = []
+    for kw in ({}, {"no_knn_tile": True}):
+        reg = Point_cloud_registration(max_scans=n, max_features=4096)
+        reg.set_debug(True, **kw)
+        set_params(reg, 1, 4, 1)
+        reg.solve_batch(m, fcs, fss, ident, ident)
+        res.append([reg.debug_knn(b, len(fcs[b]), len(fss[b])) for b in (0, 1, 19)])
+        reg.close()
+    for (ci, cd, si, sd), (ci2, cd2, si2, sd2), b in zip(res[0], res[1], (0, 1, 19)):
+        assert np.array_equal(ci, ci2) and np.array_equal(cd, cd2) and np.array_equal(si, si2) and np.array_equal(sd, sd2)
+        fc = fcs[b]
+        ok = np.isfinite(fc[:, :3]).all(axis=1)
+        oi, od = tree.knn(fc[ok, :3], 5)
+        inside = od < 2.0
+        assert np.array_equal(np.where(inside, oi, -1), ci[ok]) and np.array_equal(np.where(inside, od, np.inf), cd[ok])
+        assert (inside.sum(axis=1) < 5).mean() > 0.3            # most lists are short ones
+        assert np.all(ci[1] == -1) and np.all(ci[2] == -1)
+        assert ci[0].tolist()[:4] == [50, 51, 52, 53]
+    m.close()
+
+
 @pytest.mark.parametrize("n,thin", [(1, 1), (20, 1), (1, 12), (16, 12)])
 def test_wavefront_search_changes_nothing(dev_map, scans, n, thin):
     """Searches by whole wavefronts (ll_knn_coop.h: every corner query of ICP iterations 0 / 1 for batches of up to 16 scans --
